@@ -1,0 +1,158 @@
+"""Hyper-parameters and seeded synthetic state dicts in the reference checkpoint layout.
+
+The checkpoint layout (166 entries for the default model) is the one
+``BeatThis.state_dict()`` produces in the reference (beat_this/model/beat_tracker.py:38-106,
+SURVEY.md Appendix A).  No checkpoint can be downloaded in this environment, so
+benchmarks and tests use weights drawn from ``numpy.random.default_rng`` (PCG64 --
+identical on every machine, unlike torch's generators) with the reference's
+initialisation statistics (beat_tracker.py:170-186) or a "lively" variant whose
+activations have O(1) dynamic range (sharper softmaxes, logits crossing 0).
+"""
+from __future__ import annotations
+
+import math
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+HPARAMS = {
+    # README.md:231-243 / launch_scripts/train.py:81-100 of the reference
+    "final0": dict(spect_dim=128, transformer_dim=512, ff_mult=4, n_layers=6, head_dim=32, stem_dim=32),
+    "small0": dict(spect_dim=128, transformer_dim=128, ff_mult=4, n_layers=6, head_dim=32, stem_dim=32),
+}
+
+
+def resolve_hparams(hp=None) -> dict:
+    base = dict(HPARAMS["final0"], sum_head=True, partial_transformers=True)
+    if isinstance(hp, str):
+        base.update(HPARAMS["small0"] if hp.startswith("small") else HPARAMS["final0"])
+    elif hp:
+        base.update({k: v for k, v in hp.items() if k in base})
+    return base
+
+
+def state_dict_shapes(hp: dict) -> "OrderedDict[str, tuple]":
+    """Ordered {key: shape} of BeatThis.state_dict() for ``hp``."""
+    hp = resolve_hparams(hp)
+    D, L, hd, S, mel = hp["transformer_dim"], hp["n_layers"], hp["head_dim"], hp["stem_dim"], hp["spect_dim"]
+    mult = hp["ff_mult"]
+    out: "OrderedDict[str, tuple]" = OrderedDict()
+
+    def bn(p, n):
+        for k in ("weight", "bias", "running_mean", "running_var"):
+            out[p + k] = (n,)
+        out[p + "num_batches_tracked"] = ()
+
+    def attn(p, dim):
+        h = dim // hd
+        out[p + "rotary_embed.freqs"] = (hd // 2,)
+        out[p + "norm.gamma"] = (dim,)
+        out[p + "to_qkv.weight"] = (3 * dim, dim)
+        out[p + "to_gates.weight"] = (h, dim)
+        out[p + "to_gates.bias"] = (h,)
+        out[p + "to_out.0.weight"] = (dim, dim)
+
+    def ff(p, dim):
+        out[p + "net.0.gamma"] = (dim,)
+        out[p + "net.1.weight"] = (mult * dim, dim)
+        out[p + "net.1.bias"] = (mult * dim,)
+        out[p + "net.4.weight"] = (dim, mult * dim)
+        out[p + "net.4.bias"] = (dim,)
+
+    bn("frontend.stem.bn1d.", mel)
+    out["frontend.stem.conv2d.weight"] = (S, 1, 4, 3)
+    bn("frontend.stem.bn2d.", S)
+    dim, f = S, mel // 4
+    for i in range(3):
+        p = f"frontend.blocks.{i}."
+        if hp["partial_transformers"]:
+            attn(p + "partial.attnF.", dim)
+            ff(p + "partial.ffF.", dim)
+            attn(p + "partial.attnT.", dim)
+            ff(p + "partial.ffT.", dim)
+        out[p + "conv2d.weight"] = (2 * dim, dim, 2, 3)
+        bn(p + "norm.", 2 * dim)
+        dim, f = 2 * dim, f // 2
+    out["frontend.linear.weight"] = (D, dim * f)
+    out["frontend.linear.bias"] = (D,)
+    for l in range(L):
+        attn(f"transformer_blocks.layers.{l}.0.", D)
+        ff(f"transformer_blocks.layers.{l}.1.", D)
+    out["transformer_blocks.norm.gamma"] = (D,)
+    out["task_heads.beat_downbeat_lin.weight"] = (2, D)
+    out["task_heads.beat_downbeat_lin.bias"] = (2,)
+    return out
+
+
+def random_state_dict(hp=None, seed: int = 0, style: str = "lively") -> "OrderedDict[str, torch.Tensor]":
+    """Seeded synthetic weights in checkpoint layout.
+
+    style="init":   the reference's init statistics (Linear N(0,0.02^2), zero bias,
+                    Conv2d Kaiming-normal fan_out, gamma=1, BN identity) plus a seeded
+                    perturbation of every 1-D parameter and BN running statistic
+                     so that no affine term is trivially 0/1.
+    style="lively": fan-in scaled weights so that attention logits and the output
+                    logits have O(1) spread (peaks, sign changes) -- a stricter
+                    numerical test than "init", same FLOPs.
+    """
+    hp = resolve_hparams(hp)
+    rng = np.random.default_rng(seed)
+    sd: "OrderedDict[str, torch.Tensor]" = OrderedDict()
+    hd = hp["head_dim"]
+    for key, shape in state_dict_shapes(hp).items():
+        leaf = key.rsplit(".", 1)[-1]
+        if key.endswith("rotary_embed.freqs"):
+            v = (1.0 / (10000.0 ** (np.arange(0, hd, 2, dtype=np.float32) / np.float32(hd)))).astype(np.float32)
+        elif leaf == "num_batches_tracked":
+            sd[key] = torch.zeros((), dtype=torch.int64)
+            continue
+        elif leaf == "running_mean":
+            v = 0.5 * rng.standard_normal(shape)
+            if key.startswith("frontend.stem.bn1d"):
+                v = 3.0 + v  # log-mel values live around 3..5
+        elif leaf == "running_var":
+            v = rng.uniform(0.5, 1.5, shape)
+            if key.startswith("frontend.stem.bn1d"):
+                v = v * 2.0
+        elif leaf == "gamma" or (leaf == "weight" and len(shape) == 1):
+            v = 1.0 + 0.1 * rng.standard_normal(shape)
+        elif leaf == "bias":
+            v = 0.1 * rng.standard_normal(shape)
+        elif len(shape) == 4:  # conv, Kaiming normal fan_out
+            fan_out = shape[0] * shape[2] * shape[3]
+            fan_in = shape[1] * shape[2] * shape[3]
+            std = math.sqrt(2.0 / fan_out) if style == "init" else 1.3 / math.sqrt(fan_in)
+            v = std * rng.standard_normal(shape)
+        else:  # linear
+            if style == "init":
+                std = 0.02
+            elif "to_qkv" in key:
+                std = 1.6 / math.sqrt(shape[1])
+            elif "task_heads" in key:
+                std = 2.0 / math.sqrt(shape[1])
+            else:
+                std = 1.0 / math.sqrt(shape[1])
+            v = std * rng.standard_normal(shape)
+        sd[key] = torch.from_numpy(np.asarray(v, dtype=np.float32).reshape(shape).copy())
+    return sd
+
+
+def synthetic_audio(seconds: float, seed: int = 0, sr: int = 22050) -> np.ndarray:
+    """White noise N(0,0.1^2) + 120 BPM click train (every 4th click doubled) -- SURVEY.md 8d."""
+    rng = np.random.default_rng(seed)
+    n = int(round(seconds * sr))
+    x = rng.normal(0.0, 0.1, n).astype(np.float32)
+    step = sr // 2
+    for i, pos in enumerate(range(0, n, step)):
+        x[pos] += 2.0 if i % 4 == 0 else 1.0
+    return x
+
+
+def synthetic_spect(n_frames: int, seed: int = 0) -> np.ndarray:
+    """Cheap seeded stand-in for a log-mel spectrogram: smooth-ish values in [0, 7]."""
+    rng = np.random.default_rng(seed)
+    base = rng.uniform(0.0, 1.0, (n_frames, 128)).astype(np.float32)
+    env = (1.0 + np.sin(np.arange(n_frames, dtype=np.float32)[:, None] * (2 * np.pi / 25.0))) * 0.5
+    tilt = np.linspace(1.0, 0.3, 128, dtype=np.float32)[None, :]
+    return np.log1p(1000.0 * 0.05 * base * (0.2 + env) * tilt).astype(np.float32)

@@ -1,0 +1,149 @@
+"""Generate tests/golden/*.npz|json by running the UNMODIFIED reference on CPU.
+
+TEST INFRASTRUCTURE ONLY.  Run in the build container (needs /root/reference):
+
+    PYTHONDONTWRITEBYTECODE=1 python oracle/make_golden.py
+
+The reference's own package is imported from /root/reference with the three
+third-party stand-ins of oracle/shims first on sys.path (torchaudio,
+rotary_embedding_torch, soxr are not installed and cannot be fetched).  Inputs are
+regenerated from seeds by beat_this_amd.weights (numpy PCG64, machine independent),
+so the fixtures hold only the reference's *outputs*.
+"""
+import json
+import os
+import sys
+
+sys.dont_write_bytecode = True
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = os.environ.get("BEAT_THIS_REFERENCE", "/root/reference")
+sys.path[:0] = [os.path.join(ROOT, "oracle", "shims"), REF, ROOT]
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from beat_this.inference import Audio2Beats, split_piece, split_predict_aggregate  # noqa: E402
+from beat_this.model.beat_tracker import BeatThis  # noqa: E402
+from beat_this.model.postprocessor import Postprocessor  # noqa: E402
+from beat_this.preprocessing import LogMelSpect  # noqa: E402
+
+from beat_this_amd import weights as W  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+MODEL_KEYS = ("spect_dim", "transformer_dim", "ff_mult", "n_layers", "head_dim", "stem_dim")
+
+# (name, hparams name, weight seed, style, T, input seed)
+MODEL_CASES = [
+    ("small0_lively_T1500", "small0", 1, "lively", 1500, 3),
+    ("small0_init_T1500", "small0", 1, "init", 1500, 3),
+    ("small0_lively_T1012", "small0", 2, "lively", 1012, 4),
+    ("small0_lively_T200", "small0", 2, "lively", 200, 5),
+    ("final0_lively_T1500", "final0", 1, "lively", 1500, 3),
+    ("final0_init_T1500", "final0", 1, "init", 1500, 3),
+]
+POSTP_CASES = {
+    # name: list of (frame, value) spikes on a -5 floor, for both beat and downbeat rows
+    "plateau2": ([(10, 2.0), (11, 2.0)], [(10, 1.0)]),
+    "plateau3": ([(10, 2.0), (11, 2.0), (12, 2.0)], [(11, 1.0)]),
+    "equal_two_apart": ([(20, 1.5), (22, 1.5)], [(20, 1.5), (22, 1.5)]),
+    "lower_within3": ([(30, 3.0), (33, 2.0)], [(33, 2.0)]),
+    "lower_at4": ([(30, 3.0), (34, 2.0)], [(34, 2.0)]),
+    "zero_logit": ([(40, 0.0), (50, 1e-6)], [(50, 0.5)]),
+    "equidistant": ([(60, 1.0), (70, 1.0)], [(65, 1.0)]),
+    "no_beats": ([], [(15, 2.0)]),
+    "edges": ([(0, 1.0), (99, 1.0)], [(0, 2.0), (99, 0.5)]),
+    "dense": ([(i, 1.0 + 0.01 * (i % 7)) for i in range(3, 97, 2)], [(i, 1.0) for i in range(5, 95, 9)]),
+}
+
+
+def reference_model(hp_name, seed, style):
+    hp = W.resolve_hparams(hp_name)
+    sd = W.random_state_dict(hp, seed=seed, style=style)
+    m = BeatThis(**{k: hp[k] for k in MODEL_KEYS}).eval()
+    m.load_state_dict(sd)
+    return m
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    torch.manual_seed(0)
+
+    # 1. split_piece table (inference.py:100-135)
+    table = {}
+    for n in (1, 7, 200, 1000, 1488, 1489, 1500, 1501, 2976, 2977, 4465, 15001):
+        chunks, starts = split_piece(torch.zeros(n, 2), 1500, border_size=6, avoid_short_end=True)
+        table[str(n)] = {"starts": [int(s) for s in starts], "lens": [int(c.shape[0]) for c in chunks]}
+    json.dump(table, open(os.path.join(OUT, "split_piece.json"), "w"), indent=1)
+
+    # 2. minimal post-processor edge cases (postprocessor.py:85-136,176-197)
+    pp = Postprocessor("minimal", fps=50)
+    post = {}
+    for name, (bs, ds) in POSTP_CASES.items():
+        b = torch.full((100,), -5.0)
+        d = torch.full((100,), -5.0)
+        for f, v in bs:
+            b[f] = v
+        for f, v in ds:
+            d[f] = v
+        bt, dt = pp(b, d)
+        post[name] = {"beat_in": bs, "down_in": ds, "beats": [float(x) for x in bt], "downbeats": [float(x) for x in dt]}
+    rng = np.random.default_rng(7)
+    rb = torch.from_numpy(rng.normal(-1.0, 1.5, 3000).astype(np.float32))
+    rd = torch.from_numpy(rng.normal(-2.0, 1.5, 3000).astype(np.float32))
+    bt, dt = pp(rb, rd)
+    post["random3000"] = {"seed": 7, "beats": [float(x) for x in bt], "downbeats": [float(x) for x in dt]}
+    json.dump(post, open(os.path.join(OUT, "postp_minimal.json"), "w"), indent=1)
+
+    # 3. log-mel (preprocessing.py:27-59)
+    spect = LogMelSpect(device="cpu")
+    a2 = W.synthetic_audio(2.0, seed=11)
+    a30 = W.synthetic_audio(30.0, seed=12)
+    tone = (0.5 * np.sin(2 * np.pi * 440.0 * np.arange(22050 * 3) / 22050.0)).astype(np.float32)
+    s2 = spect(torch.from_numpy(a2)).numpy()
+    s30 = spect(torch.from_numpy(a30)).numpy()
+    st = spect(torch.from_numpy(tone)).numpy()
+    sel = np.r_[0:6, 700:706, 1495:1501]
+    np.savez_compressed(os.path.join(OUT, "logmel.npz"), s2=s2, s30_sel=s30[sel], s30_rows=sel,
+                        s30_shape=np.array(s30.shape), tone_sel=st[[0, 1, 75, 149, 150]],
+                        tone_rows=np.array([0, 1, 75, 149, 150]))
+
+    # 4. model forward (beat_tracker.py:188-192)
+    arrs = {}
+    for name, hpn, wseed, style, T, iseed in MODEL_CASES:
+        m = reference_model(hpn, wseed, style)
+        x = torch.from_numpy(W.synthetic_spect(T, seed=iseed))[None]
+        with torch.inference_mode():
+            r = m(x)
+        arrs[name + "_beat"] = r["beat"][0].numpy()
+        arrs[name + "_downbeat"] = r["downbeat"][0].numpy()
+        print(name, float(r["beat"].std()), float((r["beat"] > 0).float().mean()))
+    # batched forward (B=3, different inputs) on small0
+    m = reference_model("small0", 1, "lively")
+    xb = torch.from_numpy(np.stack([W.synthetic_spect(1500, seed=20 + i) for i in range(3)]))
+    with torch.inference_mode():
+        r = m(xb)
+    arrs["small0_lively_B3_beat"] = r["beat"].numpy()
+    arrs["small0_lively_B3_downbeat"] = r["downbeat"].numpy()
+    # 5. split_predict_aggregate over a 3100-frame piece (inference.py:188-230)
+    piece = torch.from_numpy(W.synthetic_spect(3100, seed=30))
+    with torch.inference_mode():
+        r = split_predict_aggregate(piece, 1500, 6, "keep_first", m)
+    arrs["small0_lively_piece3100_beat"] = r["beat"].numpy()
+    arrs["small0_lively_piece3100_downbeat"] = r["downbeat"].numpy()
+    np.savez_compressed(os.path.join(OUT, "model_logits.npz"), **arrs)
+
+    # 6. end to end from the 22.05 kHz waveform (inference.py:279-303), small0-lively weights
+    a2b = Audio2Beats(checkpoint_path=None, device="cpu")
+    hp = W.resolve_hparams("small0")
+    a2b.model = reference_model("small0", 1, "lively")
+    sig = W.synthetic_audio(40.0, seed=13)
+    beats, downbeats = a2b(sig, 22050)
+    with torch.inference_mode():
+        bl, dl = a2b.spect2frames(a2b.signal2spect(sig, 22050))
+    np.savez_compressed(os.path.join(OUT, "e2e_small0.npz"), beats=beats, downbeats=downbeats,
+                        beat_logits=bl.numpy(), downbeat_logits=dl.numpy())
+    print("e2e beats", len(beats), "downbeats", len(downbeats))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,153 @@
+"""The CPU oracle (oracle/beat_this_oracle.py) against the committed golden outputs of
+the reference (tests/golden, made by oracle/make_golden.py), and against the live
+reference when /root/reference is present."""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, REFERENCE, ROOT, have_reference
+from beat_this_amd import weights as W
+from oracle import beat_this_oracle as O
+from oracle.make_golden import MODEL_CASES, POSTP_CASES
+
+
+def test_split_piece_table():
+    table = json.load(open(os.path.join(GOLDEN, "split_piece.json")))
+    for n, row in table.items():
+        n = int(n)
+        starts = O.split_starts(n)
+        assert [int(s) for s in starts] == row["starts"], n
+        chunks, _ = O.split_chunks(torch.zeros(n, 2))
+        assert [int(c.shape[0]) for c in chunks] == row["lens"], n
+    # the surprises of SURVEY.md section 0 item 1
+    assert table["1500"]["starts"] == [-6, 6] and table["1488"]["starts"] == [-6]
+    assert len(table["15001"]["starts"]) == 11 and table["1000"]["lens"] == [1012]
+
+
+def test_postprocessor_edge_cases():
+    post = json.load(open(os.path.join(GOLDEN, "postp_minimal.json")))
+    for name, (bs, ds) in POSTP_CASES.items():
+        b = torch.full((100,), -5.0)
+        d = torch.full((100,), -5.0)
+        for f, v in bs:
+            b[f] = v
+        for f, v in ds:
+            d[f] = v
+        bt, dt = O.postp_minimal(b, d)
+        assert bt.tolist() == post[name]["beats"], name
+        assert dt.tolist() == post[name]["downbeats"], name
+    rng = np.random.default_rng(post["random3000"]["seed"])
+    rb = torch.from_numpy(rng.normal(-1.0, 1.5, 3000).astype(np.float32))
+    rd = torch.from_numpy(rng.normal(-2.0, 1.5, 3000).astype(np.float32))
+    bt, dt = O.postp_minimal(rb, rd)
+    assert bt.tolist() == post["random3000"]["beats"]
+    assert dt.tolist() == post["random3000"]["downbeats"]
+    # the plateau quirk
+    assert post["plateau3"]["beats"] == [10.5 / 50, 12 / 50]
+
+
+def test_logmel_golden():
+    g = np.load(os.path.join(GOLDEN, "logmel.npz"))
+    s2 = O.logmel(torch.from_numpy(W.synthetic_audio(2.0, seed=11))).numpy()
+    assert s2.shape == g["s2"].shape == (101, 128)
+    assert np.abs(s2 - g["s2"]).max() < 2e-5
+    s30 = O.logmel(torch.from_numpy(W.synthetic_audio(30.0, seed=12))).numpy()
+    assert tuple(g["s30_shape"]) == s30.shape == (1501, 128)
+    assert np.abs(s30[g["s30_rows"]] - g["s30_sel"]).max() < 2e-5
+    tone = (0.5 * np.sin(2 * np.pi * 440.0 * np.arange(22050 * 3) / 22050.0)).astype(np.float32)
+    st = O.logmel(torch.from_numpy(tone)).numpy()
+    # pure tone: empty bands amplify fp32 FFT noise by 1000 -> looser bound there
+    assert np.abs(st[g["tone_rows"]] - g["tone_sel"]).max() < 5e-4
+    # fp64 evaluation agrees with the fp32 reference output
+    s2d = O.logmel(torch.from_numpy(W.synthetic_audio(2.0, seed=11)), torch.float64).numpy()
+    assert np.abs(s2d - g["s2"]).max() < 2e-5
+
+
+def test_mel_filterbank_structure():
+    fb = O.mel_filterbank()
+    assert fb.shape == (513, 128)
+    assert int((fb > 0).sum()) == 1004
+    nz = (fb > 0).sum(0)
+    assert int(nz.min()) == 2 and int(nz.max()) == 26
+
+
+@pytest.mark.parametrize("case", [c for c in MODEL_CASES if c[1] == "small0"] + [MODEL_CASES[4]])
+def test_model_forward_golden(case):
+    name, hpn, wseed, style, T, iseed = case
+    g = np.load(os.path.join(GOLDEN, "model_logits.npz"))
+    sd = W.random_state_dict(hpn, seed=wseed, style=style)
+    x = torch.from_numpy(W.synthetic_spect(T, seed=iseed))[None]
+    with torch.inference_mode():
+        b, d = O.model_forward(sd, x)
+    assert np.abs(b[0].numpy() - g[name + "_beat"]).max() < 5e-5
+    assert np.abs(d[0].numpy() - g[name + "_downbeat"]).max() < 5e-5
+
+
+def test_model_batched_and_piece_golden():
+    g = np.load(os.path.join(GOLDEN, "model_logits.npz"))
+    sd = W.random_state_dict("small0", seed=1, style="lively")
+    xb = torch.from_numpy(np.stack([W.synthetic_spect(1500, seed=20 + i) for i in range(3)]))
+    with torch.inference_mode():
+        b, d = O.model_forward(sd, xb)
+        assert np.abs(b.numpy() - g["small0_lively_B3_beat"]).max() < 5e-5
+        assert np.abs(d.numpy() - g["small0_lively_B3_downbeat"]).max() < 5e-5
+        piece = torch.from_numpy(W.synthetic_spect(3100, seed=30))
+        pb, pd = O.spect2frames(sd, piece)
+    assert pb.shape == (3100,)
+    assert np.abs(pb.numpy() - g["small0_lively_piece3100_beat"]).max() < 5e-5
+    assert np.abs(pd.numpy() - g["small0_lively_piece3100_downbeat"]).max() < 5e-5
+
+
+def test_end_to_end_golden():
+    g = np.load(os.path.join(GOLDEN, "e2e_small0.npz"))
+    sd = W.random_state_dict("small0", seed=1, style="lively")
+    sig = W.synthetic_audio(40.0, seed=13)
+    with torch.inference_mode():
+        spect = O.logmel(torch.from_numpy(sig))
+        bl, dl = O.spect2frames(sd, spect)
+        assert np.abs(bl.numpy() - g["beat_logits"]).max() < 1e-4
+        # identical logits -> identical beat lists, bit for bit
+        bt, dt = O.postp_minimal(torch.from_numpy(g["beat_logits"]), torch.from_numpy(g["downbeat_logits"]))
+    assert np.array_equal(bt, g["beats"]) and np.array_equal(dt, g["downbeats"])
+    bt2, dt2 = O.postp_minimal(bl, dl)
+    assert np.array_equal(bt2, g["beats"]) and np.array_equal(dt2, g["downbeats"])
+
+
+def test_state_dict_layout():
+    sd = W.random_state_dict("final0", seed=0)
+    assert len(sd) == 166
+    def count(d):  # nn.Module.parameters() sees the shared rotary ``freqs`` once
+        return 16 + sum(v.numel() for k, v in d.items()
+                        if v.dtype == torch.float32 and "running_" not in k and "freqs" not in k)
+    assert count(sd) == 20_251_712
+    sds = W.random_state_dict("small0", seed=0)
+    assert count(sds) == 2_099_960
+    fr = sd["transformer_blocks.layers.0.0.rotary_embed.freqs"]
+    assert torch.allclose(fr, 10000.0 ** (-torch.arange(0, 32, 2).float() / 32))
+
+
+@pytest.mark.skipif(not have_reference(), reason="/root/reference not present (GPU box)")
+def test_oracle_against_live_reference():
+    sys.dont_write_bytecode = True
+    sys.path[:0] = [os.path.join(ROOT, "oracle", "shims"), REFERENCE]
+    try:
+        from beat_this.model.beat_tracker import BeatThis
+        from beat_this.preprocessing import LogMelSpect
+    finally:
+        del sys.path[:2]
+    sd = W.random_state_dict("small0", seed=5, style="lively")
+    hp = W.resolve_hparams("small0")
+    m = BeatThis(**{k: hp[k] for k in ("spect_dim", "transformer_dim", "ff_mult", "n_layers", "head_dim", "stem_dim")}).eval()
+    assert list(m.state_dict().keys()) == list(sd.keys())
+    m.load_state_dict(sd)
+    x = torch.from_numpy(W.synthetic_spect(700, seed=9))[None]
+    with torch.inference_mode():
+        r = m(x)
+        b, d = O.model_forward(sd, x)
+    assert (b - r["beat"]).abs().max() < 5e-5 and (d - r["downbeat"]).abs().max() < 5e-5
+    a = torch.from_numpy(W.synthetic_audio(3.0, seed=2))
+    assert (LogMelSpect()(a) - O.logmel(a)).abs().max() < 2e-5
