@@ -1,0 +1,148 @@
+"""ctypes binding of libbeat_this_amd.so (C ABI declared in include/beat_this_amd.h).
+
+The library is loaded AFTER ``import torch`` so that its HIP symbols resolve to the ROCm
+runtime torch has already loaded (same SONAME libamdhip64.so.7): device pointers of torch
+tensors and torch's streams are then directly usable.  There is deliberately no CPU or
+PyTorch fallback: if the library is missing or a device is not a ROCm GPU, we raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import torch  # noqa: F401  (must precede loading the HIP library)
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(PKG_DIR, "libbeat_this_amd.so")
+SOURCES = ["gemm.hip", "attn.hip", "frontend.hip", "logmel.hip", "engine.hip"]
+HEADERS = ["common.h", "kernels.h", os.path.join("..", "..", "include", "beat_this_amd.h")]
+
+BT_OK, BT_ERR_ARG, BT_ERR_HIP, BT_ERR_WORKSPACE = 0, -1, -2, -3
+PREC_F32, PREC_BF16 = 0, 1
+MAX_LAYERS = 32
+PROFILE_CATEGORIES = ["stem", "qkv_gemm", "attn_freq", "attn_flash", "out_gemm", "ff1_gemm", "ff2_gemm", "conv_gemm",
+                      "linear_gemm", "head"]
+
+GEMM_EPI_STORE, GEMM_EPI_RESID, GEMM_EPI_QKV = 0, 1, 2
+GEMM_F_RMS, GEMM_F_BIAS, GEMM_F_GELU, GEMM_F_OUT_F32, GEMM_F_A_F32, GEMM_F_CONV, GEMM_F_ROWMAP = 1, 2, 4, 8, 16, 32, 64
+
+
+class PairWeights(C.Structure):
+    _fields_ = [("dim", C.c_int32), ("heads", C.c_int32), ("w_qkvg", C.c_void_p * 2), ("b_gates", C.c_void_p),
+                ("w_out", C.c_void_p * 2), ("w_ff1", C.c_void_p * 2), ("b_ff1", C.c_void_p),
+                ("w_ff2", C.c_void_p * 2), ("b_ff2", C.c_void_p)]
+
+
+class ModelDesc(C.Structure):
+    _fields_ = [("transformer_dim", C.c_int32), ("n_layers", C.c_int32), ("sum_head", C.c_int32),
+                ("partial_transformers", C.c_int32),
+                ("bn1_scale", C.c_void_p), ("bn1_shift", C.c_void_p), ("stem_w", C.c_void_p), ("stem_b", C.c_void_p),
+                ("front", (PairWeights * 2) * 3),
+                ("conv_w", (C.c_void_p * 2) * 3), ("conv_b", C.c_void_p * 3),
+                ("lin_w", C.c_void_p * 2), ("lin_b", C.c_void_p),
+                ("layers", PairWeights * MAX_LAYERS),
+                ("head_w", C.c_void_p), ("head_b", C.c_float * 2), ("rope", C.c_void_p)]
+
+
+class LogmelTables(C.Structure):
+    _fields_ = [("window", C.c_void_p), ("twiddle", C.c_void_p), ("mel_start", C.c_void_p),
+                ("mel_len", C.c_void_p), ("mel_w", C.c_void_p)]
+
+
+class GemmArgs(C.Structure):
+    _fields_ = [("A", C.c_void_p), ("lda", C.c_int64), ("W", C.c_void_p), ("M", C.c_int32), ("N", C.c_int32),
+                ("K", C.c_int32), ("epi", C.c_int32), ("flags", C.c_int32), ("bias", C.c_void_p),
+                ("out", C.c_void_p), ("ldo", C.c_int64), ("x", C.c_void_p), ("ldx", C.c_int64),
+                ("conv_C2", C.c_int32), ("conv_T", C.c_int32), ("conv_F", C.c_int32), ("gates", C.c_void_p),
+                ("inner", C.c_int32), ("heads", C.c_int32), ("rope", C.c_void_p), ("pdiv", C.c_int32),
+                ("pmod", C.c_int32), ("map_T", C.c_int32), ("map_F", C.c_int32)]
+
+
+class AttnArgs(C.Structure):
+    _fields_ = [("qkv", C.c_void_p), ("ld", C.c_int64), ("gates", C.c_void_p), ("out", C.c_void_p),
+                ("n_seq", C.c_int32), ("L", C.c_int32), ("heads", C.c_int32), ("inner", C.c_int32),
+                ("o_div", C.c_int32), ("o_outer", C.c_int64), ("o_inner", C.c_int64), ("o_tok", C.c_int64)]
+
+
+EXPORTS = {
+    "bt_last_error": (C.c_char_p, []),
+    "bt_version": (C.c_int, []),
+    "bt_struct_sizes": (None, [C.POINTER(C.c_int32)]),
+    "bt_engine_create": (C.c_int, [C.POINTER(ModelDesc), C.POINTER(C.c_void_p)]),
+    "bt_engine_destroy": (None, [C.c_void_p]),
+    "bt_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
+    "bt_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t,
+                             C.c_void_p, C.c_void_p]),
+    "bt_split_chunks": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "bt_aggregate": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int64,
+                               C.c_void_p, C.c_void_p]),
+    "bt_logmel": (C.c_int, [C.c_void_p, C.POINTER(LogmelTables), C.c_void_p, C.c_int64, C.c_void_p]),
+    "bt_peaks": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]),
+    "bt_postprocess_host": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_double, C.c_void_p,
+                                      C.POINTER(C.c_int32), C.c_void_p, C.POINTER(C.c_int32)]),
+    "bt_profile_begin": (None, []),
+    "bt_profile_end": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
+    "bt_gemm": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(GemmArgs)]),
+    "bt_attention": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(AttnArgs), C.c_int]),
+}
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile the HIP sources for gfx950 into libbeat_this_amd.so (in tree)."""
+    src_dir = os.path.join(PKG_DIR, "csrc")
+    srcs = [os.path.join(src_dir, s) for s in SOURCES]
+    deps = srcs + [os.path.join(src_dir, h) for h in HEADERS]
+    if not force and os.path.exists(LIB_PATH) and all(
+            os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
+        return LIB_PATH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", *srcs, "-o", LIB_PATH]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    """The loaded library; raises ImportError if it was never built (no fallback path exists)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(needs hipcc); beat_this_amd has no CPU/PyTorch fallback")
+        handle = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+        for name, (res, args) in EXPORTS.items():
+            fn = getattr(handle, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(rc: int) -> None:
+    if rc == BT_OK:
+        return
+    msg = lib().bt_last_error().decode("utf-8", "replace")
+    if rc == BT_ERR_ARG:
+        raise ValueError(msg)
+    raise RuntimeError(f"beat_this_amd: {msg} (code {rc})")
+
+
+def require_gpu(t: torch.Tensor, what: str = "tensor") -> None:
+    if not t.is_cuda:
+        raise RuntimeError(
+            f"beat_this_amd runs on ROCm GPUs only: {what} is on '{t.device}'. "
+            "Construct the model with device='cuda' (there is no CPU path in this package).")
+
+
+def stream_ptr(device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def ptr(t) -> int:
+    return 0 if t is None else t.data_ptr()

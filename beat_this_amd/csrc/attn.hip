@@ -1,0 +1,340 @@
+// Attention kernels (head_dim = 32, non-causal, no mask) replacing
+// F.scaled_dot_product_attention + the per-head sigmoid gate of the reference
+// (beat_this/model/roformer.py:67-80,125-131).
+//
+// q arrives pre-scaled: the QKV GEMM folds 1/sqrt(32) * log2(e) into the q rows of the
+// weight, RoPE was applied in that GEMM's epilogue, so softmax here is exp2(s - max).
+//
+// attn_flash: one wave owns 32 queries, a 256-thread workgroup 128; keys stream through
+// LDS in tiles of 64.  Scores are computed TRANSPOSED (S^T = K . Q^T) so that a lane holds
+// 16 of the 32 key-scores of ONE query: row max / row sum are lane-local plus a single
+// exchange with lane^32, and the probabilities are already in the B-operand layout of the
+// second MFMA (O^T = V^T . P^T) -- no cross-lane traffic for P at all.  For bf16 the V tile
+// is transposed on its way into LDS so the A operand (V^T) is read with two ds_read_b64;
+// for fp32 (k = 2 MFMA) V is read row-major.
+//
+// attn_small: the frequency-direction partial attention (8/16/32 tokens, heads*tokens = 32):
+// one thread per (time step, head, query); K/V of 8 time steps live in LDS; fp32 VALU math.
+#include <type_traits>
+
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+constexpr int KT = 64;          // keys per tile
+constexpr int VT_PITCH = 136;   // bytes per d-row of the transposed bf16 V tile (64 keys * 2 + 8)
+
+template <typename T> struct KV8;  // 8 contiguous elements staged in registers
+template <> struct KV8<float> { f32x4 v[2]; };
+template <> struct KV8<bf16> { bf16x8 v; };
+
+template <typename T> DEVI KV8<T> ldg8(const T* p, bool ok);
+template <> DEVI KV8<float> ldg8<float>(const float* p, bool ok) {
+  KV8<float> r;
+  if (ok) {
+    r.v[0] = reinterpret_cast<const f32x4*>(p)[0];
+    r.v[1] = reinterpret_cast<const f32x4*>(p)[1];
+  } else {
+    r.v[0] = f32x4{0.f, 0.f, 0.f, 0.f};
+    r.v[1] = r.v[0];
+  }
+  return r;
+}
+template <> DEVI KV8<bf16> ldg8<bf16>(const bf16* p, bool ok) {
+  KV8<bf16> r;
+  typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+  u32x4 z = {0, 0, 0, 0};
+  r.v = ok ? *reinterpret_cast<const bf16x8*>(p) : __builtin_bit_cast(bf16x8, z);
+  return r;
+}
+DEVI void sts8(char* dst, const KV8<float>& r) {
+  reinterpret_cast<f32x4*>(dst)[0] = r.v[0];
+  reinterpret_cast<f32x4*>(dst)[1] = r.v[1];
+}
+DEVI void sts8(char* dst, const KV8<bf16>& r) { *reinterpret_cast<bf16x8*>(dst) = r.v; }
+
+template <typename T> struct VSize;
+template <> struct VSize<float> { static constexpr int BYTES = KT * Tile<float>::PITCH; };
+template <> struct VSize<bf16> { static constexpr int BYTES = 32 * VT_PITCH; };
+
+template <typename T>
+__global__ __launch_bounds__(256) void attn_flash_kernel(const AttnP p) {
+  constexpr int PITCH = Tile<T>::PITCH;
+  __shared__ __attribute__((aligned(16))) char smem[KT * PITCH + VSize<T>::BYTES];
+  char* Ks = smem;
+  char* Vs = smem + KT * PITCH;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 5, lr = lane & 31;
+  const int seq = blockIdx.y / p.heads, head = blockIdx.y % p.heads;
+  const int L = p.L;
+  const long row0 = (long)seq * L;
+  const T* qkv = reinterpret_cast<const T*>(p.qkv);
+  const int qcol = head * 32, kcol = p.inner + head * 32, vcol = 2 * p.inner + head * 32;
+
+  const int qi = blockIdx.x * 128 + wave * 32 + lr;
+  const bool q_ok = qi < L;
+  // Q^T as B operand: lane (q = lr, half g) holds d in [16 g, 16 g + 16)
+  Frag<T> fq;
+  {
+    const T* qp = qkv + (row0 + (q_ok ? qi : L - 1)) * p.ld + qcol + 16 * g;
+    if constexpr (std::is_same<T, float>::value) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fq.v[i] = reinterpret_cast<const f32x4*>(qp)[i];
+    } else {
+      fq.v[0] = reinterpret_cast<const bf16x8*>(qp)[0];
+      fq.v[1] = reinterpret_cast<const bf16x8*>(qp)[1];
+    }
+  }
+
+  // staging: thread -> (key = tid / 4, 8 d-values at 8 * (tid % 4))
+  const int skey = tid >> 2, spart = tid & 3;
+  auto loadKV = [&](int kt, KV8<T>& rk, KV8<T>& rv) {
+    int key = kt * KT + skey;
+    bool ok = key < L;
+    const T* base = qkv + (row0 + (ok ? key : 0)) * p.ld + spart * 8;
+    rk = ldg8<T>(base + kcol, ok);
+    rv = ldg8<T>(base + vcol, ok);
+  };
+
+  f32x16 acc_o;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc_o[r] = 0.f;
+  float m_run = -1e30f, l_run = 0.f;
+
+  const int ntiles = (L + KT - 1) / KT;
+  KV8<T> rk, rv;
+  loadKV(0, rk, rv);
+  for (int kt = 0; kt < ntiles; ++kt) {
+    __syncthreads();
+    sts8(Ks + skey * PITCH + spart * 8 * (int)sizeof(T), rk);
+    if constexpr (std::is_same<T, float>::value) {
+      sts8(Vs + skey * PITCH + spart * 8 * (int)sizeof(T), rv);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) *reinterpret_cast<bf16*>(Vs + (spart * 8 + i) * VT_PITCH + skey * 2) = rv.v[i];
+    }
+    __syncthreads();
+    if (kt + 1 < ntiles) loadKV(kt + 1, rk, rv);
+
+    // ---- S^T = K . Q^T : two 32-key blocks ------------------------------------------
+    f32x16 sc[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sc[c][r] = 0.f;
+      Frag<T> fk = ld_frag<T>(Ks + (c * 32 + lr) * PITCH, g);
+      mma32(sc[c], fk, fq);
+    }
+    if (kt == ntiles - 1) {  // mask keys beyond L (last tile only)
+      const int kbase = kt * KT;
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (kbase + c * 32 + crow(r, g) >= L) sc[c][r] = -1e30f;
+    }
+    // ---- online softmax (per query = per lane pair (l, l^32)) ------------------------
+    float mloc = sc[0][0];
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, sc[c][r]);
+    mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
+    const float m_new = fmaxf(m_run, mloc);
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+    m_run = m_new;
+    float psum = 0.f;
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float e = __builtin_amdgcn_exp2f(sc[c][r] - m_new);
+        sc[c][r] = e;
+        psum += e;
+      }
+    l_run = l_run * alpha + psum;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc_o[r] *= alpha;
+
+    // ---- O^T += V^T . P^T -----------------------------------------------------------
+    if constexpr (std::is_same<T, float>::value) {
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float vv = *reinterpret_cast<const float*>(Vs + (c * 32 + crow(r, g)) * PITCH + lr * 4);
+          acc_o = __builtin_amdgcn_mfma_f32_32x32x2f32(vv, sc[c][r], acc_o, 0, 0, 0);
+        }
+    } else {
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          const char* vp = Vs + lr * VT_PITCH + (c * 32 + s * 16 + 4 * g) * 2;
+          bf16x4 v0 = *reinterpret_cast<const bf16x4*>(vp);
+          bf16x4 v1 = *reinterpret_cast<const bf16x4*>(vp + 16);
+          bf16x8 va = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+          bf16x8 pb;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) pb[j] = (bf16)sc[c][s * 8 + j];
+          acc_o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va, pb, acc_o, 0, 0, 0);
+        }
+    }
+  }
+
+  // ---- epilogue: normalise, gate, store ------------------------------------------------
+  const float l_tot = l_run + __shfl_xor(l_run, 32);
+  if (q_ok) {
+    const float gate = p.gates[(row0 + qi) * p.heads + head];
+    const float scale = gate / l_tot;
+    const long orow = (long)(seq / p.o_div) * p.o_outer + (long)(seq % p.o_div) * p.o_inner + (long)qi * p.o_tok;
+    T* op = reinterpret_cast<T*>(p.out) + orow * p.inner + head * 32 + 4 * g;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      if constexpr (std::is_same<T, float>::value) {
+        *reinterpret_cast<f32x4*>(op + 8 * a) = f32x4{acc_o[4 * a] * scale, acc_o[4 * a + 1] * scale,
+                                                       acc_o[4 * a + 2] * scale, acc_o[4 * a + 3] * scale};
+      } else {
+        bf16x4 o = {(bf16)(acc_o[4 * a] * scale), (bf16)(acc_o[4 * a + 1] * scale),
+                    (bf16)(acc_o[4 * a + 2] * scale), (bf16)(acc_o[4 * a + 3] * scale)};
+        *reinterpret_cast<bf16x4*>(op + 8 * a) = o;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+template <typename T> DEVI f32x4 ldg4f(const T* p);
+template <> DEVI f32x4 ldg4f<float>(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+template <> DEVI f32x4 ldg4f<bf16>(const bf16* p) {
+  bf16x4 v = *reinterpret_cast<const bf16x4*>(p);
+  return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+}
+
+constexpr int SM_ROWS = 8;     // time steps per workgroup
+constexpr int SM_HPITCH = 36;  // floats per head slice in LDS (32 + 4 pad -> distinct 16 B slots)
+
+template <typename T, int F>
+__global__ __launch_bounds__(256) void attn_small_kernel(const AttnP p) {
+  constexpr int H = 32 / F;              // heads
+  constexpr int TOKP = H * SM_HPITCH;    // floats per token
+  __shared__ __attribute__((aligned(16))) float Ks[SM_ROWS * F * TOKP];
+  __shared__ __attribute__((aligned(16))) float Vs[SM_ROWS * F * TOKP];
+  const int tid = threadIdx.x;
+  const long n_steps = p.n_seq;          // sequences = (b, t) pairs
+  const long step0 = (long)blockIdx.x * SM_ROWS;
+  const T* qkv = reinterpret_cast<const T*>(p.qkv);
+  const int inner = 32 * H;
+
+  // cooperative K/V load: SM_ROWS * F tokens, inner/4 float4 each
+  constexpr int C4 = (32 * H) / 4;
+  for (int idx = tid; idx < SM_ROWS * F * C4; idx += 256) {
+    int tok = idx / C4, c4 = idx - tok * C4;
+    long grow = step0 * F + tok;
+    int col = c4 * 4, hh = col >> 5, d = col & 31;
+    f32x4 kv = f32x4{0.f, 0.f, 0.f, 0.f}, vv = kv;
+    if (grow < n_steps * F) {
+      const T* base = qkv + grow * p.ld;
+      kv = ldg4f<T>(base + inner + col);
+      vv = ldg4f<T>(base + 2 * inner + col);
+    }
+    *reinterpret_cast<f32x4*>(&Ks[tok * TOKP + hh * SM_HPITCH + d]) = kv;
+    *reinterpret_cast<f32x4*>(&Vs[tok * TOKP + hh * SM_HPITCH + d]) = vv;
+  }
+  const int r = tid >> 5, idx = tid & 31;
+  const int head = idx / F, f = idx - head * F;
+  const long step = step0 + r;
+  const bool ok = step < n_steps;
+  const long qrow = (ok ? step : 0) * F + f;
+  float q[32];
+  {
+    const T* qp = qkv + qrow * p.ld + head * 32;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      f32x4 v = ldg4f<T>(qp + 4 * i);
+      q[4 * i] = v[0]; q[4 * i + 1] = v[1]; q[4 * i + 2] = v[2]; q[4 * i + 3] = v[3];
+    }
+  }
+  __syncthreads();
+  const float* kb = &Ks[(r * F) * TOKP + head * SM_HPITCH];
+  const float* vb = &Vs[(r * F) * TOKP + head * SM_HPITCH];
+  float s[F];
+  float mx = -1e30f;
+#pragma unroll
+  for (int j = 0; j < F; ++j) {
+    float a = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      f32x4 kk = *reinterpret_cast<const f32x4*>(kb + j * TOKP + 4 * i);
+      a = fmaf(q[4 * i], kk[0], a); a = fmaf(q[4 * i + 1], kk[1], a);
+      a = fmaf(q[4 * i + 2], kk[2], a); a = fmaf(q[4 * i + 3], kk[3], a);
+    }
+    s[j] = a;
+    mx = fmaxf(mx, a);
+  }
+  float l = 0.f;
+#pragma unroll
+  for (int j = 0; j < F; ++j) {
+    s[j] = __builtin_amdgcn_exp2f(s[j] - mx);
+    l += s[j];
+  }
+  float o[32];
+#pragma unroll
+  for (int i = 0; i < 32; ++i) o[i] = 0.f;
+#pragma unroll
+  for (int j = 0; j < F; ++j) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      f32x4 vv = *reinterpret_cast<const f32x4*>(vb + j * TOKP + 4 * i);
+      o[4 * i] = fmaf(s[j], vv[0], o[4 * i]); o[4 * i + 1] = fmaf(s[j], vv[1], o[4 * i + 1]);
+      o[4 * i + 2] = fmaf(s[j], vv[2], o[4 * i + 2]); o[4 * i + 3] = fmaf(s[j], vv[3], o[4 * i + 3]);
+    }
+  }
+  if (ok) {
+    const float scale = p.gates[qrow * H + head] / l;
+    T* op = reinterpret_cast<T*>(p.out) + qrow * inner + head * 32;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      if constexpr (std::is_same<T, float>::value) {
+        *reinterpret_cast<f32x4*>(op + 4 * i) =
+            f32x4{o[4 * i] * scale, o[4 * i + 1] * scale, o[4 * i + 2] * scale, o[4 * i + 3] * scale};
+      } else {
+        bf16x4 ov = {(bf16)(o[4 * i] * scale), (bf16)(o[4 * i + 1] * scale), (bf16)(o[4 * i + 2] * scale),
+                     (bf16)(o[4 * i + 3] * scale)};
+        *reinterpret_cast<bf16x4*>(op + 4 * i) = ov;
+      }
+    }
+  }
+}
+
+template <typename T>
+int launch_small_t(const AttnP& p, hipStream_t s) {
+  dim3 grid((unsigned)((p.n_seq + SM_ROWS - 1) / SM_ROWS)), block(256);
+  switch (p.L) {
+    case 32: hipLaunchKernelGGL((attn_small_kernel<T, 32>), grid, block, 0, s, p); break;
+    case 16: hipLaunchKernelGGL((attn_small_kernel<T, 16>), grid, block, 0, s, p); break;
+    case 8: hipLaunchKernelGGL((attn_small_kernel<T, 8>), grid, block, 0, s, p); break;
+    default: return -2;
+  }
+  return (int)hipGetLastError();
+}
+
+}  // namespace
+
+int launch_attn_flash(const AttnP& p, int prec, hipStream_t s) {
+  if (p.L <= 0 || p.n_seq <= 0 || p.inner != p.heads * 32) return -2;
+  dim3 grid((p.L + 127) / 128, (unsigned)((long)p.n_seq * p.heads)), block(256);
+  if (grid.y > 65535) return -3;
+  if (prec == BT_PREC_F32)
+    hipLaunchKernelGGL((attn_flash_kernel<float>), grid, block, 0, s, p);
+  else
+    hipLaunchKernelGGL((attn_flash_kernel<bf16>), grid, block, 0, s, p);
+  return (int)hipGetLastError();
+}
+
+int launch_attn_small(const AttnP& p, int prec, hipStream_t s) {
+  if (p.heads * p.L != 32 || p.inner != p.heads * 32) return -2;
+  return prec == BT_PREC_F32 ? launch_small_t<float>(p, s) : launch_small_t<bf16>(p, s);
+}

@@ -1,0 +1,357 @@
+// C ABI + forward orchestration of the BeatThis network on one MI355X.
+// Follows BeatThis.forward (beat_this/model/beat_tracker.py:188-192): frontend (stem, three
+// partial-transformer + conv blocks, linear), six RoFormer layers, final norm + SumHead.
+// All launches go to the caller's stream; scratch comes from the caller's workspace.
+#include <algorithm>
+#include <cmath>
+#include <cstddef>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/beat_this_amd.h"
+#include "common.h"
+#include "kernels.h"
+
+static thread_local std::string g_err;
+static int bt_set_error(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+
+struct bt_engine {
+  bt_model_desc d;
+};
+
+// Optional per-launch timing with HIP events on the caller's stream (bench.py roofline leg).
+// Off by default: a normal bt_forward records nothing and never synchronises.
+namespace prof {
+struct Rec { int cat; hipEvent_t a, b; };
+static bool on = false;
+static std::vector<Rec> recs;
+struct Scope {
+  bool live; size_t idx; hipStream_t s;
+  Scope(int cat, hipStream_t st) : live(on), idx(0), s(st) {
+    if (!live) return;
+    Rec r; r.cat = cat;
+    (void)hipEventCreate(&r.a); (void)hipEventCreate(&r.b);
+    (void)hipEventRecord(r.a, s);
+    idx = recs.size(); recs.push_back(r);
+  }
+  ~Scope() { if (live) (void)hipEventRecord(recs[idx].b, s); }
+};
+}  // namespace prof
+enum { CAT_STEM = 0, CAT_QKV, CAT_ATTN_SMALL, CAT_ATTN_FLASH, CAT_OUT, CAT_FF1, CAT_FF2, CAT_CONV, CAT_LINEAR,
+       CAT_HEAD, CAT_COUNT };
+
+namespace {
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+struct Workspace {
+  float* xa; float* xb; float* xm; float* gates;
+  void* qkv; void* ao; void* hid;
+  size_t total;
+};
+
+Workspace carve(char* base, int B, int T, int D, int prec) {
+  const size_t es = prec == BT_PREC_F32 ? 4 : 2;
+  const size_t bt = (size_t)B * T;
+  const size_t dmax = std::max<size_t>(1024, D);
+  size_t off = 0;
+  auto take = [&](size_t bytes) { size_t o = off; off += align_up(bytes, 256); return base ? base + o : (char*)nullptr; };
+  Workspace w;
+  w.xa = (float*)take(bt * 1024 * 4);
+  w.xb = (float*)take(bt * 1024 * 4);
+  w.xm = (float*)take(bt * D * 4);
+  w.gates = (float*)take(bt * std::max(32, D / 32) * 4);
+  w.qkv = take(bt * 3 * dmax * es);
+  w.ao = take(bt * dmax * es);
+  w.hid = take(bt * 4 * dmax * es);
+  w.total = off;
+  return w;
+}
+
+#define CHECK_RC(what)                                                         \
+  if (_rc != 0) {                                                              \
+    char buf[160];                                                             \
+    snprintf(buf, sizeof buf, "%s failed (code %d: %s)", what, _rc,            \
+             _rc > 0 ? hipGetErrorString((hipError_t)_rc) : "bad arguments");  \
+    return bt_set_error(_rc > 0 ? BT_ERR_HIP : BT_ERR_ARG, buf);               \
+  }
+#define LAUNCH(expr, what) \
+  do { int _rc = (expr); CHECK_RC(what) } while (0)
+#define LAUNCH_CAT(cat, st, expr, what) \
+  do { int _rc; { prof::Scope _ps(cat, st); _rc = (expr); } CHECK_RC(what) } while (0)
+
+// mode 0: main transformer (sequences = chunks, tokens = frames)
+// mode 1: frequency direction (sequences = (b,t), tokens = f)      -- attn_small
+// mode 2: time direction      (sequences = (b,f), tokens = t)      -- rows permuted around attn_flash
+int run_pair(const bt_pair_weights& pw, const float* rope, float* x, const Workspace& ws, int B, int T, int F,
+             int mode, int prec, hipStream_t s) {
+  const int C = pw.dim, H = pw.heads;
+  const long M = (long)B * T * F;
+  if (M > 0x7fffffffL) return bt_set_error(BT_ERR_ARG, "batch too large for one forward call");
+  GemmP g;
+  // ---- q|k|v|gates = RMSNorm(x) . W^T, RoPE, sigmoid ------------------------------------
+  memset(&g, 0, sizeof g);
+  g.A = x; g.lda = C; g.W = pw.w_qkvg[prec]; g.M = (int)M; g.N = 3 * C + H; g.K = C;
+  g.epi = GEMM_EPI_QKV; g.flags = GEMM_F_RMS | GEMM_F_A_F32 | (mode == 2 ? GEMM_F_ROWMAP : 0);
+  g.bias = pw.b_gates; g.out = ws.qkv; g.ldo = 3 * C; g.gates = ws.gates; g.inner = C; g.heads = H;
+  g.rope = rope; g.map_T = T; g.map_F = F;
+  if (mode == 0) { g.pdiv = 1; g.pmod = T; }
+  else if (mode == 1) { g.pdiv = 1; g.pmod = F; }
+  else { g.pdiv = F; g.pmod = T; }
+  LAUNCH_CAT(CAT_QKV, s, launch_gemm(g, prec, s), "qkv gemm");
+  // ---- attention ------------------------------------------------------------------------
+  AttnP a;
+  memset(&a, 0, sizeof a);
+  a.qkv = ws.qkv; a.ld = 3 * C; a.gates = ws.gates; a.out = ws.ao; a.heads = H; a.inner = C;
+  if (mode == 1) {
+    a.n_seq = B * T; a.L = F; a.o_div = 1; a.o_outer = F; a.o_inner = 0; a.o_tok = 1;
+    LAUNCH_CAT(CAT_ATTN_SMALL, s, launch_attn_small(a, prec, s), "frequency attention");
+  } else if (mode == 2) {
+    a.n_seq = B * F; a.L = T; a.o_div = F; a.o_outer = (long)T * F; a.o_inner = 1; a.o_tok = F;
+    LAUNCH_CAT(CAT_ATTN_FLASH, s, launch_attn_flash(a, prec, s), "time attention");
+  } else {
+    a.n_seq = B; a.L = T; a.o_div = 1; a.o_outer = T; a.o_inner = 0; a.o_tok = 1;
+    LAUNCH_CAT(CAT_ATTN_FLASH, s, launch_attn_flash(a, prec, s), "attention");
+  }
+  // ---- x += ao . Wout^T -------------------------------------------------------------------
+  memset(&g, 0, sizeof g);
+  g.A = ws.ao; g.lda = C; g.W = pw.w_out[prec]; g.M = (int)M; g.N = C; g.K = C;
+  g.epi = GEMM_EPI_RESID; g.flags = 0; g.x = x; g.ldx = C;
+  LAUNCH_CAT(CAT_OUT, s, launch_gemm(g, prec, s), "out-proj gemm");
+  // ---- h = gelu(RMSNorm(x) . W1^T + b1) ------------------------------------------------------
+  memset(&g, 0, sizeof g);
+  g.A = x; g.lda = C; g.W = pw.w_ff1[prec]; g.M = (int)M; g.N = 4 * C; g.K = C;
+  g.epi = GEMM_EPI_STORE; g.flags = GEMM_F_RMS | GEMM_F_A_F32 | GEMM_F_BIAS | GEMM_F_GELU;
+  g.bias = pw.b_ff1; g.out = ws.hid; g.ldo = 4 * C;
+  LAUNCH_CAT(CAT_FF1, s, launch_gemm(g, prec, s), "ff1 gemm");
+  // ---- x += h . W2^T + b2 ---------------------------------------------------------------------
+  memset(&g, 0, sizeof g);
+  g.A = ws.hid; g.lda = 4 * C; g.W = pw.w_ff2[prec]; g.M = (int)M; g.N = C; g.K = 4 * C;
+  g.epi = GEMM_EPI_RESID; g.flags = GEMM_F_BIAS; g.bias = pw.b_ff2; g.x = x; g.ldx = C;
+  LAUNCH_CAT(CAT_FF2, s, launch_gemm(g, prec, s), "ff2 gemm");
+  return BT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* bt_last_error(void) { return g_err.c_str(); }
+int bt_version(void) { return 100; }
+void bt_struct_sizes(int32_t* out) {
+  out[0] = (int32_t)sizeof(bt_pair_weights); out[1] = (int32_t)sizeof(bt_model_desc);
+  out[2] = (int32_t)sizeof(bt_logmel_tables); out[3] = (int32_t)sizeof(bt_gemm_args);
+  out[4] = (int32_t)sizeof(bt_attn_args); out[5] = (int32_t)offsetof(bt_model_desc, layers);
+  out[6] = (int32_t)offsetof(bt_model_desc, rope);
+}
+
+int bt_engine_create(const bt_model_desc* desc, bt_engine** out) {
+  if (!desc || !out) return bt_set_error(BT_ERR_ARG, "null argument");
+  if (desc->transformer_dim % 32 || desc->transformer_dim < 32 || desc->transformer_dim > 1024 ||
+      desc->n_layers < 0 || desc->n_layers > BT_MAX_LAYERS)
+    return bt_set_error(BT_ERR_ARG, "unsupported transformer_dim / n_layers");
+  bt_engine* e = new bt_engine;
+  e->d = *desc;
+  *out = e;
+  return BT_OK;
+}
+void bt_engine_destroy(bt_engine* e) { delete e; }
+
+size_t bt_workspace_bytes(const bt_engine* e, int B, int T, int prec) {
+  if (!e || B <= 0 || T <= 0) return 0;
+  return carve(nullptr, B, T, e->d.transformer_dim, prec).total;
+}
+
+int bt_forward(bt_engine* e, void* stream, int prec, const float* d_spect, int B, int T, void* d_ws, size_t ws_bytes,
+               float* d_beat, float* d_downbeat) {
+  if (!e || !d_spect || !d_ws || !d_beat || !d_downbeat) return bt_set_error(BT_ERR_ARG, "null argument");
+  if (B <= 0 || T <= 0 || T > 1536) return bt_set_error(BT_ERR_ARG, "need B >= 1 and 1 <= T <= 1536");
+  if (prec != BT_PREC_F32 && prec != BT_PREC_BF16) return bt_set_error(BT_ERR_ARG, "unknown precision");
+  const bt_model_desc& d = e->d;
+  const int D = d.transformer_dim;
+  Workspace ws = carve((char*)d_ws, B, T, D, prec);
+  if (ws.total > ws_bytes) return bt_set_error(BT_ERR_WORKSPACE, "workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+
+  StemP sp;
+  sp.spect = d_spect; sp.x = ws.xa; sp.bn1_scale = d.bn1_scale; sp.bn1_shift = d.bn1_shift;
+  sp.w = d.stem_w; sp.bias = d.stem_b; sp.B = B; sp.T = T;
+  LAUNCH_CAT(CAT_STEM, s, launch_stem(sp, s), "stem");
+
+  float* x = ws.xa;
+  float* xn = ws.xb;
+  for (int blk = 0; blk < 3; ++blk) {
+    const int C = 32 << blk, F = 32 >> blk;
+    if (d.partial_transformers) {
+      int rc = run_pair(d.front[blk][0], d.rope, x, ws, B, T, F, 1, prec, s);
+      if (rc) return rc;
+      rc = run_pair(d.front[blk][1], d.rope, x, ws, B, T, F, 2, prec, s);
+      if (rc) return rc;
+    }
+    GemmP g;
+    memset(&g, 0, sizeof g);
+    g.A = x; g.W = d.conv_w[blk][prec]; g.M = B * T * (F / 2); g.N = 2 * C; g.K = 6 * C;
+    g.epi = GEMM_EPI_STORE; g.flags = GEMM_F_CONV | GEMM_F_A_F32 | GEMM_F_BIAS | GEMM_F_GELU | GEMM_F_OUT_F32;
+    g.bias = d.conv_b[blk]; g.out = xn; g.ldo = 2 * C;
+    g.conv_C2 = 2 * C; g.conv_T = T; g.conv_F = F / 2;
+    LAUNCH_CAT(CAT_CONV, s, launch_gemm(g, prec, s), "frontend conv gemm");
+    std::swap(x, xn);
+  }
+  {
+    GemmP g;
+    memset(&g, 0, sizeof g);
+    g.A = x; g.lda = 1024; g.W = d.lin_w[prec]; g.M = B * T; g.N = D; g.K = 1024;
+    g.epi = GEMM_EPI_STORE; g.flags = GEMM_F_A_F32 | GEMM_F_BIAS | GEMM_F_OUT_F32;
+    g.bias = d.lin_b; g.out = ws.xm; g.ldo = D;
+    LAUNCH_CAT(CAT_LINEAR, s, launch_gemm(g, prec, s), "frontend linear gemm");
+  }
+  for (int l = 0; l < d.n_layers; ++l) {
+    int rc = run_pair(d.layers[l], d.rope, ws.xm, ws, B, T, 1, 0, prec, s);
+    if (rc) return rc;
+  }
+  HeadP hp;
+  hp.x = ws.xm; hp.w = d.head_w; hp.b0 = d.head_b[0]; hp.b1 = d.head_b[1];
+  hp.beat = d_beat; hp.downbeat = d_downbeat; hp.M = B * T; hp.D = D; hp.sum_head = d.sum_head;
+  LAUNCH_CAT(CAT_HEAD, s, launch_head(hp, s), "head");
+  return BT_OK;
+}
+
+int bt_split_chunks(void* stream, const float* d_spect, int64_t n_frames, const int32_t* d_starts, int B, int T,
+                    float* d_chunks) {
+  if (!d_spect || !d_starts || !d_chunks || B <= 0 || T <= 0 || n_frames <= 0)
+    return bt_set_error(BT_ERR_ARG, "bad argument to bt_split_chunks");
+  LAUNCH(launch_split(d_spect, n_frames, d_starts, B, T, d_chunks, (hipStream_t)stream), "split");
+  return BT_OK;
+}
+
+int bt_aggregate(void* stream, const float* cb, const float* cd, const int32_t* d_starts, int B, int T, int border,
+                 int64_t n_frames, float* d_beat, float* d_downbeat) {
+  if (!cb || !cd || !d_starts || !d_beat || !d_downbeat || B <= 0 || T <= 0 || n_frames <= 0 || border < 0)
+    return bt_set_error(BT_ERR_ARG, "bad argument to bt_aggregate");
+  LAUNCH(launch_aggregate(cb, cd, d_starts, B, T, border, n_frames, d_beat, d_downbeat, (hipStream_t)stream),
+         "aggregate");
+  return BT_OK;
+}
+
+int bt_logmel(void* stream, const bt_logmel_tables* t, const float* d_audio, int64_t n_samples, float* d_spect) {
+  if (!t || !d_audio || !d_spect) return bt_set_error(BT_ERR_ARG, "null argument");
+  if (n_samples <= 512) return bt_set_error(BT_ERR_ARG, "signal too short: reflect padding needs more than 512 samples");
+  LogmelP p;
+  p.audio = d_audio; p.n_samples = n_samples; p.window = t->window; p.twiddle = t->twiddle;
+  p.mel_start = t->mel_start; p.mel_len = t->mel_len; p.mel_w = t->mel_w; p.spect = d_spect;
+  p.n_frames = 1 + n_samples / 441;
+  LAUNCH(launch_logmel(p, (hipStream_t)stream), "logmel");
+  return BT_OK;
+}
+
+int bt_peaks(void* stream, const float* d_logits, int64_t n, int n_arrays, int32_t* d_idx, int32_t* d_count) {
+  if (!d_logits || !d_idx || !d_count || n <= 0 || n_arrays <= 0) return bt_set_error(BT_ERR_ARG, "bad argument");
+  LAUNCH(launch_peaks(d_logits, n, n_arrays, d_idx, d_count, (hipStream_t)stream), "peaks");
+  return BT_OK;
+}
+
+static int dedup_host(const int32_t* idx, int n, double* out) {
+  // running-mean merge of frames not more than 1 apart (postprocessor.py:176-197)
+  if (n <= 0) return 0;
+  int m = 0;
+  double mean = (double)idx[0];
+  int count = 1;
+  for (int i = 1; i < n; ++i) {
+    double nxt = (double)idx[i];
+    if (nxt - mean <= 1.0) {
+      ++count;
+      mean += (nxt - mean) / count;
+    } else {
+      out[m++] = mean;
+      mean = nxt;
+      count = 1;
+    }
+  }
+  out[m++] = mean;
+  return m;
+}
+
+int bt_postprocess_host(const int32_t* beat_idx, int nb, const int32_t* down_idx, int nd, double fps, double* beats,
+                        int32_t* n_beats, double* downbeats, int32_t* n_downbeats) {
+  if ((nb > 0 && (!beat_idx || !beats)) || (nd > 0 && (!down_idx || !downbeats)) || !n_beats || !n_downbeats ||
+      !(fps > 0))
+    return bt_set_error(BT_ERR_ARG, "bad argument to bt_postprocess_host");
+  int mb = dedup_host(beat_idx, nb, beats);
+  for (int i = 0; i < mb; ++i) beats[i] = beats[i] / fps;
+  int md = dedup_host(down_idx, nd, downbeats);
+  for (int i = 0; i < md; ++i) downbeats[i] = downbeats[i] / fps;
+  if (mb > 0) {
+    for (int i = 0; i < md; ++i) {  // np.argmin(|beat - d|): first minimum wins
+      double best = std::fabs(beats[0] - downbeats[i]);
+      int bi = 0;
+      for (int j = 1; j < mb; ++j) {
+        double dd = std::fabs(beats[j] - downbeats[i]);
+        if (dd < best) { best = dd; bi = j; }
+      }
+      downbeats[i] = beats[bi];
+    }
+  }
+  std::sort(downbeats, downbeats + md);  // np.unique
+  md = (int)(std::unique(downbeats, downbeats + md) - downbeats);
+  *n_beats = mb;
+  *n_downbeats = md;
+  return BT_OK;
+}
+
+void bt_profile_begin(void) {
+  for (auto& r : prof::recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+  prof::recs.clear();
+  prof::on = true;
+}
+
+int bt_profile_end(double* ms_by_category, int32_t* launches_by_category, int n_categories) {
+  prof::on = false;
+  if (!ms_by_category || !launches_by_category || n_categories < CAT_COUNT)
+    return bt_set_error(BT_ERR_ARG, "need room for BT_PROFILE_CATEGORIES entries");
+  for (int i = 0; i < n_categories; ++i) { ms_by_category[i] = 0.0; launches_by_category[i] = 0; }
+  for (auto& r : prof::recs) {
+    hipError_t e = hipEventSynchronize(r.b);
+    float ms = 0.f;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, r.a, r.b);
+    if (e != hipSuccess) return bt_set_error(BT_ERR_HIP, hipGetErrorString(e));
+    ms_by_category[r.cat] += ms;
+    launches_by_category[r.cat] += 1;
+    (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b);
+  }
+  prof::recs.clear();
+  return BT_OK;
+}
+
+int bt_gemm(void* stream, int prec, const bt_gemm_args* a) {
+  if (!a) return bt_set_error(BT_ERR_ARG, "null argument");
+  GemmP g;
+  memset(&g, 0, sizeof g);
+  g.A = a->A; g.lda = a->lda; g.W = a->W; g.M = a->M; g.N = a->N; g.K = a->K; g.epi = a->epi; g.flags = a->flags;
+  g.bias = a->bias; g.out = a->out; g.ldo = a->ldo; g.x = a->x; g.ldx = a->ldx;
+  g.conv_C2 = a->conv_C2; g.conv_T = a->conv_T; g.conv_F = a->conv_F;
+  g.gates = a->gates; g.inner = a->inner; g.heads = a->heads; g.rope = a->rope;
+  g.pdiv = a->pdiv; g.pmod = a->pmod; g.map_T = a->map_T; g.map_F = a->map_F;
+  LAUNCH(launch_gemm(g, prec, (hipStream_t)stream), "gemm");
+  return BT_OK;
+}
+
+int bt_attention(void* stream, int prec, const bt_attn_args* a, int small_kernel) {
+  if (!a) return bt_set_error(BT_ERR_ARG, "null argument");
+  AttnP p;
+  memset(&p, 0, sizeof p);
+  p.qkv = a->qkv; p.ld = a->ld; p.gates = a->gates; p.out = a->out; p.n_seq = a->n_seq; p.L = a->L;
+  p.heads = a->heads; p.inner = a->inner; p.o_div = a->o_div; p.o_outer = a->o_outer; p.o_inner = a->o_inner;
+  p.o_tok = a->o_tok;
+  if (small_kernel)
+    LAUNCH(launch_attn_small(p, prec, (hipStream_t)stream), "attention (small)");
+  else
+    LAUNCH(launch_attn_flash(p, prec, (hipStream_t)stream), "attention (flash)");
+  return BT_OK;
+}
+
+}  // extern "C"

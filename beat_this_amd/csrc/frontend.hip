@@ -1,0 +1,172 @@
+// Small bandwidth-bound kernels around the GEMM/attention core:
+//   stem       BeatThis.make_stem   (beat_tracker.py:108-126)  BN1d -> conv(4x3,s(4,1)) -> BN2d -> GELU
+//   head       final RMSNorm + SumHead (roformer.py:180, beat_tracker.py:315-330)
+//   split      split_piece / zeropad  (inference.py:90-135)   chunk gather with zero padding
+//   aggregate  aggregate_prediction, keep_first (inference.py:138-185)
+//   peaks      postp_minimal peak mask + ordered compaction (postprocessor.py:93-99,119-120)
+// Activation layout everywhere: (b, t, f, c) row-major, i.e. one (b,t) row = F*C = 1024 floats.
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+// one workgroup per (b, t); thread -> co = tid & 31, f = (tid >> 5) * 4 + i
+__global__ __launch_bounds__(256) void stem_kernel(const StemP p) {
+  __shared__ float in[3][128];
+  const int tid = threadIdx.x;
+  const long bt = blockIdx.x;
+  const int t = (int)(bt % p.T);
+  for (int i = tid; i < 384; i += 256) {
+    int tap = i >> 7, mel = i & 127;
+    int tt = t + tap - 1;
+    float v = 0.f;  // zero padding is applied AFTER BatchNorm1d (conv pads its own input)
+    if (tt >= 0 && tt < p.T) v = fmaf(p.spect[(bt + tap - 1) * 128 + mel], p.bn1_scale[mel], p.bn1_shift[mel]);
+    in[tap][mel] = v;
+  }
+  const int co = tid & 31, fg = tid >> 5;
+  float w[12];
+#pragma unroll
+  for (int i = 0; i < 12; ++i) w[i] = p.w[co * 12 + i];
+  const float bias = p.bias[co];
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int f = fg * 4 + i;
+    float a = bias;
+#pragma unroll
+    for (int df = 0; df < 4; ++df)
+#pragma unroll
+      for (int dt = 0; dt < 3; ++dt) a = fmaf(w[df * 3 + dt], in[dt][4 * f + df], a);
+    p.x[bt * 1024 + f * 32 + co] = gelu_erf(a);
+  }
+}
+
+// one wave per token row
+__global__ __launch_bounds__(256) void head_kernel(const HeadP p) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= p.M) return;
+  const float* x = p.x + row * p.D;
+  float ss = 0.f, d0 = 0.f, d1 = 0.f;
+  for (int k = lane; k < p.D; k += 64) {
+    float v = x[k];
+    ss = fmaf(v, v, ss);
+    d0 = fmaf(v, p.w[k], d0);
+    d1 = fmaf(v, p.w[p.D + k], d1);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    ss += __shfl_xor(ss, o);
+    d0 += __shfl_xor(d0, o);
+    d1 += __shfl_xor(d1, o);
+  }
+  if (lane == 0) {
+    const float sc = sqrtf((float)p.D) / fmaxf(sqrtf(ss), 1e-12f);
+    const float y0 = d0 * sc + p.b0, y1 = d1 * sc + p.b1;
+    p.beat[row] = p.sum_head ? y0 + y1 : y0;
+    p.downbeat[row] = y1;
+  }
+}
+
+__global__ void split_kernel(const float* __restrict__ spect, long n_frames, const int* __restrict__ starts, int B,
+                             int T, float* __restrict__ chunks) {
+  const long total = (long)B * T * 32;  // float4 units
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    long row = i >> 5;
+    int c4 = (int)(i & 31);
+    int b = (int)(row / T), t = (int)(row - (long)b * T);
+    long src = (long)starts[b] + t;
+    f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (src >= 0 && src < n_frames) v = reinterpret_cast<const f32x4*>(spect + src * 128)[c4];
+    reinterpret_cast<f32x4*>(chunks + row * 128)[c4] = v;
+  }
+}
+
+__global__ void aggregate_kernel(const float* __restrict__ cb, const float* __restrict__ cd,
+                                 const int* __restrict__ starts, int B, int T, int border, long n_frames,
+                                 float* __restrict__ beat, float* __restrict__ downbeat) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n_frames; i += (long)gridDim.x * blockDim.x) {
+    float vb = -1000.0f, vd = -1000.0f;
+    for (int c = 0; c < B; ++c) {  // first (earliest) chunk whose kept span covers frame i wins
+      long s = starts[c];
+      if (i >= s + border && i < s + T - border) {
+        vb = cb[(long)c * T + (i - s)];
+        vd = cd[(long)c * T + (i - s)];
+        break;
+      }
+    }
+    beat[i] = vb;
+    downbeat[i] = vd;
+  }
+}
+
+// grid.x = number of logit arrays (stride n); one workgroup scans one array in order.
+__global__ __launch_bounds__(1024) void peaks_kernel(const float* __restrict__ logits, long n, int* __restrict__ idx,
+                                                     int* __restrict__ count) {
+  __shared__ int wave_tot[16];
+  __shared__ int base_s;
+  const float* x = logits + (long)blockIdx.x * n;
+  int* out = idx + (long)blockIdx.x * n;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) base_s = 0;
+  __syncthreads();
+  for (long t0 = 0; t0 < n; t0 += 1024) {
+    const long i = t0 + tid;
+    bool flag = false;
+    if (i < n) {
+      const float v = x[i];
+      float mx = v;
+#pragma unroll
+      for (int d = -3; d <= 3; ++d) {
+        long j = i + d;
+        if (j >= 0 && j < n) mx = fmaxf(mx, x[j]);
+      }
+      flag = (v == mx) && (v > 0.0f);
+    }
+    const unsigned long long mask = __ballot(flag);
+    const int prefix = __popcll(mask & ((1ull << lane) - 1ull));
+    if (lane == 0) wave_tot[wave] = __popcll(mask);
+    __syncthreads();
+    int woff = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+      int c = wave_tot[w];
+      if (w < wave) woff += c;
+      tot += c;
+    }
+    const int base = base_s;
+    if (flag) out[base + woff + prefix] = (int)i;
+    __syncthreads();
+    if (tid == 0) base_s = base + tot;
+    __syncthreads();
+  }
+  if (tid == 0) count[blockIdx.x] = base_s;
+}
+
+}  // namespace
+
+int launch_stem(const StemP& p, hipStream_t s) {
+  hipLaunchKernelGGL(stem_kernel, dim3((unsigned)((long)p.B * p.T)), dim3(256), 0, s, p);
+  return (int)hipGetLastError();
+}
+int launch_head(const HeadP& p, hipStream_t s) {
+  hipLaunchKernelGGL(head_kernel, dim3((unsigned)((p.M + 3) / 4)), dim3(256), 0, s, p);
+  return (int)hipGetLastError();
+}
+int launch_split(const float* spect, long n_frames, const int* starts, int B, int T, float* chunks, hipStream_t s) {
+  long total = (long)B * T * 32;
+  unsigned grid = (unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  hipLaunchKernelGGL(split_kernel, dim3(grid), dim3(256), 0, s, spect, n_frames, starts, B, T, chunks);
+  return (int)hipGetLastError();
+}
+int launch_aggregate(const float* cb, const float* cd, const int* starts, int B, int T, int border, long n_frames,
+                     float* beat, float* downbeat, hipStream_t s) {
+  unsigned grid = (unsigned)((n_frames + 255) / 256 < 2048 ? (n_frames + 255) / 256 : 2048);
+  hipLaunchKernelGGL(aggregate_kernel, dim3(grid), dim3(256), 0, s, cb, cd, starts, B, T, border, n_frames, beat,
+                     downbeat);
+  return (int)hipGetLastError();
+}
+int launch_peaks(const float* logits, long n, int n_arrays, int* idx, int* count, hipStream_t s) {
+  hipLaunchKernelGGL(peaks_kernel, dim3((unsigned)n_arrays), dim3(1024), 0, s, logits, n, idx, count);
+  return (int)hipGetLastError();
+}

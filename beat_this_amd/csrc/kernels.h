@@ -1,0 +1,101 @@
+// Internal launch interface between the engine (engine.hip) and the kernel files.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#ifndef BT_PREC_F32
+#define BT_PREC_F32 0
+#define BT_PREC_BF16 1
+#endif
+
+// ---- GEMM: C[M,N] = epilogue( A[M,K] . W[N,K]^T ) ------------------------------------
+enum {
+  GEMM_EPI_STORE = 0,  // [*rowscale] [+bias] [gelu] -> out (compute dtype, or fp32 if OUT_F32)
+  GEMM_EPI_RESID = 1,  // [+bias] + x -> x (fp32, in place)
+  GEMM_EPI_QKV = 2     // *rowscale, RoPE on q|k, sigmoid(+bias) on gate columns
+};
+enum {
+  GEMM_F_RMS = 1,      // accumulate row sum-of-squares of A while staging, scale rows in the epilogue
+  GEMM_F_BIAS = 2,
+  GEMM_F_GELU = 4,
+  GEMM_F_OUT_F32 = 8,  // EPI_STORE writes fp32 even in bf16 mode
+  GEMM_F_A_F32 = 16,   // A is fp32 in memory even in bf16 mode (residual stream)
+  GEMM_F_CONV = 32,    // A rows are gathered: 3 time taps x C2 contiguous channels (implicit GEMM conv)
+  GEMM_F_ROWMAP = 64   // QKV: store rows in (b,f,t) order instead of (b,t,f)
+};
+
+struct GemmP {
+  const void* A;
+  long lda;        // elements
+  const void* W;   // [N padded to 128, K] compute dtype
+  int M, N, K;     // N = number of real output columns
+  int epi, flags;
+  const float* bias;
+  void* out;
+  long ldo;
+  float* x;        // EPI_RESID: residual stream, ld = ldx
+  long ldx;
+  // conv gather (GEMM_F_CONV): output row m = (b, t, f'), A = x[b, t-1..t+1, f', 0..C2)
+  int conv_C2, conv_T, conv_F;
+  // QKV epilogue
+  float* gates;    // [rows, heads] fp32
+  int inner;       // heads * 32
+  int heads;
+  const float* rope;  // [pos][16][2] (cos, sin) fp32
+  int pdiv, pmod;  // pos = (m / pdiv) % pmod
+  int map_T, map_F;  // GEMM_F_ROWMAP
+};
+int launch_gemm(const GemmP& p, int prec, hipStream_t s);
+
+// ---- attention ---------------------------------------------------------------------
+struct AttnP {
+  const void* qkv;    // [n_seq * L rows, ld] compute dtype; q | k | v column blocks of width inner
+  long ld;
+  const float* gates; // [n_seq * L, heads]
+  void* out;          // compute dtype, [rows, inner]
+  int n_seq, L, heads, inner;
+  // output row of token t of sequence s:  (s / o_div) * o_outer + (s % o_div) * o_inner + t * o_tok
+  int o_div;
+  long o_outer, o_inner, o_tok;
+};
+int launch_attn_flash(const AttnP& p, int prec, hipStream_t s);
+int launch_attn_small(const AttnP& p, int prec, hipStream_t s);  // L in {8,16,32}, heads*L == 32
+
+// ---- small model kernels (frontend.hip) ---------------------------------------------
+struct StemP {
+  const float* spect;  // [B, T, 128]
+  float* x;            // [B, T, 32, 32]  (b, t, f, c)
+  const float* bn1_scale; const float* bn1_shift;  // [128]
+  const float* w;      // [32][12] (co, df*3+dt) with bn2 scale folded
+  const float* bias;   // [32] bn2 shift
+  int B, T;
+};
+int launch_stem(const StemP& p, hipStream_t s);
+
+struct HeadP {
+  const float* x;      // [M, D]
+  const float* w;      // [2, D] with final-norm gamma folded
+  float b0, b1;
+  float* beat; float* downbeat;  // [M]
+  int M, D, sum_head;
+};
+int launch_head(const HeadP& p, hipStream_t s);
+
+int launch_split(const float* spect, long n_frames, const int* starts, int B, int T, float* chunks, hipStream_t s);
+int launch_aggregate(const float* cb, const float* cd, const int* starts, int B, int T, int border, long n_frames,
+                     float* beat, float* downbeat, hipStream_t s);
+// logits: [n_arrays][n]; idx: [n_arrays][n] ascending frame indices; count: [n_arrays]
+int launch_peaks(const float* logits, long n, int n_arrays, int* idx, int* count, hipStream_t s);
+
+// ---- log-mel -----------------------------------------------------------------------
+struct LogmelP {
+  const float* audio; long n_samples;
+  const float* window;    // [1024]
+  const float* twiddle;   // see logmel.hip
+  const int* mel_start;   // [128]
+  const int* mel_len;     // [128]
+  const float* mel_w;     // [128][32]
+  float* spect;           // [n_frames, 128]
+  long n_frames;
+};
+int launch_logmel(const LogmelP& p, hipStream_t s);

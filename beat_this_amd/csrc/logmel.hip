@@ -1,0 +1,164 @@
+// Log-mel front end on the GPU: replaces LogMelSpect.forward (beat_this/preprocessing.py:56-59),
+// i.e. torchaudio MelSpectrogram(sr 22050, n_fft 1024, hop 441, hann periodic, center/reflect,
+// normalized="frame_length", power 1, 128 slaney mels 30..11000 Hz) followed by log1p(1000 x).
+//
+// One wavefront per frame.  The 1024-point real FFT is a 512-point complex FFT of the
+// (even, odd) packed windowed samples plus the standard split step.  512 = 8 x 8 x 8: each of
+// the 64 lanes holds 8 complex values and does three radix-8 butterflies in registers; data
+// moves between the three stages through LDS (split re/im arrays, index padded by idx/8 so
+// both the writes and the stride-9 reads are bank-conflict free).  |X|/32 goes to LDS, the
+// mel projection is a banded gather (1004 non-zeros, <= 26 per filter), then log1p.
+// HBM traffic = the waveform once (hop-overlapped re-reads hit L2) + the (frames,128) output.
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+struct cplx { float re, im; };
+DEVI cplx cadd(cplx a, cplx b) { return {a.re + b.re, a.im + b.im}; }
+DEVI cplx csub(cplx a, cplx b) { return {a.re - b.re, a.im - b.im}; }
+DEVI cplx cmul(cplx a, cplx b) { return {a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; }
+DEVI cplx mul_mi(cplx a) { return {a.im, -a.re}; }  // * (-i)
+
+// in-place 8-point DFT, X[p] = sum_a x[a] exp(-2 pi i a p / 8)
+DEVI void dft8(cplx (&x)[8]) {
+  const float h = 0.70710678118654752440f;
+  cplx t0 = cadd(x[0], x[4]), t1 = csub(x[0], x[4]);
+  cplx t2 = cadd(x[2], x[6]), t3 = csub(x[2], x[6]);
+  cplx t4 = cadd(x[1], x[5]), t5 = csub(x[1], x[5]);
+  cplx t6 = cadd(x[3], x[7]), t7 = csub(x[3], x[7]);
+  cplx e0 = cadd(t0, t2), e2 = csub(t0, t2);
+  cplx e1 = cadd(t1, mul_mi(t3)), e3 = csub(t1, mul_mi(t3));
+  cplx o0 = cadd(t4, t6), o2 = csub(t4, t6);
+  cplx o1 = cadd(t5, mul_mi(t7)), o3 = csub(t5, mul_mi(t7));
+  // twiddle the odd half: w^1 = (1 - i)/sqrt2, w^2 = -i, w^3 = (-1 - i)/sqrt2
+  cplx w1 = {(o1.re + o1.im) * h, (o1.im - o1.re) * h};
+  cplx w2 = mul_mi(o2);
+  cplx w3 = {(o3.im - o3.re) * h, -(o3.re + o3.im) * h};
+  x[0] = cadd(e0, o0); x[4] = csub(e0, o0);
+  x[1] = cadd(e1, w1); x[5] = csub(e1, w1);
+  x[2] = cadd(e2, w2); x[6] = csub(e2, w2);
+  x[3] = cadd(e3, w3); x[7] = csub(e3, w3);
+}
+
+constexpr int XPAD = 576;  // 512 + 512/8
+
+// twiddle table layout (float2 each): [0,64) tw1[b*8+p] = e^{-2 pi i b p/64};
+// [64,576) tw2[c*64+m] = e^{-2 pi i c m/512}; [576,1089) tw3[k] = e^{-2 pi i k/1024}, k=0..512
+__global__ __launch_bounds__(256) void logmel_kernel(const LogmelP p) {
+  __shared__ float sre[4][XPAD];
+  __shared__ float sim[4][XPAD];
+  __shared__ float smag[4][520];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long frame = (long)blockIdx.x * 4 + wave;
+  const bool active = frame < p.n_frames;
+  float* re = sre[wave];
+  float* im = sim[wave];
+  float* mag = smag[wave];
+  const f32x2* tw = reinterpret_cast<const f32x2*>(p.twiddle);
+  const long N = p.n_samples;
+  const long s0 = (active ? frame : 0) * 441 - 512;
+
+  // ---- load + window: lane holds z[64 a + lane], z[n] = x[2n] + i x[2n+1] -------------
+  cplx x[8];
+#pragma unroll
+  for (int a = 0; a < 8; ++a) {
+    const int n = 64 * a + lane;
+    long j0 = s0 + 2 * n, j1 = j0 + 1;
+    j0 = j0 < 0 ? -j0 : (j0 >= N ? 2 * (N - 1) - j0 : j0);
+    j1 = j1 < 0 ? -j1 : (j1 >= N ? 2 * (N - 1) - j1 : j1);
+    const f32x2 w = *reinterpret_cast<const f32x2*>(p.window + 2 * n);
+    x[a].re = p.audio[j0] * w.x;
+    x[a].im = p.audio[j1] * w.y;
+  }
+  // ---- stage 1: DFT over a; lane = (b, c) = (lane >> 3, lane & 7) -----------------------
+  dft8(x);
+  {
+    const int b = lane >> 3, c = lane & 7;
+#pragma unroll
+    for (int q = 1; q < 8; ++q) {
+      f32x2 t = tw[b * 8 + q];
+      x[q] = cmul(x[q], cplx{t.x, t.y});
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      re[q * 72 + b * 9 + c] = x[q].re;
+      im[q * 72 + b * 9 + c] = x[q].im;
+    }
+  }
+  __syncthreads();
+  // ---- stage 2: DFT over b; lane = (p, c) ------------------------------------------------
+  {
+    const int pp = lane >> 3, c = lane & 7;
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+      x[b].re = re[pp * 72 + b * 9 + c];
+      x[b].im = im[pp * 72 + b * 9 + c];
+    }
+    dft8(x);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      f32x2 t = tw[64 + c * 64 + pp + 8 * q];
+      x[q] = cmul(x[q], cplx{t.x, t.y});
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      re[q * 72 + pp * 9 + c] = x[q].re;
+      im[q * 72 + pp * 9 + c] = x[q].im;
+    }
+  }
+  __syncthreads();
+  // ---- stage 3: DFT over c; lane = (q, p) = (lane >> 3, lane & 7); Z[p + 8q + 64r] ---------
+  {
+    const int q = lane >> 3, pp = lane & 7;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      x[c].re = re[q * 72 + pp * 9 + c];
+      x[c].im = im[q * 72 + pp * 9 + c];
+    }
+    dft8(x);
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {  // k = (p + 8 q) + 64 r = lane + 64 r
+      re[lane + 64 * r] = x[r].re;
+      im[lane + 64 * r] = x[r].im;
+    }
+  }
+  __syncthreads();
+  // ---- split step: X[k], k = 0..512, magnitude / sqrt(1024) --------------------------------
+#pragma unroll
+  for (int j = 0; j < 9; ++j) {
+    const int k = lane + 64 * j;
+    if (k <= 512) {
+      const int k0 = k & 511, m = (512 - k) & 511;
+      const float a = re[k0], b = im[k0], c = re[m], d = im[m];
+      const float er = 0.5f * (a + c), ei = 0.5f * (b - d);
+      const float orr = 0.5f * (a - c), oi = 0.5f * (b + d);
+      const f32x2 t = tw[576 + k];  // (cos, -sin)
+      const float xr = er + (t.x * oi + t.y * orr);
+      const float xi = ei - (t.x * orr - t.y * oi);
+      mag[k] = sqrtf(xr * xr + xi * xi) * 0.03125f;
+    }
+  }
+  __syncthreads();
+  // ---- banded mel projection + log1p(1000 x) ------------------------------------------------
+  if (active) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int m = lane + 64 * h;
+      const int st = p.mel_start[m], len = p.mel_len[m];
+      float acc = 0.f;
+      for (int i = 0; i < len; ++i) acc = fmaf(mag[st + i], p.mel_w[m * 32 + i], acc);
+      p.spect[frame * 128 + m] = log1pf(1000.0f * acc);
+    }
+  }
+}
+
+}  // namespace
+
+int launch_logmel(const LogmelP& p, hipStream_t s) {
+  if (p.n_samples <= 512 || p.n_frames <= 0) return -2;
+  hipLaunchKernelGGL(logmel_kernel, dim3((unsigned)((p.n_frames + 3) / 4)), dim3(256), 0, s, p);
+  return (int)hipGetLastError();
+}

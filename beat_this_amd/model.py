@@ -1,0 +1,85 @@
+"""``BeatThis`` -- drop-in for beat_this.model.beat_tracker.BeatThis (beat_tracker.py:18-203).
+
+Same constructor signature, same ``state_dict`` keys (so reference checkpoints load with
+``load_state_dict``), same ``forward(x: (B,T,128)) -> {"beat": (B,T), "downbeat": (B,T)}``;
+the arithmetic runs in the hand-written HIP kernels of libbeat_this_amd.so.  Precision
+follows the caller exactly like the reference: under ``torch.autocast`` (what
+``Spect2Frames(float16=True)`` enters, inference.py:246) the bf16-MFMA path runs, otherwise
+the exact-fp32 MFMA path.  There is no CPU implementation here.
+"""
+from __future__ import annotations
+
+import torch
+from torch import nn
+
+from . import _lib
+from .pack import Engine, PackedModel
+from .weights import random_state_dict, resolve_hparams, state_dict_shapes
+
+_BUFFER_LEAVES = ("running_mean", "running_var", "num_batches_tracked")
+
+
+class _Node(nn.Module):
+    """Plain container; exists only so parameters carry the reference's dotted names."""
+
+
+def _attach(root: nn.Module, key: str, value: torch.Tensor) -> None:
+    *path, leaf = key.split(".")
+    node = root
+    for part in path:
+        if part not in node._modules:
+            node.add_module(part, _Node())
+        node = node._modules[part]
+    if leaf in _BUFFER_LEAVES:
+        node.register_buffer(leaf, value)
+    else:
+        node.register_parameter(leaf, nn.Parameter(value, requires_grad=False))
+
+
+class BeatThis(nn.Module):
+    def __init__(self, spect_dim: int = 128, transformer_dim: int = 512, ff_mult: int = 4, n_layers: int = 6,
+                 head_dim: int = 32, stem_dim: int = 32, dropout: dict = {"frontend": 0.1, "transformer": 0.2},
+                 sum_head: bool = True, partial_transformers: bool = True):
+        super().__init__()
+        self.hparams = resolve_hparams(dict(
+            spect_dim=spect_dim, transformer_dim=transformer_dim, ff_mult=ff_mult, n_layers=n_layers,
+            head_dim=head_dim, stem_dim=stem_dim, sum_head=sum_head, partial_transformers=partial_transformers))
+        # reference init statistics (beat_tracker.py:170-186); inference-only, so plain tensors
+        init = random_state_dict(self.hparams, seed=0, style="init0")
+        for key in state_dict_shapes(self.hparams):
+            _attach(self, key, init[key])
+        self._engine = None
+        self.eval()
+
+    # -- state dict plumbing (beat_tracker.py:194-203: strip torch.compile's "_orig_mod.") ----
+    def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False):
+        state_dict = {k.replace("_orig_mod.", ""): v for k, v in state_dict.items()}
+        self._engine = None
+        return super().load_state_dict(state_dict, strict=strict, assign=assign)
+
+    def _apply(self, fn, *args, **kwargs):
+        self._engine = None
+        return super()._apply(fn, *args, **kwargs)
+
+    @property
+    def device(self) -> torch.device:
+        return self.task_heads.beat_downbeat_lin.weight.device
+
+    def engine(self) -> Engine:
+        if self._engine is None:
+            dev = self.device
+            if dev.type != "cuda":
+                raise RuntimeError(
+                    f"beat_this_amd.BeatThis has no CPU implementation (parameters are on '{dev}'); "
+                    "move the model to a ROCm GPU: model.to('cuda')")
+            _lib.lib()  # fail loudly if the HIP library is missing
+            self._engine = Engine(PackedModel(self.state_dict(), self.hparams, dev))
+        return self._engine
+
+    def forward(self, x: torch.Tensor) -> dict:
+        if x.dim() != 3:
+            raise ValueError(f"expected (batch, time, {self.hparams['spect_dim']}) input, got {tuple(x.shape)}")
+        _lib.require_gpu(x, "model input")
+        half = torch.is_autocast_enabled("cuda") if hasattr(torch, "is_autocast_enabled") else False
+        beat, down = self.engine().forward(x, _lib.PREC_BF16 if half else _lib.PREC_F32)
+        return {"beat": beat, "downbeat": down}

@@ -1,0 +1,154 @@
+"""Pack a reference-layout BeatThis state dict into the kernel
+layouts of include/beat_this_amd.h: fold RMSNorm gammas / BatchNorm statistics into the
+adjacent weights, append the gate rows to the QKV projection, permute the conv and the
+frontend.linear weights to the (b, t, f, c) activation layout, pad N to 128 rows and keep an
+fp32 and a bf16 device copy of every matrix.  One-time host work (torch CPU ops)."""
+from __future__ import annotations
+
+import ctypes as C
+import math
+
+import torch
+
+from . import _lib, tables
+
+LOG2E = 1.4426950408889634
+BN_EPS = 1e-5
+
+
+def _pad_rows(w: torch.Tensor, mult: int = 128) -> torch.Tensor:
+    n = w.shape[0]
+    n_pad = (n + mult - 1) // mult * mult
+    if n_pad == n:
+        return w.contiguous()
+    out = torch.zeros((n_pad, w.shape[1]), dtype=w.dtype)
+    out[:n] = w
+    return out
+
+
+class PackedModel:
+    """Owns the device tensors and the bt_model_desc that points into them."""
+
+    def __init__(self, state_dict: dict, hparams: dict, device: torch.device):
+        sd = {k: v.detach().to("cpu", torch.float32) if v.is_floating_point() else v.detach().cpu()
+              for k, v in state_dict.items()}
+        self.device = torch.device(device)
+        self._keep: list[torch.Tensor] = []
+        self.desc = _lib.ModelDesc()
+        d = self.desc
+        D = int(hparams["transformer_dim"])
+        L = int(hparams["n_layers"])
+        if int(hparams.get("head_dim", 32)) != 32 or int(hparams.get("stem_dim", 32)) != 32 or \
+                int(hparams.get("spect_dim", 128)) != 128 or int(hparams.get("ff_mult", 4)) != 4:
+            raise ValueError("beat_this_amd kernels are built for head_dim=32, stem_dim=32, spect_dim=128, ff_mult=4")
+        if L > _lib.MAX_LAYERS or D % 32:
+            raise ValueError(f"unsupported transformer_dim={D} / n_layers={L}")
+        d.transformer_dim, d.n_layers = D, L
+        d.sum_head = int(bool(hparams.get("sum_head", True)))
+        d.partial_transformers = int(bool(hparams.get("partial_transformers", True)))
+
+        # ---- stem: BN1d -> scale/shift, BN2d folded into the conv ------------------------
+        s1 = sd["frontend.stem.bn1d.weight"] / torch.sqrt(sd["frontend.stem.bn1d.running_var"] + BN_EPS)
+        d.bn1_scale = self._f32(s1)
+        d.bn1_shift = self._f32(sd["frontend.stem.bn1d.bias"] - sd["frontend.stem.bn1d.running_mean"] * s1)
+        s2 = sd["frontend.stem.bn2d.weight"] / torch.sqrt(sd["frontend.stem.bn2d.running_var"] + BN_EPS)
+        d.stem_w = self._f32(sd["frontend.stem.conv2d.weight"].reshape(32, 12) * s2[:, None])  # [co][df*3+dt]
+        d.stem_b = self._f32(sd["frontend.stem.bn2d.bias"] - sd["frontend.stem.bn2d.running_mean"] * s2)
+
+        # ---- frontend blocks ---------------------------------------------------------------
+        dim = 32
+        for i in range(3):
+            p = f"frontend.blocks.{i}."
+            if d.partial_transformers:
+                self._pair(d.front[i][0], sd, p + "partial.attnF.", p + "partial.ffF.", dim)
+                self._pair(d.front[i][1], sd, p + "partial.attnT.", p + "partial.ffT.", dim)
+            sc = sd[p + "norm.weight"] / torch.sqrt(sd[p + "norm.running_var"] + BN_EPS)
+            w = sd[p + "conv2d.weight"] * sc[:, None, None, None]           # [co, ci, df, dt]
+            w = w.permute(0, 3, 2, 1).reshape(2 * dim, 6 * dim)             # [co][dt][df][ci]
+            d.conv_w[i][0], d.conv_w[i][1] = self._mat(w)
+            d.conv_b[i] = self._f32(sd[p + "norm.bias"] - sd[p + "norm.running_mean"] * sc)
+            dim *= 2
+        # ---- frontend.linear: reference column = c*4 + f, ours = f*256 + c -----------------
+        w = sd["frontend.linear.weight"].view(D, dim, 4).permute(0, 2, 1).reshape(D, 4 * dim)
+        d.lin_w[0], d.lin_w[1] = self._mat(w)
+        d.lin_b = self._f32(sd["frontend.linear.bias"])
+        # ---- transformer layers ----------------------------------------------------------------
+        for l in range(L):
+            p = f"transformer_blocks.layers.{l}."
+            self._pair(d.layers[l], sd, p + "0.", p + "1.", D)
+        g = sd["transformer_blocks.norm.gamma"]
+        d.head_w = self._f32(sd["task_heads.beat_downbeat_lin.weight"] * g[None, :])
+        hb = sd["task_heads.beat_downbeat_lin.bias"]
+        d.head_b[0], d.head_b[1] = float(hb[0]), float(hb[1])
+        freqs = next(v for k, v in sd.items() if k.endswith("rotary_embed.freqs"))
+        d.rope = self._f32(torch.from_numpy(tables.rope_table(freqs)))
+
+    # ------------------------------------------------------------------------------------------
+    def _f32(self, t: torch.Tensor) -> int:
+        t = t.to(torch.float32).contiguous().to(self.device)
+        self._keep.append(t)
+        return t.data_ptr()
+
+    def _mat(self, w: torch.Tensor):
+        w = _pad_rows(w.to(torch.float32))
+        a = w.to(self.device)
+        b = w.to(torch.bfloat16).to(self.device)
+        self._keep += [a, b]
+        return a.data_ptr(), b.data_ptr()
+
+    def _pair(self, pw, sd, pa: str, pf: str, dim: int) -> None:
+        heads = dim // 32
+        pw.dim, pw.heads = dim, heads
+        ga = sd[pa + "norm.gamma"]
+        wqkv = sd[pa + "to_qkv.weight"].clone()            # rows (qkv h d)
+        wqkv[:dim] *= LOG2E / math.sqrt(32.0)              # softmax scale + exp2 domain into q
+        wg = sd[pa + "to_gates.weight"]
+        w = torch.cat([wqkv, wg], 0) * ga[None, :]
+        pw.w_qkvg[0], pw.w_qkvg[1] = self._mat(w)
+        pw.b_gates = self._f32(sd[pa + "to_gates.bias"])
+        pw.w_out[0], pw.w_out[1] = self._mat(sd[pa + "to_out.0.weight"])
+        gf = sd[pf + "net.0.gamma"]
+        pw.w_ff1[0], pw.w_ff1[1] = self._mat(sd[pf + "net.1.weight"] * gf[None, :])
+        pw.b_ff1 = self._f32(sd[pf + "net.1.bias"])
+        pw.w_ff2[0], pw.w_ff2[1] = self._mat(sd[pf + "net.4.weight"])
+        pw.b_ff2 = self._f32(sd[pf + "net.4.bias"])
+
+
+class Engine:
+    """bt_engine handle + a growable workspace on one device."""
+
+    def __init__(self, packed: PackedModel):
+        self.packed = packed
+        self.device = packed.device
+        h = C.c_void_p()
+        _lib.check(_lib.lib().bt_engine_create(C.byref(packed.desc), C.byref(h)))
+        self._h = h
+        self._ws = None
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                _lib.lib().bt_engine_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def forward(self, spect: torch.Tensor, prec: int):
+        """spect: (B, T, 128) fp32 on the engine's device -> (beat, downbeat) fp32 (B, T)."""
+        _lib.require_gpu(spect, "input spectrogram")
+        B, T, M = spect.shape
+        if M != 128:
+            raise ValueError(f"expected 128 mel bins, got {M}")
+        x = spect.to(torch.float32).contiguous()
+        need = _lib.lib().bt_workspace_bytes(self._h, B, T, prec)
+        if need == 0:
+            raise ValueError("empty batch")
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = None
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        beat = torch.empty((B, T), dtype=torch.float32, device=self.device)
+        down = torch.empty((B, T), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().bt_forward(self._h, _lib.stream_ptr(self.device), prec, x.data_ptr(), B, T,
+                                             self._ws.data_ptr(), self._ws.numel(), beat.data_ptr(), down.data_ptr()))
+        return beat, down

@@ -1,0 +1,98 @@
+"""Multi-GPU sharding of the chunk batch: one process per GPU, torch.distributed (backend
+"nccl" = RCCL over xGMI on ROCm; "gloo" in the CPU tests).
+
+The reference has no in-process multi-GPU path (README.md:53-56 runs N independent CLI
+processes).  Chunks are independent forwards (inference.py:215), so the path shards with a
+single exchange: weights replicated, the global chunk list block-partitioned over ranks, one
+``all_gather`` of the per-chunk logits (2 x 1500 fp32 = 12 KB per chunk), then every rank
+holds everything needed for aggregation + post-processing.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import inference as inf
+
+
+def partition(n_items: int, world: int, rank: int):
+    """Contiguous block partition with equal (padded) block size: (lo, hi, per_rank)."""
+    per = (n_items + world - 1) // world if n_items else 0
+    lo = min(rank * per, n_items)
+    hi = min(lo + per, n_items)
+    return lo, hi, per
+
+
+def _hip_aggregate(cb, cd, starts, T, border, n):
+    from . import _lib
+
+    dev = cb.device
+    d_starts = torch.as_tensor(np.asarray(starts, dtype=np.int32), device=dev)
+    beat = torch.empty((n,), dtype=torch.float32, device=dev)
+    down = torch.empty((n,), dtype=torch.float32, device=dev)
+    cb, cd = cb.contiguous(), cd.contiguous()
+    with torch.cuda.device(dev):
+        _lib.check(_lib.lib().bt_aggregate(_lib.stream_ptr(dev), cb.data_ptr(), cd.data_ptr(), d_starts.data_ptr(),
+                                           len(starts), T, border, n, beat.data_ptr(), down.data_ptr()))
+    return beat, down
+
+
+def _hip_gather(spect, starts, T):
+    return inf._gather_chunks(spect, np.asarray(starts), T)[0]
+
+
+def forward_chunks_sharded(model, spects, chunk_size=1500, border=6, group=None, gather=_hip_gather,
+                           aggregate=_hip_aggregate, run=None):
+    """[(T_i,128)] -> [(beat_i, downbeat_i)], chunks of all full-length pieces sharded over the
+    ranks of ``group`` (or run locally when torch.distributed is not initialised)."""
+    run = run or inf._run_batched
+    distributed = dist.is_available() and dist.is_initialized()
+    world = dist.get_world_size(group) if distributed else 1
+    rank = dist.get_rank(group) if distributed else 0
+    spects = [s.to(torch.float32).contiguous() for s in spects]
+    plan = []   # (piece, start) for every full-length chunk, in piece order
+    meta = []
+    for i, s in enumerate(spects):
+        n = s.shape[0]
+        starts = inf.chunk_starts(n, chunk_size, border)
+        T = inf.chunk_length(n, chunk_size, border)
+        meta.append((n, starts, T))
+        if T == chunk_size:
+            plan += [(i, int(st)) for st in starts]
+    results = [None] * len(spects)
+    # short pieces: a single (n+12)-frame chunk each, cheap -> computed redundantly on every rank
+    for i, (n, starts, T) in enumerate(meta):
+        if T != chunk_size:
+            cb, cd = run(model, gather(spects[i], starts, T))
+            results[i] = aggregate(cb.float(), cd.float(), starts, T, border, n)
+    if plan:
+        dev = spects[0].device
+        lo, hi, per = partition(len(plan), world, rank)
+        mine = plan[lo:hi]
+        parts = []
+        j = 0
+        while j < len(mine):  # consecutive chunks of one piece are gathered by one kernel launch
+            k = j
+            while k < len(mine) and mine[k][0] == mine[j][0]:
+                k += 1
+            parts.append(gather(spects[mine[j][0]], [st for _, st in mine[j:k]], chunk_size))
+            j = k
+        local = torch.zeros((per, 2, chunk_size), dtype=torch.float32, device=dev)
+        if parts:
+            chunks = parts[0] if len(parts) == 1 else torch.cat(parts)
+            cb, cd = run(model, chunks)
+            local[: hi - lo, 0] = cb.float()
+            local[: hi - lo, 1] = cd.float()
+        if world > 1:
+            full = torch.empty((world * per, 2, chunk_size), dtype=torch.float32, device=dev)
+            dist.all_gather_into_tensor(full, local, group=group)
+        else:
+            full = local
+        pos = 0
+        for i, (n, starts, T) in enumerate(meta):
+            if T == chunk_size:
+                seg = full[pos: pos + len(starts)]
+                results[i] = aggregate(seg[:, 0].contiguous(), seg[:, 1].contiguous(), starts, T, border, n)
+                pos += len(starts)
+    return results

@@ -92,6 +92,8 @@ def random_state_dict(hp=None, seed: int = 0, style: str = "lively") -> "Ordered
                     Conv2d Kaiming-normal fan_out, gamma=1, BN identity) plus a seeded
                     perturbation of every 1-D parameter and BN running statistic
                      so that no affine term is trivially 0/1.
+    style="init0":  the reference's init statistics exactly (no perturbation) -- what
+                    ``BeatThis()`` holds before a checkpoint is loaded.
     style="lively": fan-in scaled weights so that attention logits and the output
                     logits have O(1) spread (peaks, sign changes) -- a stricter
                     numerical test than "init", same FLOPs.
@@ -107,6 +109,8 @@ def random_state_dict(hp=None, seed: int = 0, style: str = "lively") -> "Ordered
         elif leaf == "num_batches_tracked":
             sd[key] = torch.zeros((), dtype=torch.int64)
             continue
+        elif style == "init0" and (len(shape) == 1 or leaf in ("running_mean", "running_var")):
+            v = np.ones(shape) if leaf in ("gamma", "weight", "running_var") else np.zeros(shape)
         elif leaf == "running_mean":
             v = 0.5 * rng.standard_normal(shape)
             if key.startswith("frontend.stem.bn1d"):
@@ -122,10 +126,10 @@ def random_state_dict(hp=None, seed: int = 0, style: str = "lively") -> "Ordered
         elif len(shape) == 4:  # conv, Kaiming normal fan_out
             fan_out = shape[0] * shape[2] * shape[3]
             fan_in = shape[1] * shape[2] * shape[3]
-            std = math.sqrt(2.0 / fan_out) if style == "init" else 1.3 / math.sqrt(fan_in)
+            std = math.sqrt(2.0 / fan_out) if style.startswith("init") else 1.3 / math.sqrt(fan_in)
             v = std * rng.standard_normal(shape)
         else:  # linear
-            if style == "init":
+            if style.startswith("init"):
                 std = 0.02
             elif "to_qkv" in key:
                 std = 1.6 / math.sqrt(shape[1])

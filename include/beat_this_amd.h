@@ -1,0 +1,156 @@
+/* beat_this_amd -- C ABI of the MI355X-native beat_this inference hot path.
+ *
+ * The reference (CPJKU/beat_this, pure Python) has no FFI; its seam is the Python
+ * API of beat_this/inference.py.  These entry points are what a binding for that
+ * seam calls -- each one cites the reference code it replaces.  All `d_*` pointers
+ * are DEVICE pointers owned by the caller (torch tensors on the Python side);
+ * `stream` is a hipStream_t (torch.cuda.current_stream().cuda_stream).  No call
+ * allocates device memory, synchronises the device, or starts threads.  Return
+ * value: BT_OK or a negative BT_ERR_* code; bt_last_error() gives the text.
+ * The library is reentrant per engine handle, not concurrently on one handle.
+ */
+#ifndef BEAT_THIS_AMD_H
+#define BEAT_THIS_AMD_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BT_OK 0
+#define BT_ERR_ARG (-1)      /* bad argument / unsupported shape  -> ValueError */
+#define BT_ERR_HIP (-2)      /* HIP runtime error                 -> RuntimeError */
+#define BT_ERR_WORKSPACE (-3)/* workspace too small               -> RuntimeError */
+
+#define BT_PREC_F32 0  /* exact fp32 MFMA (v_mfma_f32_32x32x2_f32), fp32 activations: float16=False */
+#define BT_PREC_BF16 1 /* bf16 MFMA operands, fp32 accumulate + fp32 residual stream: float16=True */
+
+#define BT_MAX_LAYERS 32
+
+typedef struct bt_engine bt_engine;
+
+/* One [RMSNorm -> gated RoPE attention -> +x ; RMSNorm -> FF -> +x] pair
+ * (roformer.py:38-61,83-132,176-179).  Weight matrices come in two device copies,
+ * index BT_PREC_F32 / BT_PREC_BF16, row-major [N padded to a multiple of 128][K]:
+ *   w_qkvg : rows = q (heads*32, scaled by log2(e)/sqrt(32)) | k | v | gate rows (heads),
+ *            every row multiplied by the attention RMSNorm gamma;
+ *   w_out  : to_out.0.weight;  w_ff1 : net.1.weight * FF gamma;  w_ff2 : net.4.weight. */
+typedef struct {
+  int32_t dim, heads;
+  const void* w_qkvg[2];
+  const float* b_gates;
+  const void* w_out[2];
+  const void* w_ff1[2];
+  const float* b_ff1;
+  const void* w_ff2[2];
+  const float* b_ff2;
+} bt_pair_weights;
+
+/* Packed BeatThis weights (beat_tracker.py:38-106).  Host-side packing is done by
+ * beat_this_amd/pack.py from a reference-layout state dict. */
+typedef struct {
+  int32_t transformer_dim, n_layers, sum_head, partial_transformers;
+  /* stem (beat_tracker.py:108-126): BN1d as scale/shift per mel bin; conv weight
+   * [32][df*3+dt] with BN2d scale folded; BN2d shift as bias. */
+  const float* bn1_scale;
+  const float* bn1_shift;
+  const float* stem_w;
+  const float* stem_b;
+  bt_pair_weights front[3][2];  /* [block][0 = frequency direction, 1 = time direction] */
+  /* frontend convs (beat_tracker.py:155-166): [2C padded][3 taps * 2 freq * C] with BN folded */
+  const void* conv_w[3][2];
+  const float* conv_b[3];
+  /* frontend.linear (beat_tracker.py:76-77), columns permuted from (c f) to (f c) */
+  const void* lin_w[2];
+  const float* lin_b;
+  bt_pair_weights layers[BT_MAX_LAYERS];
+  const float* head_w; /* [2][D] task_heads weight * final RMSNorm gamma */
+  float head_b[2];
+  const float* rope;   /* [1536][16][2] cos/sin of pos * freqs (rotary-embedding-torch) */
+} bt_model_desc;
+
+typedef struct {
+  const float* window;   /* [1024] periodic Hann */
+  const float* twiddle;  /* [1089][2]  (see csrc/logmel.hip) */
+  const int32_t* mel_start; /* [128] first FFT bin of each mel filter */
+  const int32_t* mel_len;   /* [128] */
+  const float* mel_w;       /* [128][32] */
+} bt_logmel_tables;
+
+const char* bt_last_error(void);
+int bt_version(void);
+/* sizeof/offsetof of the structs above as this library was compiled (binding self-check):
+ * out[7] = {pair_weights, model_desc, logmel_tables, gemm_args, attn_args, offsetof layers, offsetof rope} */
+void bt_struct_sizes(int32_t* out);
+
+/* BeatThis(**hparams) + load_state_dict (inference.py:56-87): keeps a copy of `desc`. */
+int bt_engine_create(const bt_model_desc* desc, bt_engine** out);
+void bt_engine_destroy(bt_engine* e);
+/* bytes of scratch bt_forward needs for a [B,T,128] batch */
+size_t bt_workspace_bytes(const bt_engine* e, int B, int T, int prec);
+
+/* BeatThis.forward (beat_tracker.py:188-192): d_spect [B,T,128] fp32 ->
+ * d_beat, d_downbeat [B,T] fp32 logits (SumHead applied). T <= 1500. */
+int bt_forward(bt_engine* e, void* stream, int prec, const float* d_spect, int B, int T, void* d_ws,
+               size_t ws_bytes, float* d_beat, float* d_downbeat);
+
+/* split_piece + zeropad (inference.py:90-135): d_chunks[b,t,:] = d_spect[d_starts[b]+t,:] or 0 */
+int bt_split_chunks(void* stream, const float* d_spect, int64_t n_frames, const int32_t* d_starts, int B, int T,
+                    float* d_chunks);
+/* aggregate_prediction, overlap_mode="keep_first" (inference.py:138-185) */
+int bt_aggregate(void* stream, const float* d_chunk_beat, const float* d_chunk_downbeat, const int32_t* d_starts,
+                 int B, int T, int border, int64_t n_frames, float* d_beat, float* d_downbeat);
+
+/* LogMelSpect.forward (preprocessing.py:56-59): d_audio [n_samples] fp32 @22.05 kHz ->
+ * d_spect [1 + n_samples/441, 128].  n_samples must exceed 512 (reflect padding). */
+int bt_logmel(void* stream, const bt_logmel_tables* tables, const float* d_audio, int64_t n_samples,
+              float* d_spect);
+
+/* Postprocessor.postp_minimal peak mask (postprocessor.py:93-99) + nonzero (:119-120):
+ * d_logits [n_arrays][n] -> d_idx [n_arrays][n] ascending frame indices, d_count [n_arrays]. */
+int bt_peaks(void* stream, const float* d_logits, int64_t n, int n_arrays, int32_t* d_idx, int32_t* d_count);
+
+/* HOST: deduplicate_peaks(width=1) (postprocessor.py:176-197), frame/fps, snap every
+ * downbeat to the nearest beat, np.unique (postprocessor.py:121-136).  Output buffers
+ * must hold n_beat_idx / n_down_idx doubles. */
+int bt_postprocess_host(const int32_t* beat_idx, int n_beat_idx, const int32_t* down_idx, int n_down_idx,
+                        double fps, double* beats, int32_t* n_beats, double* downbeats, int32_t* n_downbeats);
+
+/* Per-launch timing of bt_forward with HIP events recorded on the caller's stream (bench.py's
+ * roofline leg).  bt_profile_begin() arms it; every bt_forward until bt_profile_end() records one
+ * event pair per kernel launch; bt_profile_end() synchronises on the events and returns summed
+ * milliseconds and launch counts per category (index = BT_CAT_*). */
+#define BT_CAT_STEM 0
+#define BT_CAT_QKV_GEMM 1
+#define BT_CAT_ATTN_FREQ 2   /* attn_small_kernel */
+#define BT_CAT_ATTN_FLASH 3  /* attn_flash_kernel: time-direction + main attention */
+#define BT_CAT_OUT_GEMM 4
+#define BT_CAT_FF1_GEMM 5
+#define BT_CAT_FF2_GEMM 6
+#define BT_CAT_CONV_GEMM 7
+#define BT_CAT_LINEAR_GEMM 8
+#define BT_CAT_HEAD 9
+#define BT_PROFILE_CATEGORIES 10
+void bt_profile_begin(void);
+int bt_profile_end(double* ms_by_category, int32_t* launches_by_category, int n_categories);
+
+/* Single-operator entry points (used by the parity tests; same kernels bt_forward launches). */
+typedef struct {
+  const void* A; int64_t lda; const void* W; int32_t M, N, K; int32_t epi, flags;
+  const float* bias; void* out; int64_t ldo; float* x; int64_t ldx;
+  int32_t conv_C2, conv_T, conv_F;
+  float* gates; int32_t inner, heads; const float* rope; int32_t pdiv, pmod, map_T, map_F;
+} bt_gemm_args;
+int bt_gemm(void* stream, int prec, const bt_gemm_args* a);
+
+typedef struct {
+  const void* qkv; int64_t ld; const float* gates; void* out;
+  int32_t n_seq, L, heads, inner, o_div; int64_t o_outer, o_inner, o_tok;
+} bt_attn_args;
+int bt_attention(void* stream, int prec, const bt_attn_args* a, int small_kernel);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

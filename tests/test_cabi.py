@@ -1,0 +1,96 @@
+"""No-GPU checks of the C-ABI library: it builds for gfx950, loads next to torch's ROCm runtime,
+exports every symbol include/beat_this_amd.h declares, and its host-only entry point
+(bt_postprocess_host) matches the oracle and the reference's golden outputs bit for bit."""
+import ctypes as C
+import json
+import os
+import re
+
+import numpy as np
+import torch
+
+from conftest import GOLDEN, ROOT
+from oracle import beat_this_oracle as O
+from oracle.cases import POSTP_CASES
+
+
+def _lib():
+    from beat_this_amd import _lib as L
+
+    L.build()
+    return L
+
+
+def test_library_exports_every_declared_symbol():
+    L = _lib()
+    header = open(os.path.join(ROOT, "include", "beat_this_amd.h")).read()
+    declared = set(re.findall(r"\b(bt_[a-z_0-9]+)\s*\(", header))
+    assert {"bt_forward", "bt_logmel", "bt_peaks", "bt_aggregate", "bt_split_chunks", "bt_engine_create"} <= declared
+    handle = L.lib()
+    for name in declared:
+        assert hasattr(handle, name), f"{name} declared in the header but not exported"
+    assert set(L.EXPORTS) == declared
+    assert handle.bt_version() >= 100
+
+
+def test_argument_errors_map_to_exceptions():
+    L = _lib()
+    import pytest
+
+    rc = L.lib().bt_forward(None, None, 0, None, 1, 1, None, 0, None, None)
+    assert rc == L.BT_ERR_ARG
+    with pytest.raises(ValueError):
+        L.check(rc)
+    assert L.lib().bt_workspace_bytes(None, 1, 1, 0) == 0
+
+
+def test_struct_layout_matches_header():
+    L = _lib()
+    sizes = (C.c_int32 * 7)()
+    L.lib().bt_struct_sizes(sizes)
+    assert list(sizes) == [C.sizeof(L.PairWeights), C.sizeof(L.ModelDesc), C.sizeof(L.LogmelTables),
+                           C.sizeof(L.GemmArgs), C.sizeof(L.AttnArgs), L.ModelDesc.layers.offset,
+                           L.ModelDesc.rope.offset]
+
+
+def test_host_postprocess_bit_exact():
+    from beat_this_amd.postprocessor import _host_post
+
+    post = json.load(open(os.path.join(GOLDEN, "postp_minimal.json")))
+    for name, (bs, ds) in POSTP_CASES.items():
+        b = torch.full((100,), -5.0)
+        d = torch.full((100,), -5.0)
+        for f, v in bs:
+            b[f] = v
+        for f, v in ds:
+            d[f] = v
+        bt, dt = _host_post(O.peak_frames(b), O.peak_frames(d), 50)
+        assert bt.tolist() == post[name]["beats"], name
+        assert dt.tolist() == post[name]["downbeats"], name
+    rng = np.random.default_rng(123)
+    for _ in range(20):
+        n = int(rng.integers(1, 4000))
+        b = torch.from_numpy(rng.normal(-0.5, 1.5, n).astype(np.float32))
+        d = torch.from_numpy(rng.normal(-1.5, 1.5, n).astype(np.float32))
+        b[rng.integers(0, n, n // 10)] = 1.25  # plateaus / equal neighbours
+        bt, dt = _host_post(O.peak_frames(b), O.peak_frames(d), 50)
+        ob, od = O.postp_minimal(b, d)
+        assert np.array_equal(bt, ob) and np.array_equal(dt, od)
+    bt, dt = _host_post(np.zeros(0, np.int32), np.array([5, 6, 30], np.int32), 50)
+    assert len(bt) == 0 and dt.tolist() == [5.5 / 50, 30 / 50]
+
+
+def test_package_fails_loudly_without_gpu():
+    import pytest
+
+    from beat_this_amd.inference import Spect2Frames
+    from beat_this_amd.model import BeatThis
+    from beat_this_amd.preprocessing import LogMelSpect
+
+    with pytest.raises(RuntimeError):
+        BeatThis()(torch.zeros(1, 50, 128))
+    with pytest.raises(RuntimeError):
+        LogMelSpect()(torch.zeros(4000))
+    s2f = Spect2Frames(checkpoint_path=None, device="cpu")
+    with pytest.raises(RuntimeError):
+        s2f(torch.zeros(100, 128))

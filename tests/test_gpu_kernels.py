@@ -1,0 +1,207 @@
+"""Per-kernel parity on the MI355X: each HIP kernel (through the C ABI) against a float64
+torch restatement of the same operator, for both precisions.  Asymmetric random operands,
+ragged M / sequence lengths, every epilogue."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from gpu_util import dev, pad_rows, report, run_attn, run_gemm, tdtype
+
+pytestmark = pytest.mark.gpu
+
+F32, BF16 = 0, 1
+TOL = {F32: 2e-5, BF16: 2.5e-2}  # relative to the output's max-abs
+
+
+def _rel(a, ref):
+    return float((a.double().cpu() - ref).abs().max() / ref.abs().max().clamp_min(1e-30))
+
+
+def _mk(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(shape, generator=g, dtype=torch.float64) * scale
+
+
+@pytest.mark.parametrize("prec", [F32, BF16])
+@pytest.mark.parametrize("M,K,N", [(300, 64, 96), (1000, 512, 200), (129, 32, 32), (257, 2048, 512)])
+def test_gemm_store_rms_bias_gelu(prec, M, K, N):
+    from beat_this_amd import _lib as L
+
+    A, W, b = _mk((M, K), 1), _mk((N, K), 2, 1 / math.sqrt(K)), _mk((N,), 3)
+    Wd = pad_rows(W.float()).to(tdtype(prec)).to(dev())
+    out = torch.zeros((M, N), dtype=tdtype(prec), device=dev())
+    run_gemm(prec, A.float().to(dev()), Wd, N, L.GEMM_EPI_STORE,
+             L.GEMM_F_RMS | L.GEMM_F_A_F32 | L.GEMM_F_BIAS | L.GEMM_F_GELU, bias=b.float().to(dev()), out=out)
+    xn = A / A.norm(dim=-1, keepdim=True).clamp_min(1e-12) * math.sqrt(K)
+    ref = torch.nn.functional.gelu(xn @ W.T + b)
+    err = _rel(out, ref)
+    report("gemm_store", prec=prec, M=M, K=K, N=N, rel=err)
+    assert err < TOL[prec]
+
+
+@pytest.mark.parametrize("prec", [F32, BF16])
+def test_gemm_plain_f32_out_and_resid(prec):
+    from beat_this_amd import _lib as L
+
+    M, K, N = 515, 128, 64
+    A, W, b, x0 = _mk((M, K), 4), _mk((N, K), 5, 0.1), _mk((N,), 6), _mk((M, N), 7)
+    Wd = pad_rows(W.float()).to(tdtype(prec)).to(dev())
+    # A in compute dtype (as produced by a previous kernel), residual in fp32
+    Ad = A.float().to(tdtype(prec)).to(dev())
+    x = x0.float().to(dev()).clone()
+    run_gemm(prec, Ad, Wd, N, L.GEMM_EPI_RESID, L.GEMM_F_BIAS, bias=b.float().to(dev()), x=x)
+    ref = x0 + Ad.double().cpu() @ Wd[:N].double().cpu().T + b
+    err = _rel(x, ref)
+    report("gemm_resid", prec=prec, rel=err)
+    assert err < (2e-5 if prec == F32 else 4e-3)
+    out = torch.zeros((M, N), dtype=torch.float32, device=dev())
+    run_gemm(prec, A.float().to(dev()), Wd, N, L.GEMM_EPI_STORE, L.GEMM_F_A_F32 | L.GEMM_F_BIAS | L.GEMM_F_OUT_F32,
+             bias=b.float().to(dev()), out=out)
+    ref = A @ W.T + b
+    err = _rel(out, ref)
+    report("gemm_f32out", prec=prec, rel=err)
+    assert err < TOL[prec]
+
+
+@pytest.mark.parametrize("prec", [F32, BF16])
+@pytest.mark.parametrize("mode", ["main", "freq", "time"])
+def test_gemm_qkv_epilogue(prec, mode):
+    """RMSNorm scale + RoPE (interleaved pairs) + gates + (b,t,f)->(b,f,t) row permutation."""
+    from beat_this_amd import _lib as L
+    from beat_this_amd.tables import rope_table
+
+    heads = 2
+    C = heads * 32
+    B, T, F = 2, 37, 1
+    if mode != "main":
+        F = 16
+    M = B * T * F
+    A = _mk((M, C), 10)
+    Wqkv, Wg, bg = _mk((3 * C, C), 11, 1 / math.sqrt(C)), _mk((heads, C), 12, 0.2), _mk((heads,), 13)
+    freqs = 10000.0 ** (-torch.arange(0, 32, 2).float() / 32)
+    rope = torch.from_numpy(rope_table(freqs)).to(dev())
+    W = pad_rows(torch.cat([Wqkv, Wg]).float()).to(tdtype(prec)).to(dev())
+    out = torch.zeros((M, 3 * C), dtype=tdtype(prec), device=dev())
+    gates = torch.zeros((M, heads), dtype=torch.float32, device=dev())
+    rows = torch.arange(M)
+    if mode == "main":
+        pdiv, pmod, pos = 1, T, rows % T
+    elif mode == "freq":
+        pdiv, pmod, pos = 1, F, rows % F
+    else:
+        pdiv, pmod, pos = F, T, (rows // F) % T
+    flags = L.GEMM_F_RMS | L.GEMM_F_A_F32 | (L.GEMM_F_ROWMAP if mode == "time" else 0)
+    run_gemm(prec, A.float().to(dev()), W, 3 * C + heads, L.GEMM_EPI_QKV, flags, bias=bg.float().to(dev()), out=out,
+             qkv=dict(gates=gates, inner=C, heads=heads, rope=rope, pdiv=pdiv, pmod=pmod, map_T=T, map_F=F))
+    xn = A / A.norm(dim=-1, keepdim=True).clamp_min(1e-12) * math.sqrt(C)
+    qkv = xn @ Wqkv.T
+    def rope_cols(block):
+        t = block.reshape(M, heads, 32)
+        ang = pos[:, None].double() * freqs[None, :].double()
+        cos, sin = ang.cos().repeat_interleave(2, -1)[:, None], ang.sin().repeat_interleave(2, -1)[:, None]
+        te, to = t[..., 0::2], t[..., 1::2]
+        rot = torch.stack((-to, te), -1).flatten(-2)
+        return (t * cos + rot * sin).reshape(M, C)
+    ref = torch.cat([rope_cols(qkv[:, :C]), rope_cols(qkv[:, C:2 * C]), qkv[:, 2 * C:]], 1)
+    gref = torch.sigmoid(xn @ Wg.T + bg)
+    if mode == "time":
+        b, t, f = rows // (T * F), (rows // F) % T, rows % F
+        perm = (b * F + f) * T + t
+        r2, g2 = torch.zeros_like(ref), torch.zeros_like(gref)
+        r2[perm], g2[perm] = ref, gref
+        ref, gref = r2, g2
+    err, gerr = _rel(out, ref), _rel(gates, gref)
+    report("gemm_qkv", prec=prec, mode=mode, rel=err, gates_rel=gerr)
+    assert err < TOL[prec] and gerr < TOL[prec]
+
+
+@pytest.mark.parametrize("prec", [F32, BF16])
+def test_gemm_conv_gather(prec):
+    """Implicit-GEMM (2,3)/(2,1) conv + folded BN bias + GELU in (b,t,f,c) layout."""
+    from beat_this_amd import _lib as L
+
+    B, T, F, Cin = 2, 21, 8, 32
+    x = _mk((B, Cin, F, T), 20)                       # reference layout b c f t
+    w = _mk((2 * Cin, Cin, 2, 3), 21, 0.1)
+    bias = _mk((2 * Cin,), 22)
+    ref = torch.nn.functional.gelu(torch.nn.functional.conv2d(x, w, stride=(2, 1), padding=(0, 1))
+                                   + bias[None, :, None, None])      # b 2c f/2 t
+    ref = ref.permute(0, 3, 2, 1).reshape(B * T * (F // 2), 2 * Cin)
+    xd = x.permute(0, 3, 2, 1).contiguous().float().to(dev())         # b t f c
+    wp = pad_rows(w.permute(0, 3, 2, 1).reshape(2 * Cin, 6 * Cin).float()).to(tdtype(prec)).to(dev())
+    out = torch.zeros((B * T * (F // 2), 2 * Cin), dtype=torch.float32, device=dev())
+    run_gemm(prec, xd.view(-1, Cin), wp, 2 * Cin, L.GEMM_EPI_STORE,
+             L.GEMM_F_CONV | L.GEMM_F_A_F32 | L.GEMM_F_BIAS | L.GEMM_F_GELU | L.GEMM_F_OUT_F32,
+             bias=bias.float().to(dev()), out=out, conv=dict(M=B * T * (F // 2), C2=2 * Cin, T=T, F=F // 2))
+    err = _rel(out, ref)
+    report("gemm_conv", prec=prec, rel=err)
+    assert err < TOL[prec]
+
+
+def _attn_ref(q, k, v, gates):
+    # q,k,v: (S, H, L, 32) float64, q already carries log2e/sqrt(d): softmax in base 2
+    s = q @ k.transpose(-1, -2) * math.log(2.0)
+    return torch.softmax(s, -1) @ v * gates[..., None]
+
+
+@pytest.mark.parametrize("prec", [F32, BF16])
+@pytest.mark.parametrize("n_seq,L,heads", [(3, 1500, 2), (2, 77, 1), (1, 128, 4), (5, 1012, 1)])
+def test_attention_flash(prec, n_seq, L, heads):
+    C = heads * 32
+    qkv = _mk((n_seq * L, 3 * C), 30)
+    qkv[:, :C] *= 0.6   # scores with std ~3.4 (in log2 units): a sharp, non-uniform softmax
+    qkv[7 % (n_seq * L), C:2 * C] *= 6.0  # one outlier key forces an online-softmax rescale mid-stream
+    gates = torch.sigmoid(_mk((n_seq * L, heads), 31))
+    qd = qkv.float().to(tdtype(prec)).to(dev())
+    out = torch.zeros((n_seq * L, C), dtype=tdtype(prec), device=dev())
+    run_attn(prec, qd, gates.float().to(dev()), out, n_seq, L, heads)
+    qq = qd.double().cpu()
+    def split(i):
+        return qq[:, i * C:(i + 1) * C].reshape(n_seq, L, heads, 32).permute(0, 2, 1, 3)
+    ref = _attn_ref(split(0), split(1), split(2), gates.reshape(n_seq, L, heads).permute(0, 2, 1))
+    ref = ref.permute(0, 2, 1, 3).reshape(n_seq * L, C)
+    err = _rel(out, ref)
+    report("attn_flash", prec=prec, n_seq=n_seq, L=L, heads=heads, rel=err)
+    assert err < (2e-5 if prec == F32 else 2e-2)
+
+
+@pytest.mark.parametrize("prec", [F32, BF16])
+def test_attention_flash_time_direction_rowmap(prec):
+    """sequences (b,f) stored contiguously, output scattered back to (b,t,f) rows."""
+    B, T, F, heads = 2, 150, 4, 1
+    C = 32
+    qkv = _mk((B * F * T, 3 * C), 33)
+    gates = torch.sigmoid(_mk((B * F * T, heads), 34))
+    qd = qkv.float().to(tdtype(prec)).to(dev())
+    out = torch.zeros((B * T * F, C), dtype=tdtype(prec), device=dev())
+    run_attn(prec, qd, gates.float().to(dev()), out, B * F, T, heads, o_div=F, o_outer=T * F, o_inner=1, o_tok=F)
+    qq = qd.double().cpu()
+    def split(i):
+        return qq[:, i * C:(i + 1) * C].reshape(B * F, T, heads, 32).permute(0, 2, 1, 3)
+    ref = _attn_ref(split(0), split(1), split(2), gates.reshape(B * F, T, heads).permute(0, 2, 1))
+    ref = ref.permute(0, 2, 1, 3).reshape(B, F, T, C).permute(0, 2, 1, 3).reshape(B * T * F, C)
+    err = _rel(out, ref)
+    report("attn_flash_rowmap", prec=prec, rel=err)
+    assert err < (2e-5 if prec == F32 else 2e-2)
+
+
+@pytest.mark.parametrize("prec", [F32, BF16])
+@pytest.mark.parametrize("L,heads", [(32, 1), (16, 2), (8, 4)])
+def test_attention_small(prec, L, heads):
+    n_seq = 21  # not a multiple of 8: exercises the ragged tail
+    C = heads * 32
+    qkv = _mk((n_seq * L, 3 * C), 40)
+    gates = torch.sigmoid(_mk((n_seq * L, heads), 41))
+    qd = qkv.float().to(tdtype(prec)).to(dev())
+    out = torch.zeros((n_seq * L, C), dtype=tdtype(prec), device=dev())
+    run_attn(prec, qd, gates.float().to(dev()), out, n_seq, L, heads, small=True)
+    qq = qd.double().cpu()
+    def split(i):
+        return qq[:, i * C:(i + 1) * C].reshape(n_seq, L, heads, 32).permute(0, 2, 1, 3)
+    ref = _attn_ref(split(0), split(1), split(2), gates.reshape(n_seq, L, heads).permute(0, 2, 1))
+    ref = ref.permute(0, 2, 1, 3).reshape(n_seq * L, C)
+    err = _rel(out, ref)
+    report("attn_small", prec=prec, L=L, heads=heads, rel=err)
+    assert err < (2e-5 if prec == F32 else 1e-2)

@@ -12,7 +12,7 @@ import torch
 from conftest import GOLDEN, REFERENCE, ROOT, have_reference
 from beat_this_amd import weights as W
 from oracle import beat_this_oracle as O
-from oracle.make_golden import MODEL_CASES, POSTP_CASES
+from oracle.cases import MODEL_CASES, POSTP_CASES
 
 
 def test_split_piece_table():
