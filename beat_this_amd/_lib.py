@@ -15,14 +15,14 @@ import torch  # noqa: F401  (must precede loading the HIP library)
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(PKG_DIR, "libbeat_this_amd.so")
-SOURCES = ["gemm.hip", "attn.hip", "frontend.hip", "logmel.hip", "engine.hip"]
+SOURCES = ["gemm.hip", "attn.hip", "fused.hip", "frontend.hip", "logmel.hip", "engine.hip"]
 HEADERS = ["common.h", "kernels.h", os.path.join("..", "..", "include", "beat_this_amd.h")]
 
 BT_OK, BT_ERR_ARG, BT_ERR_HIP, BT_ERR_WORKSPACE = 0, -1, -2, -3
 PREC_F32, PREC_BF16 = 0, 1
 MAX_LAYERS = 32
 PROFILE_CATEGORIES = ["stem", "qkv_gemm", "attn_freq", "attn_flash", "out_gemm", "ff1_gemm", "ff2_gemm", "conv_gemm",
-                      "linear_gemm", "head"]
+                      "linear_gemm", "head", "ff_fused", "attn_freq_fused"]
 
 GEMM_EPI_STORE, GEMM_EPI_RESID, GEMM_EPI_QKV = 0, 1, 2
 GEMM_F_RMS, GEMM_F_BIAS, GEMM_F_GELU, GEMM_F_OUT_F32, GEMM_F_A_F32, GEMM_F_CONV, GEMM_F_ROWMAP = 1, 2, 4, 8, 16, 32, 64
@@ -31,7 +31,8 @@ GEMM_F_RMS, GEMM_F_BIAS, GEMM_F_GELU, GEMM_F_OUT_F32, GEMM_F_A_F32, GEMM_F_CONV,
 class PairWeights(C.Structure):
     _fields_ = [("dim", C.c_int32), ("heads", C.c_int32), ("w_qkvg", C.c_void_p * 2), ("b_gates", C.c_void_p),
                 ("w_out", C.c_void_p * 2), ("w_ff1", C.c_void_p * 2), ("b_ff1", C.c_void_p),
-                ("w_ff2", C.c_void_p * 2), ("b_ff2", C.c_void_p)]
+                ("w_ff2", C.c_void_p * 2), ("b_ff2", C.c_void_p), ("w_outp", C.c_void_p * 2),
+                ("w_ff2p", C.c_void_p * 2)]
 
 
 class ModelDesc(C.Structure):
@@ -85,6 +86,8 @@ EXPORTS = {
     "bt_profile_end": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "bt_gemm": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(GemmArgs)]),
     "bt_attention": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(AttnArgs), C.c_int]),
+    "bt_ff_fused": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(PairWeights), C.c_void_p, C.c_int64]),
+    "bt_attn_freq_fused": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(PairWeights), C.c_void_p, C.c_void_p, C.c_int64]),
 }
 
 

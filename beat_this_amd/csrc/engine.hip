@@ -43,7 +43,7 @@ struct Scope {
 };
 }  // namespace prof
 enum { CAT_STEM = 0, CAT_QKV, CAT_ATTN_SMALL, CAT_ATTN_FLASH, CAT_OUT, CAT_FF1, CAT_FF2, CAT_CONV, CAT_LINEAR,
-       CAT_HEAD, CAT_COUNT };
+       CAT_HEAD, CAT_FF_FUSED, CAT_ATTN_FREQ_FUSED, CAT_COUNT };
 
 namespace {
 
@@ -94,6 +94,13 @@ int run_pair(const bt_pair_weights& pw, const float* rope, float* x, const Works
   const long M = (long)B * T * F;
   if (M > 0x7fffffffL) return bt_set_error(BT_ERR_ARG, "batch too large for one forward call");
   GemmP g;
+  const bool fused_ok = C <= 128 && pw.w_outp[prec] && pw.w_ff2p[prec];
+  if (mode == 1 && fused_ok) {  // whole frequency-direction attention block in one register-resident kernel
+    FusedAttnP fa;
+    fa.x = x; fa.M = M; fa.C = C; fa.w_qkvg = pw.w_qkvg[prec]; fa.b_gates = pw.b_gates; fa.w_outp = pw.w_outp[prec];
+    fa.rope = rope;
+    LAUNCH_CAT(CAT_ATTN_FREQ_FUSED, s, launch_attn_freq_fused(fa, prec, s), "fused frequency attention");
+  } else {
   // ---- q|k|v|gates = RMSNorm(x) . W^T, RoPE, sigmoid ------------------------------------
   memset(&g, 0, sizeof g);
   g.A = x; g.lda = C; g.W = pw.w_qkvg[prec]; g.M = (int)M; g.N = 3 * C + H; g.K = C;
@@ -123,6 +130,13 @@ int run_pair(const bt_pair_weights& pw, const float* rope, float* x, const Works
   g.A = ws.ao; g.lda = C; g.W = pw.w_out[prec]; g.M = (int)M; g.N = C; g.K = C;
   g.epi = GEMM_EPI_RESID; g.flags = 0; g.x = x; g.ldx = C;
   LAUNCH_CAT(CAT_OUT, s, launch_gemm(g, prec, s), "out-proj gemm");
+  }
+  if (fused_ok) {
+    FusedFFP ff;
+    ff.x = x; ff.M = M; ff.C = C; ff.w1 = pw.w_ff1[prec]; ff.b1 = pw.b_ff1; ff.w2p = pw.w_ff2p[prec]; ff.b2 = pw.b_ff2;
+    LAUNCH_CAT(CAT_FF_FUSED, s, launch_ff_fused(ff, prec, s), "fused feed-forward");
+    return BT_OK;
+  }
   // ---- h = gelu(RMSNorm(x) . W1^T + b1) ------------------------------------------------------
   memset(&g, 0, sizeof g);
   g.A = x; g.lda = C; g.W = pw.w_ff1[prec]; g.M = (int)M; g.N = 4 * C; g.K = C;
@@ -324,6 +338,24 @@ int bt_profile_end(double* ms_by_category, int32_t* launches_by_category, int n_
     (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b);
   }
   prof::recs.clear();
+  return BT_OK;
+}
+
+int bt_ff_fused(void* stream, int prec, const bt_pair_weights* w, float* d_x, int64_t M) {
+  if (!w || !d_x || M <= 0 || w->dim > 128 || !w->w_ff2p[prec]) return bt_set_error(BT_ERR_ARG, "bad argument to bt_ff_fused");
+  FusedFFP ff;
+  ff.x = d_x; ff.M = M; ff.C = w->dim; ff.w1 = w->w_ff1[prec]; ff.b1 = w->b_ff1; ff.w2p = w->w_ff2p[prec]; ff.b2 = w->b_ff2;
+  LAUNCH(launch_ff_fused(ff, prec, (hipStream_t)stream), "fused feed-forward");
+  return BT_OK;
+}
+
+int bt_attn_freq_fused(void* stream, int prec, const bt_pair_weights* w, const float* d_rope, float* d_x, int64_t M) {
+  if (!w || !d_x || !d_rope || M <= 0 || w->dim > 128 || !w->w_outp[prec])
+    return bt_set_error(BT_ERR_ARG, "bad argument to bt_attn_freq_fused");
+  FusedAttnP fa;
+  fa.x = d_x; fa.M = M; fa.C = w->dim; fa.w_qkvg = w->w_qkvg[prec]; fa.b_gates = w->b_gates; fa.w_outp = w->w_outp[prec];
+  fa.rope = d_rope;
+  LAUNCH(launch_attn_freq_fused(fa, prec, (hipStream_t)stream), "fused frequency attention");
   return BT_OK;
 }
 

@@ -61,6 +61,21 @@ struct AttnP {
 int launch_attn_flash(const AttnP& p, int prec, hipStream_t s);
 int launch_attn_small(const AttnP& p, int prec, hipStream_t s);  // L in {8,16,32}, heads*L == 32
 
+// ---- register-chained fused frontend blocks (fused.hip), C in {32, 64, 128} ----------------------
+struct FusedFFP {
+  float* x; long M; int C;           // residual stream [M, C] fp32, updated in place
+  const void* w1; const float* b1;   // [4C (padded), C] with FF gamma folded; [4C]
+  const void* w2p; const float* b2;  // [C (padded), 4C] columns in PERM32 order; [C]
+};
+int launch_ff_fused(const FusedFFP& p, int prec, hipStream_t s);
+struct FusedAttnP {
+  float* x; long M; int C;
+  const void* w_qkvg; const float* b_gates;  // as for the QKV GEMM
+  const void* w_outp;                        // [C (padded), C] columns in PERM32 order
+  const float* rope;
+};
+int launch_attn_freq_fused(const FusedAttnP& p, int prec, hipStream_t s);
+
 // ---- small model kernels (frontend.hip) ---------------------------------------------
 struct StemP {
   const float* spect;  // [B, T, 128]

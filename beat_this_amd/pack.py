@@ -16,6 +16,14 @@ LOG2E = 1.4426950408889634
 BN_EPS = 1e-5
 
 
+def perm32(w: torch.Tensor) -> torch.Tensor:
+    """Reorder the columns inside every block of 32: new[16 g + r] = old[(r&3) + 8 (r>>2) + 4 g]
+    (the MFMA 32x32 C-layout row order), see csrc/fused.hip."""
+    idx = torch.tensor([(r & 3) + 8 * (r >> 2) + 4 * g for g in range(2) for r in range(16)])
+    n, k = w.shape
+    return w.reshape(n, k // 32, 32)[:, :, idx].reshape(n, k).contiguous()
+
+
 def _pad_rows(w: torch.Tensor, mult: int = 128) -> torch.Tensor:
     n = w.shape[0]
     n_pad = (n + mult - 1) // mult * mult
@@ -107,11 +115,28 @@ class PackedModel:
         pw.w_qkvg[0], pw.w_qkvg[1] = self._mat(w)
         pw.b_gates = self._f32(sd[pa + "to_gates.bias"])
         pw.w_out[0], pw.w_out[1] = self._mat(sd[pa + "to_out.0.weight"])
+        if dim <= 128:
+            pw.w_outp[0], pw.w_outp[1] = self._mat(perm32(sd[pa + "to_out.0.weight"]))
+            pw.w_ff2p[0], pw.w_ff2p[1] = self._mat(perm32(sd[pf + "net.4.weight"]))
         gf = sd[pf + "net.0.gamma"]
         pw.w_ff1[0], pw.w_ff1[1] = self._mat(sd[pf + "net.1.weight"] * gf[None, :])
         pw.b_ff1 = self._f32(sd[pf + "net.1.bias"])
         pw.w_ff2[0], pw.w_ff2[1] = self._mat(sd[pf + "net.4.weight"])
         pw.b_ff2 = self._f32(sd[pf + "net.4.bias"])
+
+
+class PackedPair:
+    """One attention+FF pair packed on its own (single-operator tests and tools)."""
+
+    def __init__(self, sd: dict, attn_prefix: str, ff_prefix: str, dim: int, device):
+        self.device = torch.device(device)
+        self._keep: list[torch.Tensor] = []
+        self.weights = _lib.PairWeights()
+        sd = {k: v.detach().to("cpu", torch.float32) for k, v in sd.items()}
+        PackedModel._pair(self, self.weights, sd, attn_prefix, ff_prefix, dim)
+
+    _f32 = PackedModel._f32
+    _mat = PackedModel._mat
 
 
 class Engine:

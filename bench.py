@@ -40,18 +40,20 @@ PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}  # MI355X_MICROARCH.md: dense MFMA 
 def flops_per_chunk(D: int, T: int = CHUNK_FRAMES):
     """Algorithmic MACs*2 per chunk, by kernel category (recomputed)."""
     cat = dict(stem=2 * T * 32 * 32 * 12, qkv_gemm=0, attn_freq=0, attn_flash=0, out_gemm=0, ff1_gemm=0, ff2_gemm=0,
-               conv_gemm=0, linear_gemm=2 * T * 1024 * D, head=2 * T * D * 2)
+               conv_gemm=0, linear_gemm=2 * T * 1024 * D, head=2 * T * D * 2, ff_fused=0, attn_freq_fused=0)
     for blk in range(3):
         Cc, F = 32 << blk, 32 >> blk
         h = Cc // 32
         tokens = T * F
         for direction in ("F", "T"):
-            cat["qkv_gemm"] += 2 * tokens * Cc * (3 * Cc + h)
-            cat["out_gemm"] += 2 * tokens * Cc * Cc
-            cat["ff1_gemm"] += 2 * tokens * Cc * 4 * Cc
-            cat["ff2_gemm"] += 2 * tokens * Cc * 4 * Cc
-            L, nseq = (F, T) if direction == "F" else (T, F)
-            cat["attn_freq" if direction == "F" else "attn_flash"] += 2 * 2 * nseq * h * L * L * 32
+            cat["ff_fused"] += 2 * 2 * tokens * Cc * 4 * Cc  # frontend FF blocks run fused (csrc/fused.hip)
+            if direction == "F":  # QKV + attention + out-proj of the frequency direction: one fused kernel
+                cat["attn_freq_fused"] += 2 * tokens * Cc * (3 * Cc + h) + 2 * tokens * Cc * Cc \
+                    + 2 * 2 * T * h * F * F * 32
+            else:
+                cat["qkv_gemm"] += 2 * tokens * Cc * (3 * Cc + h)
+                cat["out_gemm"] += 2 * tokens * Cc * Cc
+                cat["attn_flash"] += 2 * 2 * F * h * T * T * 32
         cat["conv_gemm"] += 2 * T * (F // 2) * (6 * Cc) * (2 * Cc)
     H = D // 32
     for _ in range(6):

@@ -45,6 +45,11 @@ typedef struct {
   const float* b_ff1;
   const void* w_ff2[2];
   const float* b_ff2;
+  /* PERM32 copies (columns reordered inside every block of 32: new[16 g + r] = old[(r & 3) +
+   * 8 (r >> 2) + 4 g], g in {0,1}, r in [0,16)) consumed by the register-chained fused kernels of
+   * csrc/fused.hip; only used for dim <= 128 (frontend), may be NULL otherwise. */
+  const void* w_outp[2];
+  const void* w_ff2p[2];
 } bt_pair_weights;
 
 /* Packed BeatThis weights (beat_tracker.py:38-106).  Host-side packing is done by
@@ -131,7 +136,9 @@ int bt_postprocess_host(const int32_t* beat_idx, int n_beat_idx, const int32_t* 
 #define BT_CAT_CONV_GEMM 7
 #define BT_CAT_LINEAR_GEMM 8
 #define BT_CAT_HEAD 9
-#define BT_PROFILE_CATEGORIES 10
+#define BT_CAT_FF_FUSED 10        /* ff_fused_kernel (frontend FF blocks) */
+#define BT_CAT_ATTN_FREQ_FUSED 11 /* attn_freq_fused_kernel (QKV + attention + out-proj) */
+#define BT_PROFILE_CATEGORIES 12
 void bt_profile_begin(void);
 int bt_profile_end(double* ms_by_category, int32_t* launches_by_category, int n_categories);
 
@@ -149,6 +156,9 @@ typedef struct {
   int32_t n_seq, L, heads, inner, o_div; int64_t o_outer, o_inner, o_tok;
 } bt_attn_args;
 int bt_attention(void* stream, int prec, const bt_attn_args* a, int small_kernel);
+/* x[M,C] += FF(x) / x += frequency-direction attention(x) with one bt_pair_weights, dim = C <= 128 */
+int bt_ff_fused(void* stream, int prec, const bt_pair_weights* w, float* d_x, int64_t M);
+int bt_attn_freq_fused(void* stream, int prec, const bt_pair_weights* w, const float* d_rope, float* d_x, int64_t M);
 
 #ifdef __cplusplus
 }

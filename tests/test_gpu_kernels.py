@@ -205,3 +205,78 @@ def test_attention_small(prec, L, heads):
     err = _rel(out, ref)
     report("attn_small", prec=prec, L=L, heads=heads, rel=err)
     assert err < (2e-5 if prec == F32 else 1e-2)
+
+
+def _pair_sd(C, seed):
+    H = C // 32
+    g = torch.Generator().manual_seed(seed)
+    def rn(*shape, s=1.0):
+        return torch.randn(*shape, generator=g, dtype=torch.float64) * s
+    return {
+        "a.norm.gamma": 1 + 0.1 * rn(C), "a.to_qkv.weight": rn(3 * C, C, s=1.6 / math.sqrt(C)),
+        "a.to_gates.weight": rn(H, C, s=0.3), "a.to_gates.bias": rn(H, s=0.3),
+        "a.to_out.0.weight": rn(C, C, s=1 / math.sqrt(C)),
+        "f.net.0.gamma": 1 + 0.1 * rn(C), "f.net.1.weight": rn(4 * C, C, s=1 / math.sqrt(C)),
+        "f.net.1.bias": rn(4 * C, s=0.2), "f.net.4.weight": rn(C, 4 * C, s=0.5 / math.sqrt(C)),
+        "f.net.4.bias": rn(C, s=0.2),
+    }
+
+
+@pytest.mark.parametrize("prec", [F32, BF16])
+@pytest.mark.parametrize("C", [32, 64, 128])
+def test_fused_ff(prec, C):
+    """x += W2 gelu(W1 rmsnorm(x) + b1) + b2 in one register-chained kernel (PERM32 weights)."""
+    import ctypes as Ct
+    from beat_this_amd import _lib as L
+    from beat_this_amd.pack import PackedPair
+
+    sd = _pair_sd(C, 50 + C)
+    M = 1000 + C  # ragged: not a multiple of 128
+    x0 = _mk((M, C), 60 + C, 1.5)
+    pp = PackedPair(sd, "a.", "f.", C, dev())
+    x = x0.float().to(dev()).clone()
+    L.check(L.lib().bt_ff_fused(L.stream_ptr(dev()), prec, Ct.byref(pp.weights), x.data_ptr(), M))
+    torch.cuda.synchronize()
+    xn = x0 / x0.norm(dim=-1, keepdim=True).clamp_min(1e-12) * math.sqrt(C) * sd["f.net.0.gamma"]
+    ref = x0 + torch.nn.functional.gelu(xn @ sd["f.net.1.weight"].T + sd["f.net.1.bias"]) @ sd["f.net.4.weight"].T \
+        + sd["f.net.4.bias"]
+    err = _rel(x, ref)
+    report("ff_fused", prec=prec, C=C, rel=err)
+    assert err < (2e-5 if prec == F32 else 1.5e-2)
+
+
+@pytest.mark.parametrize("prec", [F32, BF16])
+@pytest.mark.parametrize("C", [32, 64, 128])
+def test_fused_freq_attention(prec, C):
+    """x += to_out(gate * softmax(rope(q) rope(k)^T / sqrt(32)) v) over the F = 1024/C tokens of each (b,t) row."""
+    import ctypes as Ct
+    from beat_this_amd import _lib as L
+    from beat_this_amd.pack import PackedPair
+    from beat_this_amd.tables import rope_table
+
+    H, F = C // 32, 1024 // C
+    sd = _pair_sd(C, 70 + C)
+    rows = 37  # (b,t) rows; 37*F tokens is not a multiple of 128
+    M = rows * F
+    x0 = _mk((M, C), 80 + C, 1.5)
+    freqs = 10000.0 ** (-torch.arange(0, 32, 2).float() / 32)
+    rope = torch.from_numpy(rope_table(freqs)).to(dev())
+    pp = PackedPair(sd, "a.", "f.", C, dev())
+    x = x0.float().to(dev()).clone()
+    L.check(L.lib().bt_attn_freq_fused(L.stream_ptr(dev()), prec, Ct.byref(pp.weights), rope.data_ptr(), x.data_ptr(), M))
+    torch.cuda.synchronize()
+    xn = x0 / x0.norm(dim=-1, keepdim=True).clamp_min(1e-12) * math.sqrt(C) * sd["a.norm.gamma"]
+    qkv = (xn @ sd["a.to_qkv.weight"].T).reshape(rows, F, 3, H, 32).permute(2, 0, 3, 1, 4)  # qkv b h n d
+    ang = torch.arange(F, dtype=torch.float64)[:, None] * freqs.double()[None, :]
+    cos, sin = ang.cos().repeat_interleave(2, -1), ang.sin().repeat_interleave(2, -1)
+    def rot(t):
+        te, to = t[..., 0::2], t[..., 1::2]
+        return t * cos + torch.stack((-to, te), -1).flatten(-2) * sin
+    q, k, v = rot(qkv[0]), rot(qkv[1]), qkv[2]
+    att = torch.softmax(q @ k.transpose(-1, -2) / math.sqrt(32.0), -1) @ v
+    gates = torch.sigmoid(xn @ sd["a.to_gates.weight"].T + sd["a.to_gates.bias"]).reshape(rows, F, H).permute(0, 2, 1)
+    out = (att * gates[..., None]).permute(0, 2, 1, 3).reshape(M, C) @ sd["a.to_out.0.weight"].T
+    ref = x0 + out
+    err = float((x.double().cpu() - ref).abs().max() / out.abs().max())
+    report("attn_freq_fused", prec=prec, C=C, rel=err)
+    assert err < (3e-5 if prec == F32 else 2e-2)
