@@ -15,7 +15,7 @@ import torch  # noqa: F401  (must precede loading the HIP library)
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(PKG_DIR, "libbeat_this_amd.so")
-SOURCES = ["gemm.hip", "attn.hip", "fused.hip", "frontend.hip", "logmel.hip", "engine.hip"]
+SOURCES = ["gemm.hip", "gemm2.hip", "attn.hip", "fused.hip", "frontend.hip", "logmel.hip", "engine.hip"]
 HEADERS = ["common.h", "kernels.h", os.path.join("..", "..", "include", "beat_this_amd.h")]
 
 BT_OK, BT_ERR_ARG, BT_ERR_HIP, BT_ERR_WORKSPACE = 0, -1, -2, -3

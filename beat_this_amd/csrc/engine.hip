@@ -50,7 +50,7 @@ namespace {
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 struct Workspace {
-  float* xa; float* xb; float* xm; float* gates;
+  float* xa; float* xb; float* xm; float* gates; void* xmb;
   void* qkv; void* ao; void* hid;
   size_t total;
 };
@@ -65,6 +65,7 @@ Workspace carve(char* base, int B, int T, int D, int prec) {
   w.xa = (float*)take(bt * 1024 * 4);
   w.xb = (float*)take(bt * 1024 * 4);
   w.xm = (float*)take(bt * D * 4);
+  w.xmb = take(bt * D * 2);  // bf16 shadow of the main residual stream (A operand of the wide GEMMs)
   w.gates = (float*)take(bt * std::max(32, D / 32) * 4);
   w.qkv = take(bt * 3 * dmax * es);
   w.ao = take(bt * dmax * es);
@@ -88,12 +89,14 @@ Workspace carve(char* base, int B, int T, int D, int prec) {
 // mode 0: main transformer (sequences = chunks, tokens = frames)
 // mode 1: frequency direction (sequences = (b,t), tokens = f)      -- attn_small
 // mode 2: time direction      (sequences = (b,f), tokens = t)      -- rows permuted around attn_flash
-int run_pair(const bt_pair_weights& pw, const float* rope, float* x, const Workspace& ws, int B, int T, int F,
-             int mode, int prec, hipStream_t s) {
+int run_pair(const bt_pair_weights& pw, const float* rope, float* x, void* xshadow, const Workspace& ws, int B, int T,
+             int F, int mode, int prec, hipStream_t s) {
   const int C = pw.dim, H = pw.heads;
   const long M = (long)B * T * F;
   if (M > 0x7fffffffL) return bt_set_error(BT_ERR_ARG, "batch too large for one forward call");
   GemmP g;
+  // main layers in bf16 mode read the bf16 shadow of x (half the operand bytes, no conversion in the k-loop)
+  const bool shadow = xshadow != nullptr && prec == BT_PREC_BF16;
   const bool fused_ok = C <= 128 && pw.w_outp[prec] && pw.w_ff2p[prec];
   if (mode == 1 && fused_ok) {  // whole frequency-direction attention block in one register-resident kernel
     FusedAttnP fa;
@@ -103,8 +106,8 @@ int run_pair(const bt_pair_weights& pw, const float* rope, float* x, const Works
   } else {
   // ---- q|k|v|gates = RMSNorm(x) . W^T, RoPE, sigmoid ------------------------------------
   memset(&g, 0, sizeof g);
-  g.A = x; g.lda = C; g.W = pw.w_qkvg[prec]; g.M = (int)M; g.N = 3 * C + H; g.K = C;
-  g.epi = GEMM_EPI_QKV; g.flags = GEMM_F_RMS | GEMM_F_A_F32 | (mode == 2 ? GEMM_F_ROWMAP : 0);
+  g.A = shadow ? xshadow : (const void*)x; g.lda = C; g.W = pw.w_qkvg[prec]; g.M = (int)M; g.N = 3 * C + H; g.K = C;
+  g.epi = GEMM_EPI_QKV; g.flags = GEMM_F_RMS | (shadow ? 0 : GEMM_F_A_F32) | (mode == 2 ? GEMM_F_ROWMAP : 0);
   g.bias = pw.b_gates; g.out = ws.qkv; g.ldo = 3 * C; g.gates = ws.gates; g.inner = C; g.heads = H;
   g.rope = rope; g.map_T = T; g.map_F = F;
   if (mode == 0) { g.pdiv = 1; g.pmod = T; }
@@ -128,25 +131,26 @@ int run_pair(const bt_pair_weights& pw, const float* rope, float* x, const Works
   // ---- x += ao . Wout^T -------------------------------------------------------------------
   memset(&g, 0, sizeof g);
   g.A = ws.ao; g.lda = C; g.W = pw.w_out[prec]; g.M = (int)M; g.N = C; g.K = C;
-  g.epi = GEMM_EPI_RESID; g.flags = 0; g.x = x; g.ldx = C;
+  g.epi = GEMM_EPI_RESID; g.flags = 0; g.x = x; g.ldx = C; g.xb = shadow ? xshadow : nullptr;
   LAUNCH_CAT(CAT_OUT, s, launch_gemm(g, prec, s), "out-proj gemm");
   }
   if (fused_ok) {
     FusedFFP ff;
     ff.x = x; ff.M = M; ff.C = C; ff.w1 = pw.w_ff1[prec]; ff.b1 = pw.b_ff1; ff.w2p = pw.w_ff2p[prec]; ff.b2 = pw.b_ff2;
+    ff.xb = shadow ? xshadow : nullptr;
     LAUNCH_CAT(CAT_FF_FUSED, s, launch_ff_fused(ff, prec, s), "fused feed-forward");
     return BT_OK;
   }
   // ---- h = gelu(RMSNorm(x) . W1^T + b1) ------------------------------------------------------
   memset(&g, 0, sizeof g);
-  g.A = x; g.lda = C; g.W = pw.w_ff1[prec]; g.M = (int)M; g.N = 4 * C; g.K = C;
-  g.epi = GEMM_EPI_STORE; g.flags = GEMM_F_RMS | GEMM_F_A_F32 | GEMM_F_BIAS | GEMM_F_GELU;
+  g.A = shadow ? xshadow : (const void*)x; g.lda = C; g.W = pw.w_ff1[prec]; g.M = (int)M; g.N = 4 * C; g.K = C;
+  g.epi = GEMM_EPI_STORE; g.flags = GEMM_F_RMS | (shadow ? 0 : GEMM_F_A_F32) | GEMM_F_BIAS | GEMM_F_GELU;
   g.bias = pw.b_ff1; g.out = ws.hid; g.ldo = 4 * C;
   LAUNCH_CAT(CAT_FF1, s, launch_gemm(g, prec, s), "ff1 gemm");
   // ---- x += h . W2^T + b2 ---------------------------------------------------------------------
   memset(&g, 0, sizeof g);
   g.A = ws.hid; g.lda = 4 * C; g.W = pw.w_ff2[prec]; g.M = (int)M; g.N = C; g.K = 4 * C;
-  g.epi = GEMM_EPI_RESID; g.flags = GEMM_F_BIAS; g.bias = pw.b_ff2; g.x = x; g.ldx = C;
+  g.epi = GEMM_EPI_RESID; g.flags = GEMM_F_BIAS; g.bias = pw.b_ff2; g.x = x; g.ldx = C; g.xb = shadow ? xshadow : nullptr;
   LAUNCH_CAT(CAT_FF2, s, launch_gemm(g, prec, s), "ff2 gemm");
   return BT_OK;
 }
@@ -192,6 +196,9 @@ int bt_forward(bt_engine* e, void* stream, int prec, const float* d_spect, int B
   if (ws.total > ws_bytes) return bt_set_error(BT_ERR_WORKSPACE, "workspace too small");
   hipStream_t s = (hipStream_t)stream;
 
+  // the bf16 shadow of the main residual stream is maintained by gemm2's epilogues only
+  const bool use_shadow = prec == BT_PREC_BF16 && D >= 128 && D % 64 == 0;
+
   StemP sp;
   sp.spect = d_spect; sp.x = ws.xa; sp.bn1_scale = d.bn1_scale; sp.bn1_shift = d.bn1_shift;
   sp.w = d.stem_w; sp.bias = d.stem_b; sp.B = B; sp.T = T;
@@ -202,9 +209,9 @@ int bt_forward(bt_engine* e, void* stream, int prec, const float* d_spect, int B
   for (int blk = 0; blk < 3; ++blk) {
     const int C = 32 << blk, F = 32 >> blk;
     if (d.partial_transformers) {
-      int rc = run_pair(d.front[blk][0], d.rope, x, ws, B, T, F, 1, prec, s);
+      int rc = run_pair(d.front[blk][0], d.rope, x, nullptr, ws, B, T, F, 1, prec, s);
       if (rc) return rc;
-      rc = run_pair(d.front[blk][1], d.rope, x, ws, B, T, F, 2, prec, s);
+      rc = run_pair(d.front[blk][1], d.rope, x, nullptr, ws, B, T, F, 2, prec, s);
       if (rc) return rc;
     }
     GemmP g;
@@ -221,11 +228,11 @@ int bt_forward(bt_engine* e, void* stream, int prec, const float* d_spect, int B
     memset(&g, 0, sizeof g);
     g.A = x; g.lda = 1024; g.W = d.lin_w[prec]; g.M = B * T; g.N = D; g.K = 1024;
     g.epi = GEMM_EPI_STORE; g.flags = GEMM_F_A_F32 | GEMM_F_BIAS | GEMM_F_OUT_F32;
-    g.bias = d.lin_b; g.out = ws.xm; g.ldo = D;
+    g.bias = d.lin_b; g.out = ws.xm; g.ldo = D; g.xb = use_shadow ? ws.xmb : nullptr;
     LAUNCH_CAT(CAT_LINEAR, s, launch_gemm(g, prec, s), "frontend linear gemm");
   }
   for (int l = 0; l < d.n_layers; ++l) {
-    int rc = run_pair(d.layers[l], d.rope, ws.xm, ws, B, T, 1, 0, prec, s);
+    int rc = run_pair(d.layers[l], d.rope, ws.xm, use_shadow ? ws.xmb : nullptr, ws, B, T, 1, 0, prec, s);
     if (rc) return rc;
   }
   HeadP hp;
@@ -345,6 +352,7 @@ int bt_ff_fused(void* stream, int prec, const bt_pair_weights* w, float* d_x, in
   if (!w || !d_x || M <= 0 || w->dim > 128 || !w->w_ff2p[prec]) return bt_set_error(BT_ERR_ARG, "bad argument to bt_ff_fused");
   FusedFFP ff;
   ff.x = d_x; ff.M = M; ff.C = w->dim; ff.w1 = w->w_ff1[prec]; ff.b1 = w->b_ff1; ff.w2p = w->w_ff2p[prec]; ff.b2 = w->b_ff2;
+  ff.xb = nullptr;
   LAUNCH(launch_ff_fused(ff, prec, (hipStream_t)stream), "fused feed-forward");
   return BT_OK;
 }

@@ -144,6 +144,9 @@ __global__ __launch_bounds__(256) void ff_fused_kernel(const FusedFFP p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] += acc2[mt][4 * a + j] + b[j];
         *xp = v;
+        if (p.xb)
+          *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16*>(p.xb) + tok * C + f0) =
+              bf16x4{(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
       }
   }
 }

@@ -262,8 +262,12 @@ int launch_epi(const GemmP& p, hipStream_t s) {
 
 }  // namespace
 
+bool gemm2_supported(const GemmP& p, int prec);
+int launch_gemm2(const GemmP& p, hipStream_t s);
+
 int launch_gemm(const GemmP& p, int prec, hipStream_t s) {
   if (p.K % 32 != 0 || p.M <= 0) return -2;
+  if (gemm2_supported(p, prec)) return launch_gemm2(p, s);
   if ((p.flags & GEMM_F_CONV) && (p.conv_C2 % 32 != 0 || p.K != 3 * p.conv_C2)) return -2;
   if (p.epi == GEMM_EPI_QKV && (p.inner % 32 != 0)) return -2;
   if (prec == BT_PREC_F32) return launch_epi<float, true>(p, s);

@@ -35,6 +35,7 @@ struct GemmP {
   long ldo;
   float* x;        // EPI_RESID: residual stream, ld = ldx
   long ldx;
+  void* xb;        // optional bf16 shadow of the fp32 result (EPI_RESID: of x; OUT_F32: of out), same ld
   // conv gather (GEMM_F_CONV): output row m = (b, t, f'), A = x[b, t-1..t+1, f', 0..C2)
   int conv_C2, conv_T, conv_F;
   // QKV epilogue
@@ -66,6 +67,7 @@ struct FusedFFP {
   float* x; long M; int C;           // residual stream [M, C] fp32, updated in place
   const void* w1; const float* b1;   // [4C (padded), C] with FF gamma folded; [4C]
   const void* w2p; const float* b2;  // [C (padded), 4C] columns in PERM32 order; [C]
+  void* xb;                          // optional bf16 shadow of the updated x (same layout), may be null
 };
 int launch_ff_fused(const FusedFFP& p, int prec, hipStream_t s);
 struct FusedAttnP {

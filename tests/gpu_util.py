@@ -27,7 +27,7 @@ def tdtype(prec):
     return torch.float32 if prec == 0 else torch.bfloat16
 
 
-def run_gemm(prec, A, W, N, epi, flags, bias=None, out=None, ldo=0, x=None, conv=None, qkv=None):
+def run_gemm(prec, A, W, N, epi, flags, bias=None, out=None, ldo=0, x=None, conv=None, qkv=None, sync=True):
     """A: device tensor (rows, lda) ; W: (Npad, K) in compute dtype."""
     from beat_this_amd import _lib
 
@@ -47,7 +47,8 @@ def run_gemm(prec, A, W, N, epi, flags, bias=None, out=None, ldo=0, x=None, conv
         a.rope, a.pdiv, a.pmod = qkv["rope"].data_ptr(), qkv["pdiv"], qkv["pmod"]
         a.map_T, a.map_F = qkv.get("map_T", 0), qkv.get("map_F", 0)
     _lib.check(_lib.lib().bt_gemm(_lib.stream_ptr(dev()), prec, C.byref(a)))
-    torch.cuda.synchronize()
+    if sync:
+        torch.cuda.synchronize()
 
 
 def run_attn(prec, qkv, gates, out, n_seq, L, heads, o_div=1, o_outer=None, o_inner=0, o_tok=1, small=False):
