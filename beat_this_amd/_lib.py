@@ -32,7 +32,7 @@ class PairWeights(C.Structure):
     _fields_ = [("dim", C.c_int32), ("heads", C.c_int32), ("w_qkvg", C.c_void_p * 2), ("b_gates", C.c_void_p),
                 ("w_out", C.c_void_p * 2), ("w_ff1", C.c_void_p * 2), ("b_ff1", C.c_void_p),
                 ("w_ff2", C.c_void_p * 2), ("b_ff2", C.c_void_p), ("w_outp", C.c_void_p * 2),
-                ("w_ff2p", C.c_void_p * 2)]
+                ("w_ff_frag", C.c_void_p * 2)]
 
 
 class ModelDesc(C.Structure):

@@ -97,7 +97,7 @@ int run_pair(const bt_pair_weights& pw, const float* rope, float* x, void* xshad
   GemmP g;
   // main layers in bf16 mode read the bf16 shadow of x (half the operand bytes, no conversion in the k-loop)
   const bool shadow = xshadow != nullptr && prec == BT_PREC_BF16;
-  const bool fused_ok = C <= 128 && pw.w_outp[prec] && pw.w_ff2p[prec];
+  const bool fused_ok = C <= 128 && pw.w_outp[prec] && pw.w_ff_frag[prec];
   if (mode == 1 && fused_ok) {  // whole frequency-direction attention block in one register-resident kernel
     FusedAttnP fa;
     fa.x = x; fa.M = M; fa.C = C; fa.w_qkvg = pw.w_qkvg[prec]; fa.b_gates = pw.b_gates; fa.w_outp = pw.w_outp[prec];
@@ -136,7 +136,7 @@ int run_pair(const bt_pair_weights& pw, const float* rope, float* x, void* xshad
   }
   if (fused_ok) {
     FusedFFP ff;
-    ff.x = x; ff.M = M; ff.C = C; ff.w1 = pw.w_ff1[prec]; ff.b1 = pw.b_ff1; ff.w2p = pw.w_ff2p[prec]; ff.b2 = pw.b_ff2;
+    ff.x = x; ff.M = M; ff.C = C; ff.wfrag = pw.w_ff_frag[prec]; ff.b1 = pw.b_ff1; ff.b2 = pw.b_ff2;
     ff.xb = shadow ? xshadow : nullptr;
     LAUNCH_CAT(CAT_FF_FUSED, s, launch_ff_fused(ff, prec, s), "fused feed-forward");
     return BT_OK;
@@ -349,9 +349,9 @@ int bt_profile_end(double* ms_by_category, int32_t* launches_by_category, int n_
 }
 
 int bt_ff_fused(void* stream, int prec, const bt_pair_weights* w, float* d_x, int64_t M) {
-  if (!w || !d_x || M <= 0 || w->dim > 128 || !w->w_ff2p[prec]) return bt_set_error(BT_ERR_ARG, "bad argument to bt_ff_fused");
+  if (!w || !d_x || M <= 0 || w->dim > 128 || !w->w_ff_frag[prec]) return bt_set_error(BT_ERR_ARG, "bad argument to bt_ff_fused");
   FusedFFP ff;
-  ff.x = d_x; ff.M = M; ff.C = w->dim; ff.w1 = w->w_ff1[prec]; ff.b1 = w->b_ff1; ff.w2p = w->w_ff2p[prec]; ff.b2 = w->b_ff2;
+  ff.x = d_x; ff.M = M; ff.C = w->dim; ff.wfrag = w->w_ff_frag[prec]; ff.b1 = w->b_ff1; ff.b2 = w->b_ff2;
   ff.xb = nullptr;
   LAUNCH(launch_ff_fused(ff, prec, (hipStream_t)stream), "fused feed-forward");
   return BT_OK;

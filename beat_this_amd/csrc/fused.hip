@@ -90,17 +90,53 @@ DEVI void zero16(f32x16& a) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Weights arrive FRAGMENT-MAJOR (pack.py: ff_fragment_major): for hidden block hb the 2*KT
+// operand tiles [W1 rows hb*32.. x k-tile kt | W2p rows mt*32.. x cols hb*32..] are stored as
+// [tile][half h][lane][8 elements], i.e. one contiguous block of 2*KT*32*32 elements per hb whose
+// LDS image is exactly what the lanes read (lane l, half h: 16 B at tile + h*1024 B + l*16 B for
+// bf16).  One workgroup (4 waves = 128 tokens) copies that block global -> LDS once per hb
+// (coalesced 16-byte chunks, double buffered, one barrier per hb) and all four waves read their
+// A fragments from LDS conflict-free.  L2 -> CU weight traffic drops 4x versus per-wave streaming.
+template <typename T> DEVI Frag<T> lds_frag(const char* tile, int lane);
+template <> DEVI Frag<bf16> lds_frag<bf16>(const char* tile, int lane) {
+  Frag<bf16> f;
+  f.v[0] = *reinterpret_cast<const bf16x8*>(tile + lane * 16);
+  f.v[1] = *reinterpret_cast<const bf16x8*>(tile + 1024 + lane * 16);
+  return f;
+}
+template <> DEVI Frag<float> lds_frag<float>(const char* tile, int lane) {
+  Frag<float> f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) f.v[i] = *reinterpret_cast<const f32x4*>(tile + i * 1024 + lane * 16);
+  return f;
+}
+
 template <typename T, int C>
 __global__ __launch_bounds__(256) void ff_fused_kernel(const FusedFFP p) {
   constexpr int KT = C / 32;       // k-tiles of the first GEMM = m-tiles of the second
   constexpr int HB = 4 * C / 32;   // hidden 32-blocks
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  constexpr int TILE_B = 32 * 32 * (int)sizeof(T);   // bytes of one operand tile
+  constexpr int BLK_B = 2 * KT * TILE_B;             // weights of one hidden block
+  constexpr int CHUNKS = BLK_B / 16 / 256;           // 16-byte chunks per thread per block
+  __shared__ __attribute__((aligned(16))) char wl[2 * BLK_B];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 5, lr = lane & 31;
   const long tok = ((long)blockIdx.x * 4 + wave) * 32 + lr;
   const bool ok = tok < p.M;
   float* xrow = p.x + (ok ? tok : 0) * C;
-  const T* W1 = reinterpret_cast<const T*>(p.w1);
-  const T* W2 = reinterpret_cast<const T*>(p.w2p);
+  const char* Wf = reinterpret_cast<const char*>(p.wfrag);
+  typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+
+  u32x4 stg[CHUNKS];
+  auto wload = [&](int hb) {
+#pragma unroll
+    for (int c = 0; c < CHUNKS; ++c) stg[c] = *reinterpret_cast<const u32x4*>(Wf + (long)hb * BLK_B + (c * 256 + tid) * 16);
+  };
+  auto wstore = [&](int buf) {
+#pragma unroll
+    for (int c = 0; c < CHUNKS; ++c) *reinterpret_cast<u32x4*>(wl + buf * BLK_B + (c * 256 + tid) * 16) = stg[c];
+  };
+  wload(0);
 
   float ss = 0.f;
   Frag<T> xf[KT];
@@ -113,13 +149,16 @@ __global__ __launch_bounds__(256) void ff_fused_kernel(const FusedFFP p) {
 #pragma unroll
   for (int mt = 0; mt < KT; ++mt) zero16(acc2[mt]);
 
-#pragma unroll 2
+  wstore(0);
+  __syncthreads();
+#pragma unroll 1
   for (int hb = 0; hb < HB; ++hb) {
+    const char* wb = wl + (hb & 1) * BLK_B;
+    if (hb + 1 < HB) wload(hb + 1);
     f32x16 acc1;
     zero16(acc1);
-    const T* w1p = W1 + (long)(hb * 32 + lr) * C + 16 * g;
 #pragma unroll
-    for (int kt = 0; kt < KT; ++kt) mma32(acc1, ldg_frag<T>(w1p + kt * 32), xf[kt]);
+    for (int kt = 0; kt < KT; ++kt) mma32(acc1, lds_frag<T>(wb + kt * TILE_B, lane), xf[kt]);
     float h[16];
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
@@ -128,9 +167,10 @@ __global__ __launch_bounds__(256) void ff_fused_kernel(const FusedFFP p) {
       for (int j = 0; j < 4; ++j) h[4 * a + j] = gelu_erf(fmaf(acc1[4 * a + j], scale, b[j]));
     }
     const Frag<T> hf = pack_frag<T>(h);
-    const T* w2p = W2 + (long)lr * (4 * C) + hb * 32 + 16 * g;
 #pragma unroll
-    for (int mt = 0; mt < KT; ++mt) mma32(acc2[mt], ldg_frag<T>(w2p + (long)mt * 32 * (4 * C)), hf);
+    for (int mt = 0; mt < KT; ++mt) mma32(acc2[mt], lds_frag<T>(wb + (KT + mt) * TILE_B, lane), hf);
+    if (hb + 1 < HB) wstore((hb + 1) & 1);
+    __syncthreads();
   }
   if (ok) {
 #pragma unroll

@@ -65,8 +65,8 @@ int launch_attn_small(const AttnP& p, int prec, hipStream_t s);  // L in {8,16,3
 // ---- register-chained fused frontend blocks (fused.hip), C in {32, 64, 128} ----------------------
 struct FusedFFP {
   float* x; long M; int C;           // residual stream [M, C] fp32, updated in place
-  const void* w1; const float* b1;   // [4C (padded), C] with FF gamma folded; [4C]
-  const void* w2p; const float* b2;  // [C (padded), 4C] columns in PERM32 order; [C]
+  const void* wfrag;                 // W1 (gamma folded) and PERM32'd W2 in fragment-major order (fused.hip)
+  const float* b1; const float* b2;  // [4C], [C]
   void* xb;                          // optional bf16 shadow of the updated x (same layout), may be null
 };
 int launch_ff_fused(const FusedFFP& p, int prec, hipStream_t s);

@@ -24,6 +24,28 @@ def perm32(w: torch.Tensor) -> torch.Tensor:
     return w.reshape(n, k // 32, 32)[:, :, idx].reshape(n, k).contiguous()
 
 
+def fragment_tiles(w: torch.Tensor) -> torch.Tensor:
+    """[R, K] (R, K multiples of 32) -> [R/32, K/32, 64, 16]: per 32x32 tile, lane l = (row l & 31,
+    16 contiguous k at 16 * (l >> 5)) -- the A/B operand fragment of one lane (csrc/common.h)."""
+    r, k = w.shape
+    t = w.reshape(r // 32, 32, k // 32, 2, 16)           # [rt, row, kt, g, i]
+    return t.permute(0, 2, 3, 1, 4).reshape(r // 32, k // 32, 64, 16)  # lane = g * 32 + row
+
+
+def ff_fragment_major(w1: torch.Tensor, w2p: torch.Tensor, elem_per_piece: int) -> torch.Tensor:
+    """Fragment-major FF weights for ff_fused_kernel: per hidden block hb, KT tiles of W1 then KT tiles of
+    PERM32'd W2; inside a tile the 16 elements of a lane are split into pieces of ``elem_per_piece``
+    (8 for bf16 = one 16-byte read, 4 for fp32) stored piece-major: [piece][lane][elem]."""
+    dim = w1.shape[1]
+    kt = dim // 32
+    t1 = fragment_tiles(w1)                      # [HB, KT, 64, 16]
+    t2 = fragment_tiles(w2p).permute(1, 0, 2, 3)  # [HB (col block), KT (row tile), 64, 16]
+    blk = torch.cat([t1, t2], dim=1)             # [HB, 2 KT, 64, 16]
+    pieces = 16 // elem_per_piece
+    blk = blk.reshape(blk.shape[0], 2 * kt, 64, pieces, elem_per_piece).permute(0, 1, 3, 2, 4)
+    return blk.contiguous().reshape(-1)
+
+
 def _pad_rows(w: torch.Tensor, mult: int = 128) -> torch.Tensor:
     n = w.shape[0]
     n_pad = (n + mult - 1) // mult * mult
@@ -117,7 +139,12 @@ class PackedModel:
         pw.w_out[0], pw.w_out[1] = self._mat(sd[pa + "to_out.0.weight"])
         if dim <= 128:
             pw.w_outp[0], pw.w_outp[1] = self._mat(perm32(sd[pa + "to_out.0.weight"]))
-            pw.w_ff2p[0], pw.w_ff2p[1] = self._mat(perm32(sd[pf + "net.4.weight"]))
+            w1 = (sd[pf + "net.1.weight"] * sd[pf + "net.0.gamma"][None, :]).to(torch.float32)
+            w2p = perm32(sd[pf + "net.4.weight"].to(torch.float32))
+            f32 = ff_fragment_major(w1, w2p, 4).to(self.device)
+            b16 = ff_fragment_major(w1, w2p, 8).to(torch.bfloat16).to(self.device)
+            self._keep += [f32, b16]
+            pw.w_ff_frag[0], pw.w_ff_frag[1] = f32.data_ptr(), b16.data_ptr()
         gf = sd[pf + "net.0.gamma"]
         pw.w_ff1[0], pw.w_ff1[1] = self._mat(sd[pf + "net.1.weight"] * gf[None, :])
         pw.b_ff1 = self._f32(sd[pf + "net.1.bias"])

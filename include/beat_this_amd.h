@@ -48,8 +48,12 @@ typedef struct {
   /* PERM32 copies (columns reordered inside every block of 32: new[16 g + r] = old[(r & 3) +
    * 8 (r >> 2) + 4 g], g in {0,1}, r in [0,16)) consumed by the register-chained fused kernels of
    * csrc/fused.hip; only used for dim <= 128 (frontend), may be NULL otherwise. */
-  const void* w_outp[2];
-  const void* w_ff2p[2];
+  const void* w_outp[2];   /* to_out.0.weight, PERM32 columns, [dim padded][dim] */
+  /* FF weights for ff_fused_kernel, fragment-major: for each hidden block hb (32 hidden units):
+   * dim/32 tiles of W1 (rows hb*32.., k-tile kt) then dim/32 tiles of PERM32'd W2 (rows mt*32..,
+   * cols hb*32..); a tile is [half h][lane 0..63][8] (bf16) or [quarter][lane][4] (fp32) with
+   * element (lane, i) = W[tile_row0 + (lane & 31)][tile_col0 + 16 (lane >> 5) + i], i in [0,16). */
+  const void* w_ff_frag[2];
 } bt_pair_weights;
 
 /* Packed BeatThis weights (beat_tracker.py:38-106).  Host-side packing is done by
