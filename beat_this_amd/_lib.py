@@ -15,8 +15,9 @@ import torch  # noqa: F401  (must precede loading the HIP library)
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(PKG_DIR, "libbeat_this_amd.so")
-SOURCES = ["gemm.hip", "gemm2.hip", "attn.hip", "fused.hip", "frontend.hip", "logmel.hip", "engine.hip"]
-HEADERS = ["common.h", "kernels.h", os.path.join("..", "..", "include", "beat_this_amd.h")]
+SOURCES = ["gemm.hip", "gemm2.hip", "attn.hip", "attn2.hip", "fused.hip", "qkv_front.hip", "frontend.hip", "logmel.hip",
+           "engine.hip"]
+HEADERS = ["common.h", "chain.h", "kernels.h", os.path.join("..", "..", "include", "beat_this_amd.h")]
 
 BT_OK, BT_ERR_ARG, BT_ERR_HIP, BT_ERR_WORKSPACE = 0, -1, -2, -3
 PREC_F32, PREC_BF16 = 0, 1
@@ -32,7 +33,7 @@ class PairWeights(C.Structure):
     _fields_ = [("dim", C.c_int32), ("heads", C.c_int32), ("w_qkvg", C.c_void_p * 2), ("b_gates", C.c_void_p),
                 ("w_out", C.c_void_p * 2), ("w_ff1", C.c_void_p * 2), ("b_ff1", C.c_void_p),
                 ("w_ff2", C.c_void_p * 2), ("b_ff2", C.c_void_p), ("w_outp", C.c_void_p * 2),
-                ("w_ff_frag", C.c_void_p * 2)]
+                ("w_ff_frag", C.c_void_p * 2), ("w_qkv_frag", C.c_void_p)]
 
 
 class ModelDesc(C.Structure):
@@ -66,6 +67,13 @@ class AttnArgs(C.Structure):
                 ("o_div", C.c_int32), ("o_outer", C.c_int64), ("o_inner", C.c_int64), ("o_tok", C.c_int64)]
 
 
+class AttnFragArgs(C.Structure):
+    _fields_ = [("q", C.c_void_p), ("k", C.c_void_p), ("v", C.c_void_p), ("gates", C.c_void_p), ("out", C.c_void_p),
+                ("n_seq", C.c_int32), ("L", C.c_int32), ("heads", C.c_int32), ("inner", C.c_int32),
+                ("nbp", C.c_int32), ("o_div", C.c_int32), ("o_outer", C.c_int64), ("o_inner", C.c_int64),
+                ("o_tok", C.c_int64)]
+
+
 EXPORTS = {
     "bt_last_error": (C.c_char_p, []),
     "bt_version": (C.c_int, []),
@@ -86,6 +94,10 @@ EXPORTS = {
     "bt_profile_end": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "bt_gemm": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(GemmArgs)]),
     "bt_attention": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(AttnArgs), C.c_int]),
+    "bt_attn_frag_blocks": (C.c_int, [C.c_int]),
+    "bt_attention_frag": (C.c_int, [C.c_void_p, C.POINTER(AttnFragArgs)]),
+    "bt_qkv_front": (C.c_int, [C.c_void_p, C.POINTER(PairWeights), C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     "bt_ff_fused": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(PairWeights), C.c_void_p, C.c_int64]),
     "bt_attn_freq_fused": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(PairWeights), C.c_void_p, C.c_void_p, C.c_int64]),
 }

@@ -1,0 +1,357 @@
+// bf16 flash attention on FRAGMENT-MAJOR operands (head_dim = 32, non-causal, no mask), the
+// BT_PREC_BF16 replacement of attn_flash_kernel for the time-direction and main-transformer
+// attention (roformer.py:67-80,125-131).
+//
+// Operand layout (written by the QKV producers, csrc/qkv_front.hip and the QKV epilogue of
+// csrc/gemm3.hip, straight from their MFMA accumulators with fully contiguous stores):
+// per (sequence, head) a run of 32-token blocks, one block = 2 KB = what the 64 lanes of a wave
+// read as MFMA operand fragments, in lane order:
+//   Q, K block : [quarter a = 0..3][token 0..31][8 dims 8a..8a+7]          (16 B per entry)
+//                lane (token lr, half g) reads entries (2g, lr) and (2g+1, lr): dims [16g, 16g+16)
+//   V block    : [s = 0..1][lane = 32 g + d][8 tokens crow(8s+j, g), j = 0..7]
+//                i.e. V^T with the token order of MFMA C registers 8s..8s+7
+// so a K/V tile is copied global -> LDS linearly (global_load_lds, 16 B per lane, no VGPRs), every
+// fragment is ONE conflict-free ds_read_b128, and nothing is transposed or shuffled anywhere.
+//
+// Softmax: S^T = K . Q^T puts one query per lane (16 of its 32 key scores per lane-half).  d = 32
+// makes this kernel VALU-bound (4 MFMAs per 512 exp), so the per-score work is cut to
+// exp + add + half a cvt_pk:
+//   * the running-max subtraction rides on the MFMA: the accumulator INPUT of the score MFMA is a
+//     register block holding -m (q is pre-scaled by log2(e)/sqrt(32), RoPE applied by the producer);
+//   * m is fixed per query from the first key block; later scores may exceed it, which is exact in
+//     fp32/bf16 (common factor 2^-m cancels in O / l) unless exp2 overflows.  Overflow or a sum
+//     >= 1e30 is detected on l at the end and the whole workgroup then re-runs the classic
+//     online-softmax loop (SAFE pass), so the result is always the exact softmax.
+#include <cstdlib>
+
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+constexpr int KB = 4;                    // 32-key blocks per LDS tile (128 keys)
+constexpr int BLK_BYTES = 2048;          // one fragment-major block
+constexpr int TILE_BYTES = KB * BLK_BYTES;
+constexpr int SMEM_BYTES = 2 * 2 * TILE_BYTES + 16;  // [buffer][K | V] + fallback flag
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+DEVI void zero16(f32x16& a) {
+#pragma unroll
+  for (int r = 0; r < 16; ++r) a[r] = 0.f;
+}
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+// 8 probabilities -> 4 dwords of packed bf16 (one v_cvt_pk_bf16_f32 each).  Operands are assembled from
+// these dwords by bit casts only: bf16-vector shuffles make hipcc (ROCm 7.2) emit 3x the conversions.
+DEVI u32x4 pack8(const f32x16& p, int s) {
+  u32x4 w;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const bf16x2 t = {(bf16)p[8 * s + 2 * j], (bf16)p[8 * s + 2 * j + 1]};
+    w[j] = __builtin_bit_cast(unsigned int, t);
+  }
+  return w;
+}
+// l += sum of this lane's 8 bf16 probabilities: D = ones(4x4) . B puts, in every output register of a
+// lane, the sum of the 4 k-values that lane supplied as B (16 independent 4x4x4 blocks, column j of
+// block b lives in lane 4b + j for B and D alike; checked by tools/ubench/mfma444_probe.hip), so the
+// row sums cost no VALU issue slots.
+DEVI void rowsum8(f32x4& l, const u32x4& w) {
+  const s16x4 ones = {0x3f80, 0x3f80, 0x3f80, 0x3f80};
+  l = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(ones, __builtin_bit_cast(s16x4, u32x2{w[0], w[1]}), l, 0, 0, 0);
+  l = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(ones, __builtin_bit_cast(s16x4, u32x2{w[2], w[3]}), l, 0, 0, 0);
+}
+
+// Per-query-block softmax state of a wave (QB query blocks of 32 queries share every K / V fragment read).
+struct QState {
+  bf16x8 q0, q1;   // Q^T operand: dims [16g, 16g+8) and [16g+8, 16g+16) of this lane's query
+  f32x16 negm;     // -m splat: accumulator input of the score MFMA (fast pass)
+  f32x16 acc;      // O^T accumulator
+  f32x4 l;         // row sum (all four registers equal)
+  float m;         // running max (SAFE pass) / reference max (fast pass)
+};
+
+// One 32-key block against the QB query blocks of this wave: scores, probabilities, O^T += V^T . P^T.
+// ABL: development-only ablations selected by the BT_ATTN_ABL environment variable (timing experiments):
+//   bit 0: stage only the first two tiles (no global traffic afterwards)   bit 1: skip the exponentials
+//   bit 2: no row-sum MFMAs   bit 3: no bf16 conversion   bit 4: no P.V MFMAs   bit 5: no score MFMAs
+//   bit 6: no LDS fragment reads
+struct KFrag { bf16x8 k0, k1; };
+struct VFrag { bf16x8 v0, v1; };
+DEVI KFrag ld_k(const char* kb, int g, int lr) {
+  KFrag f;
+  f.k0 = *reinterpret_cast<const bf16x8*>(kb + ((2 * g) * 32 + lr) * 16);
+  f.k1 = *reinterpret_cast<const bf16x8*>(kb + ((2 * g + 1) * 32 + lr) * 16);
+  return f;
+}
+DEVI VFrag ld_v(const char* vb, int lane) {
+  VFrag f;
+  f.v0 = *reinterpret_cast<const bf16x8*>(vb + lane * 16);
+  f.v1 = *reinterpret_cast<const bf16x8*>(vb + 1024 + lane * 16);
+  return f;
+}
+
+template <bool SAFE, bool MASK, int ABL, int QB>
+DEVI void do_block(const KFrag& kf, const VFrag& vf, int g, QState (&st)[QB], int key0, int L) {
+  const bf16x8 k0 = kf.k0, k1 = kf.k1, v0 = vf.v0, v1 = vf.v1;
+  f32x16 sc[QB];
+#pragma unroll
+  for (int j = 0; j < QB; ++j) {
+    if constexpr ((ABL & 32) != 0) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sc[j][r] = st[j].negm[r] + (float)k0[r & 7];
+      continue;
+    }
+    if constexpr (SAFE) {
+      zero16(sc[j]);
+      sc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, st[j].q0, sc[j], 0, 0, 0);
+    } else {
+      sc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, st[j].q0, st[j].negm, 0, 0, 0);
+    }
+    sc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, st[j].q1, sc[j], 0, 0, 0);
+  }
+#pragma unroll
+  for (int j = 0; j < QB; ++j) {
+    if constexpr (SAFE) {
+      if constexpr (MASK) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (key0 + crow(r, g) >= L) sc[j][r] = -1e30f;
+      }
+      float bm = sc[j][0];
+#pragma unroll
+      for (int r = 1; r < 16; ++r) bm = fmaxf(bm, sc[j][r]);
+      bm = fmaxf(bm, __shfl_xor(bm, 32));
+      const float m_new = fmaxf(st[j].m, bm);
+      const float alpha = __builtin_amdgcn_exp2f(st[j].m - m_new);
+      st[j].m = m_new;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) st[j].l[r] *= alpha;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) st[j].acc[r] *= alpha;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sc[j][r] = __builtin_amdgcn_exp2f(sc[j][r] - m_new);
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sc[j][r] = (ABL & 2) ? sc[j][r] : __builtin_amdgcn_exp2f(sc[j][r]);
+      if constexpr (MASK) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (key0 + crow(r, g) >= L) sc[j][r] = 0.f;
+      }
+    }
+    u32x4 w0, w1;
+    if constexpr ((ABL & 8) != 0) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { w0[r] = __builtin_bit_cast(unsigned, sc[j][r] + sc[j][r + 8]); w1[r] = __builtin_bit_cast(unsigned, sc[j][r + 4] + sc[j][r + 12]); }
+    } else {
+      w0 = pack8(sc[j], 0); w1 = pack8(sc[j], 1);
+    }
+    if constexpr ((ABL & 4) == 0) {
+      rowsum8(st[j].l, w0);
+      rowsum8(st[j].l, w1);
+    }
+    if constexpr ((ABL & 16) != 0) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { st[j].acc[r] += __builtin_bit_cast(float, w0[r]); st[j].acc[r + 4] += __builtin_bit_cast(float, w1[r]); }
+    } else {
+      st[j].acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v0, __builtin_bit_cast(bf16x8, w0), st[j].acc, 0, 0, 0);
+      st[j].acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v1, __builtin_bit_cast(bf16x8, w1), st[j].acc, 0, 0, 0);
+    }
+  }
+}
+
+// Copy K tile `tile` and V tile `tile` (KB blocks each, contiguous in global memory) into LDS buffer
+// `buf`: buffer_load ... lds with ONE per-lane offset register (tid * 16) for the whole kernel, the
+// tile / piece offset in an SGPR, so no address lives in (spillable) VGPRs.
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+DEVI void stage_tile(rsrc_t rk, rsrc_t rv, int tile, char* smem, int buf, int tid, int wave) {
+  char* kd = smem + buf * 2 * TILE_BYTES + wave * 1024;
+  char* vd = kd + TILE_BYTES;
+  const int so = tile * TILE_BYTES;
+  // (the instruction's immediate offset would be added to the LDS address as well: keep it 0)
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, (lptr_t)kd, 16, tid * 16, so, 0, 0);
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, (lptr_t)(kd + 4096), 16, tid * 16, so + 4096, 0, 0);
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (lptr_t)vd, 16, tid * 16, so, 0, 0);
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (lptr_t)(vd + 4096), 16, tid * 16, so + 4096, 0, 0);
+  static_assert(TILE_BYTES == 8192, "stage_tile copies two 4 KB pieces per operand");
+}
+
+template <bool SAFE, int ABL, int QB>
+DEVI void attn_pass(rsrc_t rk, rsrc_t rv, char* smem, int tid, int wave, int lane, int g, int lr, QState (&st)[QB],
+                    int L, int nblk) {
+  const int ntiles = (nblk + KB - 1) / KB;
+  const bool partial = (L & 31) != 0;
+  stage_tile(rk, rv, 0, smem, 0, tid, wave);
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < QB; ++j) {
+    zero16(st[j].negm);
+    zero16(st[j].acc);
+    st[j].l = f32x4{0.f, 0.f, 0.f, 0.f};
+    st[j].m = -1e30f;
+  }
+  if constexpr (!SAFE) {  // reference max of each query: its scores against key block 0
+    const KFrag k00 = ld_k(smem, g, lr);
+    const bf16x8 k0 = k00.k0, k1 = k00.k1;
+#pragma unroll
+    for (int j = 0; j < QB; ++j) {
+      f32x16 sc;
+      zero16(sc);
+      sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, st[j].q0, sc, 0, 0, 0);
+      sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, st[j].q1, sc, 0, 0, 0);
+      float bm = -1e30f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) bm = fmaxf(bm, (crow(r, g) < L) ? sc[r] : -1e30f);
+      bm = fmaxf(bm, __shfl_xor(bm, 32));
+      st[j].m = bm;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) st[j].negm[r] = -bm;
+    }
+  }
+  // Fragment reads are software pipelined by hand: V of block c and K of block c+1 are issued before the
+  // score MFMAs of block c (LDS latency under 16 waves of traffic is several hundred cycles; issued
+  // just-in-time it was the largest stall of the loop).
+  KFrag kf = ld_k(smem, g, lr);
+  for (int t = 0; t < ntiles; ++t) {
+    if (t + 1 < ntiles && !((ABL & 1) && t >= 1)) stage_tile(rk, rv, t + 1, smem, (t + 1) & 1, tid, wave);
+    const char* kb = smem + (t & 1) * 2 * TILE_BYTES;
+    const char* vb = kb + TILE_BYTES;
+    const int nb = min(KB, nblk - t * KB);
+    if (nb == KB && !(partial && t == ntiles - 1)) {
+#pragma unroll
+      for (int c = 0; c < KB; ++c) {
+        const VFrag vf = ld_v(vb + c * BLK_BYTES, lane);
+        KFrag kn = kf;
+        if (c + 1 < KB) kn = ld_k(kb + (c + 1) * BLK_BYTES, g, lr);
+        __builtin_amdgcn_sched_barrier(0);
+        do_block<SAFE, false, ABL, QB>(kf, vf, g, st, (t * KB + c) * 32, L);
+        kf = kn;
+      }
+    } else {
+      for (int c = 0; c < nb; ++c) {
+        const int blk = t * KB + c;
+        const VFrag vf = ld_v(vb + c * BLK_BYTES, lane);
+        if (c > 0) kf = ld_k(kb + c * BLK_BYTES, g, lr);
+        if (partial && blk == nblk - 1)
+          do_block<SAFE, true, 0, QB>(kf, vf, g, st, blk * 32, L);
+        else
+          do_block<SAFE, false, 0, QB>(kf, vf, g, st, blk * 32, L);
+      }
+    }
+    __syncthreads();  // tile t+1 has landed (every wave waited for its own copies), tile t is free
+    if (t + 1 < ntiles) kf = ld_k(smem + ((t + 1) & 1) * 2 * TILE_BYTES, g, lr);
+  }
+}
+
+template <int ABL, int QB>
+__global__ __launch_bounds__(256, (QB == 1 ? 4 : 2)) void attn_frag_kernel(const AttnFragP p, int nqt, int sh_total) {
+  __shared__ __attribute__((aligned(16))) char smem[SMEM_BYTES];
+  // XCD-aware order: the q-tiles of one (sequence, head) run on one XCD (block b -> XCD b % 8), so its
+  // K/V stream is fetched into one L2
+  const int bid = blockIdx.x;
+  const int idx = bid >> 3;
+  const int sh = (idx / nqt) * 8 + (bid & 7);
+  const int qt = idx % nqt;
+  if (sh >= sh_total) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 5, lr = lane & 31;
+  const int L = p.L;
+  const int nblk = (L + 31) >> 5;
+  const long seq_off = (long)sh * p.nbp * BLK_BYTES;
+  const char* kseq = reinterpret_cast<const char*>(p.k) + seq_off;
+  const char* vseq = reinterpret_cast<const char*>(p.v) + seq_off;
+  int* flag = reinterpret_cast<int*>(smem + 4 * TILE_BYTES);
+  if (tid == 0) *flag = 0;
+
+  QState st[QB];
+  const int qb0 = (qt * 4 + wave) * QB;  // this wave's first query block
+#pragma unroll
+  for (int j = 0; j < QB; ++j) {
+    const int qbc = min(qb0 + j, nblk - 1);
+    const char* qblk = reinterpret_cast<const char*>(p.q) + seq_off + (long)qbc * BLK_BYTES;
+    st[j].q0 = *reinterpret_cast<const bf16x8*>(qblk + ((2 * g) * 32 + lr) * 16);
+    st[j].q1 = *reinterpret_cast<const bf16x8*>(qblk + ((2 * g + 1) * 32 + lr) * 16);
+  }
+  const unsigned seq_bytes = (unsigned)p.nbp * BLK_BYTES;
+  const rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(kseq), 0, seq_bytes, 0x00020000);
+  const rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(vseq), 0, seq_bytes, 0x00020000);
+  const long long tc0 = clock64(), tw0 = wall_clock64();
+  attn_pass<false, ABL, QB>(rk, rv, smem, tid, wave, lane, g, lr, st, L, nblk);
+  if constexpr ((ABL & 128) != 0) {  // development: shader-clock ticks vs 100 MHz wall ticks of the pass
+    if (lane == 0) {
+      long long* dbg = reinterpret_cast<long long*>(const_cast<float*>(p.gates));
+      dbg[((long)bid * 4 + wave) * 2] = clock64() - tc0;
+      dbg[((long)bid * 4 + wave) * 2 + 1] = wall_clock64() - tw0;
+    }
+  }
+  float l_tot[QB];
+  bool bad = false;
+#pragma unroll
+  for (int j = 0; j < QB; ++j) {
+    l_tot[j] = st[j].l[0] + __shfl_xor(st[j].l[0], 32);
+    const bool valid = qb0 + j < nblk && (qb0 + j) * 32 + lr < L;
+    bad = bad || (valid && !(l_tot[j] < 1e30f));  // overflow / NaN: this query needs the running-max pass
+  }
+  if (__any(bad) && lane == 0) *flag = 1;
+  __syncthreads();
+  if (*flag) {  // workgroup-uniform
+    __syncthreads();
+    attn_pass<true, 0, QB>(rk, rv, smem, tid, wave, lane, g, lr, st, L, nblk);
+#pragma unroll
+    for (int j = 0; j < QB; ++j) l_tot[j] = st[j].l[0] + __shfl_xor(st[j].l[0], 32);
+  }
+
+  const int seq = sh / p.heads, head = sh - seq * p.heads;
+#pragma unroll
+  for (int j = 0; j < QB; ++j) {
+    const int qi = (qb0 + j) * 32 + lr;
+    if (qb0 + j < nblk && qi < L) {
+      const float gate = p.gates[(long)sh * p.nbp * 32 + qi];
+      const float scale = gate / l_tot[j];
+      const long orow = (long)(seq / p.o_div) * p.o_outer + (long)(seq % p.o_div) * p.o_inner + (long)qi * p.o_tok;
+      bf16* op = reinterpret_cast<bf16*>(p.out) + orow * p.inner + head * 32 + 4 * g;
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        const bf16x4 o = {(bf16)(st[j].acc[4 * a] * scale), (bf16)(st[j].acc[4 * a + 1] * scale),
+                          (bf16)(st[j].acc[4 * a + 2] * scale), (bf16)(st[j].acc[4 * a + 3] * scale)};
+        *reinterpret_cast<bf16x4*>(op + 8 * a) = o;
+      }
+    }
+  }
+}
+
+}  // namespace
+
+int attn_frag_blocks(int L) { return ((L + 31) / 32 + KB - 1) / KB * KB; }
+
+template <int ABL, int QB>
+static void launch_v(const AttnFragP& p, hipStream_t s) {
+  const int nblk = (p.L + 31) / 32;
+  const int nqt = (nblk + 4 * QB - 1) / (4 * QB);
+  const long sh = (long)p.n_seq * p.heads;
+  const long grid = (sh + 7) / 8 * 8 * nqt;
+  hipLaunchKernelGGL((attn_frag_kernel<ABL, QB>), dim3((unsigned)grid), dim3(256), 0, s, p, nqt, (int)sh);
+}
+
+int launch_attn_frag(const AttnFragP& p, hipStream_t s) {
+  if (p.L <= 0 || p.n_seq <= 0 || p.heads <= 0 || p.inner != p.heads * 32 || p.nbp < attn_frag_blocks(p.L)) return -2;
+  if ((long)p.n_seq * p.heads * ((p.L + 127) / 128) > 0x3fffffffL) return -3;
+  // development switches: BT_ATTN_ABL (ablations, see do_block), BT_ATTN_QB (query blocks per wave)
+  static const int abl = getenv("BT_ATTN_ABL") ? atoi(getenv("BT_ATTN_ABL")) : 0;
+  static const int qb = getenv("BT_ATTN_QB") ? atoi(getenv("BT_ATTN_QB")) : 1;
+  if (qb == 2) {
+    launch_v<0, 2>(p, s);
+  } else {
+    switch (abl) {
+      case 1: launch_v<1, 1>(p, s); break;
+      case 3: launch_v<3, 1>(p, s); break;
+      case 128: launch_v<128, 1>(p, s); break;
+      default: launch_v<0, 1>(p, s);
+    }
+  }
+  return (int)hipGetLastError();
+}

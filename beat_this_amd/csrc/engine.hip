@@ -52,6 +52,7 @@ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 struct Workspace {
   float* xa; float* xb; float* xm; float* gates; void* xmb;
   void* qkv; void* ao; void* hid;
+  void* qf; void* kf; void* vf; float* gates_h; int nbp;  // fragment-major attention operands (bf16 path)
   size_t total;
 };
 
@@ -70,6 +71,13 @@ Workspace carve(char* base, int B, int T, int D, int prec) {
   w.qkv = take(bt * 3 * dmax * es);
   w.ao = take(bt * dmax * es);
   w.hid = take(bt * 4 * dmax * es);
+  w.nbp = attn_frag_blocks(T);
+  w.qf = w.kf = w.vf = nullptr; w.gates_h = nullptr;
+  if (prec == BT_PREC_BF16) {  // (sequences x heads) = 32 B in the frontend, (D / 32) B in the main layers
+    const size_t sh = (size_t)B * std::max(32, D / 32);
+    w.qf = take(sh * w.nbp * 2048); w.kf = take(sh * w.nbp * 2048); w.vf = take(sh * w.nbp * 2048);
+    w.gates_h = (float*)take(sh * w.nbp * 32 * 4);
+  }
   w.total = off;
   return w;
 }
@@ -103,6 +111,22 @@ int run_pair(const bt_pair_weights& pw, const float* rope, float* x, void* xshad
     fa.x = x; fa.M = M; fa.C = C; fa.w_qkvg = pw.w_qkvg[prec]; fa.b_gates = pw.b_gates; fa.w_outp = pw.w_outp[prec];
     fa.rope = rope;
     LAUNCH_CAT(CAT_ATTN_FREQ_FUSED, s, launch_attn_freq_fused(fa, prec, s), "fused frequency attention");
+  } else if (mode == 2 && fused_ok && prec == BT_PREC_BF16 && pw.w_qkv_frag) {
+    // bf16 time direction: fragment-major QKV straight from the projection, flash attention on it
+    QkvFrontP qp;
+    memset(&qp, 0, sizeof qp);
+    qp.x = x; qp.B = B; qp.T = T; qp.F = F; qp.C = C; qp.wfrag = pw.w_qkv_frag; qp.b_gates = pw.b_gates; qp.rope = rope;
+    qp.q = ws.qf; qp.k = ws.kf; qp.v = ws.vf; qp.gates = ws.gates_h; qp.nbp = ws.nbp;
+    LAUNCH_CAT(CAT_QKV, s, launch_qkv_front(qp, s), "frontend qkv projection");
+    AttnFragP a;
+    memset(&a, 0, sizeof a);
+    a.q = ws.qf; a.k = ws.kf; a.v = ws.vf; a.gates = ws.gates_h; a.out = ws.ao; a.n_seq = B * F; a.L = T; a.heads = H;
+    a.inner = C; a.nbp = ws.nbp; a.o_div = F; a.o_outer = (long)T * F; a.o_inner = 1; a.o_tok = F;
+    LAUNCH_CAT(CAT_ATTN_FLASH, s, launch_attn_frag(a, s), "time attention");
+    memset(&g, 0, sizeof g);
+    g.A = ws.ao; g.lda = C; g.W = pw.w_out[prec]; g.M = (int)M; g.N = C; g.K = C;
+    g.epi = GEMM_EPI_RESID; g.flags = 0; g.x = x; g.ldx = C; g.xb = nullptr;
+    LAUNCH_CAT(CAT_OUT, s, launch_gemm(g, prec, s), "out-proj gemm");
   } else {
   // ---- q|k|v|gates = RMSNorm(x) . W^T, RoPE, sigmoid ------------------------------------
   memset(&g, 0, sizeof g);
@@ -166,6 +190,7 @@ void bt_struct_sizes(int32_t* out) {
   out[2] = (int32_t)sizeof(bt_logmel_tables); out[3] = (int32_t)sizeof(bt_gemm_args);
   out[4] = (int32_t)sizeof(bt_attn_args); out[5] = (int32_t)offsetof(bt_model_desc, layers);
   out[6] = (int32_t)offsetof(bt_model_desc, rope);
+  out[7] = (int32_t)sizeof(bt_attn_frag_args);
 }
 
 int bt_engine_create(const bt_model_desc* desc, bt_engine** out) {
@@ -391,6 +416,31 @@ int bt_attention(void* stream, int prec, const bt_attn_args* a, int small_kernel
     LAUNCH(launch_attn_small(p, prec, (hipStream_t)stream), "attention (small)");
   else
     LAUNCH(launch_attn_flash(p, prec, (hipStream_t)stream), "attention (flash)");
+  return BT_OK;
+}
+
+int bt_attn_frag_blocks(int L) { return L > 0 ? attn_frag_blocks(L) : 0; }
+
+int bt_attention_frag(void* stream, const bt_attn_frag_args* a) {
+  if (!a || !a->q || !a->k || !a->v || !a->gates || !a->out) return bt_set_error(BT_ERR_ARG, "null argument");
+  AttnFragP p;
+  memset(&p, 0, sizeof p);
+  p.q = a->q; p.k = a->k; p.v = a->v; p.gates = a->gates; p.out = a->out; p.n_seq = a->n_seq; p.L = a->L;
+  p.heads = a->heads; p.inner = a->inner; p.nbp = a->nbp; p.o_div = a->o_div; p.o_outer = a->o_outer;
+  p.o_inner = a->o_inner; p.o_tok = a->o_tok;
+  LAUNCH(launch_attn_frag(p, (hipStream_t)stream), "attention (fragment-major)");
+  return BT_OK;
+}
+
+int bt_qkv_front(void* stream, const bt_pair_weights* w, const float* d_rope, const float* d_x, int B, int T, int F,
+                 void* d_q, void* d_k, void* d_v, float* d_gates, int nbp) {
+  if (!w || !w->w_qkv_frag || !d_rope || !d_x || !d_q || !d_k || !d_v || !d_gates || w->dim > 128)
+    return bt_set_error(BT_ERR_ARG, "bad argument to bt_qkv_front");
+  QkvFrontP p;
+  memset(&p, 0, sizeof p);
+  p.x = d_x; p.B = B; p.T = T; p.F = F; p.C = w->dim; p.wfrag = w->w_qkv_frag; p.b_gates = w->b_gates; p.rope = d_rope;
+  p.q = d_q; p.k = d_k; p.v = d_v; p.gates = d_gates; p.nbp = nbp;
+  LAUNCH(launch_qkv_front(p, (hipStream_t)stream), "frontend qkv projection");
   return BT_OK;
 }
 

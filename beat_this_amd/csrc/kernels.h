@@ -60,6 +60,31 @@ struct AttnP {
   long o_outer, o_inner, o_tok;
 };
 int launch_attn_flash(const AttnP& p, int prec, hipStream_t s);
+
+// bf16 attention on fragment-major operands (attn2.hip; layout described there)
+struct AttnFragP {
+  const void* q; const void* k; const void* v;  // [n_seq * heads][nbp][1024] bf16
+  const float* gates;                            // [n_seq * heads][nbp * 32] fp32
+  void* out;                                     // bf16 [rows, inner], row mapping as AttnP
+  int n_seq, L, heads, inner, nbp;
+  int o_div;
+  long o_outer, o_inner, o_tok;
+};
+int attn_frag_blocks(int L);  // 32-token blocks to allocate per (sequence, head): ceil(L/32) rounded up to a tile
+int launch_attn_frag(const AttnFragP& p, hipStream_t s);
+
+// time-direction QKV projection of the frontend (qkv_front.hip), bf16, fragment-major outputs
+struct QkvFrontP {
+  const float* x;        // residual stream [B, T, F, C] fp32
+  int B, T, F, C;
+  const void* wfrag;     // bt_pair_weights.w_qkv_frag
+  const float* b_gates;  // [C / 32]
+  const float* rope;     // [pos][16][2]
+  void* q; void* k; void* v;  // [B * F * heads][nbp][1024] bf16
+  float* gates;          // [B * F * heads][nbp * 32]
+  int nbp;
+};
+int launch_qkv_front(const QkvFrontP& p, hipStream_t s);
 int launch_attn_small(const AttnP& p, int prec, hipStream_t s);  // L in {8,16,32}, heads*L == 32
 
 // ---- register-chained fused frontend blocks (fused.hip), C in {32, 64, 128} ----------------------

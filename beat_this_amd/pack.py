@@ -46,6 +46,18 @@ def ff_fragment_major(w1: torch.Tensor, w2p: torch.Tensor, elem_per_piece: int) 
     return blk.contiguous().reshape(-1)
 
 
+def qkv_fragment_major(w: torch.Tensor, dim: int) -> torch.Tensor:
+    """bf16 QKV+gate weights for qkv_front_kernel: ``w`` = [3 dim + heads (padded to >= 3 dim + 32), dim];
+    per head the k-tiles of its q, k, v row blocks, then the k-tiles of the gate row block; a tile is
+    [half h][lane][8] (see fragment_tiles)."""
+    heads = dim // 32
+    t = fragment_tiles(w[:3 * dim + 32])                       # [3 heads + 1, KT, 64, 16]
+    order = [blk * heads + hd for hd in range(heads) for blk in range(3)] + [3 * heads]
+    t = t[order]                                               # [(hd, q|k|v)..., gate][KT][64][16]
+    t = t.reshape(t.shape[0], t.shape[1], 64, 2, 8).permute(0, 1, 3, 2, 4)
+    return t.contiguous().reshape(-1)
+
+
 def _pad_rows(w: torch.Tensor, mult: int = 128) -> torch.Tensor:
     n = w.shape[0]
     n_pad = (n + mult - 1) // mult * mult
@@ -135,6 +147,10 @@ class PackedModel:
         wg = sd[pa + "to_gates.weight"]
         w = torch.cat([wqkv, wg], 0) * ga[None, :]
         pw.w_qkvg[0], pw.w_qkvg[1] = self._mat(w)
+        if dim <= 128:
+            qf = qkv_fragment_major(_pad_rows(w.to(torch.float32)), dim).to(torch.bfloat16).to(self.device)
+            self._keep.append(qf)
+            pw.w_qkv_frag = qf.data_ptr()
         pw.b_gates = self._f32(sd[pa + "to_gates.bias"])
         pw.w_out[0], pw.w_out[1] = self._mat(sd[pa + "to_out.0.weight"])
         if dim <= 128:

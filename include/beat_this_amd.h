@@ -54,6 +54,11 @@ typedef struct {
    * cols hb*32..); a tile is [half h][lane 0..63][8] (bf16) or [quarter][lane][4] (fp32) with
    * element (lane, i) = W[tile_row0 + (lane & 31)][tile_col0 + 16 (lane >> 5) + i], i in [0,16). */
   const void* w_ff_frag[2];
+  /* bf16 QKV+gate weights for qkv_front_kernel (time-direction attention of the frontend, dim <= 128),
+   * fragment-major tiles [half h][lane][8] as above, in the order: for every head hd the dim/32 k-tiles
+   * of its 32 q rows, then of its k rows, then of its v rows; after the last head dim/32 tiles of the
+   * gate rows (w_qkvg rows 3 dim .. 3 dim + 31).  NULL for dim > 128. */
+  const void* w_qkv_frag;
 } bt_pair_weights;
 
 /* Packed BeatThis weights (beat_tracker.py:38-106).  Host-side packing is done by
@@ -90,7 +95,8 @@ typedef struct {
 const char* bt_last_error(void);
 int bt_version(void);
 /* sizeof/offsetof of the structs above as this library was compiled (binding self-check):
- * out[7] = {pair_weights, model_desc, logmel_tables, gemm_args, attn_args, offsetof layers, offsetof rope} */
+ * out[8] = {pair_weights, model_desc, logmel_tables, gemm_args, attn_args, offsetof layers, offsetof rope,
+ * attn_frag_args} */
 void bt_struct_sizes(int32_t* out);
 
 /* BeatThis(**hparams) + load_state_dict (inference.py:56-87): keeps a copy of `desc`. */
@@ -160,6 +166,20 @@ typedef struct {
   int32_t n_seq, L, heads, inner, o_div; int64_t o_outer, o_inner, o_tok;
 } bt_attn_args;
 int bt_attention(void* stream, int prec, const bt_attn_args* a, int small_kernel);
+
+/* bf16 attention on FRAGMENT-MAJOR operands (csrc/attn2.hip): per (sequence, head) `nbp` blocks of
+ * 32 tokens, 2 KB each.  Q/K block: [quarter a][token][8 dims 8a..8a+7]; V block: [s][lane = 32 g + d]
+ * [8 tokens 16 s + 8 (j >> 2) + 4 g + (j & 3)]; gates [n_seq * heads][nbp * 32] fp32.  q must be
+ * pre-scaled by log2(e)/sqrt(32).  nbp >= bt_attn_frag_blocks(L).  Output as bt_attention (bf16). */
+typedef struct {
+  const void* q; const void* k; const void* v; const float* gates; void* out;
+  int32_t n_seq, L, heads, inner, nbp, o_div; int64_t o_outer, o_inner, o_tok;
+} bt_attn_frag_args;
+int bt_attn_frag_blocks(int L);
+int bt_attention_frag(void* stream, const bt_attn_frag_args* a);
+/* Time-direction QKV projection of a frontend block: d_x [B,T,F,C] fp32 -> fragment-major q, k, v, gates */
+int bt_qkv_front(void* stream, const bt_pair_weights* w, const float* d_rope, const float* d_x, int B, int T, int F,
+                 void* d_q, void* d_k, void* d_v, float* d_gates, int nbp);
 /* x[M,C] += FF(x) / x += frequency-direction attention(x) with one bt_pair_weights, dim = C <= 128 */
 int bt_ff_fused(void* stream, int prec, const bt_pair_weights* w, float* d_x, int64_t M);
 int bt_attn_freq_fused(void* stream, int prec, const bt_pair_weights* w, const float* d_rope, float* d_x, int64_t M);

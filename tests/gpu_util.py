@@ -69,3 +69,44 @@ def pad_rows(w, mult=128):
     out = torch.zeros((npad, w.shape[1]), dtype=w.dtype)
     out[:n] = w
     return out
+
+
+# ---- fragment-major attention operands (csrc/attn2.hip) ---------------------------------------------
+def frag_qk(x, nbp):
+    """[SH, L, 32] -> bf16 [SH, nbp, 4 (quarter), 32 (token), 8]"""
+    SH, L, _ = x.shape
+    pad = torch.zeros((SH, nbp * 32, 32), dtype=x.dtype)
+    pad[:, :L] = x
+    return pad.view(SH, nbp, 32, 4, 8).permute(0, 1, 3, 2, 4).contiguous().to(torch.bfloat16)
+
+
+def unfrag_qk(fr, L):
+    SH, nbp = fr.shape[:2]
+    return fr.view(SH, nbp, 4, 32, 8).permute(0, 1, 3, 2, 4).reshape(SH, nbp * 32, 32)[:, :L]
+
+
+def frag_v(x, nbp):
+    """[SH, L, 32] -> bf16 [SH, nbp, 2 (s), 2 (g), 32 (d), 8]; token = 16 s + 8 (j >> 2) + 4 g + (j & 3)"""
+    SH, L, _ = x.shape
+    pad = torch.zeros((SH, nbp * 32, 32), dtype=x.dtype)
+    pad[:, :L] = x
+    t = pad.view(SH, nbp, 2, 2, 2, 4, 32)           # [s][jh][g][jl][d]
+    return t.permute(0, 1, 2, 4, 6, 3, 5).contiguous().view(SH, nbp, 2, 2, 32, 8).to(torch.bfloat16)
+
+
+def unfrag_v(fr, L):
+    SH, nbp = fr.shape[:2]
+    t = fr.view(SH, nbp, 2, 2, 32, 2, 4)             # [s][g][d][jh][jl]
+    return t.permute(0, 1, 2, 5, 3, 6, 4).reshape(SH, nbp * 32, 32)[:, :L]
+
+
+def run_attn_frag(qf, kf, vf, gates, out, n_seq, L, heads, nbp, o_div=1, o_outer=None, o_inner=0, o_tok=1):
+    from beat_this_amd import _lib
+
+    a = _lib.AttnFragArgs()
+    a.q, a.k, a.v, a.gates, a.out = qf.data_ptr(), kf.data_ptr(), vf.data_ptr(), gates.data_ptr(), out.data_ptr()
+    a.n_seq, a.L, a.heads, a.inner, a.nbp, a.o_div = n_seq, L, heads, heads * 32, nbp, o_div
+    a.o_outer = L if o_outer is None else o_outer
+    a.o_inner, a.o_tok = o_inner, o_tok
+    _lib.check(_lib.lib().bt_attention_frag(_lib.stream_ptr(dev()), C.byref(a)))
+    torch.cuda.synchronize()

@@ -1,0 +1,171 @@
+"""Parity of the fragment-major bf16 attention path on the MI355X (csrc/attn2.hip, csrc/qkv_front.hip)
+against float64 torch restatements of roformer.py:83-132: attention on pre-arranged operands (all
+sequence-length edge cases, the time-direction row scatter, the overflow fallback), and the frontend's
+time-direction QKV projection producing those operands."""
+import ctypes as Ct
+import math
+
+import pytest
+import torch
+
+from gpu_util import dev, frag_qk, frag_v, report, run_attn_frag, unfrag_qk, unfrag_v
+
+pytestmark = pytest.mark.gpu
+
+
+def _mk(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(shape, generator=g, dtype=torch.float64) * scale
+
+
+def _rel(a, ref):
+    return float((a.double().cpu() - ref).abs().max() / ref.abs().max().clamp_min(1e-30))
+
+
+def _attn_ref(q, k, v, gates):
+    s = q @ k.transpose(-1, -2) * math.log(2.0)  # q carries log2(e)/sqrt(d): softmax in base 2
+    return torch.softmax(s, -1) @ v * gates[..., None]
+
+
+def _run(q, k, v, gates, n_seq, L, heads, **omap):
+    """q, k, v: [SH, L, 32] float64 (already bf16-representable); gates [SH, L]."""
+    from beat_this_amd import _lib as Lb
+
+    nbp = Lb.lib().bt_attn_frag_blocks(L)
+    SH = n_seq * heads
+    gh = torch.zeros((SH, nbp * 32), dtype=torch.float32)
+    gh[:, :L] = gates.float()
+    rows = n_seq * L
+    out = torch.zeros((rows, heads * 32), dtype=torch.bfloat16, device=dev())
+    # poison the padding blocks of K/V beyond ceil(L/32): they must never be consumed
+    kf, vf = frag_qk(k.float(), nbp), frag_v(v.float(), nbp)
+    nblk = (L + 31) // 32
+    kf[:, nblk:] = float("nan")
+    vf[:, nblk:] = float("nan")
+    run_attn_frag(frag_qk(q.float(), nbp).to(dev()), kf.to(dev()), vf.to(dev()), gh.to(dev()), out, n_seq, L, heads, nbp,
+                  **omap)
+    return out
+
+
+@pytest.mark.parametrize("n_seq,L,heads", [(3, 1500, 2), (2, 77, 1), (1, 128, 4), (5, 1012, 1), (2, 1, 1), (2, 33, 2),
+                                           (1, 1499, 1), (2, 129, 1), (9, 96, 1)])
+def test_attention_frag(n_seq, L, heads):
+    SH = n_seq * heads
+    q = _mk((SH, L, 32), 30, 0.6).float().to(torch.bfloat16).double()
+    k = _mk((SH, L, 32), 31).float().to(torch.bfloat16).double()
+    v = _mk((SH, L, 32), 32).float().to(torch.bfloat16).double()
+    k[0, 7 % L] *= 6.0  # one outlier key
+    k = k.float().to(torch.bfloat16).double()
+    gates = torch.sigmoid(_mk((SH, L), 33))
+    out = _run(q, k, v, gates, n_seq, L, heads)
+    ref = _attn_ref(q, k, v, gates)  # [SH, L, 32]
+    ref = ref.view(n_seq, heads, L, 32).permute(0, 2, 1, 3).reshape(n_seq * L, heads * 32)
+    err = _rel(out, ref)
+    report("attn_frag", n_seq=n_seq, L=L, heads=heads, rel=err)
+    assert err < 2e-2
+
+
+def test_attention_frag_time_direction_rowmap():
+    B, T, F, heads = 2, 150, 4, 1
+    SH = B * F
+    q, k, v = (_mk((SH, T, 32), 40 + i).float().to(torch.bfloat16).double() for i in range(3))
+    gates = torch.sigmoid(_mk((SH, T), 44))
+    out = _run(q, k, v, gates, SH, T, heads, o_div=F, o_outer=T * F, o_inner=1, o_tok=F)
+    ref = _attn_ref(q, k, v, gates).view(B, F, T, 32).permute(0, 2, 1, 3).reshape(B * T * F, 32)
+    err = _rel(out, ref)
+    report("attn_frag_rowmap", rel=err)
+    assert err < 2e-2
+
+
+@pytest.mark.parametrize("L", [300, 1500])
+def test_attention_frag_overflow_fallback(L):
+    """Scores that exceed the first key block's maximum by more than exp2 can hold force the SAFE
+    (running-max) pass; the result must still be the exact softmax."""
+    SH = 3
+    q = _mk((SH, L, 32), 50, 0.5)
+    k = _mk((SH, L, 32), 51)
+    v = _mk((SH, L, 32), 52)
+    # sequence 1: a late key aligned with query 5 with a huge score (~ +600 in log2 units)
+    q[1, 5] = 0.0
+    q[1, 5, 0] = 25.0
+    k[1, L - 40] = 0.0
+    k[1, L - 40, 0] = 24.0
+    q, k, v = (t.float().to(torch.bfloat16).double() for t in (q, k, v))
+    gates = torch.ones((SH, L), dtype=torch.float64)
+    out = _run(q, k, v, gates, SH, L, 1)
+    ref = _attn_ref(q, k, v, gates).reshape(SH * L, 32)
+    assert torch.isfinite(out.float()).all()
+    err = _rel(out, ref)
+    report("attn_frag_overflow", L=L, rel=err)
+    assert err < 2e-2
+
+
+def _pair_sd(C, seed):
+    H = C // 32
+    g = torch.Generator().manual_seed(seed)
+
+    def rn(*shape, s=1.0):
+        return torch.randn(*shape, generator=g, dtype=torch.float64) * s
+    return {
+        "a.norm.gamma": 1 + 0.1 * rn(C), "a.to_qkv.weight": rn(3 * C, C, s=1.6 / math.sqrt(C)),
+        "a.to_gates.weight": rn(H, C, s=0.3), "a.to_gates.bias": rn(H, s=0.3),
+        "a.to_out.0.weight": rn(C, C, s=1 / math.sqrt(C)),
+        "f.net.0.gamma": 1 + 0.1 * rn(C), "f.net.1.weight": rn(4 * C, C, s=1 / math.sqrt(C)),
+        "f.net.1.bias": rn(4 * C, s=0.2), "f.net.4.weight": rn(C, 4 * C, s=0.5 / math.sqrt(C)),
+        "f.net.4.bias": rn(C, s=0.2),
+    }
+
+
+@pytest.mark.parametrize("C", [32, 64, 128])
+@pytest.mark.parametrize("T", [70, 1500])
+def test_qkv_front(C, T):
+    """RMSNorm + QKV + RoPE(time) + gates of the "(b f) t c" view, emitted fragment-major."""
+    from beat_this_amd import _lib as L
+    from beat_this_amd.pack import LOG2E, PackedPair
+    from beat_this_amd.tables import rope_table
+
+    H, F = C // 32, 1024 // C
+    B = 2 if T < 1000 else 1
+    if T >= 1000:
+        F = 2  # keep the fp64 reference small; F is a runtime argument of the kernel
+    sd = _pair_sd(C, 170 + C)
+    x0 = _mk((B, T, F, C), 180 + C, 1.5)
+    freqs = 10000.0 ** (-torch.arange(0, 32, 2).float() / 32)
+    rope = torch.from_numpy(rope_table(freqs)).to(dev())
+    pp = PackedPair(sd, "a.", "f.", C, dev())
+    nbp = L.lib().bt_attn_frag_blocks(T)
+    SH = B * F * H
+    qf = torch.full((SH, nbp, 1024), float("nan"), dtype=torch.bfloat16, device=dev())
+    kf, vf = qf.clone(), qf.clone()
+    gh = torch.zeros((SH, nbp * 32), dtype=torch.float32, device=dev())
+    xd = x0.float().to(dev())
+    L.check(L.lib().bt_qkv_front(L.stream_ptr(dev()), Ct.byref(pp.weights), rope.data_ptr(), xd.data_ptr(), B, T, F,
+                                 qf.data_ptr(), kf.data_ptr(), vf.data_ptr(), gh.data_ptr(), nbp))
+    torch.cuda.synchronize()
+    x = x0.float().double()
+    xn = x / x.norm(dim=-1, keepdim=True).clamp_min(1e-12) * math.sqrt(C) * sd["a.norm.gamma"]
+    qkv = (xn @ sd["a.to_qkv.weight"].T).reshape(B, T, F, 3, H, 32).permute(3, 0, 2, 4, 1, 5)  # qkv b f h t d
+    ang = torch.arange(T, dtype=torch.float64)[:, None] * freqs.double()[None, :]
+    cos, sin = ang.cos().repeat_interleave(2, -1), ang.sin().repeat_interleave(2, -1)
+
+    def rot(t):
+        te, to = t[..., 0::2], t[..., 1::2]
+        return t * cos + torch.stack((-to, te), -1).flatten(-2) * sin
+    q = rot(qkv[0]).reshape(SH, T, 32) * (LOG2E / math.sqrt(32.0))
+    k = rot(qkv[1]).reshape(SH, T, 32)
+    v = qkv[2].reshape(SH, T, 32)
+    gates = torch.sigmoid(xn @ sd["a.to_gates.weight"].T + sd["a.to_gates.bias"])  # b t f h
+    gates = gates.permute(0, 2, 3, 1).reshape(SH, T)
+    nblk = (T + 31) // 32
+    eq = _rel(unfrag_qk(qf.cpu()[:, :nblk], T), q)
+    ek = _rel(unfrag_qk(kf.cpu()[:, :nblk], T), k)
+    ev = _rel(unfrag_v(vf.cpu()[:, :nblk], T), v)
+    eg = _rel(gh.cpu()[:, :T], gates)
+    report("qkv_front", C=C, T=T, q=eq, k=ek, v=ev, gates=eg)
+    assert max(eq, ek, ev) < 1.5e-2 and eg < 1e-2
+    # tokens beyond T inside the last block are written as exact zeros for K and V (the attention kernel relies on it)
+    if T % 32:
+        tail_k = kf.cpu()[:, nblk - 1].view(SH, 4, 32, 8)[:, :, T % 32:, :]
+        assert torch.all(tail_k.float() == 0)
+        tail_v = unfrag_v(vf.cpu()[:, nblk - 1:nblk], 32)[:, T % 32:]
+        assert torch.all(tail_v.float() == 0)
