@@ -15,7 +15,7 @@ import torch  # noqa: F401  (must precede loading the HIP library)
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(PKG_DIR, "libbeat_this_amd.so")
-SOURCES = ["gemm.hip", "gemm2.hip", "attn.hip", "attn2.hip", "fused.hip", "qkv_front.hip", "frontend.hip", "logmel.hip",
+SOURCES = ["gemm.hip", "gemm2.hip", "gemm3.hip", "attn.hip", "attn2.hip", "fused.hip", "qkv_front.hip", "frontend.hip", "logmel.hip",
            "engine.hip"]
 HEADERS = ["common.h", "chain.h", "kernels.h", os.path.join("..", "..", "include", "beat_this_amd.h")]
 
@@ -74,6 +74,17 @@ class AttnFragArgs(C.Structure):
                 ("o_tok", C.c_int64)]
 
 
+class Gemm3Args(C.Structure):
+    _fields_ = [("A", C.c_void_p), ("lda", C.c_int64), ("M", C.c_int32), ("K", C.c_int32), ("W", C.c_void_p),
+                ("N", C.c_int32), ("epi", C.c_int32), ("bias", C.c_void_p), ("ssq_in", C.c_void_p),
+                ("ssq_parts", C.c_int32), ("out", C.c_void_p), ("ldo", C.c_int64), ("x", C.c_void_p),
+                ("ldx", C.c_int64), ("xb", C.c_void_p), ("ssq_out", C.c_void_p), ("n_seq", C.c_int32),
+                ("L", C.c_int32), ("nbp", C.c_int32), ("heads", C.c_int32), ("rope", C.c_void_p), ("qf", C.c_void_p),
+                ("kf", C.c_void_p), ("vf", C.c_void_p), ("gates", C.c_void_p), ("b_gates", C.c_void_p)]
+
+
+G3_FF1, G3_RESID, G3_QKV = 0, 1, 2
+
 EXPORTS = {
     "bt_last_error": (C.c_char_p, []),
     "bt_version": (C.c_int, []),
@@ -94,6 +105,7 @@ EXPORTS = {
     "bt_profile_end": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "bt_gemm": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(GemmArgs)]),
     "bt_attention": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(AttnArgs), C.c_int]),
+    "bt_gemm3": (C.c_int, [C.c_void_p, C.POINTER(Gemm3Args)]),
     "bt_attn_frag_blocks": (C.c_int, [C.c_int]),
     "bt_attention_frag": (C.c_int, [C.c_void_p, C.POINTER(AttnFragArgs)]),
     "bt_qkv_front": (C.c_int, [C.c_void_p, C.POINTER(PairWeights), C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,

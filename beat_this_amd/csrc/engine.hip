@@ -53,6 +53,7 @@ struct Workspace {
   float* xa; float* xb; float* xm; float* gates; void* xmb;
   void* qkv; void* ao; void* hid;
   void* qf; void* kf; void* vf; float* gates_h; int nbp;  // fragment-major attention operands (bf16 path)
+  float* ssq[2];  // [D / 64][B T] partial row sums of squares of the main residual stream (ping-pong)
   size_t total;
 };
 
@@ -77,6 +78,10 @@ Workspace carve(char* base, int B, int T, int D, int prec) {
     const size_t sh = (size_t)B * std::max(32, D / 32);
     w.qf = take(sh * w.nbp * 2048); w.kf = take(sh * w.nbp * 2048); w.vf = take(sh * w.nbp * 2048);
     w.gates_h = (float*)take(sh * w.nbp * 32 * 4);
+    w.ssq[0] = (float*)take(bt * (D / 64 + 1) * 4);
+    w.ssq[1] = (float*)take(bt * (D / 64 + 1) * 4);
+  } else {
+    w.ssq[0] = w.ssq[1] = nullptr;
   }
   w.total = off;
   return w;
@@ -97,6 +102,40 @@ Workspace carve(char* base, int B, int T, int D, int prec) {
 // mode 0: main transformer (sequences = chunks, tokens = frames)
 // mode 1: frequency direction (sequences = (b,t), tokens = f)      -- attn_small
 // mode 2: time direction      (sequences = (b,f), tokens = t)      -- rows permuted around attn_flash
+// Main transformer layer in BT_PREC_BF16 on the gemm3 / attn2 kernels.  ws.ssq[0] holds the partial row sums of
+// squares of x on entry and on exit (written by the producer of x: frontend.linear or the previous FF2), ws.ssq[1]
+// those of x after the attention half.
+int run_layer_bf16(const bt_pair_weights& pw, const float* rope, const Workspace& ws, int B, int T, hipStream_t s) {
+  const int D = pw.dim, H = pw.heads;
+  const int M = B * T;
+  const int parts = D / 64;
+  Gemm3P g;
+  memset(&g, 0, sizeof g);
+  g.A = ws.xmb; g.lda = D; g.M = M; g.K = D; g.W = pw.w_qkvg[BT_PREC_BF16]; g.N = 3 * D + H; g.epi = G3_QKV;
+  g.ssq_in = ws.ssq[0]; g.ssq_parts = parts;
+  g.n_seq = B; g.L = T; g.nblk = (T + 31) / 32; g.nbp = ws.nbp; g.heads = H; g.inner = D; g.rope = rope;
+  g.qf = ws.qf; g.kf = ws.kf; g.vf = ws.vf; g.gates = ws.gates_h; g.b_gates = pw.b_gates;
+  LAUNCH_CAT(CAT_QKV, s, launch_gemm3(g, s), "qkv gemm");
+  AttnFragP a;
+  memset(&a, 0, sizeof a);
+  a.q = ws.qf; a.k = ws.kf; a.v = ws.vf; a.gates = ws.gates_h; a.out = ws.ao; a.n_seq = B; a.L = T; a.heads = H;
+  a.inner = D; a.nbp = ws.nbp; a.o_div = 1; a.o_outer = T; a.o_inner = 0; a.o_tok = 1;
+  LAUNCH_CAT(CAT_ATTN_FLASH, s, launch_attn_frag(a, s), "attention");
+  memset(&g, 0, sizeof g);
+  g.A = ws.ao; g.lda = D; g.M = M; g.K = D; g.W = pw.w_out[BT_PREC_BF16]; g.N = D; g.epi = G3_RESID;
+  g.x = ws.xm; g.ldx = D; g.xb = ws.xmb; g.ssq_out = ws.ssq[1];
+  LAUNCH_CAT(CAT_OUT, s, launch_gemm3(g, s), "out-proj gemm");
+  memset(&g, 0, sizeof g);
+  g.A = ws.xmb; g.lda = D; g.M = M; g.K = D; g.W = pw.w_ff1[BT_PREC_BF16]; g.N = 4 * D; g.epi = G3_FF1;
+  g.bias = pw.b_ff1; g.ssq_in = ws.ssq[1]; g.ssq_parts = parts; g.out = ws.hid; g.ldo = 4 * D;
+  LAUNCH_CAT(CAT_FF1, s, launch_gemm3(g, s), "ff1 gemm");
+  memset(&g, 0, sizeof g);
+  g.A = ws.hid; g.lda = 4 * D; g.M = M; g.K = 4 * D; g.W = pw.w_ff2[BT_PREC_BF16]; g.N = D; g.epi = G3_RESID;
+  g.bias = pw.b_ff2; g.x = ws.xm; g.ldx = D; g.xb = ws.xmb; g.ssq_out = ws.ssq[0];
+  LAUNCH_CAT(CAT_FF2, s, launch_gemm3(g, s), "ff2 gemm");
+  return BT_OK;
+}
+
 int run_pair(const bt_pair_weights& pw, const float* rope, float* x, void* xshadow, const Workspace& ws, int B, int T,
              int F, int mode, int prec, hipStream_t s) {
   const int C = pw.dim, H = pw.heads;
@@ -191,6 +230,7 @@ void bt_struct_sizes(int32_t* out) {
   out[4] = (int32_t)sizeof(bt_attn_args); out[5] = (int32_t)offsetof(bt_model_desc, layers);
   out[6] = (int32_t)offsetof(bt_model_desc, rope);
   out[7] = (int32_t)sizeof(bt_attn_frag_args);
+  out[8] = (int32_t)sizeof(bt_gemm3_args);
 }
 
 int bt_engine_create(const bt_model_desc* desc, bt_engine** out) {
@@ -221,8 +261,10 @@ int bt_forward(bt_engine* e, void* stream, int prec, const float* d_spect, int B
   if (ws.total > ws_bytes) return bt_set_error(BT_ERR_WORKSPACE, "workspace too small");
   hipStream_t s = (hipStream_t)stream;
 
-  // the bf16 shadow of the main residual stream is maintained by gemm2's epilogues only
+  // the bf16 shadow of the main residual stream is maintained by the gemm2 / gemm3 epilogues only
   const bool use_shadow = prec == BT_PREC_BF16 && D >= 128 && D % 64 == 0;
+  // main layers on gemm3 + fragment-major attention (needs q | k | v column blocks that are whole 128-tiles)
+  const bool fast_layers = use_shadow && D % 128 == 0 && (long)B * T * 4 * D * 2 < 0x7fffffffL;
 
   StemP sp;
   sp.spect = d_spect; sp.x = ws.xa; sp.bn1_scale = d.bn1_scale; sp.bn1_shift = d.bn1_shift;
@@ -254,10 +296,12 @@ int bt_forward(bt_engine* e, void* stream, int prec, const float* d_spect, int B
     g.A = x; g.lda = 1024; g.W = d.lin_w[prec]; g.M = B * T; g.N = D; g.K = 1024;
     g.epi = GEMM_EPI_STORE; g.flags = GEMM_F_A_F32 | GEMM_F_BIAS | GEMM_F_OUT_F32;
     g.bias = d.lin_b; g.out = ws.xm; g.ldo = D; g.xb = use_shadow ? ws.xmb : nullptr;
+    g.ssq_out = fast_layers ? ws.ssq[0] : nullptr;
     LAUNCH_CAT(CAT_LINEAR, s, launch_gemm(g, prec, s), "frontend linear gemm");
   }
   for (int l = 0; l < d.n_layers; ++l) {
-    int rc = run_pair(d.layers[l], d.rope, ws.xm, use_shadow ? ws.xmb : nullptr, ws, B, T, 1, 0, prec, s);
+    int rc = fast_layers ? run_layer_bf16(d.layers[l], d.rope, ws, B, T, s)
+                         : run_pair(d.layers[l], d.rope, ws.xm, use_shadow ? ws.xmb : nullptr, ws, B, T, 1, 0, prec, s);
     if (rc) return rc;
   }
   HeadP hp;
@@ -416,6 +460,20 @@ int bt_attention(void* stream, int prec, const bt_attn_args* a, int small_kernel
     LAUNCH(launch_attn_small(p, prec, (hipStream_t)stream), "attention (small)");
   else
     LAUNCH(launch_attn_flash(p, prec, (hipStream_t)stream), "attention (flash)");
+  return BT_OK;
+}
+
+int bt_gemm3(void* stream, const bt_gemm3_args* a) {
+  if (!a || !a->A || !a->W) return bt_set_error(BT_ERR_ARG, "null argument");
+  Gemm3P g;
+  memset(&g, 0, sizeof g);
+  g.A = a->A; g.lda = a->lda; g.M = a->M; g.K = a->K; g.W = a->W; g.N = a->N; g.epi = a->epi; g.bias = a->bias;
+  g.ssq_in = a->ssq_in; g.ssq_parts = a->ssq_parts; g.out = a->out; g.ldo = a->ldo; g.x = a->x; g.ldx = a->ldx;
+  g.xb = a->xb; g.ssq_out = a->ssq_out; g.n_seq = a->n_seq; g.L = a->L; g.nblk = (a->L + 31) / 32; g.nbp = a->nbp;
+  g.heads = a->heads; g.inner = a->heads * 32; g.rope = a->rope; g.qf = a->qf; g.kf = a->kf; g.vf = a->vf;
+  g.gates = a->gates; g.b_gates = a->b_gates;
+  if (!gemm3_supported(g)) return bt_set_error(BT_ERR_ARG, "shape not supported by bt_gemm3");
+  LAUNCH(launch_gemm3(g, (hipStream_t)stream), "gemm3");
   return BT_OK;
 }
 

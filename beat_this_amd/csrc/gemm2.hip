@@ -297,7 +297,7 @@ __global__ __launch_bounds__(256, 2) void gemm2_kernel(const GemmP p, int n_tile
       for (int it = 0; it < 8; ++it) {
         const int row_l = (tid >> 5) + 8 * (half8 * 8 + it);
         const long gm = m0 + row_l;
-        if (gm >= p.M || !col_ok) continue;
+        const bool ok = gm < p.M && col_ok;  // wave-uniform in gm (a wave covers 2 rows x 32 chunks)
         const float sc = rms ? rs[row_l] : 1.0f;
         f32x4 v = *reinterpret_cast<const f32x4*>(stage + row_l * SP + ch * 16);
 #pragma unroll
@@ -315,8 +315,16 @@ __global__ __launch_bounds__(256, 2) void gemm2_kernel(const GemmP p, int n_tile
           }
           dst = reinterpret_cast<float*>(p.out); ld = p.ldo;
         }
-        *reinterpret_cast<f32x4*>(dst + gm * ld + col) = v;
-        if (xb) *reinterpret_cast<bf16x4*>(xb + gm * ld + col) = bf16x4{(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+        if (ok) {
+          *reinterpret_cast<f32x4*>(dst + gm * ld + col) = v;
+          if (xb) *reinterpret_cast<bf16x4*>(xb + gm * ld + col) = bf16x4{(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+        }
+        if (p.ssq_out) {  // partial sums of squares per 64 columns (16 consecutive lanes), for the consumer's RMSNorm
+          float ss = ok ? fmaf(v[0], v[0], fmaf(v[1], v[1], fmaf(v[2], v[2], v[3] * v[3]))) : 0.f;
+#pragma unroll
+          for (int o = 8; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+          if ((ch & 15) == 0 && gm < p.M && col < p.N) p.ssq_out[(long)(col >> 6) * p.M + gm] = ss;
+        }
       }
     }
   }

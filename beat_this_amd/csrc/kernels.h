@@ -36,6 +36,7 @@ struct GemmP {
   float* x;        // EPI_RESID: residual stream, ld = ldx
   long ldx;
   void* xb;        // optional bf16 shadow of the fp32 result (EPI_RESID: of x; OUT_F32: of out), same ld
+  float* ssq_out;  // optional (gemm2 fp32 epilogues): [N / 64][M] partial row sums of squares of the fp32 result
   // conv gather (GEMM_F_CONV): output row m = (b, t, f'), A = x[b, t-1..t+1, f', 0..C2)
   int conv_C2, conv_T, conv_F;
   // QKV epilogue
@@ -47,6 +48,24 @@ struct GemmP {
   int map_T, map_F;  // GEMM_F_ROWMAP
 };
 int launch_gemm(const GemmP& p, int prec, hipStream_t s);
+
+// ---- bf16 GEMM of the main layers (gemm3.hip): LDS-DMA ring, transposed product, register epilogues --------
+enum { G3_FF1 = 0, G3_RESID = 1, G3_QKV = 2 };
+struct Gemm3P {
+  const void* A; long lda; int M, K;   // bf16 [M, lda]
+  const void* W; int N;                // bf16 [N padded to 128, K]
+  int epi;
+  const float* bias;                   // FF1: [N]; RESID: [N] or null
+  const float* ssq_in; int ssq_parts;  // RMSNorm of A: [parts][M] partial row sums of squares, or null
+  void* out; long ldo;                 // FF1: bf16 [M, ldo] = gelu(rms(A) W^T + bias)
+  float* x; long ldx; void* xb;        // RESID: x += A W^T + bias (fp32, in place), xb = bf16 shadow (or null)
+  float* ssq_out;                      // RESID: [N / 64][M] partial sums of squares of the new x (or null)
+  // QKV: rows are (sequence, token) with n_seq sequences of L tokens (M = n_seq * L); columns q | k | v | gates
+  int n_seq, L, nblk, nbp, heads, inner;
+  const float* rope; void* qf; void* kf; void* vf; float* gates; const float* b_gates;
+};
+bool gemm3_supported(const Gemm3P& p);
+int launch_gemm3(const Gemm3P& p, hipStream_t s);
 
 // ---- attention ---------------------------------------------------------------------
 struct AttnP {

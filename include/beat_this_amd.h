@@ -95,8 +95,8 @@ typedef struct {
 const char* bt_last_error(void);
 int bt_version(void);
 /* sizeof/offsetof of the structs above as this library was compiled (binding self-check):
- * out[8] = {pair_weights, model_desc, logmel_tables, gemm_args, attn_args, offsetof layers, offsetof rope,
- * attn_frag_args} */
+ * out[9] = {pair_weights, model_desc, logmel_tables, gemm_args, attn_args, offsetof layers, offsetof rope,
+ * attn_frag_args, gemm3_args} */
 void bt_struct_sizes(int32_t* out);
 
 /* BeatThis(**hparams) + load_state_dict (inference.py:56-87): keeps a copy of `desc`. */
@@ -175,6 +175,17 @@ typedef struct {
   const void* q; const void* k; const void* v; const float* gates; void* out;
   int32_t n_seq, L, heads, inner, nbp, o_div; int64_t o_outer, o_inner, o_tok;
 } bt_attn_frag_args;
+/* bf16 GEMM of the main layers (csrc/gemm3.hip), single-operator entry for the parity tests.
+ * epi 0: out[M,ldo] (bf16) = gelu(rms(A) W^T + bias);  epi 1: x[M,ldx] (fp32) += A W^T + bias, bf16 shadow xb,
+ * partial row sums of squares ssq_out[N/64][M];  epi 2: q|k|v|gates = rms(A) W^T with RoPE / sigmoid, written
+ * fragment-major (layout of bt_attention_frag) for n_seq sequences of L tokens (M = n_seq L).
+ * rms(A) uses ssq_in[ssq_parts][M] (partial row sums of squares of the fp32 source of A), NULL = no RMSNorm. */
+typedef struct {
+  const void* A; int64_t lda; int32_t M, K; const void* W; int32_t N, epi; const float* bias;
+  const float* ssq_in; int32_t ssq_parts; void* out; int64_t ldo; float* x; int64_t ldx; void* xb; float* ssq_out;
+  int32_t n_seq, L, nbp, heads; const float* rope; void* qf; void* kf; void* vf; float* gates; const float* b_gates;
+} bt_gemm3_args;
+int bt_gemm3(void* stream, const bt_gemm3_args* a);
 int bt_attn_frag_blocks(int L);
 int bt_attention_frag(void* stream, const bt_attn_frag_args* a);
 /* Time-direction QKV projection of a frontend block: d_x [B,T,F,C] fp32 -> fragment-major q, k, v, gates */

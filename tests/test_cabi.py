@@ -46,11 +46,11 @@ def test_argument_errors_map_to_exceptions():
 
 def test_struct_layout_matches_header():
     L = _lib()
-    sizes = (C.c_int32 * 8)()
+    sizes = (C.c_int32 * 9)()
     L.lib().bt_struct_sizes(sizes)
     assert list(sizes) == [C.sizeof(L.PairWeights), C.sizeof(L.ModelDesc), C.sizeof(L.LogmelTables),
                            C.sizeof(L.GemmArgs), C.sizeof(L.AttnArgs), L.ModelDesc.layers.offset,
-                           L.ModelDesc.rope.offset, C.sizeof(L.AttnFragArgs)]
+                           L.ModelDesc.rope.offset, C.sizeof(L.AttnFragArgs), C.sizeof(L.Gemm3Args)]
 
 
 def test_host_postprocess_bit_exact():
