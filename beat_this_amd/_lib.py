@@ -15,7 +15,7 @@ import torch  # noqa: F401  (must precede loading the HIP library)
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(PKG_DIR, "libbeat_this_amd.so")
-SOURCES = ["gemm.hip", "gemm2.hip", "gemm3.hip", "attn.hip", "attn2.hip", "fused.hip", "qkv_front.hip", "frontend.hip", "logmel.hip",
+SOURCES = ["gemm.hip", "gemm2.hip", "gemm3.hip", "attn.hip", "attn2.hip", "fused.hip", "fused2.hip", "qkv_front.hip", "frontend.hip", "logmel.hip",
            "engine.hip"]
 HEADERS = ["common.h", "chain.h", "kernels.h", os.path.join("..", "..", "include", "beat_this_amd.h")]
 
@@ -33,7 +33,8 @@ class PairWeights(C.Structure):
     _fields_ = [("dim", C.c_int32), ("heads", C.c_int32), ("w_qkvg", C.c_void_p * 2), ("b_gates", C.c_void_p),
                 ("w_out", C.c_void_p * 2), ("w_ff1", C.c_void_p * 2), ("b_ff1", C.c_void_p),
                 ("w_ff2", C.c_void_p * 2), ("b_ff2", C.c_void_p), ("w_outp", C.c_void_p * 2),
-                ("w_ff_frag", C.c_void_p * 2), ("w_qkv_frag", C.c_void_p)]
+                ("w_ff_frag", C.c_void_p * 2), ("w_qkv_frag", C.c_void_p),
+                ("w_outff_frag", C.c_void_p * 2), ("w_attnff_frag", C.c_void_p * 2)]
 
 
 class ModelDesc(C.Structure):
@@ -110,6 +111,8 @@ EXPORTS = {
     "bt_attention_frag": (C.c_int, [C.c_void_p, C.POINTER(AttnFragArgs)]),
     "bt_qkv_front": (C.c_int, [C.c_void_p, C.POINTER(PairWeights), C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
+    "bt_outff_fused": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(PairWeights), C.c_void_p, C.c_void_p, C.c_int64]),
+    "bt_attnff_fused": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(PairWeights), C.c_void_p, C.c_void_p, C.c_int64]),
     "bt_ff_fused": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(PairWeights), C.c_void_p, C.c_int64]),
     "bt_attn_freq_fused": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(PairWeights), C.c_void_p, C.c_void_p, C.c_int64]),
 }

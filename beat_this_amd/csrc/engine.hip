@@ -145,6 +145,21 @@ int run_pair(const bt_pair_weights& pw, const float* rope, float* x, void* xshad
   // main layers in bf16 mode read the bf16 shadow of x (half the operand bytes, no conversion in the k-loop)
   const bool shadow = xshadow != nullptr && prec == BT_PREC_BF16;
   const bool fused_ok = C <= 128 && pw.w_outp[prec] && pw.w_ff_frag[prec];
+  const bool fused2_ok = fused_ok && pw.w_outff_frag[prec] && pw.w_attnff_frag[prec];
+  auto outff = [&]() -> int {  // x += to_out(ws.ao); x += FF(x) in one launch
+    FusedOutFFP f;
+    f.x = x; f.M = M; f.C = C; f.ao = ws.ao; f.wfrag = pw.w_outff_frag[prec]; f.b1 = pw.b_ff1; f.b2 = pw.b_ff2;
+    f.xb = nullptr;
+    LAUNCH_CAT(CAT_FF_FUSED, s, launch_outff_fused(f, prec, s), "fused out-projection + feed-forward");
+    return BT_OK;
+  };
+  if (mode == 1 && fused2_ok) {  // whole frequency-direction half (attention + FF) in one register-resident kernel
+    FusedAttnFFP f;
+    f.x = x; f.M = M; f.C = C; f.b_gates = pw.b_gates; f.rope = rope; f.wfrag = pw.w_attnff_frag[prec];
+    f.b1 = pw.b_ff1; f.b2 = pw.b_ff2;
+    LAUNCH_CAT(CAT_ATTN_FREQ_FUSED, s, launch_attnff_fused(f, prec, s), "fused frequency attention + feed-forward");
+    return BT_OK;
+  }
   if (mode == 1 && fused_ok) {  // whole frequency-direction attention block in one register-resident kernel
     FusedAttnP fa;
     fa.x = x; fa.M = M; fa.C = C; fa.w_qkvg = pw.w_qkvg[prec]; fa.b_gates = pw.b_gates; fa.w_outp = pw.w_outp[prec];
@@ -162,6 +177,7 @@ int run_pair(const bt_pair_weights& pw, const float* rope, float* x, void* xshad
     a.q = ws.qf; a.k = ws.kf; a.v = ws.vf; a.gates = ws.gates_h; a.out = ws.ao; a.n_seq = B * F; a.L = T; a.heads = H;
     a.inner = C; a.nbp = ws.nbp; a.o_div = F; a.o_outer = (long)T * F; a.o_inner = 1; a.o_tok = F;
     LAUNCH_CAT(CAT_ATTN_FLASH, s, launch_attn_frag(a, s), "time attention");
+    if (fused2_ok) return outff();
     memset(&g, 0, sizeof g);
     g.A = ws.ao; g.lda = C; g.W = pw.w_out[prec]; g.M = (int)M; g.N = C; g.K = C;
     g.epi = GEMM_EPI_RESID; g.flags = 0; g.x = x; g.ldx = C; g.xb = nullptr;
@@ -191,6 +207,7 @@ int run_pair(const bt_pair_weights& pw, const float* rope, float* x, void* xshad
     a.n_seq = B; a.L = T; a.o_div = 1; a.o_outer = T; a.o_inner = 0; a.o_tok = 1;
     LAUNCH_CAT(CAT_ATTN_FLASH, s, launch_attn_flash(a, prec, s), "attention");
   }
+  if (mode == 2 && fused2_ok) return outff();
   // ---- x += ao . Wout^T -------------------------------------------------------------------
   memset(&g, 0, sizeof g);
   g.A = ws.ao; g.lda = C; g.W = pw.w_out[prec]; g.M = (int)M; g.N = C; g.K = C;
@@ -460,6 +477,26 @@ int bt_attention(void* stream, int prec, const bt_attn_args* a, int small_kernel
     LAUNCH(launch_attn_small(p, prec, (hipStream_t)stream), "attention (small)");
   else
     LAUNCH(launch_attn_flash(p, prec, (hipStream_t)stream), "attention (flash)");
+  return BT_OK;
+}
+
+int bt_outff_fused(void* stream, int prec, const bt_pair_weights* w, const void* d_ao, float* d_x, int64_t M) {
+  if (!w || !d_ao || !d_x || M <= 0 || w->dim > 128 || !w->w_outff_frag[prec])
+    return bt_set_error(BT_ERR_ARG, "bad argument to bt_outff_fused");
+  FusedOutFFP f;
+  f.x = d_x; f.M = M; f.C = w->dim; f.ao = d_ao; f.wfrag = w->w_outff_frag[prec]; f.b1 = w->b_ff1; f.b2 = w->b_ff2;
+  f.xb = nullptr;
+  LAUNCH(launch_outff_fused(f, prec, (hipStream_t)stream), "fused out-projection + feed-forward");
+  return BT_OK;
+}
+
+int bt_attnff_fused(void* stream, int prec, const bt_pair_weights* w, const float* d_rope, float* d_x, int64_t M) {
+  if (!w || !d_x || !d_rope || M <= 0 || w->dim > 128 || !w->w_attnff_frag[prec])
+    return bt_set_error(BT_ERR_ARG, "bad argument to bt_attnff_fused");
+  FusedAttnFFP f;
+  f.x = d_x; f.M = M; f.C = w->dim; f.b_gates = w->b_gates; f.rope = d_rope; f.wfrag = w->w_attnff_frag[prec];
+  f.b1 = w->b_ff1; f.b2 = w->b_ff2;
+  LAUNCH(launch_attnff_fused(f, prec, (hipStream_t)stream), "fused frequency attention + feed-forward");
   return BT_OK;
 }
 

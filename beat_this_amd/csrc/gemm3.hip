@@ -17,6 +17,8 @@
 //   * RMSNorm: the producer of the residual stream (EPI_RESID here, gemm2's fp32 epilogues for
 //     frontend.linear) writes per-row partial sums of squares per 64 columns; the consumers (QKV, FF1)
 //     add the partials -- no pass over A for the statistics (LDS-DMA data never visits registers).
+#include <cstdlib>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -51,7 +53,9 @@ DEVI void store_row_bf16(bf16* row32, const float (&v)[16], int g) {
   }
 }
 
-template <int EPI>
+// ABL (development, BT_G3_ABL): bit 0 = no LDS-DMA after the prologue, bit 1 = FF1 epilogue without GELU,
+// bit 2 = no fragment reads / MFMAs in the loop (staging + barriers only)
+template <int EPI, int ABL = 0>
 __global__ __launch_bounds__(256, 3) void gemm3_kernel(const Gemm3P p, int n_tiles, int total_tiles, int per_xcd) {
   __shared__ __attribute__((aligned(16))) char smem[NST * ST_BYTES];
   // XCD-aware tile order: the n-tiles sharing one 128-row A panel run on the same XCD (block b -> XCD b % 8)
@@ -118,13 +122,13 @@ __global__ __launch_bounds__(256, 3) void gemm3_kernel(const Gemm3P p, int n_til
   if (nk > 1) issue(1, 1);
   int stage = 0, stage2 = 2;
   for (int kt = 0; kt < nk; ++kt) {
-    if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    if (kt + 1 < nk && !(ABL & 1)) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if (kt + 2 < nk) issue(kt + 2, stage2);
+    if (kt + 2 < nk && !(ABL & 1)) issue(kt + 2, stage2);
     const char* st = smem + stage * ST_BYTES;
 #pragma unroll
-    for (int m = 0; m < 2; ++m) {
+    for (int m = 0; m < ((ABL & 4) ? (kt == 0 ? 1 : 0) : 2); ++m) {
       const int kc = m == 0 ? kc0 : kc1;
       bf16x8 fp[2], fq[2];
 #pragma unroll
@@ -182,7 +186,10 @@ __global__ __launch_bounds__(256, 3) void gemm3_kernel(const Gemm3P p, int n_til
       for (int b = 0; b < 2; ++b) {
         float v[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) v[r] = gelu_erf(fmaf(acc[a][b][r], rs[b], bq[r >> 2][r & 3]));
+        for (int r = 0; r < 16; ++r) {
+          const float u = fmaf(acc[a][b][r], rs[b], bq[r >> 2][r & 3]);
+          v[r] = (ABL & 2) ? u : gelu_erf(u);
+        }
         if (trow[b] >= 0) store_row_bf16(out + trow[b] * p.ldo + nb, v, g);
       }
     }
@@ -301,7 +308,16 @@ int launch_gemm3(const Gemm3P& p, hipStream_t s) {
   per = (per + n_tiles - 1) / n_tiles * n_tiles;
   dim3 grid((unsigned)(per * 8)), block(256);
   switch (p.epi) {
-    case G3_FF1: hipLaunchKernelGGL((gemm3_kernel<G3_FF1>), grid, block, 0, s, p, n_tiles, (int)total, (int)per); break;
+    case G3_FF1: {
+      static const int abl = getenv("BT_G3_ABL") ? atoi(getenv("BT_G3_ABL")) : 0;
+      if (abl == 1) hipLaunchKernelGGL((gemm3_kernel<G3_FF1, 1>), grid, block, 0, s, p, n_tiles, (int)total, (int)per);
+      else if (abl == 2) hipLaunchKernelGGL((gemm3_kernel<G3_FF1, 2>), grid, block, 0, s, p, n_tiles, (int)total, (int)per);
+      else if (abl == 3) hipLaunchKernelGGL((gemm3_kernel<G3_FF1, 3>), grid, block, 0, s, p, n_tiles, (int)total, (int)per);
+      else if (abl == 4) hipLaunchKernelGGL((gemm3_kernel<G3_FF1, 4>), grid, block, 0, s, p, n_tiles, (int)total, (int)per);
+      else if (abl == 6) hipLaunchKernelGGL((gemm3_kernel<G3_FF1, 6>), grid, block, 0, s, p, n_tiles, (int)total, (int)per);
+      else hipLaunchKernelGGL((gemm3_kernel<G3_FF1>), grid, block, 0, s, p, n_tiles, (int)total, (int)per);
+      break;
+    }
     case G3_RESID: hipLaunchKernelGGL((gemm3_kernel<G3_RESID>), grid, block, 0, s, p, n_tiles, (int)total, (int)per); break;
     case G3_QKV: hipLaunchKernelGGL((gemm3_kernel<G3_QKV>), grid, block, 0, s, p, n_tiles, (int)total, (int)per); break;
     default: return -1;

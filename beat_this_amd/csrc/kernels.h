@@ -122,6 +122,23 @@ struct FusedAttnP {
 };
 int launch_attn_freq_fused(const FusedAttnP& p, int prec, hipStream_t s);
 
+// ---- fused halves of a PartialFTTransformer (fused2.hip): x read once, written once -----------------------------
+struct FusedOutFFP {  // x += Wout . ao ; x += FF(x)      (time direction, after the flash attention)
+  float* x; long M; int C;
+  const void* ao;                    // attention output [M, C], compute dtype
+  const void* wfrag;                 // bt_pair_weights.w_outff_frag
+  const float* b1; const float* b2;
+  void* xb;                          // optional bf16 shadow of the new x
+};
+int launch_outff_fused(const FusedOutFFP& p, int prec, hipStream_t s);
+struct FusedAttnFFP {  // x += AttnF(x) ; x += FF(x)      (frequency direction)
+  float* x; long M; int C;
+  const float* b_gates; const float* rope;
+  const void* wfrag;                 // bt_pair_weights.w_attnff_frag
+  const float* b1; const float* b2;
+};
+int launch_attnff_fused(const FusedAttnFFP& p, int prec, hipStream_t s);
+
 // ---- small model kernels (frontend.hip) ---------------------------------------------
 struct StemP {
   const float* spect;  // [B, T, 128]

@@ -161,6 +161,31 @@ class PackedModel:
             b16 = ff_fragment_major(w1, w2p, 8).to(torch.bfloat16).to(self.device)
             self._keep += [f32, b16]
             pw.w_ff_frag[0], pw.w_ff_frag[1] = f32.data_ptr(), b16.data_ptr()
+            # fused2.hip: out-projection tiles (natural k order), then the FF stream with PERM32'd W1 columns
+            wo = sd[pa + "to_out.0.weight"].to(torch.float32)
+            w1p = perm32(w1)
+            for i, (epp, dt) in enumerate(((4, torch.float32), (8, torch.bfloat16))):
+                ot = fragment_tiles(wo)                                   # [mt, kt, 64, 16]
+                ot = ot.reshape(ot.shape[0], ot.shape[1], 64, 16 // epp, epp).permute(0, 1, 3, 2, 4)
+                ot = torch.cat([ot, torch.zeros_like(ot)], 1).reshape(-1)  # every step is 2 KT tiles: pad with zeros
+                t = torch.cat([ot, ff_fragment_major(w1p, w2p, epp)]).to(dt).to(self.device)
+                self._keep.append(t)
+                pw.w_outff_frag[i] = t.data_ptr()
+                # fused frequency-direction half: [gates | pad], per head [q | k] [v | outp tiles], FF steps
+                kt = dim // 32
+
+                def pieces(tiles):  # [..., 64, 16] -> piece-major tiles, flattened
+                    sh = tiles.shape[:-2]
+                    return tiles.reshape(*sh, 64, 16 // epp, epp).transpose(-3, -2).reshape(-1)
+                qt = fragment_tiles(_pad_rows(w.to(torch.float32))[:3 * dim + 32])   # [3 heads + 1, KT, 64, 16]
+                opt = fragment_tiles(perm32(wo))                                    # [mt, kt (head), 64, 16]
+                steps = [pieces(qt[3 * heads]), torch.zeros(kt * 32 * 32)]
+                for hd in range(heads):
+                    steps += [pieces(qt[hd]), pieces(qt[heads + hd]), pieces(qt[2 * heads + hd]), pieces(opt[:, hd])]
+                steps.append(ff_fragment_major(w1p, w2p, epp))
+                t = torch.cat(steps).to(dt).to(self.device)
+                self._keep.append(t)
+                pw.w_attnff_frag[i] = t.data_ptr()
         gf = sd[pf + "net.0.gamma"]
         pw.w_ff1[0], pw.w_ff1[1] = self._mat(sd[pf + "net.1.weight"] * gf[None, :])
         pw.b_ff1 = self._f32(sd[pf + "net.1.bias"])

@@ -59,6 +59,15 @@ typedef struct {
    * of its 32 q rows, then of its k rows, then of its v rows; after the last head dim/32 tiles of the
    * gate rows (w_qkvg rows 3 dim .. 3 dim + 31).  NULL for dim > 128. */
   const void* w_qkv_frag;
+  /* Weights of the fused out-projection + FF kernels (csrc/fused2.hip), fragment-major tiles as above, two
+   * precisions, uniform steps of 2 dim/32 tiles: per 32-row block mt of to_out.0.weight its dim/32 k-tiles
+   * (natural k order) + as many zero tiles, then
+   * the w_ff_frag stream with W1's columns PERM32-ordered as well.  NULL for dim > 128. */
+  const void* w_outff_frag[2];
+  /* Weights of the fused frequency-direction kernel (attention + FF), fragment-major, steps of 2 dim/32 tiles:
+   * [gate rows of w_qkvg | zero tiles], per head [q rows | k rows] [v rows | PERM32'd to_out tiles (row block
+   * mt, the head's 32 columns)], then the FF steps as in w_outff_frag.  NULL for dim > 128. */
+  const void* w_attnff_frag[2];
 } bt_pair_weights;
 
 /* Packed BeatThis weights (beat_tracker.py:38-106).  Host-side packing is done by
@@ -194,6 +203,9 @@ int bt_qkv_front(void* stream, const bt_pair_weights* w, const float* d_rope, co
 /* x[M,C] += FF(x) / x += frequency-direction attention(x) with one bt_pair_weights, dim = C <= 128 */
 int bt_ff_fused(void* stream, int prec, const bt_pair_weights* w, float* d_x, int64_t M);
 int bt_attn_freq_fused(void* stream, int prec, const bt_pair_weights* w, const float* d_rope, float* d_x, int64_t M);
+/* fused halves (csrc/fused2.hip): x += to_out(ao) then x += FF(x);  x += AttnF(x) then x += FF(x) */
+int bt_outff_fused(void* stream, int prec, const bt_pair_weights* w, const void* d_ao, float* d_x, int64_t M);
+int bt_attnff_fused(void* stream, int prec, const bt_pair_weights* w, const float* d_rope, float* d_x, int64_t M);
 
 #ifdef __cplusplus
 }

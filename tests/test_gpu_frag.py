@@ -169,3 +169,99 @@ def test_qkv_front(C, T):
         assert torch.all(tail_k.float() == 0)
         tail_v = unfrag_v(vf.cpu()[:, nblk - 1:nblk], 32)[:, T % 32:]
         assert torch.all(tail_v.float() == 0)
+
+
+def _ff_ref(sd, x):
+    C = x.shape[-1]
+    xn = x / x.norm(dim=-1, keepdim=True).clamp_min(1e-12) * math.sqrt(C) * sd["f.net.0.gamma"]
+    return x + torch.nn.functional.gelu(xn @ sd["f.net.1.weight"].T + sd["f.net.1.bias"]) @ sd["f.net.4.weight"].T \
+        + sd["f.net.4.bias"]
+
+
+@pytest.mark.parametrize("prec", [0, 1])
+@pytest.mark.parametrize("C", [32, 64, 128])
+def test_fused_out_ff(prec, C):
+    """x += to_out(ao); x += FF(x) in one launch (csrc/fused2.hip), both precisions, ragged M."""
+    from beat_this_amd import _lib as L
+    from beat_this_amd.pack import PackedPair
+
+    sd = _pair_sd(C, 250 + C)
+    M = 1000 + C
+    x0 = _mk((M, C), 260 + C, 1.5)
+    dt = torch.float32 if prec == 0 else torch.bfloat16
+    ao = _mk((M, C), 270 + C).float().to(dt)
+    pp = PackedPair(sd, "a.", "f.", C, dev())
+    x = x0.float().to(dev()).clone()
+    aod = ao.to(dev())
+    L.check(L.lib().bt_outff_fused(L.stream_ptr(dev()), prec, Ct.byref(pp.weights), aod.data_ptr(), x.data_ptr(), M))
+    torch.cuda.synchronize()
+    x1 = x0.float().double() + ao.double() @ sd["a.to_out.0.weight"].T
+    ref = _ff_ref(sd, x1)
+    err = _rel(x, ref)
+    report("outff_fused", prec=prec, C=C, rel=err)
+    assert err < (2e-5 if prec == 0 else 1.5e-2)
+
+
+@pytest.mark.parametrize("prec", [0, 1])
+@pytest.mark.parametrize("C", [32, 64, 128])
+def test_fused_attn_ff(prec, C):
+    """x += AttnF(x); x += FF(x) over the F = 1024/C tokens of each (b,t) row in one launch."""
+    from beat_this_amd import _lib as L
+    from beat_this_amd.pack import PackedPair
+    from beat_this_amd.tables import rope_table
+
+    H, F = C // 32, 1024 // C
+    sd = _pair_sd(C, 370 + C)
+    rows = 37
+    M = rows * F
+    x0 = _mk((M, C), 380 + C, 1.5)
+    freqs = 10000.0 ** (-torch.arange(0, 32, 2).float() / 32)
+    rope = torch.from_numpy(rope_table(freqs)).to(dev())
+    pp = PackedPair(sd, "a.", "f.", C, dev())
+    x = x0.float().to(dev()).clone()
+    L.check(L.lib().bt_attnff_fused(L.stream_ptr(dev()), prec, Ct.byref(pp.weights), rope.data_ptr(), x.data_ptr(), M))
+    torch.cuda.synchronize()
+    xx = x0.float().double()
+    xn = xx / xx.norm(dim=-1, keepdim=True).clamp_min(1e-12) * math.sqrt(C) * sd["a.norm.gamma"]
+    qkv = (xn @ sd["a.to_qkv.weight"].T).reshape(rows, F, 3, H, 32).permute(2, 0, 3, 1, 4)
+    ang = torch.arange(F, dtype=torch.float64)[:, None] * freqs.double()[None, :]
+    cos, sin = ang.cos().repeat_interleave(2, -1), ang.sin().repeat_interleave(2, -1)
+
+    def rot(t):
+        te, to = t[..., 0::2], t[..., 1::2]
+        return t * cos + torch.stack((-to, te), -1).flatten(-2) * sin
+    q, k, v = rot(qkv[0]), rot(qkv[1]), qkv[2]
+    att = torch.softmax(q @ k.transpose(-1, -2) / math.sqrt(32.0), -1) @ v
+    gates = torch.sigmoid(xn @ sd["a.to_gates.weight"].T + sd["a.to_gates.bias"]).reshape(rows, F, H).permute(0, 2, 1)
+    out = (att * gates[..., None]).permute(0, 2, 1, 3).reshape(M, C) @ sd["a.to_out.0.weight"].T
+    ref = _ff_ref(sd, xx + out)
+    err = _rel(x, ref)
+    report("attnff_fused", prec=prec, C=C, rel=err)
+    assert err < (3e-5 if prec == 0 else 2e-2)
+
+
+@pytest.mark.parametrize("C", [32, 128])
+def test_fused_halves_at_scale_match_unfused(C):
+    """Many workgroups per CU (model scale): the LDS-DMA weight ring of fused2.hip against the register-staged
+    kernels of fused.hip on the same input, three launches (a counted-vmcnt race showed up only here)."""
+    from beat_this_amd import _lib as L
+    from beat_this_amd.pack import PackedPair
+    from beat_this_amd.tables import rope_table
+
+    sd = _pair_sd(C, 5 + C)
+    pp = PackedPair(sd, "a.", "f.", C, dev())
+    M = 1500 * 1024 // C
+    rope = torch.from_numpy(rope_table(10000.0 ** (-torch.arange(0, 32, 2).float() / 32))).to(dev())
+    x0 = _mk((M, C), 7 + C, 1.5).float().to(dev())
+    st = L.stream_ptr(dev())
+    xa = x0.clone()
+    L.check(L.lib().bt_attn_freq_fused(st, 1, Ct.byref(pp.weights), rope.data_ptr(), xa.data_ptr(), M))
+    L.check(L.lib().bt_ff_fused(st, 1, Ct.byref(pp.weights), xa.data_ptr(), M))
+    worst = 0.0
+    for _ in range(3):
+        xb = x0.clone()
+        L.check(L.lib().bt_attnff_fused(st, 1, Ct.byref(pp.weights), rope.data_ptr(), xb.data_ptr(), M))
+        torch.cuda.synchronize()
+        worst = max(worst, float((xa - xb).abs().max() / xa.abs().max()))
+    report("fused2_scale", C=C, rel=worst)
+    assert worst < 2e-3
