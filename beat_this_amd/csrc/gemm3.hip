@@ -22,12 +22,22 @@
 #include "common.h"
 #include "kernels.h"
 
+// Tile configurations.  S: 128 x 128 x 32, 4 waves (2 x 2), 3-stage ring, 48 KB -> 3 workgroups per CU: every
+// epilogue, small / ragged shapes.  B: 256 x 256 x 64, 8 waves (2 token x 4 feature, 128 x 64 each), 2 stages,
+// 128 KB -> 1 workgroup per CU: half the L2 -> LDS operand traffic per flop (the 128^2 FF GEMMs were bound by
+// LDS-DMA fill rate, not MFMA: 84 us with the MFMAs removed vs 95 us with them), and 128-byte LDS rows, i.e. every
+// fetched cache line is used whole.  FF1 / RESID only (the V columns of QKV need a square wave tile).
+struct G3CfgS { static constexpr int BM = 128, BN = 128, BK = 32, WGM = 2, WGN = 2, NST = 3, OCC = 3; };
+struct G3CfgB { static constexpr int BM = 256, BN = 256, BK = 64, WGM = 2, WGN = 4, NST = 2, OCC = 1; };
+// experimental: M = 128^2 with 128-byte rows (2 / CU), C = 256 x 128 x 32 with 8 waves of 64 x 64 (2 / CU)
+struct G3CfgM { static constexpr int BM = 128, BN = 128, BK = 64, WGM = 2, WGN = 2, NST = 2, OCC = 2; };
+struct G3CfgC { static constexpr int BM = 256, BN = 128, BK = 32, WGM = 4, WGN = 2, NST = 3, OCC = 2; };
+
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 32;
-constexpr int NST = 3;                        // ring stages
-constexpr int OP_BYTES = BM * BK * 2;         // one operand tile (8 KB)
-constexpr int ST_BYTES = 2 * OP_BYTES;        // A + W
+typedef G3CfgS CfgS;
+typedef G3CfgB CfgB;
+
 constexpr unsigned OOB = 0x80000000u;         // voffset of a lane that must read zeros (beyond num_records)
 
 typedef __amdgpu_buffer_rsrc_t rsrc_t;
@@ -40,23 +50,35 @@ DEVI unsigned pk2(float a, float b) {
   return __builtin_bit_cast(unsigned, t);
 }
 
-// 16 values of one lane (features crow(r, g) of its row) -> two 16-byte stores of 8 consecutive features:
-// after the half exchange lane g = 0 holds features 16k .. 16k+7, lane g = 1 features 16k+8 .. 16k+15.
-DEVI void store_row_bf16(bf16* row32, const float (&v)[16], int g) {
+// 16 values of one lane (features crow(r, g) of its row) -> two 16-byte pieces of 8 consecutive features each:
+// after the half exchange lane g = 0 holds features 16k .. 16k+7, lane g = 1 features 16k+8 .. 16k+15 (k = 0, 1).
+DEVI void pack_row_bf16(const float (&v)[16], u32x4 (&piece)[2]) {
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
     unsigned x0 = pk2(v[8 * k], v[8 * k + 1]), x1 = pk2(v[8 * k + 2], v[8 * k + 3]);
     unsigned y0 = pk2(v[8 * k + 4], v[8 * k + 5]), y1 = pk2(v[8 * k + 6], v[8 * k + 7]);
     auto r0 = __builtin_amdgcn_permlane32_swap(x0, y0, false, false);
     auto r1 = __builtin_amdgcn_permlane32_swap(x1, y1, false, false);
-    *reinterpret_cast<u32x4*>(row32 + 16 * k + 8 * g) = u32x4{r0[0], r1[0], r0[1], r1[1]};
+    piece[k] = u32x4{r0[0], r1[0], r0[1], r1[1]};
   }
 }
 
 // ABL (development, BT_G3_ABL): bit 0 = no LDS-DMA after the prologue, bit 1 = FF1 epilogue without GELU,
 // bit 2 = no fragment reads / MFMAs in the loop (staging + barriers only)
-template <int EPI, int ABL = 0>
-__global__ __launch_bounds__(256, 3) void gemm3_kernel(const Gemm3P p, int n_tiles, int total_tiles, int per_xcd) {
+template <int EPI, typename CFG, int ABL = 0>
+__global__ __launch_bounds__(64 * CFG::WGM * CFG::WGN, (CFG::OCC * CFG::WGM * CFG::WGN + 3) / 4)
+void gemm3_kernel(const Gemm3P p, int n_tiles, int total_tiles, int per_xcd) {
+  constexpr int BM = CFG::BM, BN = CFG::BN, BK = CFG::BK, NST = CFG::NST;
+  constexpr int NW = CFG::WGM * CFG::WGN, NT = 64 * NW;
+  constexpr int TB = BM / CFG::WGM / 32;       // 32-token blocks per wave
+  constexpr int FB = BN / CFG::WGN / 32;       // 32-feature blocks per wave
+  constexpr int ROWB = BK * 2;                 // bytes per LDS row
+  constexpr int CPR = ROWB / 16;               // 16-byte chunks per row (4 or 8)
+  constexpr int RPI = 64 / CPR;                // rows covered by one wave-instruction (1 KB)
+  constexpr int A_BYTES = BM * ROWB, W_BYTES = BN * ROWB, ST_BYTES = A_BYTES + W_BYTES;
+  constexpr int APC = A_BYTES / (NT * 16), WPC = W_BYTES / (NT * 16);  // LDS-DMA pieces per thread and k-step
+  static_assert(EPI != G3_QKV || TB == FB, "the V columns swap the operand roles: square wave tile needed");
+  static_assert(BN / CFG::WGN == 64, "ssq partials are per 64 columns = one wave");
   __shared__ __attribute__((aligned(16))) char smem[NST * ST_BYTES];
   // XCD-aware tile order: the n-tiles sharing one 128-row A panel run on the same XCD (block b -> XCD b % 8)
   const int bid = blockIdx.x;
@@ -66,8 +88,9 @@ __global__ __launch_bounds__(256, 3) void gemm3_kernel(const Gemm3P p, int n_til
   const int m0 = m_tile * BM, n0 = n_tile * BN;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 5, lr = lane & 31;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / CFG::WGN, wn = wave % CFG::WGN;
   const int nk = p.K / BK;
+  auto swz = [](int r) { return BK == 32 ? (r >> 2) & 3 : (r >> 1) & 7; };  // chunk XOR of LDS row r
   const int Lv = p.nblk * 32;  // QKV: rows are addressed per sequence, padded to whole 32-token blocks
 
   // QKV column tile kind: 0 = q, 1 = k (lane = token, RoPE), 2 = v (lane = feature), 3 = gates
@@ -76,13 +99,16 @@ __global__ __launch_bounds__(256, 3) void gemm3_kernel(const Gemm3P p, int n_til
   const bool normal = EPI == G3_QKV && kind == 2;
 
   // ---- staging: per-lane source offsets (bytes) of the two 4 KB pieces of each operand ---------------------
-  const rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A), 0, (unsigned)((long)p.M * p.lda * 2), 0x00020000);
-  const rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.W), 0, (unsigned)((long)n_tiles * BN * p.K * 2), 0x00020000);
-  unsigned voffA[2], voffW[2];
+  const unsigned a_bytes = (unsigned)((long)p.M * p.lda * 2), w_bytes = (unsigned)((long)n_tiles * BN * p.K * 2);
+  static_assert(APC >= 1 && WPC >= 1, "tile too small for the workgroup");
+  // (fixed-size arrays: an array whose size depends on a template parameter, used as an argument of the LDS-DMA
+  // builtin, is what makes the HOST pass drop the kernel stub)
+  static_assert(APC <= 4 && WPC <= 4, "voffA / voffW hold at most 4 pieces");
+  unsigned voffA[4], voffW[4];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int r = i * 64 + wave * 16 + (lane >> 2);
-    const int c = (lane & 3) ^ ((r >> 2) & 3);
+  for (int i = 0; i < APC; ++i) {
+    const int r = (i * NW + wave) * RPI + lane / CPR;
+    const int c = (lane % CPR) ^ swz(r);
     long row = (long)m0 + r;
     bool ok = row < p.M;
     if constexpr (EPI == G3_QKV) {
@@ -91,66 +117,82 @@ __global__ __launch_bounds__(256, 3) void gemm3_kernel(const Gemm3P p, int n_til
       row = (long)seq * p.L + t;
     }
     voffA[i] = ok ? (unsigned)(row * p.lda * 2 + c * 16) : OOB;
+  }
+#pragma unroll
+  for (int i = 0; i < WPC; ++i) {
+    const int r = (i * NW + wave) * RPI + lane / CPR;
+    const int c = (lane % CPR) ^ swz(r);
     voffW[i] = (unsigned)((long)(n0 + r) * p.K * 2 + c * 16);
   }
-  auto issue = [&](int kt, int stage) {
-    char* st = smem + stage * ST_BYTES + wave * 1024;
-    const int so = kt * (BK * 2);
-    // (the instruction's immediate offset would also move the LDS address: keep it 0)
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lptr_t)st, 16, voffA[0], so, 0, 0);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lptr_t)(st + 4096), 16, voffA[1], so, 0, 0);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (lptr_t)(st + OP_BYTES), 16, voffW[0], so, 0, 0);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (lptr_t)(st + OP_BYTES + 4096), 16, voffW[1], so, 0, 0);
-  };
+  // LDS-DMA of one k-step: APC pieces of the A tile, WPC of the W tile (1 KB per wave-instruction; the pieces of a
+  // thread are NW KB apart).  The instruction's immediate offset would also move the LDS address, so it stays 0 and
+  // the k offset goes into the scalar offset.
+  const rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A), 0, a_bytes, 0x00020000);
+  const rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.W), 0, w_bytes, 0x00020000);
+#define G3_ISSUE(kt, stage)                                                                                          \
+  do {                                                                                                                \
+    char* st_ = smem + (stage) * ST_BYTES + wave * 1024;                                                              \
+    const int so_ = (kt) * ROWB;                                                                                      \
+    _Pragma("unroll") for (int i_ = 0; i_ < APC; ++i_)                                                                \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lptr_t)(st_ + i_ * NW * 1024), 16, voffA[i_], so_, 0, 0);       \
+    _Pragma("unroll") for (int i_ = 0; i_ < WPC; ++i_)                                                                \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (lptr_t)(st_ + A_BYTES + i_ * NW * 1024), 16, voffW[i_], so_, 0, 0); \
+  } while (0)
 
   // ---- fragment addresses: P = rows that become accumulator ROWS (registers), Q = rows that become LANES ----
   // transposed (default): P = W tile, Q = A tile  -> lane = token;   normal (V columns): P = A, Q = W.
-  const int pofs = (normal ? wm * 64 * 64 : OP_BYTES + wn * 64 * 64) + lr * 64;
-  const int qofs = (normal ? OP_BYTES + wn * 64 * 64 : wm * 64 * 64) + lr * 64;
-  const int sw = (lr >> 2) & 3;
-  const int kc0 = ((0 + g) ^ sw) * 16, kc1 = ((2 + g) ^ sw) * 16;  // k16 step 0 / 1: chunk 2 m + g
+  constexpr int NP = FB, NQ = TB;  // (equal when `normal` is possible)
+  const int pofs = (normal ? wm * (TB * 32) * ROWB : A_BYTES + wn * (FB * 32) * ROWB) + lr * ROWB;
+  const int qofs = (normal ? A_BYTES + wn * (FB * 32) * ROWB : wm * (TB * 32) * ROWB) + lr * ROWB;
+  const int sw = swz(lr);
+  int kc[BK / 16];
+#pragma unroll
+  for (int m = 0; m < BK / 16; ++m) kc[m] = ((2 * m + g) ^ sw) * 16;  // k16 step m: chunk 2 m + g
 
-  f32x16 acc[2][2];
+  f32x16 acc[NP][NQ];
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+  for (int a = 0; a < NP; ++a)
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
+    for (int b = 0; b < NQ; ++b)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-  issue(0, 0);
-  if (nk > 1) issue(1, 1);
-  int stage = 0, stage2 = 2;
+  constexpr int LPS = APC + WPC;  // LDS-DMA instructions per thread and k-step
+#pragma unroll
+  for (int s0 = 0; s0 < NST - 1; ++s0)
+    if (s0 < nk) G3_ISSUE(s0, s0);
+  int stage = 0, stage2 = NST - 1;
   for (int kt = 0; kt < nk; ++kt) {
-    if (kt + 1 < nk && !(ABL & 1)) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    // tile kt has landed in every wave; NST - 2 younger tiles may stay in flight across the barrier
+    if (NST > 2 && kt + 1 < nk && !(ABL & 1)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * LPS) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if (kt + 2 < nk && !(ABL & 1)) issue(kt + 2, stage2);
+    if (kt + NST - 1 < nk && !(ABL & 1)) G3_ISSUE(kt + NST - 1, stage2);
     const char* st = smem + stage * ST_BYTES;
 #pragma unroll
-    for (int m = 0; m < ((ABL & 4) ? (kt == 0 ? 1 : 0) : 2); ++m) {
-      const int kc = m == 0 ? kc0 : kc1;
-      bf16x8 fp[2], fq[2];
+    for (int m = 0; m < ((ABL & 4) ? 0 : BK / 16); ++m) {
+      bf16x8 fp[NP], fq[NQ];
 #pragma unroll
-      for (int a = 0; a < 2; ++a) fp[a] = *reinterpret_cast<const bf16x8*>(st + pofs + a * 32 * 64 + kc);
+      for (int a = 0; a < NP; ++a) fp[a] = *reinterpret_cast<const bf16x8*>(st + pofs + a * 32 * ROWB + kc[m]);
 #pragma unroll
-      for (int b = 0; b < 2; ++b) fq[b] = *reinterpret_cast<const bf16x8*>(st + qofs + b * 32 * 64 + kc);
+      for (int b = 0; b < NQ; ++b) fq[b] = *reinterpret_cast<const bf16x8*>(st + qofs + b * 32 * ROWB + kc[m]);
 #pragma unroll
-      for (int a = 0; a < 2; ++a)
+      for (int a = 0; a < NP; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fp[a], fq[b], acc[a][b], 0, 0, 0);
+        for (int b = 0; b < NQ; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fp[a], fq[b], acc[a][b], 0, 0, 0);
     }
     stage = stage == NST - 1 ? 0 : stage + 1;
     stage2 = stage2 == NST - 1 ? 0 : stage2 + 1;
   }
 
+#undef G3_ISSUE
   // ---- epilogue ---------------------------------------------------------------------------------------------
   // token rows of this wave: block j (32 rows), this lane's token = row0 + 32 j + lr  (lane = token view)
-  const int row0 = m0 + wm * 64;
-  long trow[2];    // real row index (A / x / ssq addressing), -1 if the row does not exist
-  int tseq[2], tblk[2];
+  const int row0 = m0 + wm * (TB * 32);
+  long trow[TB];    // real row index (A / x / ssq addressing), -1 if the row does not exist
+  int tseq[TB], tblk[TB];
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
+  for (int j = 0; j < TB; ++j) {
     const long v = (long)row0 + 32 * j + lr;
     if constexpr (EPI == G3_QKV) {
       const int vb = row0 + 32 * j;  // wave-uniform
@@ -163,76 +205,115 @@ __global__ __launch_bounds__(256, 3) void gemm3_kernel(const Gemm3P p, int n_til
       trow[j] = v < p.M ? v : -1;
     }
   }
-  float rs[2] = {1.f, 1.f};
-  if (p.ssq_in) {
+  float rs[TB];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      float s = 0.f;
-      if (trow[j] >= 0)
-        for (int q = 0; q < p.ssq_parts; ++q) s += p.ssq_in[(long)q * p.M + trow[j]];
-      rs[j] = trow[j] >= 0 ? sqrtf((float)p.K) / fmaxf(sqrtf(s), 1e-12f) : 0.f;
+  for (int j = 0; j < TB; ++j) rs[j] = 1.f;
+  if (p.ssq_in) {
+    // all partial sums of all token blocks are requested before the first is used: issued one at a time (runtime
+    // trip count) they cost one memory round trip EACH, ~16 us per workgroup at 1 workgroup per CU
+    float s[TB];
+#pragma unroll
+    for (int j = 0; j < TB; ++j) s[j] = 0.f;
+    for (int q0 = 0; q0 < p.ssq_parts; q0 += 8) {
+      float part[TB][8];
+#pragma unroll
+      for (int j = 0; j < TB; ++j)
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+          part[j][q] = (trow[j] >= 0 && q0 + q < p.ssq_parts) ? p.ssq_in[(long)(q0 + q) * p.M + trow[j]] : 0.f;
+#pragma unroll
+      for (int j = 0; j < TB; ++j)
+#pragma unroll
+        for (int q = 0; q < 8; ++q) s[j] += part[j][q];
     }
+#pragma unroll
+    for (int j = 0; j < TB; ++j) rs[j] = trow[j] >= 0 ? sqrtf((float)p.K) / fmaxf(sqrtf(s[j]), 1e-12f) : 0.f;
   }
 
+  // FF1 / RESID results leave through LDS (free after the k-loop), one private 8 KB area per wave, one 32-token
+  // block at a time: lanes write their token's pieces with the 16-byte chunk index XORed by the row (conflict free),
+  // then read the block back ROW-major so that every global access of a wave-instruction covers whole 128-byte lines
+  // (8 lanes = one 128 B row piece).  Storing straight from the MFMA layout (lane = token: 32 rows x 32 B at a 1-4 KB
+  // stride per instruction, every line written in 4 pieces) ran at ~1.2 TB/s: FF1 took 81 us with its MFMAs removed.
+  __syncthreads();
+  char* wst = smem + wave * 8192;
   if constexpr (EPI == G3_FF1) {
     bf16* out = reinterpret_cast<bf16*>(p.out);
+    const int nb0 = n0 + wn * 64;  // first feature of this wave
 #pragma unroll
-    for (int a = 0; a < 2; ++a) {
-      const int nb = n0 + wn * 64 + a * 32;  // first feature of this 32-block
-      f32x4 bq[4];
+    for (int b = 0; b < TB; ++b) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) bq[q] = *reinterpret_cast<const f32x4*>(p.bias + nb + 8 * q + 4 * g);
+      for (int a = 0; a < FB; ++a) {
+        f32x4 bq[4];
 #pragma unroll
-      for (int b = 0; b < 2; ++b) {
+        for (int q = 0; q < 4; ++q) bq[q] = *reinterpret_cast<const f32x4*>(p.bias + nb0 + a * 32 + 8 * q + 4 * g);
         float v[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const float u = fmaf(acc[a][b][r], rs[b], bq[r >> 2][r & 3]);
           v[r] = (ABL & 2) ? u : gelu_erf(u);
         }
-        if (trow[b] >= 0) store_row_bf16(out + trow[b] * p.ldo + nb, v, g);
+        u32x4 piece[2];
+        pack_row_bf16(v, piece);
+#pragma unroll
+        for (int k = 0; k < 2; ++k)  // 128 B per token row: chunk c = 4 a + 2 k + g, stored at chunk c ^ (row & 7)
+          *reinterpret_cast<u32x4*>(wst + lr * 128 + (((4 * a + 2 * k + g) ^ (lr & 7)) << 4)) = piece[k];
+      }
+      static_assert(FB == 2, "row = 64 features = 128 B");
+#pragma unroll
+      for (int ps = 0; ps < 4; ++ps) {  // 8 rows x 128 B per wave-instruction
+        const int r = ps * 8 + (lane >> 3), cp = lane & 7;
+        const u32x4 w = *reinterpret_cast<const u32x4*>(wst + r * 128 + (cp << 4));
+        const long row = (long)row0 + 32 * b + r;
+        if (row < p.M) *reinterpret_cast<u32x4*>(out + row * p.ldo + nb0 + ((cp ^ (r & 7)) << 3)) = w;
       }
     }
   } else if constexpr (EPI == G3_RESID) {
     bf16* xb = reinterpret_cast<bf16*>(p.xb);
+    const int nb0 = n0 + wn * 64;
 #pragma unroll
-    for (int b = 0; b < 2; ++b) {
-      float ssq = 0.f;
-      const bool ok = trow[b] >= 0;
-      float* xr = p.x + (ok ? trow[b] : 0) * p.ldx;
+    for (int b = 0; b < TB; ++b) {
 #pragma unroll
-      for (int a = 0; a < 2; ++a) {
-        const int nb = n0 + wn * 64 + a * 32;
-        f32x4 xv[4];
+      for (int a = 0; a < FB; ++a)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) xv[q] = ok ? *reinterpret_cast<const f32x4*>(xr + nb + 8 * q + 4 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
-        float v[16];
+        for (int q = 0; q < 4; ++q)  // 256 B per token row: 16-byte chunk c = 8 a + 2 q + g at chunk c ^ (row & 15)
+          *reinterpret_cast<f32x4*>(wst + lr * 256 + (((8 * a + 2 * q + g) ^ (lr & 15)) << 4)) =
+              f32x4{acc[a][b][4 * q], acc[a][b][4 * q + 1], acc[a][b][4 * q + 2], acc[a][b][4 * q + 3]};
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          f32x4 bb = {0.f, 0.f, 0.f, 0.f};
-          if (p.bias) bb = *reinterpret_cast<const f32x4*>(p.bias + nb + 8 * q + 4 * g);
+      for (int ps = 0; ps < 8; ++ps) {  // 4 rows x 256 B per wave-instruction
+        const int r = ps * 4 + (lane >> 4), cp = lane & 15;
+        const int col = nb0 + ((cp ^ (r & 15)) << 2);
+        const long row = (long)row0 + 32 * b + r;
+        const bool ok = row < p.M;
+        f32x4 v = *reinterpret_cast<const f32x4*>(wst + r * 256 + (cp << 4));
+        if (p.bias) {
+          const f32x4 bb = *reinterpret_cast<const f32x4*>(p.bias + col);
 #pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const float o = acc[a][b][4 * q + i] + bb[i] + xv[q][i];
-            v[4 * q + i] = o;
-            ssq = fmaf(o, o, ssq);
-          }
-          if (ok) *reinterpret_cast<f32x4*>(xr + nb + 8 * q + 4 * g) = f32x4{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+          for (int i = 0; i < 4; ++i) v[i] += bb[i];
         }
-        if (xb && ok) store_row_bf16(xb + trow[b] * p.ldx + nb, v, g);
+        float* xr = p.x + (ok ? row : 0) * p.ldx + col;
+        if (ok) {
+          const f32x4 xv = *reinterpret_cast<const f32x4*>(xr);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) v[i] += xv[i];
+          *reinterpret_cast<f32x4*>(xr) = v;
+          if (xb) *reinterpret_cast<u32x2*>(xb + row * p.ldx + col) = u32x2{pk2(v[0], v[1]), pk2(v[2], v[3])};
+        }
+        float ssq = ok ? fmaf(v[0], v[0], fmaf(v[1], v[1], fmaf(v[2], v[2], v[3] * v[3]))) : 0.f;
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) ssq += __shfl_xor(ssq, o);
+        if (p.ssq_out && ok && cp == 0) p.ssq_out[(long)(n0 / 64 + wn) * p.M + row] = ssq;
       }
-      ssq += __shfl_xor(ssq, 32);
-      if (p.ssq_out && ok && g == 0) p.ssq_out[(long)(n0 / 64 + wn) * p.M + trow[b]] = ssq;
     }
   } else {  // G3_QKV
     if (kind < 2) {  // q / k: RoPE, fragment-major [quarter][token][8 dims]
       bf16* dst = reinterpret_cast<bf16*>(kind == 0 ? p.qf : p.kf);
 #pragma unroll
-      for (int b = 0; b < 2; ++b) {
+      for (int b = 0; b < TB; ++b) {
         if (tseq[b] >= p.n_seq) continue;  // wave-uniform
         const int pos = tblk[b] * 32 + lr;
 #pragma unroll
-        for (int a = 0; a < 2; ++a) {
+        for (int a = 0; a < FB; ++a) {
           const int head = (n0 - kind * p.inner + wn * 64 + a * 32) >> 5;
           bf16* blk = dst + (((long)tseq[b] * p.heads + head) * p.nbp + tblk[b]) * 1024;
 #pragma unroll
@@ -249,13 +330,13 @@ __global__ __launch_bounds__(256, 3) void gemm3_kernel(const Gemm3P p, int n_til
     } else if (kind == 2) {  // v: lane = feature (dim), registers = tokens -> V^T fragments
       bf16* dst = reinterpret_cast<bf16*>(p.vf);
 #pragma unroll
-      for (int a = 0; a < 2; ++a) {  // token block a of this wave (accumulator rows)
+      for (int a = 0; a < TB; ++a) {  // token block a of this wave (accumulator rows)
         if (tseq[a] >= p.n_seq) continue;
         float sk[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) sk[r] = __shfl(rs[a], crow(r, g));
 #pragma unroll
-        for (int b = 0; b < 2; ++b) {  // feature block b (lanes)
+        for (int b = 0; b < FB; ++b) {  // feature block b (lanes)
           const int head = (n0 - 2 * p.inner + wn * 64 + b * 32) >> 5;
           bf16* blk = dst + (((long)tseq[a] * p.heads + head) * p.nbp + tblk[a]) * 1024;
 #pragma unroll
@@ -270,11 +351,11 @@ __global__ __launch_bounds__(256, 3) void gemm3_kernel(const Gemm3P p, int n_til
       }
     } else {  // gates: features 3 inner + h
 #pragma unroll
-      for (int b = 0; b < 2; ++b) {
+      for (int b = 0; b < TB; ++b) {
         if (tseq[b] >= p.n_seq) continue;
         const int t = tblk[b] * 32 + lr;
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
+        for (int a = 0; a < FB; ++a)
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int h = n0 - 3 * p.inner + wn * 64 + a * 32 + crow(r, g);
@@ -286,11 +367,23 @@ __global__ __launch_bounds__(256, 3) void gemm3_kernel(const Gemm3P p, int n_til
   }
 }
 
+template <int EPI, typename CFG, int ABL = 0>
+void launch_cfg(const Gemm3P& p, hipStream_t s) {
+  const int n_tiles = (p.N + CFG::BN - 1) / CFG::BN;
+  const long rows = p.epi == G3_QKV ? (long)p.n_seq * p.nblk * 32 : (long)p.M;
+  const long m_tiles = (rows + CFG::BM - 1) / CFG::BM;
+  const long total = m_tiles * n_tiles;
+  long per = (total + 7) / 8;
+  per = (per + n_tiles - 1) / n_tiles * n_tiles;
+  dim3 grid((unsigned)(per * 8)), block(64 * CFG::WGM * CFG::WGN);
+  hipLaunchKernelGGL((gemm3_kernel<EPI, CFG, ABL>), grid, block, 0, s, p, n_tiles, (int)total, (int)per);
+}
+
 }  // namespace
 
 bool gemm3_supported(const Gemm3P& p) {
-  if (p.M <= 0 || p.K % BK != 0 || p.K < 2 * BK || p.lda % 8 != 0) return false;
-  if ((long)p.M * p.lda * 2 >= 0x7fffffffL || (long)(p.N + 127) / 128 * 128 * p.K * 2 >= 0x7fffffffL) return false;
+  if (p.M <= 0 || p.K % 64 != 0 || p.K < 128 || p.lda % 8 != 0) return false;
+  if ((long)p.M * p.lda * 2 >= 0x7fffffffL || (long)(p.N + 255) / 256 * 256 * p.K * 2 >= 0x7fffffffL) return false;
   if (p.epi == G3_QKV) return p.inner % 128 == 0 && p.inner == p.heads * 32 && p.L > 0 && p.L <= 1536;
   if (p.epi == G3_FF1) return p.N % 128 == 0 && p.ldo % 8 == 0;
   if (p.epi == G3_RESID) return p.N % 128 == 0 && p.ldx % 8 == 0;
@@ -299,27 +392,36 @@ bool gemm3_supported(const Gemm3P& p) {
 
 int launch_gemm3(const Gemm3P& p, hipStream_t s) {
   if (!gemm3_supported(p)) return -2;
-  const int n_tiles = (p.N + BN - 1) / BN;
-  const long rows = p.epi == G3_QKV ? (long)p.n_seq * p.nblk * 32 : (long)p.M;
-  const long m_tiles = (rows + BM - 1) / BM;
-  const long total = m_tiles * n_tiles;
-  if (total > 0x3fffffffL) return -3;
-  long per = (total + 7) / 8;
-  per = (per + n_tiles - 1) / n_tiles * n_tiles;
-  dim3 grid((unsigned)(per * 8)), block(256);
+  // development switches: BT_G3_ABL (ablations of the FF1 kernel), BT_G3_BIG = 0 / 1 forces the tile configuration
+  static const int abl = getenv("BT_G3_ABL") ? atoi(getenv("BT_G3_ABL")) : 0;
+  static const int force_big = getenv("BT_G3_BIG") ? atoi(getenv("BT_G3_BIG")) : -1;
+  static const int cfg = getenv("BT_G3_CFG") ? atoi(getenv("BT_G3_CFG")) : 0;  // 1 = M, 2 = C (FF1 / RESID probes)
+  if (cfg == 1 && p.epi == G3_FF1) { launch_cfg<G3_FF1, G3CfgM>(p, s); return (int)hipGetLastError(); }
+  if (cfg == 1 && p.epi == G3_RESID) { launch_cfg<G3_RESID, G3CfgM>(p, s); return (int)hipGetLastError(); }
+  if (cfg == 2 && p.epi == G3_FF1) { launch_cfg<G3_FF1, G3CfgC>(p, s); return (int)hipGetLastError(); }
+  if (cfg == 2 && p.epi == G3_RESID) { launch_cfg<G3_RESID, G3CfgC>(p, s); return (int)hipGetLastError(); }
+  // Measured on the final0 shapes (M = 24000): the 256^2 configuration is no faster in isolation (FF1 85 vs 86 us,
+  // FF2 80 vs 83 us) and slower inside the forward (4.19 vs 4.11 ms per step: one workgroup per CU cannot hide its
+  // epilogue behind another workgroup's k-loop), so 128^2 is the default and 256^2 stays an opt-in experiment.
+  const bool big = force_big == 1 && p.epi != G3_QKV && p.N % 256 == 0;
   switch (p.epi) {
-    case G3_FF1: {
-      static const int abl = getenv("BT_G3_ABL") ? atoi(getenv("BT_G3_ABL")) : 0;
-      if (abl == 1) hipLaunchKernelGGL((gemm3_kernel<G3_FF1, 1>), grid, block, 0, s, p, n_tiles, (int)total, (int)per);
-      else if (abl == 2) hipLaunchKernelGGL((gemm3_kernel<G3_FF1, 2>), grid, block, 0, s, p, n_tiles, (int)total, (int)per);
-      else if (abl == 3) hipLaunchKernelGGL((gemm3_kernel<G3_FF1, 3>), grid, block, 0, s, p, n_tiles, (int)total, (int)per);
-      else if (abl == 4) hipLaunchKernelGGL((gemm3_kernel<G3_FF1, 4>), grid, block, 0, s, p, n_tiles, (int)total, (int)per);
-      else if (abl == 6) hipLaunchKernelGGL((gemm3_kernel<G3_FF1, 6>), grid, block, 0, s, p, n_tiles, (int)total, (int)per);
-      else hipLaunchKernelGGL((gemm3_kernel<G3_FF1>), grid, block, 0, s, p, n_tiles, (int)total, (int)per);
+    case G3_FF1:
+      if (big) {
+        if (abl == 1) launch_cfg<G3_FF1, CfgB, 1>(p, s);
+        else if (abl == 2) launch_cfg<G3_FF1, CfgB, 2>(p, s);
+        else if (abl == 4) launch_cfg<G3_FF1, CfgB, 4>(p, s);
+        else launch_cfg<G3_FF1, CfgB>(p, s);
+      } else {
+        if (abl == 1) launch_cfg<G3_FF1, CfgS, 1>(p, s);
+        else if (abl == 4) launch_cfg<G3_FF1, CfgS, 4>(p, s);
+        else launch_cfg<G3_FF1, CfgS>(p, s);
+      }
       break;
-    }
-    case G3_RESID: hipLaunchKernelGGL((gemm3_kernel<G3_RESID>), grid, block, 0, s, p, n_tiles, (int)total, (int)per); break;
-    case G3_QKV: hipLaunchKernelGGL((gemm3_kernel<G3_QKV>), grid, block, 0, s, p, n_tiles, (int)total, (int)per); break;
+    case G3_RESID:
+      if (big) launch_cfg<G3_RESID, CfgB>(p, s);
+      else launch_cfg<G3_RESID, CfgS>(p, s);
+      break;
+    case G3_QKV: launch_cfg<G3_QKV, CfgS>(p, s); break;
     default: return -1;
   }
   return (int)hipGetLastError();
