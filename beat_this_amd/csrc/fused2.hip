@@ -95,7 +95,7 @@ DEVI void ff_tail(WRing<T, C>& ws, int step0, float (&xn)[C / 32][16], const flo
     for (int a = 0; a < 4; ++a) {
       const f32x4 b = *reinterpret_cast<const f32x4*>(b1s + hb * 32 + 8 * a + 4 * g);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) h[4 * a + j] = gelu_erf(fmaf(acc1[4 * a + j], scale, b[j]));
+      for (int j = 0; j < 4; ++j) h[4 * a + j] = gelu_t<T>(fmaf(acc1[4 * a + j], scale, b[j]));
     }
     const Frag<T> hf = pack_frag<T>(h);
 #pragma unroll

@@ -32,6 +32,11 @@ struct G3CfgB { static constexpr int BM = 256, BN = 256, BK = 64, WGM = 2, WGN =
 // experimental: M = 128^2 with 128-byte rows (2 / CU), C = 256 x 128 x 32 with 8 waves of 64 x 64 (2 / CU)
 struct G3CfgM { static constexpr int BM = 128, BN = 128, BK = 64, WGM = 2, WGN = 2, NST = 2, OCC = 2; };
 struct G3CfgC { static constexpr int BM = 256, BN = 128, BK = 32, WGM = 4, WGN = 2, NST = 3, OCC = 2; };
+// E = 256^2 x 32 with a 4-stage ring (3 x 32 KB in flight at half the bytes per flop), F = 128^2 x 32 with 5 stages
+struct G3CfgE { static constexpr int BM = 256, BN = 256, BK = 32, WGM = 2, WGN = 4, NST = 4, OCC = 1; };
+struct G3CfgF { static constexpr int BM = 128, BN = 128, BK = 32, WGM = 2, WGN = 2, NST = 5, OCC = 2; };
+// D = 256 x 128 x 32 with 4 waves of 128 x 64 (0.75 LDS reads per MFMA, 2 / CU so epilogues overlap k-loops)
+struct G3CfgD { static constexpr int BM = 256, BN = 128, BK = 32, WGM = 2, WGN = 2, NST = 3, OCC = 2; };
 
 namespace {
 
@@ -162,11 +167,17 @@ void gemm3_kernel(const Gemm3P p, int n_tiles, int total_tiles, int per_xcd) {
   for (int s0 = 0; s0 < NST - 1; ++s0)
     if (s0 < nk) G3_ISSUE(s0, s0);
   int stage = 0, stage2 = NST - 1;
+  long long t_wait = 0, t_bar = 0, t_loop0 = 0;
+  if constexpr ((ABL & 8) != 0) t_loop0 = clock64();
   for (int kt = 0; kt < nk; ++kt) {
+    long long tq0 = 0, tq1 = 0;
+    if constexpr ((ABL & 8) != 0) tq0 = clock64();
     // tile kt has landed in every wave; NST - 2 younger tiles may stay in flight across the barrier
     if (NST > 2 && kt + 1 < nk && !(ABL & 1)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * LPS) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr ((ABL & 8) != 0) tq1 = clock64();
     __builtin_amdgcn_s_barrier();
+    if constexpr ((ABL & 8) != 0) { const long long tq2 = clock64(); t_wait += tq1 - tq0; t_bar += tq2 - tq1; }
     if (kt + NST - 1 < nk && !(ABL & 1)) G3_ISSUE(kt + NST - 1, stage2);
     const char* st = smem + stage * ST_BYTES;
 #pragma unroll
@@ -186,6 +197,8 @@ void gemm3_kernel(const Gemm3P p, int n_tiles, int total_tiles, int per_xcd) {
   }
 
 #undef G3_ISSUE
+  long long t_loop1 = 0;
+  if constexpr ((ABL & 8) != 0) t_loop1 = clock64();
   // ---- epilogue ---------------------------------------------------------------------------------------------
   // token rows of this wave: block j (32 rows), this lane's token = row0 + 32 j + lr  (lane = token view)
   const int row0 = m0 + wm * (TB * 32);
@@ -251,7 +264,7 @@ void gemm3_kernel(const Gemm3P p, int n_tiles, int total_tiles, int per_xcd) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const float u = fmaf(acc[a][b][r], rs[b], bq[r >> 2][r & 3]);
-          v[r] = (ABL & 2) ? u : gelu_erf(u);
+          v[r] = (ABL & 2) ? u : gelu_tanh(u);
         }
         u32x4 piece[2];
         pack_row_bf16(v, piece);
@@ -365,6 +378,15 @@ void gemm3_kernel(const Gemm3P p, int n_tiles, int total_tiles, int per_xcd) {
       }
     }
   }
+  if constexpr ((ABL & 8) != 0) {  // development timing dump over the head of the (already written) output
+    const long long t_end = clock64();
+    __syncthreads();
+    if (lane == 0) {
+      long long* dbg = reinterpret_cast<long long*>(p.ssq_in ? const_cast<float*>(p.ssq_in) : p.ssq_out);
+      long long* d = dbg + ((long)blockIdx.x * NW + wave) * 4;
+      d[0] = t_loop1 - t_loop0; d[1] = t_wait; d[2] = t_bar; d[3] = t_end - t_loop1;
+    }
+  }
 }
 
 template <int EPI, typename CFG, int ABL = 0>
@@ -400,6 +422,12 @@ int launch_gemm3(const Gemm3P& p, hipStream_t s) {
   if (cfg == 1 && p.epi == G3_RESID) { launch_cfg<G3_RESID, G3CfgM>(p, s); return (int)hipGetLastError(); }
   if (cfg == 2 && p.epi == G3_FF1) { launch_cfg<G3_FF1, G3CfgC>(p, s); return (int)hipGetLastError(); }
   if (cfg == 2 && p.epi == G3_RESID) { launch_cfg<G3_RESID, G3CfgC>(p, s); return (int)hipGetLastError(); }
+  if (cfg == 3 && p.epi == G3_FF1) { launch_cfg<G3_FF1, G3CfgD>(p, s); return (int)hipGetLastError(); }
+  if (cfg == 3 && p.epi == G3_RESID) { launch_cfg<G3_RESID, G3CfgD>(p, s); return (int)hipGetLastError(); }
+  if (cfg == 4 && p.epi == G3_FF1 && p.N % 256 == 0) { launch_cfg<G3_FF1, G3CfgE>(p, s); return (int)hipGetLastError(); }
+  if (cfg == 4 && p.epi == G3_RESID && p.N % 256 == 0) { launch_cfg<G3_RESID, G3CfgE>(p, s); return (int)hipGetLastError(); }
+  if (cfg == 5 && p.epi == G3_FF1) { launch_cfg<G3_FF1, G3CfgF>(p, s); return (int)hipGetLastError(); }
+  if (cfg == 5 && p.epi == G3_RESID) { launch_cfg<G3_RESID, G3CfgF>(p, s); return (int)hipGetLastError(); }
   // Measured on the final0 shapes (M = 24000): the 256^2 configuration is no faster in isolation (FF1 85 vs 86 us,
   // FF2 80 vs 83 us) and slower inside the forward (4.19 vs 4.11 ms per step: one workgroup per CU cannot hide its
   // epilogue behind another workgroup's k-loop), so 128^2 is the default and 256^2 stays an opt-in experiment.
@@ -414,6 +442,7 @@ int launch_gemm3(const Gemm3P& p, hipStream_t s) {
       } else {
         if (abl == 1) launch_cfg<G3_FF1, CfgS, 1>(p, s);
         else if (abl == 4) launch_cfg<G3_FF1, CfgS, 4>(p, s);
+        else if (abl == 8) launch_cfg<G3_FF1, CfgS, 8>(p, s);
         else launch_cfg<G3_FF1, CfgS>(p, s);
       }
       break;

@@ -42,7 +42,15 @@ if "ff1" in which:
     W, b, out = rnd(4 * D, D, scale=0.05), rnd(4 * D, dtype=torch.float32), torch.empty((M, 4 * D), dtype=torch.bfloat16, device=dev)
     a.A, a.lda, a.M, a.K, a.W, a.N, a.epi = x.data_ptr(), D, M, D, W.data_ptr(), 4 * D, 0
     a.bias, a.ssq_in, a.ssq_parts, a.out, a.ldo = b.data_ptr(), ssq.data_ptr(), D // 64, out.data_ptr(), 4 * D
+    if os.environ.get("BT_G3_ABL") == "8":
+        ssq = torch.zeros((8 * 1024 * 1024,), device=dev)  # room for the timing dump
+        a.ssq_in = ssq.data_ptr()
     timeit("ff1 (N=2048,K=512)", a, 2.0 * M * D * 4 * D)
+    if os.environ.get("BT_G3_ABL") == "8":
+        torch.cuda.synchronize()
+        nw = 3008 * 4
+        d = ssq.view(torch.int64)[: nw * 4].view(-1, 4).cpu().double()
+        print(f"   per wave: loop {d[:,0].mean():.0f} cyc (vmcnt wait {d[:,1].mean():.0f}, barrier {d[:,2].mean():.0f}), epilogue {d[:,3].mean():.0f}")
 if "ff2" in which:
     a = _lib.Gemm3Args()
     h, W, b = rnd(M, 4 * D), rnd(D, 4 * D, scale=0.02), rnd(D, dtype=torch.float32)
