@@ -162,10 +162,51 @@ void gemm3_kernel(const Gemm3P p, int n_tiles, int total_tiles, int per_xcd) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
+  // token rows of this wave: block j (32 rows), this lane's token = row0 + 32 j + lr  (lane = token view)
+  const int row0 = m0 + wm * (TB * 32);
+  long trow[TB];    // real row index (A / x / ssq addressing), -1 if the row does not exist
+  int tseq[TB], tblk[TB];
+#pragma unroll
+  for (int j = 0; j < TB; ++j) {
+    const long v = (long)row0 + 32 * j + lr;
+    if constexpr (EPI == G3_QKV) {
+      const int vb = row0 + 32 * j;  // wave-uniform
+      tseq[j] = vb / Lv;
+      tblk[j] = (vb - tseq[j] * Lv) >> 5;
+      const int t = tblk[j] * 32 + lr;
+      trow[j] = (tseq[j] < p.n_seq && t < p.L) ? (long)tseq[j] * p.L + t : -1;
+    } else {
+      tseq[j] = tblk[j] = 0;
+      trow[j] = v < p.M ? v : -1;
+    }
+  }
+  // RMSNorm factors: the partial sums of squares are requested BEFORE the LDS-DMA prologue and consumed right after
+  // it behind an explicit vmcnt(0) (ordinary loads and LDS-DMA do not return in order, so no counted wait may separate
+  // them): their latency overlaps the first tiles' instead of sitting in the epilogue (~2 k cycles of a 31 k wave life).
+  float rs[TB], part[TB][8];
+#pragma unroll
+  for (int j = 0; j < TB; ++j) {
+    rs[j] = 1.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+      part[j][q] = (p.ssq_in && trow[j] >= 0 && q < p.ssq_parts) ? p.ssq_in[(long)q * p.M + trow[j]] : 0.f;
+  }
   constexpr int LPS = APC + WPC;  // LDS-DMA instructions per thread and k-step
 #pragma unroll
   for (int s0 = 0; s0 < NST - 1; ++s0)
     if (s0 < nk) G3_ISSUE(s0, s0);
+  if (p.ssq_in) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < TB; ++j) {
+      float sum = 0.f;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) sum += part[j][q];
+      for (int q = 8; q < p.ssq_parts; ++q) sum += trow[j] >= 0 ? p.ssq_in[(long)q * p.M + trow[j]] : 0.f;  // D > 512
+      rs[j] = trow[j] >= 0 ? sqrtf((float)p.K) / fmaxf(sqrtf(sum), 1e-12f) : 0.f;
+    }
+  }
   int stage = 0, stage2 = NST - 1;
   long long t_wait = 0, t_bar = 0, t_loop0 = 0;
   if constexpr ((ABL & 8) != 0) t_loop0 = clock64();
@@ -200,49 +241,6 @@ void gemm3_kernel(const Gemm3P p, int n_tiles, int total_tiles, int per_xcd) {
   long long t_loop1 = 0;
   if constexpr ((ABL & 8) != 0) t_loop1 = clock64();
   // ---- epilogue ---------------------------------------------------------------------------------------------
-  // token rows of this wave: block j (32 rows), this lane's token = row0 + 32 j + lr  (lane = token view)
-  const int row0 = m0 + wm * (TB * 32);
-  long trow[TB];    // real row index (A / x / ssq addressing), -1 if the row does not exist
-  int tseq[TB], tblk[TB];
-#pragma unroll
-  for (int j = 0; j < TB; ++j) {
-    const long v = (long)row0 + 32 * j + lr;
-    if constexpr (EPI == G3_QKV) {
-      const int vb = row0 + 32 * j;  // wave-uniform
-      tseq[j] = vb / Lv;
-      tblk[j] = (vb - tseq[j] * Lv) >> 5;
-      const int t = tblk[j] * 32 + lr;
-      trow[j] = (tseq[j] < p.n_seq && t < p.L) ? (long)tseq[j] * p.L + t : -1;
-    } else {
-      tseq[j] = tblk[j] = 0;
-      trow[j] = v < p.M ? v : -1;
-    }
-  }
-  float rs[TB];
-#pragma unroll
-  for (int j = 0; j < TB; ++j) rs[j] = 1.f;
-  if (p.ssq_in) {
-    // all partial sums of all token blocks are requested before the first is used: issued one at a time (runtime
-    // trip count) they cost one memory round trip EACH, ~16 us per workgroup at 1 workgroup per CU
-    float s[TB];
-#pragma unroll
-    for (int j = 0; j < TB; ++j) s[j] = 0.f;
-    for (int q0 = 0; q0 < p.ssq_parts; q0 += 8) {
-      float part[TB][8];
-#pragma unroll
-      for (int j = 0; j < TB; ++j)
-#pragma unroll
-        for (int q = 0; q < 8; ++q)
-          part[j][q] = (trow[j] >= 0 && q0 + q < p.ssq_parts) ? p.ssq_in[(long)(q0 + q) * p.M + trow[j]] : 0.f;
-#pragma unroll
-      for (int j = 0; j < TB; ++j)
-#pragma unroll
-        for (int q = 0; q < 8; ++q) s[j] += part[j][q];
-    }
-#pragma unroll
-    for (int j = 0; j < TB; ++j) rs[j] = trow[j] >= 0 ? sqrtf((float)p.K) / fmaxf(sqrtf(s[j]), 1e-12f) : 0.f;
-  }
-
   // FF1 / RESID results leave through LDS (free after the k-loop), one private 8 KB area per wave, one 32-token
   // block at a time: lanes write their token's pieces with the 16-byte chunk index XORed by the row (conflict free),
   // then read the block back ROW-major so that every global access of a wave-instruction covers whole 128-byte lines
@@ -448,6 +446,9 @@ int launch_gemm3(const Gemm3P& p, hipStream_t s) {
       break;
     case G3_RESID:
       if (big) launch_cfg<G3_RESID, CfgB>(p, s);
+      else if (abl == 8) launch_cfg<G3_RESID, CfgS, 8>(p, s);
+      else if (abl == 1) launch_cfg<G3_RESID, CfgS, 1>(p, s);
+      else if (abl == 4) launch_cfg<G3_RESID, CfgS, 4>(p, s);
       else launch_cfg<G3_RESID, CfgS>(p, s);
       break;
     case G3_QKV: launch_cfg<G3_QKV, CfgS>(p, s); break;

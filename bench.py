@@ -12,8 +12,8 @@ all-gathered (RCCL) inside the step, so every rank ends with all logits (weak sc
 value = N * 16 * 30 audio-seconds / step time (max over ranks).
 
 Extra objects on the JSON line:
-  roofline      dominant kernel (attn_flash_kernel, MFMA bound): algorithmic FLOP of its launches
-                in one forward / their summed duration, HIP events on the launch stream
+  roofline      dominant launch category (attention: attn_frag_kernel, MFMA bound): algorithmic FLOP of
+                its launches in one forward / their summed duration, HIP events on the launch stream
                 (a separate profiled pass of the same workload after the timed region).
   cpu_baseline  the CPU oracle (torch fp32 restatement of the reference, kind "port") timed on
                 this host on a bounded sample (a few single-chunk forwards), rank 0, N = 1 only.
@@ -38,22 +38,26 @@ PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}  # MI355X_MICROARCH.md: dense MFMA 
 
 
 def flops_per_chunk(D: int, T: int = CHUNK_FRAMES):
-    """Algorithmic MACs*2 per chunk, by kernel category (recomputed)."""
+    """Algorithmic MACs*2 per chunk, by launch category of csrc/engine.hip (SURVEY.md Appendix B, recomputed;
+    the sum is the 134.71 GFLOP / chunk of SURVEY.md section 8d for final0).  bf16 path:
+      attn_freq_fused = attnff_fused_kernel   frequency direction: QKV+gates, attention, out-proj AND its FF
+      ff_fused        = outff_fused_kernel    time direction: out-proj and its FF
+      qkv_gemm        = gemm3 QKV (main layers) + qkv_front_kernel (time-direction QKV of the frontend)
+      attn_flash      = attn_frag_kernel      time-direction + main attention
+      out_gemm / ff1_gemm / ff2_gemm = gemm3  main layers only"""
     cat = dict(stem=2 * T * 32 * 32 * 12, qkv_gemm=0, attn_freq=0, attn_flash=0, out_gemm=0, ff1_gemm=0, ff2_gemm=0,
                conv_gemm=0, linear_gemm=2 * T * 1024 * D, head=2 * T * D * 2, ff_fused=0, attn_freq_fused=0)
     for blk in range(3):
         Cc, F = 32 << blk, 32 >> blk
         h = Cc // 32
         tokens = T * F
-        for direction in ("F", "T"):
-            cat["ff_fused"] += 2 * 2 * tokens * Cc * 4 * Cc  # frontend FF blocks run fused (csrc/fused.hip)
-            if direction == "F":  # QKV + attention + out-proj of the frequency direction: one fused kernel
-                cat["attn_freq_fused"] += 2 * tokens * Cc * (3 * Cc + h) + 2 * tokens * Cc * Cc \
-                    + 2 * 2 * T * h * F * F * 32
-            else:
-                cat["qkv_gemm"] += 2 * tokens * Cc * (3 * Cc + h)
-                cat["out_gemm"] += 2 * tokens * Cc * Cc
-                cat["attn_flash"] += 2 * 2 * F * h * T * T * 32
+        ff = 2 * 2 * tokens * Cc * 4 * Cc
+        qkv = 2 * tokens * Cc * (3 * Cc + h)
+        out = 2 * tokens * Cc * Cc
+        cat["attn_freq_fused"] += qkv + out + 2 * 2 * T * h * F * F * 32 + ff
+        cat["qkv_gemm"] += qkv
+        cat["attn_flash"] += 2 * 2 * F * h * T * T * 32
+        cat["ff_fused"] += out + ff
         cat["conv_gemm"] += 2 * T * (F // 2) * (6 * Cc) * (2 * Cc)
     H = D // 32
     for _ in range(6):
@@ -155,8 +159,17 @@ def main():
         dom = max(breakdown, key=lambda k: breakdown[k]["ms_per_step"])
         d = breakdown[dom]
         peak = PEAK_TFLOPS[args.prec]
+        # HBM bytes per launch of the dominant category: PMC counters collected in separate rocprofv3 passes
+        # (tools/pmc_traffic.sh) for exactly this workload, committed under profiles/; null for any other workload
+        traffic = None
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+            if tj["workload"] == {"model": args.model, "prec": args.prec, "chunks": B} and dom in tj:
+                traffic = tj[dom]["bytes_per_launch"]
+        except (OSError, ValueError, KeyError):
+            pass
         roofline = {"kernel": dom, "bound": "mfma", "achieved": d["tflops"], "peak": peak, "unit": "TFLOP/s",
-                    "frac": round(d["tflops"] / peak, 4), "traffic": None,
+                    "frac": round(d["tflops"] / peak, 4), "traffic": traffic,
                     "avg_launch_ms": round(d["ms_per_step"] / d["launches_per_step"], 4),
                     "flop_per_launch": fl[dom] * B / d["launches_per_step"],
                     "whole_forward_tflops": round(sum(fl.values()) * B / (ms_per_step * 1e-3) / 1e12, 2)}

@@ -11,12 +11,12 @@ typedef __amdgpu_buffer_rsrc_t rsrc_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
 template <int PAT>
-__global__ __launch_bounds__(256) void k(const char* src, unsigned bytes, int steps, int* sink, int wgs_per_cu_hint) {
+__global__ __launch_bounds__(256) void k(const char* src, unsigned bytes, int steps, int* sink, int big) {
   __shared__ __attribute__((aligned(16))) char smem[4 * 16384];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(src), 0, bytes, 0x00020000);
   // each WG works on a different 128-row panel (like different n-tiles), panel = blockIdx % 16
-  const unsigned panel = (blockIdx.x % 16) * 128;
+  const unsigned panel = (big ? blockIdx.x : (blockIdx.x % 16)) * 128;
   unsigned voff[4];
   int npc;  // pieces (1 KB per wave) per thread per tile
   if (PAT == 0 || PAT == 3) {
@@ -28,10 +28,10 @@ __global__ __launch_bounds__(256) void k(const char* src, unsigned bytes, int st
     for (int i = 0; i < 4; ++i) { const int r = (i * 4 + wave) * 8 + lane / 8; voff[i] = (panel + r) * 1024 + (lane % 8) * 16; }
   } else {
     npc = 2;
-    for (int i = 0; i < 2; ++i) voff[i] = (blockIdx.x % 16) * 131072 + (i * 4 + wave) * 1024 + lane * 16;
+    for (int i = 0; i < 2; ++i) voff[i] = (big ? blockIdx.x * 524288u : (blockIdx.x % 16) * 131072u) + (i * 4 + wave) * 1024 + lane * 16;
   }
   const int kstep = PAT == 1 ? 128 : (PAT == 2 ? 8192 : 64);
-  const int wrap = PAT == 2 ? 16 : (PAT == 3 ? 64 : (PAT == 1 ? 8 : 16));  // k-steps per row before wrapping
+  const int wrap = PAT == 2 ? (big ? 64 : 16) : (PAT == 3 ? 64 : (PAT == 1 ? 8 : 16));  // k-steps per row before wrapping
   auto issue = [&](int s) {
     char* st = smem + (s & 3) * 16384 + wave * 1024;
     const int so = (s % wrap) * kstep;
@@ -51,12 +51,13 @@ __global__ __launch_bounds__(256) void k(const char* src, unsigned bytes, int st
 }
 
 template <int PAT>
-void run(const char* name, const char* d, unsigned bytes, int* sink, int wgs) {
-  const int steps = 512;
+void run(const char* name, const char* d, unsigned bytes, int* sink, int wgs, int big = 0) {
+  const int steps = big ? 64 : 512;
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-  hipLaunchKernelGGL(k<PAT>, dim3(wgs), dim3(256), 0, 0, d, bytes, steps, sink, 0);
+  hipLaunchKernelGGL(k<PAT>, dim3(wgs), dim3(256), 0, 0, d, bytes, steps, sink, big);
+  if (big) hipMemsetAsync(const_cast<char*>(d) + (1u << 30), 2, 1u << 30, 0);  // flush the 256 MB last-level cache
   hipEventRecord(e0, 0);
-  hipLaunchKernelGGL(k<PAT>, dim3(wgs), dim3(256), 0, 0, d, bytes, steps, sink, 0);
+  hipLaunchKernelGGL(k<PAT>, dim3(wgs), dim3(256), 0, 0, d, bytes, steps, sink, big);
   hipEventRecord(e1, 0);
   hipDeviceSynchronize();
   float ms; hipEventElapsedTime(&ms, e0, e1);
@@ -66,8 +67,8 @@ void run(const char* name, const char* d, unsigned bytes, int* sink, int wgs) {
 }
 
 int main() {
-  const unsigned bytes = 16u << 20;  // 16 MB buffer (2048 rows x ... ); L2 / MALL resident
-  char* d; hipMalloc(&d, bytes); hipMemset(d, 1, bytes);
+  const unsigned bytes = 16u << 20;  // 16 MB working set: L2 / MALL resident
+  char* d; hipMalloc(&d, 2ull << 30); hipMemset(d, 1, 2ull << 30);
   int* sink; hipMalloc(&sink, 4);
   for (int wgs : {256, 512, 768}) {
     run<0>("rows 64 B @ 1 KB stride (row-major, BK=32)", d, bytes, sink, wgs);
@@ -75,5 +76,8 @@ int main() {
     run<3>("rows 64 B @ 4 KB stride (K=2048, BK=32)", d, bytes, sink, wgs);
     run<2>("contiguous 8 KB tiles (pre-tiled)", d, bytes, sink, wgs);
   }
+  // HBM-sourced: every workgroup streams its OWN 128-row x 4 KB panel (768 x 512 KB = 393 MB, cache flushed before)
+  run<3>("HBM: rows 64 B @ 4 KB stride, own panel per WG", d, 1u << 30, sink, 768, 1);
+  run<2>("HBM: contiguous 8 KB tiles, own 512 KB per WG", d, 1u << 30, sink, 768, 1);
   return 0;
 }
