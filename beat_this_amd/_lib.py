@@ -99,6 +99,8 @@ EXPORTS = {
     "bt_aggregate": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int64,
                                C.c_void_p, C.c_void_p]),
     "bt_logmel": (C.c_int, [C.c_void_p, C.POINTER(LogmelTables), C.c_void_p, C.c_int64, C.c_void_p]),
+    "bt_resample": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
+                              C.c_int64]),
     "bt_peaks": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]),
     "bt_postprocess_host": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_double, C.c_void_p,
                                       C.POINTER(C.c_int32), C.c_void_p, C.POINTER(C.c_int32)]),

@@ -356,6 +356,15 @@ int bt_logmel(void* stream, const bt_logmel_tables* t, const float* d_audio, int
   return BT_OK;
 }
 
+int bt_resample(void* stream, const float* d_in, int64_t n_in, int up, int down, const float* d_filter, int half_len,
+                float* d_out, int64_t n_out) {
+  if (!d_in || !d_filter || !d_out || n_in <= 0 || n_out <= 0 || up <= 0 || down <= 0 || half_len < 0)
+    return bt_set_error(BT_ERR_ARG, "bad argument to bt_resample");
+  if (n_out > (n_in * up + down - 1) / down) return bt_set_error(BT_ERR_ARG, "n_out exceeds ceil(n_in * up / down)");
+  LAUNCH(launch_resample(d_in, n_in, up, down, d_filter, half_len, d_out, n_out, (hipStream_t)stream), "resample");
+  return BT_OK;
+}
+
 int bt_peaks(void* stream, const float* d_logits, int64_t n, int n_arrays, int32_t* d_idx, int32_t* d_count) {
   if (!d_logits || !d_idx || !d_count || n <= 0 || n_arrays <= 0) return bt_set_error(BT_ERR_ARG, "bad argument");
   LAUNCH(launch_peaks(d_logits, n, n_arrays, d_idx, d_count, (hipStream_t)stream), "peaks");

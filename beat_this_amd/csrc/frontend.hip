@@ -143,7 +143,35 @@ __global__ __launch_bounds__(1024) void peaks_kernel(const float* __restrict__ l
   if (tid == 0) count[blockIdx.x] = base_s;
 }
 
+// Rational resampler (replaces the host soxr.resample call of inference.py:274-275):
+//   y[m] = sum_k x[k] * h[m * down + half - k * up],   h = up * firwin(2 half + 1, 1 / max(up, down), kaiser 5.0),
+// i.e. upsample by `up`, zero-phase FIR low-pass, keep every `down`-th sample (the polyphase form of
+// scipy.signal.resample_poly, zero extension at the ends).  One thread per output sample, ~20 max(up,down)/up + 1
+// taps; x and h reads of neighbouring threads overlap and stay in L1/L2, so the kernel is bound by its
+// 4 B/sample in + 4 B/sample out of HBM traffic.
+__global__ __launch_bounds__(256) void resample_kernel(const float* __restrict__ x, long n_in, int up, int down,
+                                                         const float* __restrict__ h, int half, float* __restrict__ y,
+                                                         long n_out) {
+  const long m = (long)blockIdx.x * 256 + threadIdx.x;
+  if (m >= n_out) return;
+  const long c = m * down + half;                 // h index of x[0]'s tap
+  long k_lo = (c - 2L * half + up - 1) / up;      // smallest k with c - k up <= 2 half (c - 2 half may be negative)
+  if (c - 2L * half < 0) k_lo = 0;
+  long k_hi = c / up;                             // largest k with c - k up >= 0
+  if (k_hi > n_in - 1) k_hi = n_in - 1;
+  float acc = 0.f;
+  for (long k = k_lo; k <= k_hi; ++k) acc = fmaf(x[k], h[c - k * up], acc);
+  y[m] = acc;
+}
+
 }  // namespace
+
+int launch_resample(const float* x, long n_in, int up, int down, const float* h, int half, float* y, long n_out,
+                    hipStream_t s) {
+  hipLaunchKernelGGL(resample_kernel, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, s, x, n_in, up, down, h, half,
+                     y, n_out);
+  return (int)hipGetLastError();
+}
 
 int launch_stem(const StemP& p, hipStream_t s) {
   hipLaunchKernelGGL(stem_kernel, dim3((unsigned)((long)p.B * p.T)), dim3(256), 0, s, p);

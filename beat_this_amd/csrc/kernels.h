@@ -162,6 +162,8 @@ int launch_head(const HeadP& p, hipStream_t s);
 int launch_split(const float* spect, long n_frames, const int* starts, int B, int T, float* chunks, hipStream_t s);
 int launch_aggregate(const float* cb, const float* cd, const int* starts, int B, int T, int border, long n_frames,
                      float* beat, float* downbeat, hipStream_t s);
+int launch_resample(const float* x, long n_in, int up, int down, const float* h, int half, float* y, long n_out,
+                    hipStream_t s);
 // logits: [n_arrays][n]; idx: [n_arrays][n] ascending frame indices; count: [n_arrays]
 int launch_peaks(const float* logits, long n, int n_arrays, int* idx, int* count, hipStream_t s);
 

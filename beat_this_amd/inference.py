@@ -185,9 +185,9 @@ class Audio2Frames(Spect2Frames):
             signal = signal.mean(1)
         elif signal.ndim != 1:
             raise ValueError(f"Expected 1D or 2D signal, got shape {signal.shape}")
-        if sr != 22050:
-            signal = resample(signal, sr, 22050)
         signal = torch.tensor(signal, dtype=torch.float32, device=self.device)
+        if sr != 22050:
+            signal = resample_gpu(signal, sr, 22050)
         return self.spect(signal)
 
     def __call__(self, signal, sr):
@@ -216,6 +216,42 @@ class File2File(File2Beats):
     def __call__(self, audio_path, output_path):
         downbeats, beats = super().__call__(audio_path)  # (sic) argument naming as in inference.py:313-315
         save_beat_tsv(downbeats, beats, output_path)
+
+
+_RESAMPLE_FILTERS: dict = {}
+
+
+def resample_gpu(signal: torch.Tensor, in_rate: int, out_rate: int) -> torch.Tensor:
+    """1-D fp32 device waveform at ``in_rate`` -> ``out_rate`` on the GPU (csrc/frontend.hip: resample_kernel), the
+    MI355X replacement of the reference's host ``soxr.resample`` (inference.py:274-275).  Polyphase
+    Kaiser-windowed-sinc FIR with scipy.signal.resample_poly's filter design; like every non-libsoxr resampler it is
+    not bit-compatible with soxr: parity is defined from the 22.05 kHz waveform onwards."""
+    import ctypes as C
+    from math import gcd
+
+    from . import tables
+
+    _lib.require_gpu(signal, "waveform")
+    if signal.dim() != 1:
+        raise ValueError(f"expected a 1-D waveform, got shape {tuple(signal.shape)}")
+    in_rate, out_rate = int(in_rate), int(out_rate)
+    g = gcd(in_rate, out_rate)
+    up, down = out_rate // g, in_rate // g
+    if up == down:
+        return signal
+    key = (up, down, signal.device)
+    if key not in _RESAMPLE_FILTERS:
+        h, half = tables.resample_filter(up, down)
+        _RESAMPLE_FILTERS[key] = (torch.from_numpy(h.astype(np.float32)).to(signal.device), half)
+    h, half = _RESAMPLE_FILTERS[key]
+    x = signal.to(torch.float32).contiguous()
+    n_in = x.shape[0]
+    n_out = -(-n_in * up // down)
+    y = torch.empty(n_out, dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.lib().bt_resample(_lib.stream_ptr(x.device), x.data_ptr(), n_in, up, down, h.data_ptr(), half,
+                                          y.data_ptr(), n_out))
+    return y
 
 
 def resample(signal: np.ndarray, in_rate: int, out_rate: int) -> np.ndarray:

@@ -65,3 +65,16 @@ def rope_table(freqs: torch.Tensor, n_pos: int = 1536) -> np.ndarray:
     """[n_pos, 16, 2] (cos, sin) of pos * freqs in fp32, as rotary-embedding-torch evaluates them."""
     ang = torch.arange(n_pos, dtype=torch.float32)[:, None] * freqs.float()[None, :]
     return torch.stack((ang.cos(), ang.sin()), dim=-1).numpy().astype(np.float32)
+
+
+def resample_filter(up: int, down: int):
+    """(h float64 [2 half + 1], half): the low-pass of scipy.signal.resample_poly(x, up, down) with its default
+    window -- firwin(2 half + 1, 1 / max(up, down), window=("kaiser", 5.0)) * up, half = 10 max(up, down) --
+    restated with numpy only (sinc * symmetric Kaiser window, unit DC gain)."""
+    max_rate = max(up, down)
+    half = 10 * max_rate
+    n = np.arange(-half, half + 1, dtype=np.float64)
+    fc = 1.0 / max_rate
+    h = fc * np.sinc(fc * n) * np.kaiser(2 * half + 1, 5.0)
+    h /= h.sum()
+    return h * up, half

@@ -131,6 +131,13 @@ int bt_aggregate(void* stream, const float* d_chunk_beat, const float* d_chunk_d
 int bt_logmel(void* stream, const bt_logmel_tables* tables, const float* d_audio, int64_t n_samples,
               float* d_spect);
 
+/* Audio2Frames.signal2spect's resampling step (inference.py:274-275, soxr.resample on the host in the reference):
+ * rational polyphase FIR on the GPU, y[m] = sum_k x[k] h[m down + half_len - k up], d_filter = 2 half_len + 1 taps
+ * (beat_this_amd/tables.py: resample_filter = up * firwin(.., 1/max(up,down), kaiser 5.0), scipy.signal.resample_poly's
+ * design), n_out <= ceil(n_in up / down).  Not bit-compatible with libsoxr (parity unpinned). */
+int bt_resample(void* stream, const float* d_in, int64_t n_in, int up, int down, const float* d_filter, int half_len,
+                float* d_out, int64_t n_out);
+
 /* Postprocessor.postp_minimal peak mask (postprocessor.py:93-99) + nonzero (:119-120):
  * d_logits [n_arrays][n] -> d_idx [n_arrays][n] ascending frame indices, d_count [n_arrays]. */
 int bt_peaks(void* stream, const float* d_logits, int64_t n, int n_arrays, int32_t* d_idx, int32_t* d_count);

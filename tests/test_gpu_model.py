@@ -220,3 +220,32 @@ def test_cpu_inputs_fail_loudly():
     s2f = Spect2Frames(checkpoint_path=None, device="cuda:0")
     with pytest.raises(RuntimeError):
         s2f(torch.zeros(100, 128))
+
+
+def test_audio2beats_44k1_input_resampled_on_gpu():
+    """44.1 kHz input: mono mix (host) -> GPU polyphase resampler -> GPU log-mel -> model, against the oracle fed
+    with the float64 scipy.signal.resample_poly waveform (the oracle's soxr stand-in): same beats, logits < 1e-3."""
+    from scipy.signal import resample_poly
+    from beat_this_amd import weights as W
+    from beat_this_amd.inference import Audio2Beats
+    from oracle import beat_this_oracle as O
+
+    hp = W.resolve_hparams("small0")
+    sd = W.random_state_dict(hp, seed=4, style="lively")
+    a2b = Audio2Beats(checkpoint_path=None, device=dev(), float16=False, dbn=False)
+    from beat_this_amd.model import BeatThis
+    m = BeatThis(**{k: hp[k] for k in ("spect_dim", "transformer_dim", "ff_mult", "n_layers", "head_dim", "stem_dim")})
+    m.load_state_dict(sd)
+    a2b.model = m.to(dev())
+    mono = W.synthetic_audio(12.0, seed=9, sr=44100)
+    stereo = np.stack([mono, 0.5 * mono], 1).astype(np.float64)          # (N, 2): exercises the mono mix too
+    beats, downbeats = a2b(stereo, 44100)
+    bl, dl = a2b.spect2frames(a2b.signal2spect(stereo, 44100))
+    sig22 = resample_poly(stereo.mean(1), 1, 2).astype(np.float32)
+    with torch.inference_mode():
+        ob, od = O.spect2frames(sd, O.logmel(torch.from_numpy(sig22)))
+    err = float((bl.cpu() - ob).abs().max())
+    obeats, odown = O.postp_minimal(ob, od)
+    report("a2b_44k1", err=err, beats=len(beats), downbeats=len(downbeats))
+    assert bl.shape == ob.shape and err < 1e-3
+    assert np.array_equal(beats, obeats) and np.array_equal(downbeats, odown)
