@@ -282,8 +282,30 @@ void gemm3_kernel(const Gemm3P p, int n_tiles, int total_tiles, int per_xcd) {
   } else if constexpr (EPI == G3_RESID) {
     bf16* xb = reinterpret_cast<bf16*>(p.xb);
     const int nb0 = n0 + wn * 64;
+    // The x loads of a token block are all requested before the first is used: one at a time (load x, add, store,
+    // next pass) they cost a memory round trip EACH -- 16 of them were 31 k of a 122 k-cycle wave life in FF2.
+    if (p.bias) {  // bias in the MFMA layout (lane = token, 4-feature runs): 8 small loads, no extra live registers
+#pragma unroll
+      for (int a = 0; a < FB; ++a)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 bb = *reinterpret_cast<const f32x4*>(p.bias + nb0 + a * 32 + 8 * q + 4 * g);
+#pragma unroll
+          for (int b = 0; b < TB; ++b)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[a][b][4 * q + i] += bb[i];
+        }
+    }
 #pragma unroll
     for (int b = 0; b < TB; ++b) {
+      f32x4 xv[8];  // (per token block: all 16 at once would not fit 168 registers next to the accumulators)
+#pragma unroll
+      for (int ps = 0; ps < 8; ++ps) {
+        const int r = ps * 4 + (lane >> 4), cp = lane & 15;
+        const long row = (long)row0 + 32 * b + r;
+        xv[ps] = row < p.M ? *reinterpret_cast<const f32x4*>(p.x + row * p.ldx + nb0 + ((cp ^ (r & 15)) << 2))
+                           : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
 #pragma unroll
       for (int a = 0; a < FB; ++a)
 #pragma unroll
@@ -297,17 +319,10 @@ void gemm3_kernel(const Gemm3P p, int n_tiles, int total_tiles, int per_xcd) {
         const long row = (long)row0 + 32 * b + r;
         const bool ok = row < p.M;
         f32x4 v = *reinterpret_cast<const f32x4*>(wst + r * 256 + (cp << 4));
-        if (p.bias) {
-          const f32x4 bb = *reinterpret_cast<const f32x4*>(p.bias + col);
 #pragma unroll
-          for (int i = 0; i < 4; ++i) v[i] += bb[i];
-        }
-        float* xr = p.x + (ok ? row : 0) * p.ldx + col;
+        for (int i = 0; i < 4; ++i) v[i] += xv[ps][i];
         if (ok) {
-          const f32x4 xv = *reinterpret_cast<const f32x4*>(xr);
-#pragma unroll
-          for (int i = 0; i < 4; ++i) v[i] += xv[i];
-          *reinterpret_cast<f32x4*>(xr) = v;
+          *reinterpret_cast<f32x4*>(p.x + row * p.ldx + col) = v;
           if (xb) *reinterpret_cast<u32x2*>(xb + row * p.ldx + col) = u32x2{pk2(v[0], v[1]), pk2(v[2], v[3])};
         }
         float ssq = ok ? fmaf(v[0], v[0], fmaf(v[1], v[1], fmaf(v[2], v[2], v[3] * v[3]))) : 0.f;
@@ -323,17 +338,19 @@ void gemm3_kernel(const Gemm3P p, int n_tiles, int total_tiles, int per_xcd) {
       for (int b = 0; b < TB; ++b) {
         if (tseq[b] >= p.n_seq) continue;  // wave-uniform
         const int pos = tblk[b] * 32 + lr;
+        f32x4 cs[4];  // (cos, sin) of this token's pairs 4 q + 2 g, +1: the same for every head, requested up front
+#pragma unroll
+        for (int q = 0; q < 4; ++q) cs[q] = *reinterpret_cast<const f32x4*>(p.rope + ((long)pos * 16 + 4 * q + 2 * g) * 2);
 #pragma unroll
         for (int a = 0; a < FB; ++a) {
           const int head = (n0 - kind * p.inner + wn * 64 + a * 32) >> 5;
           bf16* blk = dst + (((long)tseq[b] * p.heads + head) * p.nbp + tblk[b]) * 1024;
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            const f32x4 cs = *reinterpret_cast<const f32x4*>(p.rope + ((long)pos * 16 + 4 * q + 2 * g) * 2);
             const float e0 = acc[a][b][4 * q] * rs[b], o0 = acc[a][b][4 * q + 1] * rs[b];
             const float e1 = acc[a][b][4 * q + 2] * rs[b], o1 = acc[a][b][4 * q + 3] * rs[b];
-            const u32x2 w = {pk2(e0 * cs[0] - o0 * cs[1], o0 * cs[0] + e0 * cs[1]),
-                             pk2(e1 * cs[2] - o1 * cs[3], o1 * cs[2] + e1 * cs[3])};
+            const u32x2 w = {pk2(e0 * cs[q][0] - o0 * cs[q][1], o0 * cs[q][0] + e0 * cs[q][1]),
+                             pk2(e1 * cs[q][2] - o1 * cs[q][3], o1 * cs[q][2] + e1 * cs[q][3])};
             *reinterpret_cast<u32x2*>(blk + (q * 32 + lr) * 8 + 4 * g) = w;
           }
         }
@@ -380,7 +397,7 @@ void gemm3_kernel(const Gemm3P p, int n_tiles, int total_tiles, int per_xcd) {
     const long long t_end = clock64();
     __syncthreads();
     if (lane == 0) {
-      long long* dbg = reinterpret_cast<long long*>(p.ssq_in ? const_cast<float*>(p.ssq_in) : p.ssq_out);
+      long long* dbg = reinterpret_cast<long long*>(EPI == G3_RESID ? p.out : (void*)const_cast<float*>(p.ssq_in));
       long long* d = dbg + ((long)blockIdx.x * NW + wave) * 4;
       d[0] = t_loop1 - t_loop0; d[1] = t_wait; d[2] = t_bar; d[3] = t_end - t_loop1;
     }

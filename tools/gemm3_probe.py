@@ -58,13 +58,13 @@ if "ff2" in which:
     a.A, a.lda, a.M, a.K, a.W, a.N, a.epi = h.data_ptr(), 4 * D, M, 4 * D, W.data_ptr(), D, 1
     a.bias, a.x, a.ldx, a.xb, a.ssq_out = b.data_ptr(), xf.data_ptr(), D, xb.data_ptr(), so.data_ptr()
     if os.environ.get("BT_G3_ABL") == "8":
-        so = torch.zeros((8 * 1024 * 1024,), device=dev)
-        a.ssq_out = so.data_ptr()
+        dbgbuf = torch.zeros((8 * 1024 * 1024,), device=dev)
+        a.out = dbgbuf.data_ptr()
     timeit("ff2 (N=512,K=2048)", a, 2.0 * M * D * 4 * D)
     if os.environ.get("BT_G3_ABL") == "8":
         torch.cuda.synchronize()
         nw = 752 * 4
-        d = so.view(torch.int64)[: nw * 4].view(-1, 4).cpu().double()
+        d = dbgbuf.view(torch.int64)[: nw * 4].view(-1, 4).cpu().double()
         print(f"   per wave: loop {d[:,0].mean():.0f} cyc (vmcnt wait {d[:,1].mean():.0f}, barrier {d[:,2].mean():.0f}), epilogue {d[:,3].mean():.0f}")
 if "out" in which:
     a = _lib.Gemm3Args()
