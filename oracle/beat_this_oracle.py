@@ -237,8 +237,9 @@ def transformer(x, sd, n_layers, heads, taps=None):
     return rmsnorm(x, sd["transformer_blocks.norm.gamma"])
 
 
-def model_forward(sd: dict, x: torch.Tensor, dtype=torch.float32, taps=None):
-    """BeatThis.forward (beat_tracker.py:188-192) with SumHead (:315-330).
+def model_forward(sd: dict, x: torch.Tensor, dtype=torch.float32, taps=None, sum_head: bool = True):
+    """BeatThis.forward (beat_tracker.py:188-192) with SumHead (:304-330), or Head (:333-346) for
+    ``sum_head=False``; blocks without partial transformers (beat_tracker.py:143-153) are recognised by their keys.
 
     sd: reference-layout state dict; x: (B,T,128).
     Returns (beat, downbeat) each (B,T) in ``dtype``.
@@ -253,7 +254,7 @@ def model_forward(sd: dict, x: torch.Tensor, dtype=torch.float32, taps=None):
     x = transformer(x, sd, n_layers, dim // 32, taps)
     bd = x @ sd["task_heads.beat_downbeat_lin.weight"].T + sd["task_heads.beat_downbeat_lin.bias"]
     beat, down = bd[..., 0], bd[..., 1]
-    return beat + down, down
+    return (beat + down if sum_head else beat), down
 
 
 def spect2frames(sd, spect, dtype=torch.float32):

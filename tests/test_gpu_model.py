@@ -249,3 +249,36 @@ def test_audio2beats_44k1_input_resampled_on_gpu():
     report("a2b_44k1", err=err, beats=len(beats), downbeats=len(downbeats))
     assert bl.shape == ob.shape and err < 1e-3
     assert np.array_equal(beats, obeats) and np.array_equal(downbeats, odown)
+
+
+@pytest.mark.parametrize("prec_half", [False, True])
+@pytest.mark.parametrize("variant", ["no_sum_head", "no_partial", "three_layers_d256"])
+def test_ablation_variants_against_oracle(variant, prec_half):
+    """Head instead of SumHead (beat_tracker.py:333-346), frontend blocks without partial transformers
+    (:143-153), other transformer_dim / n_layers -- against the oracle on seeded weights."""
+    from beat_this_amd import weights as W
+    from beat_this_amd.model import BeatThis
+    from oracle import beat_this_oracle as O
+
+    hp = dict(W.resolve_hparams("small0"))
+    if variant == "no_sum_head":
+        hp["sum_head"] = False
+    elif variant == "no_partial":
+        hp["partial_transformers"] = False
+    else:
+        hp.update(transformer_dim=256, n_layers=3)
+    sd = W.random_state_dict(hp, seed=21, style="lively")
+    m = BeatThis(**{k: hp[k] for k in ("spect_dim", "transformer_dim", "ff_mult", "n_layers", "head_dim", "stem_dim",
+                                       "sum_head", "partial_transformers")})
+    m.load_state_dict(sd)
+    m = m.to(dev())
+    x = torch.from_numpy(np.stack([W.synthetic_spect(700, seed=31), W.synthetic_spect(700, seed=32)]))
+    with torch.inference_mode(), torch.autocast("cuda", enabled=prec_half):
+        r = m(x.to(dev()))
+    with torch.inference_mode():
+        ob, od = O.model_forward(sd, x, sum_head=hp["sum_head"])
+    eb = float((r["beat"].cpu() - ob).abs().max())
+    ed = float((r["downbeat"].cpu() - od).abs().max())
+    report("ablation", variant=variant, half=prec_half, err_beat=eb, err_downbeat=ed, spread=float(ob.std()))
+    tol = 0.25 * max(float(ob.std()), 0.2) if prec_half else 1e-3
+    assert eb < tol and ed < tol
