@@ -298,7 +298,8 @@ void gemm3_kernel(const Gemm3P p, int n_tiles, int total_tiles, int per_xcd) {
     }
 #pragma unroll
     for (int b = 0; b < TB; ++b) {
-      f32x4 xv[8];  // (per token block: all 16 at once would not fit 168 registers next to the accumulators)
+      f32x4 xv[8];  // (per token block: more at once -- all blocks, or a prefetch of the next one -- spills next to the
+                    // accumulators and measured slower)
 #pragma unroll
       for (int ps = 0; ps < 8; ++ps) {
         const int r = ps * 4 + (lane >> 4), cp = lane & 15;
@@ -464,7 +465,10 @@ int launch_gemm3(const Gemm3P& p, hipStream_t s) {
     case G3_RESID:
       // (the 128-byte-row configurations M / B run FF2 in 72 us instead of 78.5 us in isolation, but inside the forward,
       // where the hidden activation was just written, the 3-stage 64-byte-row ring is faster: 0.495 vs 0.512 ms per step)
-      if (big) launch_cfg<G3_RESID, CfgB>(p, s);
+      // long-K residual GEMM (FF2, K = 4 D): the 256^2 x 64 configuration (half the operand traffic per flop, 128-byte
+      // rows) wins inside the forward as well, 0.452 vs 0.487 ms per step; its epilogue is amortised over 32 k-steps
+      if ((big || (force_big != 0 && p.K >= 1024 && p.N % 256 == 0 && p.M >= 4096)) && abl == 8) launch_cfg<G3_RESID, CfgB, 8>(p, s);
+      else if (big || (force_big != 0 && p.K >= 1024 && p.N % 256 == 0 && p.M >= 4096)) launch_cfg<G3_RESID, CfgB>(p, s);
       else if (abl == 8) launch_cfg<G3_RESID, CfgS, 8>(p, s);
       else if (abl == 1) launch_cfg<G3_RESID, CfgS, 1>(p, s);
       else if (abl == 4) launch_cfg<G3_RESID, CfgS, 4>(p, s);

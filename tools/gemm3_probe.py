@@ -63,7 +63,7 @@ if "ff2" in which:
     timeit("ff2 (N=512,K=2048)", a, 2.0 * M * D * 4 * D)
     if os.environ.get("BT_G3_ABL") == "8":
         torch.cuda.synchronize()
-        nw = 752 * 4
+        nw = 188 * 8 if os.environ.get('BT_G3_BIG') != '0' else 752 * 4
         d = dbgbuf.view(torch.int64)[: nw * 4].view(-1, 4).cpu().double()
         print(f"   per wave: loop {d[:,0].mean():.0f} cyc (vmcnt wait {d[:,1].mean():.0f}, barrier {d[:,2].mean():.0f}), epilogue {d[:,3].mean():.0f}")
 if "out" in which:
