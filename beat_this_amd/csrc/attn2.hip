@@ -78,7 +78,7 @@ struct QState {
 // ABL: development-only ablations selected by the BT_ATTN_ABL environment variable (timing experiments):
 //   bit 0: stage only the first two tiles (no global traffic afterwards)   bit 1: skip the exponentials
 //   bit 2: no row-sum MFMAs   bit 3: no bf16 conversion   bit 4: no P.V MFMAs   bit 5: no score MFMAs
-//   bit 6: no LDS fragment reads
+//   bit 7: dump shader-clock / wall-clock ticks of the pass   bit 10: unpipelined key loop (bits 0-5 need it)
 struct KFrag { bf16x8 k0, k1; };
 struct VFrag { bf16x8 v0, v1; };
 DEVI KFrag ld_k(const char* kb, int g, int lr) {
@@ -247,6 +247,118 @@ DEVI void attn_pass(rsrc_t rk, rsrc_t rv, char* smem, int tid, int wave, int lan
   }
 }
 
+// ---- software-pipelined fast pass ------------------------------------------------------------------------
+// The scores of key block c+1 are issued BEFORE the exponentials of block c, so the matrix pipe works on
+// the next block while this wave converts the current one (no MFMA -> VALU hazard bubbles), on top of the
+// overlap between waves.  One barrier per tile, placed at the start of the tile's LAST block: every
+// wave has then issued and received its last fragment reads of tile t, so the freed buffer takes tile t+2.
+template <int QB>
+DEVI void score_fast(const KFrag& kf, const QState (&st)[QB], f32x16 (&sc)[QB]) {
+#pragma unroll
+  for (int j = 0; j < QB; ++j) {
+    sc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf.k0, st[j].q0, st[j].negm, 0, 0, 0);
+    sc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf.k1, st[j].q1, sc[j], 0, 0, 0);
+  }
+}
+template <int QB>
+DEVI void finish_fast(f32x16 (&sc)[QB], const VFrag& vf, QState (&st)[QB]) {
+#pragma unroll
+  for (int j = 0; j < QB; ++j) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sc[j][r] = __builtin_amdgcn_exp2f(sc[j][r]);
+    const u32x4 w0 = pack8(sc[j], 0), w1 = pack8(sc[j], 1);
+    rowsum8(st[j].l, w0);
+    rowsum8(st[j].l, w1);
+    st[j].acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf.v0, __builtin_bit_cast(bf16x8, w0), st[j].acc, 0, 0, 0);
+    st[j].acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf.v1, __builtin_bit_cast(bf16x8, w1), st[j].acc, 0, 0, 0);
+  }
+}
+
+template <int QB>
+DEVI void attn_pass_pipe(rsrc_t rk, rsrc_t rv, char* smem, int tid, int wave, int lane, int g, int lr,
+                         QState (&st)[QB], int L, int nblk) {
+  const int ntiles = (nblk + KB - 1) / KB;
+  const bool partial = (L & 31) != 0;
+  int nfull = nblk / KB;  // tiles of KB unmasked blocks
+  if (partial && nfull * KB == nblk) --nfull;
+  stage_tile(rk, rv, 0, smem, 0, tid, wave);
+  __syncthreads();
+  if (ntiles > 1) stage_tile(rk, rv, 1, smem, 1, tid, wave);
+#pragma unroll
+  for (int j = 0; j < QB; ++j) {
+    zero16(st[j].acc);
+    st[j].l = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  {  // reference max of each query: its scores against key block 0
+    const KFrag k00 = ld_k(smem, g, lr);
+#pragma unroll
+    for (int j = 0; j < QB; ++j) {
+      f32x16 sc;
+      zero16(sc);
+      sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k00.k0, st[j].q0, sc, 0, 0, 0);
+      sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k00.k1, st[j].q1, sc, 0, 0, 0);
+      float bm = -1e30f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) bm = fmaxf(bm, (crow(r, g) < L) ? sc[r] : -1e30f);
+      bm = fmaxf(bm, __shfl_xor(bm, 32));
+      st[j].m = bm;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) st[j].negm[r] = -bm;
+    }
+  }
+  if (nfull > 0) {
+    f32x16 sc[QB];
+    KFrag kn = ld_k(smem, g, lr);
+    score_fast<QB>(kn, st, sc);
+    kn = ld_k(smem + BLK_BYTES, g, lr);
+    for (int t = 0; t < nfull; ++t) {
+      const char* kb = smem + (t & 1) * 2 * TILE_BYTES;
+      const char* vb = kb + TILE_BYTES;
+      const char* kb_next = smem + ((t + 1) & 1) * 2 * TILE_BYTES;
+#pragma unroll
+      for (int c = 0; c < KB; ++c) {
+        const VFrag vf = ld_v(vb + c * BLK_BYTES, lane);
+        if (c + 1 < KB) {
+          f32x16 sn[QB];
+          score_fast<QB>(kn, st, sn);
+          if (c + 2 < KB) kn = ld_k(kb + (c + 2) * BLK_BYTES, g, lr);
+          __builtin_amdgcn_sched_barrier(0);
+          finish_fast<QB>(sc, vf, st);
+#pragma unroll
+          for (int j = 0; j < QB; ++j) sc[j] = sn[j];
+        } else {
+          __syncthreads();  // tile t+1 has landed; nobody reads tile t any more (vf above has arrived)
+          if (t + 2 < ntiles) stage_tile(rk, rv, t + 2, smem, t & 1, tid, wave);
+          const bool more = t + 1 < nfull;  // (uniform)
+          KFrag k0n = kn;
+          if (more) {
+            k0n = ld_k(kb_next, g, lr);
+            kn = ld_k(kb_next + BLK_BYTES, g, lr);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          finish_fast<QB>(sc, vf, st);
+          if (more) score_fast<QB>(k0n, st, sc);
+        }
+      }
+    }
+  }
+  if (nfull < ntiles) {  // last tile: fewer than KB blocks and / or a masked last block
+    const char* kb = smem + (nfull & 1) * 2 * TILE_BYTES;
+    const char* vb = kb + TILE_BYTES;
+    const int nb = nblk - nfull * KB;
+    for (int c = 0; c < nb; ++c) {
+      const int blk = nfull * KB + c;
+      const VFrag vf = ld_v(vb + c * BLK_BYTES, lane);
+      const KFrag kf = ld_k(kb + c * BLK_BYTES, g, lr);
+      if (partial && blk == nblk - 1)
+        do_block<false, true, 0, QB>(kf, vf, g, st, blk * 32, L);
+      else
+        do_block<false, false, 0, QB>(kf, vf, g, st, blk * 32, L);
+    }
+  }
+  __syncthreads();
+}
+
 template <int ABL, int QB>
 __global__ __launch_bounds__(256, (QB == 1 ? 4 : 2)) void attn_frag_kernel(const AttnFragP p, int nqt, int sh_total) {
   __shared__ __attribute__((aligned(16))) char smem[SMEM_BYTES];
@@ -280,7 +392,10 @@ __global__ __launch_bounds__(256, (QB == 1 ? 4 : 2)) void attn_frag_kernel(const
   const rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(kseq), 0, seq_bytes, 0x00020000);
   const rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(vseq), 0, seq_bytes, 0x00020000);
   const long long tc0 = clock64(), tw0 = wall_clock64();
-  attn_pass<false, ABL, QB>(rk, rv, smem, tid, wave, lane, g, lr, st, L, nblk);
+  if constexpr ((ABL & 1024) == 0 && QB == 1)  // (bit 10: the unpipelined loop, kept for comparisons)
+    attn_pass_pipe<QB>(rk, rv, smem, tid, wave, lane, g, lr, st, L, nblk);
+  else
+    attn_pass<false, ABL, QB>(rk, rv, smem, tid, wave, lane, g, lr, st, L, nblk);
   if constexpr ((ABL & 128) != 0) {  // development: shader-clock ticks vs 100 MHz wall ticks of the pass
     if (lane == 0) {
       long long* dbg = reinterpret_cast<long long*>(const_cast<float*>(p.gates));
@@ -347,9 +462,10 @@ int launch_attn_frag(const AttnFragP& p, hipStream_t s) {
     launch_v<0, 2>(p, s);
   } else {
     switch (abl) {
-      case 1: launch_v<1, 1>(p, s); break;
-      case 3: launch_v<3, 1>(p, s); break;
+      case 1025: launch_v<1025, 1>(p, s); break;
+      case 1027: launch_v<1027, 1>(p, s); break;
       case 128: launch_v<128, 1>(p, s); break;
+      case 1024: launch_v<1024, 1>(p, s); break;
       default: launch_v<0, 1>(p, s);
     }
   }
