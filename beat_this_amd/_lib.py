@@ -81,7 +81,9 @@ class Gemm3Args(C.Structure):
                 ("ssq_parts", C.c_int32), ("out", C.c_void_p), ("ldo", C.c_int64), ("x", C.c_void_p),
                 ("ldx", C.c_int64), ("xb", C.c_void_p), ("ssq_out", C.c_void_p), ("n_seq", C.c_int32),
                 ("L", C.c_int32), ("nbp", C.c_int32), ("heads", C.c_int32), ("rope", C.c_void_p), ("qf", C.c_void_p),
-                ("kf", C.c_void_p), ("vf", C.c_void_p), ("gates", C.c_void_p), ("b_gates", C.c_void_p)]
+                ("kf", C.c_void_p), ("vf", C.c_void_p), ("gates", C.c_void_p), ("b_gates", C.c_void_p),
+                ("f8", C.c_int32), ("wscale", C.c_void_p), ("ascale", C.c_void_p), ("x8", C.c_void_p),
+                ("ascale_out", C.c_void_p)]
 
 
 G3_FF1, G3_RESID, G3_QKV = 0, 1, 2

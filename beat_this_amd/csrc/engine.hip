@@ -518,6 +518,7 @@ int bt_gemm3(void* stream, const bt_gemm3_args* a) {
   g.xb = a->xb; g.ssq_out = a->ssq_out; g.n_seq = a->n_seq; g.L = a->L; g.nblk = (a->L + 31) / 32; g.nbp = a->nbp;
   g.heads = a->heads; g.inner = a->heads * 32; g.rope = a->rope; g.qf = a->qf; g.kf = a->kf; g.vf = a->vf;
   g.gates = a->gates; g.b_gates = a->b_gates;
+  g.f8 = a->f8; g.wscale = a->wscale; g.ascale = a->ascale; g.x8 = a->x8; g.ascale_out = a->ascale_out;
   if (!gemm3_supported(g)) return bt_set_error(BT_ERR_ARG, "shape not supported by bt_gemm3");
   LAUNCH(launch_gemm3(g, (hipStream_t)stream), "gemm3");
   return BT_OK;

@@ -27,21 +27,21 @@
 // 128 KB -> 1 workgroup per CU: half the L2 -> LDS operand traffic per flop (the 128^2 FF GEMMs were bound by
 // LDS-DMA fill rate, not MFMA: 84 us with the MFMAs removed vs 95 us with them), and 128-byte LDS rows, i.e. every
 // fetched cache line is used whole.  FF1 / RESID only (the V columns of QKV need a square wave tile).
-struct G3CfgS { static constexpr int BM = 128, BN = 128, BK = 32, WGM = 2, WGN = 2, NST = 3, OCC = 3; };
-struct G3CfgB { static constexpr int BM = 256, BN = 256, BK = 64, WGM = 2, WGN = 4, NST = 2, OCC = 1; };
-// experimental: M = 128^2 with 128-byte rows (2 / CU), C = 256 x 128 x 32 with 8 waves of 64 x 64 (2 / CU)
-struct G3CfgM { static constexpr int BM = 128, BN = 128, BK = 64, WGM = 2, WGN = 2, NST = 2, OCC = 2; };
-struct G3CfgC { static constexpr int BM = 256, BN = 128, BK = 32, WGM = 4, WGN = 2, NST = 3, OCC = 2; };
-// E = 256^2 x 32 with a 4-stage ring (3 x 32 KB in flight at half the bytes per flop), F = 128^2 x 32 with 5 stages
-struct G3CfgE { static constexpr int BM = 256, BN = 256, BK = 32, WGM = 2, WGN = 4, NST = 4, OCC = 1; };
-struct G3CfgF { static constexpr int BM = 128, BN = 128, BK = 32, WGM = 2, WGN = 2, NST = 5, OCC = 2; };
-// D = 256 x 128 x 32 with 4 waves of 128 x 64 (0.75 LDS reads per MFMA, 2 / CU so epilogues overlap k-loops)
-struct G3CfgD { static constexpr int BM = 256, BN = 128, BK = 32, WGM = 2, WGN = 2, NST = 3, OCC = 2; };
+struct G3CfgS { static constexpr int BM = 128, BN = 128, BK = 32, WGM = 2, WGN = 2, NST = 3, OCC = 3, ES = 2; };
+struct G3CfgB { static constexpr int BM = 256, BN = 256, BK = 64, WGM = 2, WGN = 4, NST = 2, OCC = 1, ES = 2; };
+// e4m3 operands (BT_PREC_FP8, ES = 1 byte per element): the same LDS images (64- / 128-byte rows) hold twice the k
+// range; one v_mfma_scale_f32_32x32x64_f8f6f4 with unit block scales per 64-byte row group (lane = row, 32
+// consecutive k bytes at 32 (lane >> 5); layout and rate -- 4.15 PFLOP/s vs 2.3 for bf16 -- checked by
+// tools/ubench/mfma_f8_probe.hip), so the k-loop is half as long for the same LDS-DMA bytes per step.
+struct G3CfgS8 { static constexpr int BM = 128, BN = 128, BK = 64, WGM = 2, WGN = 2, NST = 3, OCC = 3, ES = 1; };
+struct G3CfgB8 { static constexpr int BM = 256, BN = 256, BK = 128, WGM = 2, WGN = 4, NST = 2, OCC = 1, ES = 1; };
 
 namespace {
 
 typedef G3CfgS CfgS;
 typedef G3CfgB CfgB;
+typedef G3CfgS8 CfgS8;
+typedef G3CfgB8 CfgB8;
 
 constexpr unsigned OOB = 0x80000000u;         // voffset of a lane that must read zeros (beyond num_records)
 
@@ -49,6 +49,18 @@ typedef __amdgpu_buffer_rsrc_t rsrc_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+typedef __attribute__((ext_vector_type(8))) int i32x8;
+
+// 4 floats -> 4 e4m3 bytes (OCP e4m3fn, round to nearest even), saturating at +-448
+DEVI unsigned pk4_f8(float a, float b, float c, float d) {
+  a = __builtin_amdgcn_fmed3f(a, -448.f, 448.f);
+  b = __builtin_amdgcn_fmed3f(b, -448.f, 448.f);
+  c = __builtin_amdgcn_fmed3f(c, -448.f, 448.f);
+  d = __builtin_amdgcn_fmed3f(d, -448.f, 448.f);
+  int w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
+  w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
+  return (unsigned)w;
+}
 
 DEVI unsigned pk2(float a, float b) {
   const bf16x2 t = {(bf16)a, (bf16)b};
@@ -77,7 +89,8 @@ void gemm3_kernel(const Gemm3P p, int n_tiles, int total_tiles, int per_xcd) {
   constexpr int NW = CFG::WGM * CFG::WGN, NT = 64 * NW;
   constexpr int TB = BM / CFG::WGM / 32;       // 32-token blocks per wave
   constexpr int FB = BN / CFG::WGN / 32;       // 32-feature blocks per wave
-  constexpr int ROWB = BK * 2;                 // bytes per LDS row
+  constexpr int ES = CFG::ES;                  // bytes per operand element: 2 = bf16, 1 = e4m3
+  constexpr int ROWB = BK * ES;                // bytes per LDS row
   constexpr int CPR = ROWB / 16;               // 16-byte chunks per row (4 or 8)
   constexpr int RPI = 64 / CPR;                // rows covered by one wave-instruction (1 KB)
   constexpr int A_BYTES = BM * ROWB, W_BYTES = BN * ROWB, ST_BYTES = A_BYTES + W_BYTES;
@@ -95,7 +108,7 @@ void gemm3_kernel(const Gemm3P p, int n_tiles, int total_tiles, int per_xcd) {
   const int g = lane >> 5, lr = lane & 31;
   const int wm = wave / CFG::WGN, wn = wave % CFG::WGN;
   const int nk = p.K / BK;
-  auto swz = [](int r) { return BK == 32 ? (r >> 2) & 3 : (r >> 1) & 7; };  // chunk XOR of LDS row r
+  auto swz = [](int r) { return ROWB == 64 ? (r >> 2) & 3 : (r >> 1) & 7; };  // chunk XOR of LDS row r
   const int Lv = p.nblk * 32;  // QKV: rows are addressed per sequence, padded to whole 32-token blocks
 
   // QKV column tile kind: 0 = q, 1 = k (lane = token, RoPE), 2 = v (lane = feature), 3 = gates
@@ -104,7 +117,7 @@ void gemm3_kernel(const Gemm3P p, int n_tiles, int total_tiles, int per_xcd) {
   const bool normal = EPI == G3_QKV && kind == 2;
 
   // ---- staging: per-lane source offsets (bytes) of the two 4 KB pieces of each operand ---------------------
-  const unsigned a_bytes = (unsigned)((long)p.M * p.lda * 2), w_bytes = (unsigned)((long)n_tiles * BN * p.K * 2);
+  const unsigned a_bytes = (unsigned)((long)p.M * p.lda * ES), w_bytes = (unsigned)((long)n_tiles * BN * p.K * ES);
   static_assert(APC >= 1 && WPC >= 1, "tile too small for the workgroup");
   // (fixed-size arrays: an array whose size depends on a template parameter, used as an argument of the LDS-DMA
   // builtin, is what makes the HOST pass drop the kernel stub)
@@ -121,13 +134,13 @@ void gemm3_kernel(const Gemm3P p, int n_tiles, int total_tiles, int per_xcd) {
       ok = seq < p.n_seq && t < p.L;
       row = (long)seq * p.L + t;
     }
-    voffA[i] = ok ? (unsigned)(row * p.lda * 2 + c * 16) : OOB;
+    voffA[i] = ok ? (unsigned)(row * p.lda * ES + c * 16) : OOB;
   }
 #pragma unroll
   for (int i = 0; i < WPC; ++i) {
     const int r = (i * NW + wave) * RPI + lane / CPR;
     const int c = (lane % CPR) ^ swz(r);
-    voffW[i] = (unsigned)((long)(n0 + r) * p.K * 2 + c * 16);
+    voffW[i] = (unsigned)((long)(n0 + r) * p.K * ES + c * 16);
   }
   // LDS-DMA of one k-step: APC pieces of the A tile, WPC of the W tile (1 KB per wave-instruction; the pieces of a
   // thread are NW KB apart).  The instruction's immediate offset would also move the LDS address, so it stays 0 and
@@ -150,9 +163,11 @@ void gemm3_kernel(const Gemm3P p, int n_tiles, int total_tiles, int per_xcd) {
   const int pofs = (normal ? wm * (TB * 32) * ROWB : A_BYTES + wn * (FB * 32) * ROWB) + lr * ROWB;
   const int qofs = (normal ? A_BYTES + wn * (FB * 32) * ROWB : wm * (TB * 32) * ROWB) + lr * ROWB;
   const int sw = swz(lr);
-  int kc[BK / 16];
+  constexpr int MS = ES == 2 ? ROWB / 32 : ROWB / 64;  // MFMA steps per k-step: 32 B (bf16 k16) / 64 B (e4m3 k64) of a row
+  int kc[ROWB / 32];
 #pragma unroll
-  for (int m = 0; m < BK / 16; ++m) kc[m] = ((2 * m + g) ^ sw) * 16;  // k16 step m: chunk 2 m + g
+  for (int m = 0; m < ROWB / 32; ++m)  // bf16 step m: chunk 2 m + g;  e4m3 step m: chunks 4 m + 2 g, + 1 (kc[2m], kc[2m+1])
+    kc[m] = ((ES == 2 ? 2 * m + g : 4 * (m >> 1) + 2 * g + (m & 1)) ^ sw) * 16;
 
   f32x16 acc[NP][NQ];
 #pragma unroll
@@ -183,10 +198,13 @@ void gemm3_kernel(const Gemm3P p, int n_tiles, int total_tiles, int per_xcd) {
   // RMSNorm factors: the partial sums of squares are requested BEFORE the LDS-DMA prologue and consumed right after
   // it behind an explicit vmcnt(0) (ordinary loads and LDS-DMA do not return in order, so no counted wait may separate
   // them): their latency overlaps the first tiles' instead of sitting in the epilogue (~2 k cycles of a 31 k wave life).
-  float rs[TB], part[TB][8];
+  // (RESID with ssq_in: the statistics are those of the OLD x rows, used as the quantisation scale of the e4m3 shadow)
+  float rs[TB], part[TB][8], asc[TB];
+  const float dimf = EPI == G3_RESID ? (float)p.N : (float)p.K;
 #pragma unroll
   for (int j = 0; j < TB; ++j) {
     rs[j] = 1.f;
+    asc[j] = (EPI != G3_RESID && p.ascale && trow[j] >= 0) ? p.ascale[trow[j]] : 1.f;
 #pragma unroll
     for (int q = 0; q < 8; ++q)
       part[j][q] = (p.ssq_in && trow[j] >= 0 && q < p.ssq_parts) ? p.ssq_in[(long)q * p.M + trow[j]] : 0.f;
@@ -204,7 +222,9 @@ void gemm3_kernel(const Gemm3P p, int n_tiles, int total_tiles, int per_xcd) {
 #pragma unroll
       for (int q = 0; q < 8; ++q) sum += part[j][q];
       for (int q = 8; q < p.ssq_parts; ++q) sum += trow[j] >= 0 ? p.ssq_in[(long)q * p.M + trow[j]] : 0.f;  // D > 512
-      rs[j] = trow[j] >= 0 ? sqrtf((float)p.K) / fmaxf(sqrtf(sum), 1e-12f) : 0.f;
+      rs[j] = trow[j] >= 0 ? sqrtf(dimf) / fmaxf(sqrtf(sum), 1e-12f) : 0.f;
+      if constexpr (EPI == G3_RESID) rs[j] = fminf(rs[j], 1048576.f);  // quantisation scale of the e4m3 shadow row
+      else rs[j] = rs[j] / asc[j];  // A holds x * asc (e4m3 shadow): undo the producer's scale
     }
   }
   int stage = 0, stage2 = NST - 1;
@@ -221,17 +241,42 @@ void gemm3_kernel(const Gemm3P p, int n_tiles, int total_tiles, int per_xcd) {
     if constexpr ((ABL & 8) != 0) { const long long tq2 = clock64(); t_wait += tq1 - tq0; t_bar += tq2 - tq1; }
     if (kt + NST - 1 < nk && !(ABL & 1)) G3_ISSUE(kt + NST - 1, stage2);
     const char* st = smem + stage * ST_BYTES;
+    if constexpr (ES == 2) {
 #pragma unroll
-    for (int m = 0; m < ((ABL & 4) ? 0 : BK / 16); ++m) {
-      bf16x8 fp[NP], fq[NQ];
+      for (int m = 0; m < ((ABL & 4) ? 0 : MS); ++m) {
+        bf16x8 fp[NP], fq[NQ];
 #pragma unroll
-      for (int a = 0; a < NP; ++a) fp[a] = *reinterpret_cast<const bf16x8*>(st + pofs + a * 32 * ROWB + kc[m]);
+        for (int a = 0; a < NP; ++a) fp[a] = *reinterpret_cast<const bf16x8*>(st + pofs + a * 32 * ROWB + kc[m]);
 #pragma unroll
-      for (int b = 0; b < NQ; ++b) fq[b] = *reinterpret_cast<const bf16x8*>(st + qofs + b * 32 * ROWB + kc[m]);
+        for (int b = 0; b < NQ; ++b) fq[b] = *reinterpret_cast<const bf16x8*>(st + qofs + b * 32 * ROWB + kc[m]);
 #pragma unroll
-      for (int a = 0; a < NP; ++a)
+        for (int a = 0; a < NP; ++a)
 #pragma unroll
-        for (int b = 0; b < NQ; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fp[a], fq[b], acc[a][b], 0, 0, 0);
+          for (int b = 0; b < NQ; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fp[a], fq[b], acc[a][b], 0, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int m = 0; m < ((ABL & 4) ? 0 : MS); ++m) {
+        i32x8 fp[NP], fq[NQ];
+#pragma unroll
+        for (int a = 0; a < NP; ++a) {
+          const u32x4 lo = *reinterpret_cast<const u32x4*>(st + pofs + a * 32 * ROWB + kc[2 * m]);
+          const u32x4 hi = *reinterpret_cast<const u32x4*>(st + pofs + a * 32 * ROWB + kc[2 * m + 1]);
+          fp[a] = i32x8{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
+        }
+#pragma unroll
+        for (int b = 0; b < NQ; ++b) {
+          const u32x4 lo = *reinterpret_cast<const u32x4*>(st + qofs + b * 32 * ROWB + kc[2 * m]);
+          const u32x4 hi = *reinterpret_cast<const u32x4*>(st + qofs + b * 32 * ROWB + kc[2 * m + 1]);
+          fq[b] = i32x8{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
+        }
+#pragma unroll
+        for (int a = 0; a < NP; ++a)
+#pragma unroll
+          for (int b = 0; b < NQ; ++b)  // e4m3 x e4m3, E8M0 block scales 127 = 1.0
+            acc[a][b] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fp[a], fq[b], acc[a][b], 0, 0, 0, 0x7f7f7f7f, 0,
+                                                                         0x7f7f7f7f);
+      }
     }
     stage = stage == NST - 1 ? 0 : stage + 1;
     stage2 = stage2 == NST - 1 ? 0 : stage2 + 1;
@@ -248,7 +293,39 @@ void gemm3_kernel(const Gemm3P p, int n_tiles, int total_tiles, int per_xcd) {
   // stride per instruction, every line written in 4 pieces) ran at ~1.2 TB/s: FF1 took 81 us with its MFMAs removed.
   __syncthreads();
   char* wst = smem + wave * 8192;
-  if constexpr (EPI == G3_FF1) {
+  if constexpr (EPI == G3_FF1 && ES == 1) {
+    // e4m3 operands: acc * (row factor) * (weight row scale) + bias -> GELU -> e4m3 hidden (unit scale, saturating).
+    // A token row of this wave is 64 features = 64 B: four 16-byte chunks c = 2 a + g, staged at chunk c ^ ((row >> 1) & 3).
+    unsigned char* out8 = reinterpret_cast<unsigned char*>(p.out);
+    const int nb0 = n0 + wn * 64;
+#pragma unroll
+    for (int b = 0; b < TB; ++b) {
+#pragma unroll
+      for (int a = 0; a < FB; ++a) {
+        unsigned d[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 bq = *reinterpret_cast<const f32x4*>(p.bias + nb0 + a * 32 + 8 * q + 4 * g);
+          const f32x4 sq = *reinterpret_cast<const f32x4*>(p.wscale + nb0 + a * 32 + 8 * q + 4 * g);
+          float v[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) v[i] = gelu_tanh(fmaf(acc[a][b][4 * q + i] * rs[b], sq[i], bq[i]));
+          d[q] = pk4_f8(v[0], v[1], v[2], v[3]);
+        }
+        auto r0 = __builtin_amdgcn_permlane32_swap(d[0], d[2], false, false);
+        auto r1 = __builtin_amdgcn_permlane32_swap(d[1], d[3], false, false);
+        *reinterpret_cast<u32x4*>(wst + lr * 64 + (((2 * a + g) ^ ((lr >> 1) & 3)) << 4)) = u32x4{r0[0], r0[1], r1[0], r1[1]};
+      }
+      static_assert(FB == 2, "row = 64 features");
+#pragma unroll
+      for (int ps = 0; ps < 2; ++ps) {  // 16 rows x 64 B per wave-instruction
+        const int r = ps * 16 + (lane >> 2), cp = lane & 3;
+        const u32x4 w = *reinterpret_cast<const u32x4*>(wst + r * 64 + (cp << 4));
+        const long row = (long)row0 + 32 * b + r;
+        if (row < p.M) *reinterpret_cast<u32x4*>(out8 + row * p.ldo + nb0 + ((cp ^ ((r >> 1) & 3)) << 4)) = w;
+      }
+    }
+  } else if constexpr (EPI == G3_FF1) {
     bf16* out = reinterpret_cast<bf16*>(p.out);
     const int nb0 = n0 + wn * 64;  // first feature of this wave
 #pragma unroll
@@ -284,6 +361,9 @@ void gemm3_kernel(const Gemm3P p, int n_tiles, int total_tiles, int per_xcd) {
     const int nb0 = n0 + wn * 64;
     // The x loads of a token block are all requested before the first is used: one at a time (load x, add, store,
     // next pass) they cost a memory round trip EACH -- 16 of them were 31 k of a 122 k-cycle wave life in FF2.
+    // (e4m3 operands: ONE dequantisation factor for the whole weight matrix, applied with the residual add below;
+    // p.bias then holds bias / factor)
+    const float wsc = ES == 1 ? p.wscale[0] : 1.f;
     if (p.bias) {  // bias in the MFMA layout (lane = token, 4-feature runs): 8 small loads, no extra live registers
 #pragma unroll
       for (int a = 0; a < FB; ++a)
@@ -321,10 +401,19 @@ void gemm3_kernel(const Gemm3P p, int n_tiles, int total_tiles, int per_xcd) {
         const bool ok = row < p.M;
         f32x4 v = *reinterpret_cast<const f32x4*>(wst + r * 256 + (cp << 4));
 #pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] += xv[ps][i];
+        for (int i = 0; i < 4; ++i) v[i] = ES == 1 ? fmaf(v[i], wsc, xv[ps][i]) : v[i] + xv[ps][i];
         if (ok) {
           *reinterpret_cast<f32x4*>(p.x + row * p.ldx + col) = v;
           if (xb) *reinterpret_cast<u32x2*>(xb + row * p.ldx + col) = u32x2{pk2(v[0], v[1]), pk2(v[2], v[3])};
+        }
+        if (p.x8) {  // e4m3 shadow x * c, c = RMSNorm factor of the OLD row (within a few % of the new one; the consumer
+                     // divides it out again, so only the e4m3 range matters); c of row r lives in lane r of rs[b]
+          const float c = __shfl(rs[b], r);
+          if (ok) {
+            *reinterpret_cast<unsigned*>(reinterpret_cast<unsigned char*>(p.x8) + row * p.ldx + col) =
+                pk4_f8(v[0] * c, v[1] * c, v[2] * c, v[3] * c);
+            if (n0 == 0 && wn == 0 && cp == 0) p.ascale_out[row] = c;
+          }
         }
         float ssq = ok ? fmaf(v[0], v[0], fmaf(v[1], v[1], fmaf(v[2], v[2], v[3] * v[3]))) : 0.f;
 #pragma unroll
@@ -420,58 +509,45 @@ void launch_cfg(const Gemm3P& p, hipStream_t s) {
 }  // namespace
 
 bool gemm3_supported(const Gemm3P& p) {
-  if (p.M <= 0 || p.K % 64 != 0 || p.K < 128 || p.lda % 8 != 0) return false;
-  if ((long)p.M * p.lda * 2 >= 0x7fffffffL || (long)(p.N + 255) / 256 * 256 * p.K * 2 >= 0x7fffffffL) return false;
+  const int es = p.f8 ? 1 : 2;
+  if (p.M <= 0 || p.K % (p.f8 ? 128 : 64) != 0 || p.K < 128 || p.lda % (16 / es) != 0) return false;
+  if ((long)p.M * p.lda * es >= 0x7fffffffL || (long)(p.N + 255) / 256 * 256 * p.K * es >= 0x7fffffffL) return false;
+  if (p.f8 && (!p.wscale || p.epi == G3_QKV)) return false;
+  if (p.x8 && (p.epi != G3_RESID || !p.ssq_in || !p.ascale_out || p.ldx % 4 != 0)) return false;
   if (p.epi == G3_QKV) return p.inner % 128 == 0 && p.inner == p.heads * 32 && p.L > 0 && p.L <= 1536;
-  if (p.epi == G3_FF1) return p.N % 128 == 0 && p.ldo % 8 == 0;
+  if (p.epi == G3_FF1) return p.N % 128 == 0 && p.ldo % (p.f8 ? 16 : 8) == 0;
   if (p.epi == G3_RESID) return p.N % 128 == 0 && p.ldx % 8 == 0;
   return false;
 }
 
 int launch_gemm3(const Gemm3P& p, hipStream_t s) {
   if (!gemm3_supported(p)) return -2;
-  // development switches: BT_G3_ABL (ablations of the FF1 kernel), BT_G3_BIG = 0 / 1 forces the tile configuration
+  // development switches: BT_G3_ABL (ablations), BT_G3_BIG = 0 / 1 forces the tile configuration
   static const int abl = getenv("BT_G3_ABL") ? atoi(getenv("BT_G3_ABL")) : 0;
   static const int force_big = getenv("BT_G3_BIG") ? atoi(getenv("BT_G3_BIG")) : -1;
-  static const int cfg = getenv("BT_G3_CFG") ? atoi(getenv("BT_G3_CFG")) : 0;  // 1 = M, 2 = C (FF1 / RESID probes)
-  if (cfg == 1 && p.epi == G3_FF1) { launch_cfg<G3_FF1, G3CfgM>(p, s); return (int)hipGetLastError(); }
-  if (cfg == 1 && p.epi == G3_RESID) { launch_cfg<G3_RESID, G3CfgM>(p, s); return (int)hipGetLastError(); }
-  if (cfg == 2 && p.epi == G3_FF1) { launch_cfg<G3_FF1, G3CfgC>(p, s); return (int)hipGetLastError(); }
-  if (cfg == 2 && p.epi == G3_RESID) { launch_cfg<G3_RESID, G3CfgC>(p, s); return (int)hipGetLastError(); }
-  if (cfg == 3 && p.epi == G3_FF1) { launch_cfg<G3_FF1, G3CfgD>(p, s); return (int)hipGetLastError(); }
-  if (cfg == 3 && p.epi == G3_RESID) { launch_cfg<G3_RESID, G3CfgD>(p, s); return (int)hipGetLastError(); }
-  if (cfg == 4 && p.epi == G3_FF1 && p.N % 256 == 0) { launch_cfg<G3_FF1, G3CfgE>(p, s); return (int)hipGetLastError(); }
-  if (cfg == 4 && p.epi == G3_RESID && p.N % 256 == 0) { launch_cfg<G3_RESID, G3CfgE>(p, s); return (int)hipGetLastError(); }
-  if (cfg == 5 && p.epi == G3_FF1) { launch_cfg<G3_FF1, G3CfgF>(p, s); return (int)hipGetLastError(); }
-  if (cfg == 5 && p.epi == G3_RESID) { launch_cfg<G3_RESID, G3CfgF>(p, s); return (int)hipGetLastError(); }
-  // Measured on the final0 shapes (M = 24000): the 256^2 configuration is no faster in isolation (FF1 85 vs 86 us,
-  // FF2 80 vs 83 us) and slower inside the forward (4.19 vs 4.11 ms per step: one workgroup per CU cannot hide its
-  // epilogue behind another workgroup's k-loop), so 128^2 is the default and 256^2 stays an opt-in experiment.
-  const bool big = force_big == 1 && p.epi != G3_QKV && p.N % 256 == 0;
+  // Measured on the final0 shapes (M = 24000): for K = 512 the 256^2 configuration is no faster in isolation (FF1 85 vs
+  // 86 us) and slower inside the forward (one workgroup per CU cannot hide its epilogue behind another workgroup's
+  // k-loop); for the long-K residual GEMM (FF2, K = 4 D: half the operand traffic per flop, epilogue amortised over 32
+  // k-steps) it wins inside the forward as well, 0.452 vs 0.487 ms per step.
+  const bool big_ok = p.epi != G3_QKV && p.N % 256 == 0;
+  const bool big = big_ok && (force_big == 1 || (force_big != 0 && p.epi == G3_RESID && p.K >= 1024 && p.M >= 4096));
+  if (p.f8) {
+    if (p.epi == G3_FF1) { if (big) launch_cfg<G3_FF1, CfgB8>(p, s); else launch_cfg<G3_FF1, CfgS8>(p, s); }
+    else { if (big) launch_cfg<G3_RESID, CfgB8>(p, s); else launch_cfg<G3_RESID, CfgS8>(p, s); }
+    return (int)hipGetLastError();
+  }
   switch (p.epi) {
     case G3_FF1:
-      if (big) {
-        if (abl == 1) launch_cfg<G3_FF1, CfgB, 1>(p, s);
-        else if (abl == 2) launch_cfg<G3_FF1, CfgB, 2>(p, s);
-        else if (abl == 4) launch_cfg<G3_FF1, CfgB, 4>(p, s);
-        else launch_cfg<G3_FF1, CfgB>(p, s);
-      } else {
-        if (abl == 1) launch_cfg<G3_FF1, CfgS, 1>(p, s);
-        else if (abl == 4) launch_cfg<G3_FF1, CfgS, 4>(p, s);
-        else if (abl == 8) launch_cfg<G3_FF1, CfgS, 8>(p, s);
-        else launch_cfg<G3_FF1, CfgS>(p, s);
-      }
+      if (big) launch_cfg<G3_FF1, CfgB>(p, s);
+      else if (abl == 1) launch_cfg<G3_FF1, CfgS, 1>(p, s);
+      else if (abl == 4) launch_cfg<G3_FF1, CfgS, 4>(p, s);
+      else if (abl == 8) launch_cfg<G3_FF1, CfgS, 8>(p, s);
+      else launch_cfg<G3_FF1, CfgS>(p, s);
       break;
     case G3_RESID:
-      // (the 128-byte-row configurations M / B run FF2 in 72 us instead of 78.5 us in isolation, but inside the forward,
-      // where the hidden activation was just written, the 3-stage 64-byte-row ring is faster: 0.495 vs 0.512 ms per step)
-      // long-K residual GEMM (FF2, K = 4 D): the 256^2 x 64 configuration (half the operand traffic per flop, 128-byte
-      // rows) wins inside the forward as well, 0.452 vs 0.487 ms per step; its epilogue is amortised over 32 k-steps
-      if ((big || (force_big != 0 && p.K >= 1024 && p.N % 256 == 0 && p.M >= 4096)) && abl == 8) launch_cfg<G3_RESID, CfgB, 8>(p, s);
-      else if (big || (force_big != 0 && p.K >= 1024 && p.N % 256 == 0 && p.M >= 4096)) launch_cfg<G3_RESID, CfgB>(p, s);
+      if (big && abl == 8) launch_cfg<G3_RESID, CfgB, 8>(p, s);
+      else if (big) launch_cfg<G3_RESID, CfgB>(p, s);
       else if (abl == 8) launch_cfg<G3_RESID, CfgS, 8>(p, s);
-      else if (abl == 1) launch_cfg<G3_RESID, CfgS, 1>(p, s);
-      else if (abl == 4) launch_cfg<G3_RESID, CfgS, 4>(p, s);
       else launch_cfg<G3_RESID, CfgS>(p, s);
       break;
     case G3_QKV: launch_cfg<G3_QKV, CfgS>(p, s); break;

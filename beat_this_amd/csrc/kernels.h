@@ -63,6 +63,13 @@ struct Gemm3P {
   // QKV: rows are (sequence, token) with n_seq sequences of L tokens (M = n_seq * L); columns q | k | v | gates
   int n_seq, L, nblk, nbp, heads, inner;
   const float* rope; void* qf; void* kf; void* vf; float* gates; const float* b_gates;
+  // BT_PREC_FP8: f8 != 0 -> A and W are e4m3 bytes (lda in elements = bytes); wscale[N] = dequantisation factor of
+  // each W row; ascale[M] (FF1 / QKV) = factor the producer multiplied row m of x by before conversion; FF1 then
+  // writes its output as e4m3 as well (unit scale).  RESID (any operand type) with x8 != null also writes the e4m3
+  // shadow x8[m] = e4m3(x_new[m] * c[m]), c = RMSNorm factor of the OLD row from ssq_in, and ascale_out[m] = c[m].
+  int f8;
+  const float* wscale; const float* ascale;
+  void* x8; float* ascale_out;
 };
 bool gemm3_supported(const Gemm3P& p);
 int launch_gemm3(const Gemm3P& p, hipStream_t s);

@@ -195,11 +195,17 @@ typedef struct {
  * epi 0: out[M,ldo] (bf16) = gelu(rms(A) W^T + bias);  epi 1: x[M,ldx] (fp32) += A W^T + bias, bf16 shadow xb,
  * partial row sums of squares ssq_out[N/64][M];  epi 2: q|k|v|gates = rms(A) W^T with RoPE / sigmoid, written
  * fragment-major (layout of bt_attention_frag) for n_seq sequences of L tokens (M = n_seq L).
- * rms(A) uses ssq_in[ssq_parts][M] (partial row sums of squares of the fp32 source of A), NULL = no RMSNorm. */
+ * rms(A) uses ssq_in[ssq_parts][M] (partial row sums of squares of the fp32 source of A), NULL = no RMSNorm.
+ * BT_PREC_FP8 (f8 != 0; epi 0 and 1): A and W are OCP e4m3 bytes (v_mfma_scale_f32_32x32x64_f8f6f4 with unit block
+ * scales).  epi 0: wscale[N] = dequantisation factor of every W row, ascale[M] = factor row m of A was multiplied by
+ * when it was quantised, out = e4m3 bytes [M,ldo] (unit scale, saturating at +-448).  epi 1: wscale[0] = ONE factor for
+ * W, bias already divided by it.  epi 1 with x8 != NULL (any operand type, needs ssq_in = statistics of the OLD x):
+ * additionally x8[M,ldx] = e4m3(x_new[m] * c[m]) and ascale_out[m] = c[m] = sqrt(N) / ||x_old[m]||. */
 typedef struct {
   const void* A; int64_t lda; int32_t M, K; const void* W; int32_t N, epi; const float* bias;
   const float* ssq_in; int32_t ssq_parts; void* out; int64_t ldo; float* x; int64_t ldx; void* xb; float* ssq_out;
   int32_t n_seq, L, nbp, heads; const float* rope; void* qf; void* kf; void* vf; float* gates; const float* b_gates;
+  int32_t f8; const float* wscale; const float* ascale; void* x8; float* ascale_out;
 } bt_gemm3_args;
 int bt_gemm3(void* stream, const bt_gemm3_args* a);
 int bt_attn_frag_blocks(int L);
