@@ -20,7 +20,7 @@ SOURCES = ["gemm.hip", "gemm2.hip", "gemm3.hip", "attn.hip", "attn2.hip", "fused
 HEADERS = ["common.h", "chain.h", "kernels.h", os.path.join("..", "..", "include", "beat_this_amd.h")]
 
 BT_OK, BT_ERR_ARG, BT_ERR_HIP, BT_ERR_WORKSPACE = 0, -1, -2, -3
-PREC_F32, PREC_BF16 = 0, 1
+PREC_F32, PREC_BF16, PREC_FP8 = 0, 1, 2
 MAX_LAYERS = 32
 PROFILE_CATEGORIES = ["stem", "qkv_gemm", "attn_freq", "attn_flash", "out_gemm", "ff1_gemm", "ff2_gemm", "conv_gemm",
                       "linear_gemm", "head", "ff_fused", "attn_freq_fused"]
@@ -34,7 +34,9 @@ class PairWeights(C.Structure):
                 ("w_out", C.c_void_p * 2), ("w_ff1", C.c_void_p * 2), ("b_ff1", C.c_void_p),
                 ("w_ff2", C.c_void_p * 2), ("b_ff2", C.c_void_p), ("w_outp", C.c_void_p * 2),
                 ("w_ff_frag", C.c_void_p * 2), ("w_qkv_frag", C.c_void_p),
-                ("w_outff_frag", C.c_void_p * 2), ("w_attnff_frag", C.c_void_p * 2)]
+                ("w_outff_frag", C.c_void_p * 2), ("w_attnff_frag", C.c_void_p * 2),
+                ("w_ff1_f8", C.c_void_p), ("s_ff1", C.c_void_p), ("w_ff2_f8", C.c_void_p), ("s_ff2", C.c_void_p),
+                ("b_ff2_f8", C.c_void_p)]
 
 
 class ModelDesc(C.Structure):

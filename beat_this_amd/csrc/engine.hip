@@ -54,10 +54,13 @@ struct Workspace {
   void* qkv; void* ao; void* hid;
   void* qf; void* kf; void* vf; float* gates_h; int nbp;  // fragment-major attention operands (bf16 path)
   float* ssq[2];  // [D / 64][B T] partial row sums of squares of the main residual stream (ping-pong)
+  void* x8; float* ascale;  // BT_PREC_FP8: e4m3 shadow of the residual stream [B T][D] and its row factors [B T]
   size_t total;
 };
 
 Workspace carve(char* base, int B, int T, int D, int prec) {
+  const bool fp8 = prec == BT_PREC_FP8;
+  if (fp8) prec = BT_PREC_BF16;
   const size_t es = prec == BT_PREC_F32 ? 4 : 2;
   const size_t bt = (size_t)B * T;
   const size_t dmax = std::max<size_t>(1024, D);
@@ -83,6 +86,11 @@ Workspace carve(char* base, int B, int T, int D, int prec) {
   } else {
     w.ssq[0] = w.ssq[1] = nullptr;
   }
+  w.x8 = nullptr; w.ascale = nullptr;
+  if (fp8) {
+    w.x8 = take(bt * D);
+    w.ascale = (float*)take(bt * 4);
+  }
   w.total = off;
   return w;
 }
@@ -105,7 +113,10 @@ Workspace carve(char* base, int B, int T, int D, int prec) {
 // Main transformer layer in BT_PREC_BF16 on the gemm3 / attn2 kernels.  ws.ssq[0] holds the partial row sums of
 // squares of x on entry and on exit (written by the producer of x: frontend.linear or the previous FF2), ws.ssq[1]
 // those of x after the attention half.
-int run_layer_bf16(const bt_pair_weights& pw, const float* rope, const Workspace& ws, int B, int T, hipStream_t s) {
+// fp8: the GEMMs whose e4m3 weights are present run on e4m3 operands (FF1 reads the e4m3 shadow of x written by the
+// out-projection's epilogue and writes an e4m3 hidden activation; FF2 reads that).
+int run_layer_bf16(const bt_pair_weights& pw, const float* rope, const Workspace& ws, int B, int T, bool fp8,
+                   hipStream_t s) {
   const int D = pw.dim, H = pw.heads;
   const int M = B * T;
   const int parts = D / 64;
@@ -124,14 +135,18 @@ int run_layer_bf16(const bt_pair_weights& pw, const float* rope, const Workspace
   memset(&g, 0, sizeof g);
   g.A = ws.ao; g.lda = D; g.M = M; g.K = D; g.W = pw.w_out[BT_PREC_BF16]; g.N = D; g.epi = G3_RESID;
   g.x = ws.xm; g.ldx = D; g.xb = ws.xmb; g.ssq_out = ws.ssq[1];
+  const bool ff8 = fp8 && pw.w_ff1_f8 && pw.w_ff2_f8;
+  if (ff8) { g.ssq_in = ws.ssq[0]; g.ssq_parts = parts; g.x8 = ws.x8; g.ascale_out = ws.ascale; }
   LAUNCH_CAT(CAT_OUT, s, launch_gemm3(g, s), "out-proj gemm");
   memset(&g, 0, sizeof g);
   g.A = ws.xmb; g.lda = D; g.M = M; g.K = D; g.W = pw.w_ff1[BT_PREC_BF16]; g.N = 4 * D; g.epi = G3_FF1;
   g.bias = pw.b_ff1; g.ssq_in = ws.ssq[1]; g.ssq_parts = parts; g.out = ws.hid; g.ldo = 4 * D;
+  if (ff8) { g.A = ws.x8; g.W = pw.w_ff1_f8; g.f8 = 1; g.wscale = pw.s_ff1; g.ascale = ws.ascale; }
   LAUNCH_CAT(CAT_FF1, s, launch_gemm3(g, s), "ff1 gemm");
   memset(&g, 0, sizeof g);
   g.A = ws.hid; g.lda = 4 * D; g.M = M; g.K = 4 * D; g.W = pw.w_ff2[BT_PREC_BF16]; g.N = D; g.epi = G3_RESID;
   g.bias = pw.b_ff2; g.x = ws.xm; g.ldx = D; g.xb = ws.xmb; g.ssq_out = ws.ssq[0];
+  if (ff8) { g.W = pw.w_ff2_f8; g.f8 = 1; g.wscale = pw.s_ff2; g.bias = pw.b_ff2_f8; }
   LAUNCH_CAT(CAT_FF2, s, launch_gemm3(g, s), "ff2 gemm");
   return BT_OK;
 }
@@ -271,12 +286,22 @@ int bt_forward(bt_engine* e, void* stream, int prec, const float* d_spect, int B
                float* d_beat, float* d_downbeat) {
   if (!e || !d_spect || !d_ws || !d_beat || !d_downbeat) return bt_set_error(BT_ERR_ARG, "null argument");
   if (B <= 0 || T <= 0 || T > 1536) return bt_set_error(BT_ERR_ARG, "need B >= 1 and 1 <= T <= 1536");
-  if (prec != BT_PREC_F32 && prec != BT_PREC_BF16) return bt_set_error(BT_ERR_ARG, "unknown precision");
+  if (prec != BT_PREC_F32 && prec != BT_PREC_BF16 && prec != BT_PREC_FP8) return bt_set_error(BT_ERR_ARG, "unknown precision");
   const bt_model_desc& d = e->d;
   const int D = d.transformer_dim;
   Workspace ws = carve((char*)d_ws, B, T, D, prec);
   if (ws.total > ws_bytes) return bt_set_error(BT_ERR_WORKSPACE, "workspace too small");
   hipStream_t s = (hipStream_t)stream;
+  const bool fp8 = prec == BT_PREC_FP8;
+  if (fp8) {  // everything but the e4m3 GEMMs of the main layers is the bf16 path
+    prec = BT_PREC_BF16;
+    if (D % 128 != 0 || (long)B * T * 4 * D * 2 >= 0x7fffffffL)
+      return bt_set_error(BT_ERR_ARG, "BT_PREC_FP8 needs transformer_dim % 128 == 0 (gemm3 main layers)");
+    for (int l = 0; l < d.n_layers; ++l)
+      if (!d.layers[l].w_ff1_f8 || !d.layers[l].w_ff2_f8 || !d.layers[l].s_ff1 || !d.layers[l].s_ff2 ||
+          !d.layers[l].b_ff2_f8)
+        return bt_set_error(BT_ERR_ARG, "BT_PREC_FP8 needs the e4m3 feed-forward weights of every layer");
+  }
 
   // the bf16 shadow of the main residual stream is maintained by the gemm2 / gemm3 epilogues only
   const bool use_shadow = prec == BT_PREC_BF16 && D >= 128 && D % 64 == 0;
@@ -317,7 +342,7 @@ int bt_forward(bt_engine* e, void* stream, int prec, const float* d_spect, int B
     LAUNCH_CAT(CAT_LINEAR, s, launch_gemm(g, prec, s), "frontend linear gemm");
   }
   for (int l = 0; l < d.n_layers; ++l) {
-    int rc = fast_layers ? run_layer_bf16(d.layers[l], d.rope, ws, B, T, s)
+    int rc = fast_layers ? run_layer_bf16(d.layers[l], d.rope, ws, B, T, fp8, s)
                          : run_pair(d.layers[l], d.rope, ws.xm, use_shadow ? ws.xmb : nullptr, ws, B, T, 1, 0, prec, s);
     if (rc) return rc;
   }

@@ -148,8 +148,10 @@ class Spect2Frames:
     def __init__(self, checkpoint_path="final0", device="cpu", float16=False):
         super().__init__()
         self.device = torch.device(device)
-        self.float16 = float16
+        self.float16 = bool(float16)
         self.model = load_model(checkpoint_path, self.device)
+        if float16 == "fp8":  # extension: float16="fp8" -> autocast + e4m3 feed-forward GEMMs (BT_PREC_FP8)
+            self.model.fp8_weights = True
 
     def spect2frames(self, spect):
         with torch.inference_mode():

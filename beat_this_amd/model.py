@@ -49,6 +49,9 @@ class BeatThis(nn.Module):
         for key in state_dict_shapes(self.hparams):
             _attach(self, key, init[key])
         self._engine = None
+        # extension (BASELINE config 5): under autocast, run the main layers' feed-forward GEMMs on e4m3 weights and
+        # activations (BT_PREC_FP8); everything else stays on the bf16 path.  Off by default.
+        self.fp8_weights = False
         self.eval()
 
     # -- state dict plumbing (beat_tracker.py:194-203: strip torch.compile's "_orig_mod.") ----
@@ -81,5 +84,6 @@ class BeatThis(nn.Module):
             raise ValueError(f"expected (batch, time, {self.hparams['spect_dim']}) input, got {tuple(x.shape)}")
         _lib.require_gpu(x, "model input")
         half = torch.is_autocast_enabled("cuda") if hasattr(torch, "is_autocast_enabled") else False
-        beat, down = self.engine().forward(x, _lib.PREC_BF16 if half else _lib.PREC_F32)
+        prec = _lib.PREC_F32 if not half else (_lib.PREC_FP8 if self.fp8_weights else _lib.PREC_BF16)
+        beat, down = self.engine().forward(x, prec)
         return {"beat": beat, "downbeat": down}

@@ -14,6 +14,7 @@ from . import _lib, tables
 
 LOG2E = 1.4426950408889634
 BN_EPS = 1e-5
+E4M3_MAX = 448.0  # largest finite OCP e4m3 (e4m3fn) value
 
 
 def perm32(w: torch.Tensor) -> torch.Tensor:
@@ -117,7 +118,7 @@ class PackedModel:
         # ---- transformer layers ----------------------------------------------------------------
         for l in range(L):
             p = f"transformer_blocks.layers.{l}."
-            self._pair(d.layers[l], sd, p + "0.", p + "1.", D)
+            self._pair(d.layers[l], sd, p + "0.", p + "1.", D, fp8=True)
         g = sd["transformer_blocks.norm.gamma"]
         d.head_w = self._f32(sd["task_heads.beat_downbeat_lin.weight"] * g[None, :])
         hb = sd["task_heads.beat_downbeat_lin.bias"]
@@ -131,6 +132,13 @@ class PackedModel:
         self._keep.append(t)
         return t.data_ptr()
 
+    def _e4m3(self, w: torch.Tensor) -> int:
+        """fp32 matrix with |w| <= 448 -> OCP e4m3 bytes on the device (round to nearest even)."""
+        t = w.to(torch.float32).clamp(-E4M3_MAX, E4M3_MAX).to(torch.float8_e4m3fn).view(torch.uint8).contiguous()
+        t = t.to(self.device)
+        self._keep.append(t)
+        return t.data_ptr()
+
     def _mat(self, w: torch.Tensor):
         w = _pad_rows(w.to(torch.float32))
         a = w.to(self.device)
@@ -138,7 +146,7 @@ class PackedModel:
         self._keep += [a, b]
         return a.data_ptr(), b.data_ptr()
 
-    def _pair(self, pw, sd, pa: str, pf: str, dim: int) -> None:
+    def _pair(self, pw, sd, pa: str, pf: str, dim: int, fp8: bool = False) -> None:
         heads = dim // 32
         pw.dim, pw.heads = dim, heads
         ga = sd[pa + "norm.gamma"]
@@ -191,6 +199,14 @@ class PackedModel:
         pw.b_ff1 = self._f32(sd[pf + "net.1.bias"])
         pw.w_ff2[0], pw.w_ff2[1] = self._mat(sd[pf + "net.4.weight"])
         pw.b_ff2 = self._f32(sd[pf + "net.4.bias"])
+        if fp8 and dim % 128 == 0:  # BT_PREC_FP8: e4m3 copies for the main layers' feed-forward GEMMs
+            w1 = _pad_rows((sd[pf + "net.1.weight"] * gf[None, :]).to(torch.float32), 256)
+            s1 = (w1.abs().amax(dim=1) / E4M3_MAX).clamp_min(1e-30)            # one factor per hidden unit
+            pw.w_ff1_f8, pw.s_ff1 = self._e4m3(w1 / s1[:, None]), self._f32(s1)
+            w2 = _pad_rows(sd[pf + "net.4.weight"].to(torch.float32), 256)
+            s2 = (w2.abs().max() / E4M3_MAX).clamp_min(1e-30)                  # one factor for the matrix
+            pw.w_ff2_f8, pw.s_ff2 = self._e4m3(w2 / s2), self._f32(s2.reshape(1))
+            pw.b_ff2_f8 = self._f32(sd[pf + "net.4.bias"] / s2)
 
 
 class PackedPair:
@@ -205,6 +221,7 @@ class PackedPair:
 
     _f32 = PackedModel._f32
     _mat = PackedModel._mat
+    _e4m3 = PackedModel._e4m3
 
 
 class Engine:

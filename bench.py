@@ -34,7 +34,7 @@ import torch.distributed as dist  # noqa: E402
 
 CHUNK_FRAMES = 1500
 CHUNK_SECONDS = 30.0
-PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}  # MI355X_MICROARCH.md: dense MFMA peaks
+PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3, "fp8": 5000.0}  # MI355X_MICROARCH.md: dense MFMA peaks
 
 
 def flops_per_chunk(D: int, T: int = CHUNK_FRAMES):
@@ -75,7 +75,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--model", default="final0")
-    ap.add_argument("--prec", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--prec", default="bf16", choices=["bf16", "f32", "fp8"],
+                    help="fp8 = BT_PREC_FP8: bf16 path with the main layers' feed-forward GEMMs on e4m3 (BASELINE config 5)")
     ap.add_argument("--chunks", type=int, default=16, help="chunks per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -104,7 +105,8 @@ def main():
     model = model.to(dev)
     B = args.chunks
     x = torch.from_numpy(np.stack([W.synthetic_spect(CHUNK_FRAMES, seed=1000 * rank + i) for i in range(B)])).to(dev)
-    half = args.prec == "bf16"
+    half = args.prec != "f32"
+    model.fp8_weights = args.prec == "fp8"
     gathered = torch.empty((world * B, 2, CHUNK_FRAMES), dtype=torch.float32, device=dev) if world > 1 else None
 
     def step():
@@ -158,7 +160,9 @@ def main():
                                    "tflops": round(fl[name] * B / (t_fwd * 1e-3) / 1e12, 2)}
         dom = max(breakdown, key=lambda k: breakdown[k]["ms_per_step"])
         d = breakdown[dom]
-        peak = PEAK_TFLOPS[args.prec]
+        # (fp8 mode: only the feed-forward GEMMs run on e4m3 operands, the other launch categories are the bf16 kernels)
+        peak = PEAK_TFLOPS["fp8" if args.prec == "fp8" and dom in ("ff1_gemm", "ff2_gemm") else
+                           ("f32" if args.prec == "f32" else "bf16")]
         # HBM bytes per launch of the dominant category: PMC counters collected in separate rocprofv3 passes
         # (tools/pmc_traffic.sh) for exactly this workload, committed under profiles/; null for any other workload
         traffic = None
@@ -212,7 +216,7 @@ def main():
             "metric": "audio-seconds processed/sec", "value": round(value, 1), "unit": "audio-seconds/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16" if half else "f32", "data": "synthetic",
+            "dtype": {"bf16": "bf16", "f32": "f32", "fp8": "bf16+fp8(e4m3 feed-forward GEMMs)"}[args.prec], "data": "synthetic",
             "config": {"workload": f"{args.model} BeatThis.forward (Spect2Frames path), {B} x 30 s chunks "
                                    f"(1500 frames x 128 mels) per GPU, random-init weights, logits all-gathered",
                        "chunks_per_gpu": B, "global_chunks": world * B, "parallelism": f"chunk-sharded x{world}"},

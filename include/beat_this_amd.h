@@ -25,6 +25,9 @@ extern "C" {
 
 #define BT_PREC_F32 0  /* exact fp32 MFMA (v_mfma_f32_32x32x2_f32), fp32 activations: float16=False */
 #define BT_PREC_BF16 1 /* bf16 MFMA operands, fp32 accumulate + fp32 residual stream: float16=True */
+#define BT_PREC_FP8 2  /* BT_PREC_BF16 with the main-layer GEMMs that have e4m3 weights (bt_pair_weights *_f8) on OCP e4m3
+                        * operands (2x the bf16 MFMA rate), fp32 accumulate + fp32 residual stream; attention, frontend
+                        * and head as in BT_PREC_BF16 */
 
 #define BT_MAX_LAYERS 32
 
@@ -68,6 +71,12 @@ typedef struct {
    * [gate rows of w_qkvg | zero tiles], per head [q rows | k rows] [v rows | PERM32'd to_out tiles (row block
    * mt, the head's 32 columns)], then the FF steps as in w_outff_frag.  NULL for dim > 128. */
   const void* w_attnff_frag[2];
+  /* BT_PREC_FP8 (main layers only; NULL elsewhere): OCP e4m3 (e4m3fn) copies of the feed-forward weights, row-major
+   * [N padded to a multiple of 256][K] bytes, value = weight / factor rounded to nearest even:
+   *   w_ff1_f8 rows / s_ff1[n] (one factor per hidden unit, fp32 [N padded]);
+   *   w_ff2_f8 / s_ff2[0] (ONE factor for the matrix), b_ff2_f8 = b_ff2 / s_ff2[0]. */
+  const void* w_ff1_f8; const float* s_ff1;
+  const void* w_ff2_f8; const float* s_ff2; const float* b_ff2_f8;
 } bt_pair_weights;
 
 /* Packed BeatThis weights (beat_tracker.py:38-106).  Host-side packing is done by

@@ -66,6 +66,37 @@ def test_forward_bf16_close_and_reported(case):
     assert eb < 0.25 * max(float(ref.std()), 0.2)
 
 
+@pytest.mark.parametrize("case", [0, 4])
+def test_forward_fp8_close_and_reported(case):
+    """BT_PREC_FP8 (model.fp8_weights under autocast; BASELINE config 5): the feed-forward GEMMs of the main layers on
+    e4m3 weights / activations.  Report-only like bf16, bounded relative to the logit spread; beat / downbeat
+    frame indices are compared with the bf16 path's."""
+    from beat_this_amd import weights as W
+    from beat_this_amd.postprocessor import Postprocessor
+
+    name, hpn, wseed, style, T, iseed = _cases()[case]
+    g = np.load(os.path.join(GOLDEN, "model_logits.npz"))
+    m = _model(hpn, wseed, style)
+    x = torch.from_numpy(W.synthetic_spect(T, seed=iseed))[None].to(dev())
+    with torch.inference_mode(), torch.autocast("cuda", enabled=True):
+        rb = m(x)
+        m.fp8_weights = True
+        r8 = m(x)
+        m.fp8_weights = False
+    ref = g[name + "_beat"]
+    b8 = r8["beat"][0].cpu().numpy()
+    eb = float(np.abs(b8 - ref).max())
+    rms = float(np.sqrt(np.mean((b8 - ref) ** 2)))
+    d_bf16 = float((r8["beat"] - rb["beat"]).abs().max())
+    assert d_bf16 > 0, "the e4m3 path did not run"
+    post = Postprocessor()
+    pb8, pd8 = post(r8["beat"][0], r8["downbeat"][0])
+    pbb, pdb = post(rb["beat"][0], rb["downbeat"][0])
+    report("forward_fp8", case=name, err_beat=eb, rms=rms, spread=float(ref.std()), vs_bf16=d_bf16,
+           beats_fp8=len(pb8), beats_bf16=len(pbb), downbeats_fp8=len(pd8), downbeats_bf16=len(pdb))
+    assert eb < 0.5 * max(float(ref.std()), 0.2)
+
+
 def test_forward_batched_and_deterministic():
     from beat_this_amd import weights as W
 

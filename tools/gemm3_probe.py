@@ -87,3 +87,26 @@ if "qkv" in which:
     a.ssq_in, a.ssq_parts, a.n_seq, a.L, a.nbp, a.heads = ssq.data_ptr(), D // 64, B, L, nbp, H
     a.rope, a.qf, a.kf, a.vf, a.gates, a.b_gates = rope.data_ptr(), qf.data_ptr(), kf.data_ptr(), vf.data_ptr(), gh.data_ptr(), bg.data_ptr()
     timeit("qkv (N=1552,K=512)", a, 2.0 * M * D * (3 * D + H))
+if "ff1_f8" in which or "ff2_f8" in which:
+    F8 = torch.float8_e4m3fn
+    x8 = (torch.randn((M, D), generator=g)).to(F8).view(torch.uint8).to(dev)
+    asc = torch.ones((M,), device=dev)
+if "ff1_f8" in which:
+    a = _lib.Gemm3Args()
+    W = (torch.randn((4 * D, D), generator=g) * 20).to(F8).view(torch.uint8).to(dev)
+    b, wsc = rnd(4 * D, dtype=torch.float32), torch.full((4 * D,), 0.002, device=dev)
+    out = torch.empty((M, 4 * D), dtype=torch.uint8, device=dev)
+    a.A, a.lda, a.M, a.K, a.W, a.N, a.epi = x8.data_ptr(), D, M, D, W.data_ptr(), 4 * D, 0
+    a.bias, a.ssq_in, a.ssq_parts, a.out, a.ldo = b.data_ptr(), ssq.data_ptr(), D // 64, out.data_ptr(), 4 * D
+    a.f8, a.wscale, a.ascale = 1, wsc.data_ptr(), asc.data_ptr()
+    timeit("ff1 e4m3 (N=2048,K=512)", a, 2.0 * M * D * 4 * D)
+if "ff2_f8" in which:
+    a = _lib.Gemm3Args()
+    h = (torch.randn((M, 4 * D), generator=g)).to(F8).view(torch.uint8).to(dev)
+    W = (torch.randn((D, 4 * D), generator=g) * 20).to(F8).view(torch.uint8).to(dev)
+    b, wsc = rnd(D, dtype=torch.float32), torch.full((1,), 0.001, device=dev)
+    xb, so = torch.empty((M, D), dtype=torch.bfloat16, device=dev), torch.empty((D // 64, M), device=dev)
+    a.A, a.lda, a.M, a.K, a.W, a.N, a.epi = h.data_ptr(), 4 * D, M, 4 * D, W.data_ptr(), D, 1
+    a.bias, a.x, a.ldx, a.xb, a.ssq_out = b.data_ptr(), xf.data_ptr(), D, xb.data_ptr(), so.data_ptr()
+    a.f8, a.wscale = 1, wsc.data_ptr()
+    timeit("ff2 e4m3 (N=512,K=2048)", a, 2.0 * M * D * 4 * D)
