@@ -308,6 +308,15 @@ int bt_forward(bt_engine* e, void* stream, int prec, const float* d_spect, int B
   // main layers on gemm3 + fragment-major attention (needs q | k | v column blocks that are whole 128-tiles)
   const bool fast_layers = use_shadow && D % 128 == 0 && (long)B * T * 4 * D * 2 < 0x7fffffffL;
 
+  // frontend.linear on gemm3 (bf16 A written by the last conv block) when its shape fits
+  bool lin3 = false;
+  if (fast_layers) {
+    Gemm3P g;
+    memset(&g, 0, sizeof g);
+    g.lda = 1024; g.M = B * T; g.K = 1024; g.N = D; g.epi = G3_RESID; g.ldx = D;
+    lin3 = gemm3_supported(g);
+  }
+
   StemP sp;
   sp.spect = d_spect; sp.x = ws.xa; sp.bn1_scale = d.bn1_scale; sp.bn1_shift = d.bn1_shift;
   sp.w = d.stem_w; sp.bias = d.stem_b; sp.B = B; sp.T = T;
@@ -327,12 +336,21 @@ int bt_forward(bt_engine* e, void* stream, int prec, const float* d_spect, int B
     memset(&g, 0, sizeof g);
     g.A = x; g.W = d.conv_w[blk][prec]; g.M = B * T * (F / 2); g.N = 2 * C; g.K = 6 * C;
     g.epi = GEMM_EPI_STORE; g.flags = GEMM_F_CONV | GEMM_F_A_F32 | GEMM_F_BIAS | GEMM_F_GELU | GEMM_F_OUT_F32;
+    // the last block's output is read by frontend.linear only: bf16 when that runs on gemm3 (same rounding point as
+    // the fp32 -> bf16 conversion of its A operand, half the bytes both ways)
+    if (blk == 2 && lin3) g.flags &= ~GEMM_F_OUT_F32;
     g.bias = d.conv_b[blk]; g.out = xn; g.ldo = 2 * C;
     g.conv_C2 = 2 * C; g.conv_T = T; g.conv_F = F / 2;
     LAUNCH_CAT(CAT_CONV, s, launch_gemm(g, prec, s), "frontend conv gemm");
     std::swap(x, xn);
   }
-  {
+  if (lin3) {
+    Gemm3P g;
+    memset(&g, 0, sizeof g);
+    g.A = x; g.lda = 1024; g.M = B * T; g.K = 1024; g.W = d.lin_w[BT_PREC_BF16]; g.N = D; g.epi = G3_RESID;
+    g.no_resid = 1; g.bias = d.lin_b; g.x = ws.xm; g.ldx = D; g.xb = ws.xmb; g.ssq_out = ws.ssq[0];
+    LAUNCH_CAT(CAT_LINEAR, s, launch_gemm3(g, s), "frontend linear gemm");
+  } else {
     GemmP g;
     memset(&g, 0, sizeof g);
     g.A = x; g.lda = 1024; g.W = d.lin_w[prec]; g.M = B * T; g.N = D; g.K = 1024;
@@ -544,6 +562,7 @@ int bt_gemm3(void* stream, const bt_gemm3_args* a) {
   g.heads = a->heads; g.inner = a->heads * 32; g.rope = a->rope; g.qf = a->qf; g.kf = a->kf; g.vf = a->vf;
   g.gates = a->gates; g.b_gates = a->b_gates;
   g.f8 = a->f8; g.wscale = a->wscale; g.ascale = a->ascale; g.x8 = a->x8; g.ascale_out = a->ascale_out;
+  g.no_resid = a->no_resid;
   if (!gemm3_supported(g)) return bt_set_error(BT_ERR_ARG, "shape not supported by bt_gemm3");
   LAUNCH(launch_gemm3(g, (hipStream_t)stream), "gemm3");
   return BT_OK;

@@ -384,8 +384,8 @@ void gemm3_kernel(const Gemm3P p, int n_tiles, int total_tiles, int per_xcd) {
       for (int ps = 0; ps < 8; ++ps) {
         const int r = ps * 4 + (lane >> 4), cp = lane & 15;
         const long row = (long)row0 + 32 * b + r;
-        xv[ps] = row < p.M ? *reinterpret_cast<const f32x4*>(p.x + row * p.ldx + nb0 + ((cp ^ (r & 15)) << 2))
-                           : f32x4{0.f, 0.f, 0.f, 0.f};
+        xv[ps] = (row < p.M && !p.no_resid) ? *reinterpret_cast<const f32x4*>(p.x + row * p.ldx + nb0 + ((cp ^ (r & 15)) << 2))
+                                            : f32x4{0.f, 0.f, 0.f, 0.f};
       }
 #pragma unroll
       for (int a = 0; a < FB; ++a)

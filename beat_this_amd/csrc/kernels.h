@@ -67,6 +67,7 @@ struct Gemm3P {
   // each W row; ascale[M] (FF1 / QKV) = factor the producer multiplied row m of x by before conversion; FF1 then
   // writes its output as e4m3 as well (unit scale).  RESID (any operand type) with x8 != null also writes the e4m3
   // shadow x8[m] = e4m3(x_new[m] * c[m]), c = RMSNorm factor of the OLD row from ssq_in, and ascale_out[m] = c[m].
+  int no_resid;  // RESID: x = A W^T + bias (x is only written: frontend.linear)
   int f8;
   const float* wscale; const float* ascale;
   void* x8; float* ascale_out;

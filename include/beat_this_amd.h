@@ -215,6 +215,7 @@ typedef struct {
   const float* ssq_in; int32_t ssq_parts; void* out; int64_t ldo; float* x; int64_t ldx; void* xb; float* ssq_out;
   int32_t n_seq, L, nbp, heads; const float* rope; void* qf; void* kf; void* vf; float* gates; const float* b_gates;
   int32_t f8; const float* wscale; const float* ascale; void* x8; float* ascale_out;
+  int32_t no_resid; /* epi 1: x = A W^T + bias, x is only written (frontend.linear) */
 } bt_gemm3_args;
 int bt_gemm3(void* stream, const bt_gemm3_args* a);
 int bt_attn_frag_blocks(int L);

@@ -198,3 +198,21 @@ def test_gemm3_resid_e4m3_shadow(M, K, N):
     err = ((got - want).abs() / (want.abs() * 2 ** -4 + 2 ** -10)).max().item()
     report("gemm3_resid_e4m3_shadow", M=M, K=K, N=N, half_ulps=err)
     assert err < 2.1  # (a result next to a rounding boundary may land on either neighbour)
+
+
+def test_gemm3_store_without_residual():
+    """epi 1 with no_resid (frontend.linear): x is written, never read (NaN-filled on entry)."""
+    M, K, N = 3000, 1024, 512
+    A = _mk((M, K), 51).float().to(torch.bfloat16)
+    W = _mk((N, K), 52, 1 / math.sqrt(K)).float().to(torch.bfloat16)
+    b = _mk((N,), 53)
+    x = torch.full((M, N), float("nan"), dtype=torch.float32, device=dev())
+    xb = torch.zeros((M, N), dtype=torch.bfloat16, device=dev())
+    ssq = torch.zeros((N // 64, M), dtype=torch.float32, device=dev())
+    _call(A=A.to(dev()), lda=K, M=M, K=K, W=W.to(dev()), N=N, epi=1, bias=b.float().to(dev()), x=x, ldx=N, xb=xb,
+          ssq_out=ssq, no_resid=1)
+    ref = A.double() @ W.double().T + b
+    err, errb = _rel(x, ref), _rel(xb, ref)
+    errs = _rel(ssq, (ref ** 2).view(M, N // 64, 64).sum(-1).T)
+    report("gemm3_store", M=M, K=K, N=N, rel=err, shadow=errb, ssq=errs)
+    assert err < 1e-5 and errb < 5e-3 and errs < 1e-4
