@@ -37,6 +37,10 @@ constexpr int SMEM_BYTES = 2 * 2 * TILE_BYTES + 16;  // [buffer][K | V] + fallba
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
+DEVI unsigned pk2(float a, float b) {
+  const bf16x2 t = {(bf16)a, (bf16)b};
+  return __builtin_bit_cast(unsigned, t);
+}
 DEVI void zero16(f32x16& a) {
 #pragma unroll
   for (int r = 0; r < 16; ++r) a[r] = 0.f;
@@ -421,20 +425,38 @@ __global__ __launch_bounds__(256, (QB == 1 ? 4 : 2)) void attn_frag_kernel(const
   }
 
   const int seq = sh / p.heads, head = sh - seq * p.heads;
+  bf16* st16[QB][2];
+  bool okq[QB];
+  float gatev[QB];
 #pragma unroll
   for (int j = 0; j < QB; ++j) {
     const int qi = (qb0 + j) * 32 + lr;
-    if (qb0 + j < nblk && qi < L) {
-      const float gate = p.gates[(long)sh * p.nbp * 32 + qi];
-      const float scale = gate / l_tot[j];
+    okq[j] = qb0 + j < nblk && qi < L;
+    gatev[j] = 0.f;
+    st16[j][0] = st16[j][1] = nullptr;
+    if (okq[j]) {
+      gatev[j] = p.gates[(long)sh * p.nbp * 32 + qi];
       const long orow = (long)(seq / p.o_div) * p.o_outer + (long)(seq % p.o_div) * p.o_inner + (long)qi * p.o_tok;
-      bf16* op = reinterpret_cast<bf16*>(p.out) + orow * p.inner + head * 32 + 4 * g;
+      bf16* op = reinterpret_cast<bf16*>(p.out) + orow * p.inner + head * 32 + 8 * g;
 #pragma unroll
-      for (int a = 0; a < 4; ++a) {
-        const bf16x4 o = {(bf16)(st[j].acc[4 * a] * scale), (bf16)(st[j].acc[4 * a + 1] * scale),
-                          (bf16)(st[j].acc[4 * a + 2] * scale), (bf16)(st[j].acc[4 * a + 3] * scale)};
-        *reinterpret_cast<bf16x4*>(op + 8 * a) = o;
-      }
+      for (int k = 0; k < 2; ++k) st16[j][k] = op + 16 * k;
+    }
+  }
+  // A lane holds 4-feature runs 8 a + 4 g of its query; the two halves of a wave exchange runs (v_permlane32_swap) so
+  // that every lane stores two 16-byte pieces (features 16 k + 8 g .. + 7) instead of four 8-byte ones: the 8-byte
+  // row-strided stores showed 1.9x write amplification in WRITE_SIZE.  (The exchange is executed by all lanes.)
+#pragma unroll
+  for (int j = 0; j < QB; ++j) {
+    const float scale = okq[j] ? gatev[j] / l_tot[j] : 0.f;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const unsigned x0 = pk2(st[j].acc[8 * k] * scale, st[j].acc[8 * k + 1] * scale);
+      const unsigned x1 = pk2(st[j].acc[8 * k + 2] * scale, st[j].acc[8 * k + 3] * scale);
+      const unsigned y0 = pk2(st[j].acc[8 * k + 4] * scale, st[j].acc[8 * k + 5] * scale);
+      const unsigned y1 = pk2(st[j].acc[8 * k + 6] * scale, st[j].acc[8 * k + 7] * scale);
+      auto r0 = __builtin_amdgcn_permlane32_swap(x0, y0, false, false);
+      auto r1 = __builtin_amdgcn_permlane32_swap(x1, y1, false, false);
+      if (okq[j]) *reinterpret_cast<u32x4*>(st16[j][k]) = u32x4{r0[0], r1[0], r0[1], r1[1]};
     }
   }
 }
