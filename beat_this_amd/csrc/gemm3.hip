@@ -33,6 +33,11 @@ struct G3CfgB { static constexpr int BM = 256, BN = 256, BK = 64, WGM = 2, WGN =
 // range; one v_mfma_scale_f32_32x32x64_f8f6f4 with unit block scales per 64-byte row group (lane = row, 32
 // consecutive k bytes at 32 (lane >> 5); layout and rate -- 4.15 PFLOP/s vs 2.3 for bf16 -- checked by
 // tools/ubench/mfma_f8_probe.hip), so the k-loop is half as long for the same LDS-DMA bytes per step.
+// T = B with 192 token rows (waves of 96 x 64): picked when it covers M in fewer CU-rounds x rows -- final0's FF2 at
+// M = 24000 is 125 x 2 = 250 tiles = one round on 98 % of the CUs instead of 188 tiles on 73 % (72 -> 65 us).
+// (A 128^2 2-stage variant at 4 workgroups per CU, 1024 slots so that QKV's 2444 tiles take 3 rounds, was no faster.)
+struct G3CfgT { static constexpr int BM = 192, BN = 256, BK = 64, WGM = 2, WGN = 4, NST = 2, OCC = 1, ES = 2; };
+struct G3CfgT8 { static constexpr int BM = 192, BN = 256, BK = 128, WGM = 2, WGN = 4, NST = 2, OCC = 1, ES = 1; };
 struct G3CfgS8 { static constexpr int BM = 128, BN = 128, BK = 64, WGM = 2, WGN = 2, NST = 3, OCC = 3, ES = 1; };
 struct G3CfgB8 { static constexpr int BM = 256, BN = 256, BK = 128, WGM = 2, WGN = 4, NST = 2, OCC = 1, ES = 1; };
 
@@ -531,9 +536,14 @@ int launch_gemm3(const Gemm3P& p, hipStream_t s) {
   // k-steps) it wins inside the forward as well, 0.452 vs 0.487 ms per step.
   const bool big_ok = p.epi != G3_QKV && p.N % 256 == 0;
   const bool big = big_ok && (force_big == 1 || (force_big != 0 && p.epi == G3_RESID && p.K >= 1024 && p.M >= 4096));
+  // 256 or 192 token rows per tile: fewer (rounds over the 256 CUs) x (rows per tile) wins
+  auto cost = [&](int bm) { const long t = ((long)p.M + bm - 1) / bm * (p.N / 256); return (t + 255) / 256 * bm; };
+  const bool rows192 = big && p.epi == G3_RESID && force_big != 1 && cost(192) < cost(256);
   if (p.f8) {
     if (p.epi == G3_FF1) { if (big) launch_cfg<G3_FF1, CfgB8>(p, s); else launch_cfg<G3_FF1, CfgS8>(p, s); }
-    else { if (big) launch_cfg<G3_RESID, CfgB8>(p, s); else launch_cfg<G3_RESID, CfgS8>(p, s); }
+    else if (rows192) launch_cfg<G3_RESID, G3CfgT8>(p, s);
+    else if (big) launch_cfg<G3_RESID, CfgB8>(p, s);
+    else launch_cfg<G3_RESID, CfgS8>(p, s);
     return (int)hipGetLastError();
   }
   switch (p.epi) {
@@ -546,6 +556,7 @@ int launch_gemm3(const Gemm3P& p, hipStream_t s) {
       break;
     case G3_RESID:
       if (big && abl == 8) launch_cfg<G3_RESID, CfgB, 8>(p, s);
+      else if (rows192) launch_cfg<G3_RESID, G3CfgT>(p, s);
       else if (big) launch_cfg<G3_RESID, CfgB>(p, s);
       else if (abl == 8) launch_cfg<G3_RESID, CfgS, 8>(p, s);
       else launch_cfg<G3_RESID, CfgS>(p, s);

@@ -54,7 +54,9 @@ def test_gemm3_ff1(M, K, N):
     assert err < 6e-3
 
 
-@pytest.mark.parametrize("M,K,N,bias", [(1500, 2048, 512, True), (777, 512, 512, False), (130, 128, 128, True)])
+# (M = 24000 runs on the 192 x 256 tiles, M = 32768 on the 256 x 256 ones, the others on 128 x 128)
+@pytest.mark.parametrize("M,K,N,bias", [(1500, 2048, 512, True), (777, 512, 512, False), (130, 128, 128, True),
+                                        (24000, 2048, 512, True), (32768, 1024, 512, False)])
 def test_gemm3_resid(M, K, N, bias):
     A = _mk((M, K), 4).float().to(torch.bfloat16)
     W = _mk((N, K), 5, 0.5 / math.sqrt(K)).float().to(torch.bfloat16)
@@ -157,7 +159,8 @@ def test_gemm3_f8_ff1(M, K, N):
     assert err < 2.1  # (a result next to a rounding boundary may land on either neighbour)
 
 
-@pytest.mark.parametrize("M,K,N,bias", [(1500, 2048, 512, True), (777, 512, 512, False), (24000, 2048, 512, True)])
+@pytest.mark.parametrize("M,K,N,bias", [(1500, 2048, 512, True), (777, 512, 512, False), (24000, 2048, 512, True),
+                                        (32768, 1024, 512, False)])
 def test_gemm3_f8_resid(M, K, N, bias):
     A8, Ad = _q8(_mk((M, K), 31).abs() * 0.7)
     W = _mk((N, K), 32, 0.5 / math.sqrt(K))
