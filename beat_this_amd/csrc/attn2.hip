@@ -280,7 +280,7 @@ DEVI void finish_fast(f32x16 (&sc)[QB], const VFrag& vf, QState (&st)[QB]) {
 
 template <int QB>
 DEVI void attn_pass_pipe(rsrc_t rk, rsrc_t rv, char* smem, int tid, int wave, int lane, int g, int lr,
-                         QState (&st)[QB], int L, int nblk) {
+                         QState (&st)[QB], int L, int nblk, long long* t_loop = nullptr) {
   const int ntiles = (nblk + KB - 1) / KB;
   const bool partial = (L & 31) != 0;
   int nfull = nblk / KB;  // tiles of KB unmasked blocks
@@ -310,6 +310,7 @@ DEVI void attn_pass_pipe(rsrc_t rk, rsrc_t rv, char* smem, int tid, int wave, in
       for (int r = 0; r < 16; ++r) st[j].negm[r] = -bm;
     }
   }
+  if (t_loop) *t_loop = wall_clock64();
   if (nfull > 0) {
     f32x16 sc[QB];
     KFrag kn = ld_k(smem, g, lr);
@@ -368,6 +369,7 @@ __global__ __launch_bounds__(256, (QB == 1 ? 4 : 2)) void attn_frag_kernel(const
   __shared__ __attribute__((aligned(16))) char smem[SMEM_BYTES];
   // XCD-aware order: the q-tiles of one (sequence, head) run on one XCD (block b -> XCD b % 8), so its
   // K/V stream is fetched into one L2
+  const long long t_entry = wall_clock64();
   const int bid = blockIdx.x;
   const int idx = bid >> 3;
   const int sh = (idx / nqt) * 8 + (bid & 7);
@@ -396,15 +398,18 @@ __global__ __launch_bounds__(256, (QB == 1 ? 4 : 2)) void attn_frag_kernel(const
   const rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(kseq), 0, seq_bytes, 0x00020000);
   const rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(vseq), 0, seq_bytes, 0x00020000);
   const long long tc0 = clock64(), tw0 = wall_clock64();
+  long long t_loop = tw0;
   if constexpr ((ABL & 1024) == 0 && QB == 1)  // (bit 10: the unpipelined loop, kept for comparisons)
-    attn_pass_pipe<QB>(rk, rv, smem, tid, wave, lane, g, lr, st, L, nblk);
+    attn_pass_pipe<QB>(rk, rv, smem, tid, wave, lane, g, lr, st, L, nblk, (ABL & 128) ? &t_loop : nullptr);
   else
     attn_pass<false, ABL, QB>(rk, rv, smem, tid, wave, lane, g, lr, st, L, nblk);
   if constexpr ((ABL & 128) != 0) {  // development: shader-clock ticks vs 100 MHz wall ticks of the pass
     if (lane == 0) {
       long long* dbg = reinterpret_cast<long long*>(const_cast<float*>(p.gates));
-      dbg[((long)bid * 4 + wave) * 2] = clock64() - tc0;
-      dbg[((long)bid * 4 + wave) * 2 + 1] = wall_clock64() - tw0;
+      dbg[((long)bid * 4 + wave) * 4] = clock64() - tc0;
+      dbg[((long)bid * 4 + wave) * 4 + 1] = wall_clock64() - tw0;
+      dbg[((long)bid * 4 + wave) * 4 + 2] = tw0 - t_entry;   // kernel entry -> pass start (descriptor setup, Q loads issued)
+      dbg[((long)bid * 4 + wave) * 4 + 3] = t_loop - tw0;    // pass start -> key loop start (tile 0 landed, reference maximum)
     }
   }
   float l_tot[QB];

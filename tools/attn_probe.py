@@ -43,6 +43,7 @@ for name, n_seq, heads in (("front", 512, 1), ("main", 16, 16)):
     if os.environ.get("BT_ATTN_ABL") == "128":
         torch.cuda.synchronize()
         n_w = ((SH + 7) // 8 * 8) * ((47 + 3) // 4) * 4
-        d = gates.view(torch.int64).flatten()[: n_w * 2].view(-1, 2).cpu().double()
+        d = gates.view(torch.int64).flatten()[: n_w * 4].view(-1, 4).cpu().double()
         print(f"   per-wave pass: {d[:,0].mean():.0f} shader ticks, {d[:,1].mean():.1f} wall ticks (100 MHz) => "
-              f"{d[:,0].sum() / d[:,1].sum() * 0.1:.3f} GHz; pass {d[:,1].mean() / 100:.1f} us")
+              f"{d[:,0].sum() / d[:,1].sum() * 0.1:.3f} GHz; pass {d[:,1].mean() / 100:.1f} us; entry -> pass "
+              f"{d[:,2].mean() / 100:.2f} us; pass start -> key loop {d[:,3].mean() / 100:.2f} us")
