@@ -14,7 +14,7 @@ import subprocess
 import torch  # noqa: F401  (must precede loading the HIP library)
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(PKG_DIR, "libbeat_this_amd.so")
+LIB_PATH = os.environ.get("BT_LIB_PATH") or os.path.join(PKG_DIR, "libbeat_this_amd.so")  # (BT_LIB_PATH: development override, an alternative build)
 SOURCES = ["gemm.hip", "gemm2.hip", "gemm3.hip", "attn.hip", "attn2.hip", "fused.hip", "fused2.hip", "qkv_front.hip", "frontend.hip", "logmel.hip",
            "engine.hip"]
 HEADERS = ["common.h", "chain.h", "kernels.h", os.path.join("..", "..", "include", "beat_this_amd.h")]

@@ -164,7 +164,7 @@ int run_pair(const bt_pair_weights& pw, const float* rope, float* x, void* xshad
   auto outff = [&]() -> int {  // x += to_out(ws.ao); x += FF(x) in one launch
     FusedOutFFP f;
     f.x = x; f.M = M; f.C = C; f.ao = ws.ao; f.wfrag = pw.w_outff_frag[prec]; f.b1 = pw.b_ff1; f.b2 = pw.b_ff2;
-    f.xb = nullptr;
+    f.xb = nullptr; f.abl = 0;
     LAUNCH_CAT(CAT_FF_FUSED, s, launch_outff_fused(f, prec, s), "fused out-projection + feed-forward");
     return BT_OK;
   };
@@ -537,7 +537,7 @@ int bt_outff_fused(void* stream, int prec, const bt_pair_weights* w, const void*
     return bt_set_error(BT_ERR_ARG, "bad argument to bt_outff_fused");
   FusedOutFFP f;
   f.x = d_x; f.M = M; f.C = w->dim; f.ao = d_ao; f.wfrag = w->w_outff_frag[prec]; f.b1 = w->b_ff1; f.b2 = w->b_ff2;
-  f.xb = nullptr;
+  f.xb = nullptr; f.abl = 0;
   LAUNCH(launch_outff_fused(f, prec, (hipStream_t)stream), "fused out-projection + feed-forward");
   return BT_OK;
 }

@@ -13,12 +13,15 @@
 // a 4-stage LDS ring (LDS-DMA), fragment-major, one step per barrier, shared by the 4 waves of a workgroup:
 //   [out-proj: KT steps of KT tiles (rows mt*32.., k-tile kt) + KT zero tiles]  (outff only)
 //   [FF: 4C/32 steps of KT tiles of W1p (rows hb*32..) + KT tiles of W2p (rows mt*32.., cols hb*32..)]
+#include <cstdlib>
 #include <type_traits>
 
 #include "chain.h"
 #include "kernels.h"
 
 namespace {
+
+// development switch BT_F2_ABL (timing experiments only): bit 0 = x / ao are not loaded, bit 1 = x is not stored
 
 typedef __amdgpu_buffer_rsrc_t rsrc_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
@@ -27,16 +30,21 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 // (buffer_load ... lds, no staging registers) into a ring of NST stages; step s + NST - 1 is issued while
 // step s is consumed, so three steps of L2 latency are covered instead of none (the register-staged
 // version waited for every step's load inside the step: ~2 k cycles x 25 steps per workgroup).
+// development: per-wave phase timing of attnff_fused_kernel (bt_debug_fused2_buffer; null = off)
+__device__ long long* g_f2_dbg = nullptr;
+
 template <typename T, int C>
 struct WRing {
   static constexpr int KT = C / 32;
   static constexpr int TILE_B = 32 * 32 * (int)sizeof(T);
   static constexpr int STEP_B = 2 * KT * TILE_B;
-  static constexpr int NST = 4;
+  static constexpr int NST = 4;  // (3 stages: C = 64 is 8 % faster back to back with itself, but not inside the forward)
   static constexpr int CH = STEP_B / 4096;  // buffer loads per thread per step (256 threads x 16 B = 4 KB each)
   rsrc_t rs;
   char* lds;
   int tid, wave, total;
+  long long t_wait = 0, t_bar = 0;  // (timing dump only)
+  bool timing = false;
   DEVI void issue(int s) {
     if (s >= total) return;
     char* dst = lds + (s % NST) * STEP_B + wave * 1024;
@@ -51,10 +59,14 @@ struct WRing {
   // make step s readable by every wave (all older LDS-DMA done in every wave), then refill the stage freed by step s-1
   DEVI const char* acquire(int s) {
     const int ahead = min(NST - 2, total - 1 - s);  // younger steps that may stay in flight
+    long long q0 = 0, q1 = 0;
+    if (timing) q0 = clock64();
     if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * CH) : "memory");
     else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CH) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (timing) q1 = clock64();
     __builtin_amdgcn_s_barrier();
+    if (timing) { const long long q2 = clock64(); t_wait += q1 - q0; t_bar += q2 - q1; }
     issue(s + NST - 1);
     return lds + (s % NST) * STEP_B;
   }
@@ -127,8 +139,9 @@ __global__ __launch_bounds__(256) void outff_fused_kernel(const FusedOutFFP p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 5, lr = lane & 31;
   const long tok = ((long)blockIdx.x * 4 + wave) * 32 + lr;
-  const bool ok = tok < p.M;
-  float* xrow = p.x + (ok ? tok : 0) * C;
+  const bool ok_st = tok < p.M && !(p.abl & 2);
+  const bool ok = tok < p.M && !(p.abl & 1);
+  float* xrow = p.x + (tok < p.M ? tok : 0) * C;
   for (int i = tid; i < 4 * C; i += 256) b1s[i] = p.b1[i];
 
   // attention output row of this token as B-operand fragments (natural k order)
@@ -167,7 +180,7 @@ __global__ __launch_bounds__(256) void outff_fused_kernel(const FusedOutFFP p) {
     for (int r = 0; r < 16; ++r) xn[mt][r] += acc[r];
   }
   bf16* xbrow = p.xb ? reinterpret_cast<bf16*>(p.xb) + tok * C : nullptr;
-  ff_tail<T, C>(ws, KT, xn, b1s, p.b2, xrow, xbrow, ok, lane, g);
+  ff_tail<T, C>(ws, KT, xn, b1s, p.b2, xrow, xbrow, ok_st, lane, g);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -189,6 +202,8 @@ __global__ __launch_bounds__(256) void attnff_fused_kernel(const FusedAttnFFP p)
   const long tok = ((long)blockIdx.x * 4 + wave) * 32 + lr;
   const bool ok = tok < p.M;
   float* xrow = p.x + (ok ? tok : 0) * C;
+  long long* dbg = g_f2_dbg;
+  const long long t_in = dbg ? clock64() : 0;
   for (int i = tid; i < 4 * C; i += 256) b1s[i] = p.b1[i];
 
   float ss = 0.f;
@@ -220,6 +235,8 @@ __global__ __launch_bounds__(256) void attnff_fused_kernel(const FusedAttnFFP p)
   // vmcnt values that assume in-order return, and LDS-DMA returns are not ordered against VGPR returns (observed:
   // RoPE factors consumed before they arrived, a few wrong rows per launch at C = 32).
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  ws.timing = dbg != nullptr;
+  const long long t_ring = dbg ? clock64() : 0;
   ws.prologue();
 
   // ---- step 0: gates of all heads; gate hd sits in register hd of the g = 0 half ----------------------------
@@ -322,7 +339,12 @@ __global__ __launch_bounds__(256) void attnff_fused_kernel(const FusedAttnFFP p)
     for (int a = 0; a < 4; ++a)
 #pragma unroll
       for (int j = 0; j < 4; ++j) xn[mt][4 * a + j] = xv[mt][a][j] + acco[mt][4 * a + j];
+  const long long t_ff = dbg ? clock64() : 0;
   ff_tail<T, C>(ws, 1 + 2 * H, xn, b1s, p.b2, xrow, nullptr, ok, lane, g);
+  if (dbg && lane == 0) {
+    long long* d = dbg + ((long)blockIdx.x * 4 + wave) * 6;
+    d[0] = t_ring - t_in; d[1] = t_ff - t_ring; d[2] = clock64() - t_ff; d[3] = ws.t_wait; d[4] = ws.t_bar; d[5] = 0;
+  }
 }
 
 template <typename T>
@@ -350,8 +372,15 @@ int launch_attnff_t(const FusedAttnFFP& p, hipStream_t s) {
 
 }  // namespace
 
-int launch_outff_fused(const FusedOutFFP& p, int prec, hipStream_t s) {
-  if (p.M <= 0) return -2;
+extern "C" int bt_debug_fused2_buffer(void* buf) {
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_f2_dbg), &buf, sizeof buf);
+}
+
+int launch_outff_fused(const FusedOutFFP& p0, int prec, hipStream_t s) {
+  if (p0.M <= 0) return -2;
+  static const int abl = getenv("BT_F2_ABL") ? atoi(getenv("BT_F2_ABL")) : 0;
+  FusedOutFFP p = p0;
+  p.abl = abl;
   return prec == BT_PREC_F32 ? launch_outff_t<float>(p, s) : launch_outff_t<bf16>(p, s);
 }
 int launch_attnff_fused(const FusedAttnFFP& p, int prec, hipStream_t s) {

@@ -137,6 +137,7 @@ struct FusedOutFFP {  // x += Wout . ao ; x += FF(x)      (time direction, after
   const void* wfrag;                 // bt_pair_weights.w_outff_frag
   const float* b1; const float* b2;
   void* xb;                          // optional bf16 shadow of the new x
+  int abl;                           // development (BT_F2_ABL)
 };
 int launch_outff_fused(const FusedOutFFP& p, int prec, hipStream_t s);
 struct FusedAttnFFP {  // x += AttnF(x) ; x += FF(x)      (frequency direction)
