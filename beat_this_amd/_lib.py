@@ -124,16 +124,25 @@ EXPORTS = {
 }
 
 
+# -amdgpu-mfma-vgpr-form: MFMA results stay in VGPRs (hipcc otherwise parks the accumulators of the register-chained
+# frontend kernels in AGPRs and moves them with v_accvgpr_read / _write: 2900 such moves in fused2.hip, 32 per FF step);
+# frequency-direction halves 0.315 -> 0.287 ms.  (-fgpu-flush-denormals-to-zero: no effect; max-ilp scheduling: slower.)
+HIPCC_FLAGS = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops", "-mllvm", "-amdgpu-mfma-vgpr-form"]
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
     """Compile the HIP sources for gfx950 into libbeat_this_amd.so (in tree)."""
     src_dir = os.path.join(PKG_DIR, "csrc")
     srcs = [os.path.join(src_dir, s) for s in SOURCES]
-    deps = srcs + [os.path.join(src_dir, h) for h in HEADERS]
+    deps = srcs + [os.path.join(src_dir, h) for h in HEADERS] + [os.path.abspath(__file__)]  # (this file: HIPCC_FLAGS)
     if not force and os.path.exists(LIB_PATH) and all(
             os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
         return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", *srcs, "-o", LIB_PATH]
+    # -packed-fp32-ops: hipcc pairs independent fp32 multiplies / adds / fmas into v_pk_*_f32, which issue at 5.5 clk per
+    # instruction on gfx950 against 2 x 1.8 for the scalar forms (tools/ubench/valu_rates.hip); without the pairing the
+    # forward is 3.7 % faster (frequency-direction fused halves 0.43 -> 0.32 ms), A/B on one box with tools/ab.sh
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", *HIPCC_FLAGS, *srcs, "-o", LIB_PATH]
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)
