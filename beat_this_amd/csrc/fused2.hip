@@ -38,7 +38,8 @@ struct WRing {
   static constexpr int KT = C / 32;
   static constexpr int TILE_B = 32 * 32 * (int)sizeof(T);
   static constexpr int STEP_B = 2 * KT * TILE_B;
-  static constexpr int NST = 4;  // (3 stages: C = 64 is 8 % faster back to back with itself, but not inside the forward)
+  static constexpr int NST = C == 128 ? 3 : 4;  // (C = 128: 3 stages = 51 KB, out-projection + FF halves 4 % faster inside the forward;
+                                                 //  C = 64: 3 stages only help back to back with itself; 3 workgroups per CU at C = 128: spills)
   static constexpr int CH = STEP_B / 4096;  // buffer loads per thread per step (256 threads x 16 B = 4 KB each)
   rsrc_t rs;
   char* lds;
