@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256) void attn_flash_kernel(const AttnP p) {
   char* Ks = smem;
   char* Vs = smem + KT * PITCH;
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // (wave index in an SGPR: uniform index math stays scalar)
   const int g = lane >> 5, lr = lane & 31;
   const int seq = blockIdx.y / p.heads, head = blockIdx.y % p.heads;
   const int L = p.L;

@@ -375,7 +375,7 @@ __global__ __launch_bounds__(256, (QB == 1 ? 4 : 2)) void attn_frag_kernel(const
   const int sh = (idx / nqt) * 8 + (bid & 7);
   const int qt = idx % nqt;
   if (sh >= sh_total) return;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // (wave index in an SGPR: uniform index math stays scalar)
   const int g = lane >> 5, lr = lane & 31;
   const int L = p.L;
   const int nblk = (L + 31) >> 5;

@@ -118,7 +118,7 @@ __global__ __launch_bounds__(1024) void peaks_kernel(const float* __restrict__ l
   __shared__ int base_s;
   const float* x = logits + (long)blockIdx.x * n;
   int* out = idx + (long)blockIdx.x * n;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // (wave index in an SGPR: uniform index math stays scalar)
   if (tid == 0) base_s = 0;
   __syncthreads();
   for (long t0 = 0; t0 < n; t0 += 1024) {

@@ -39,7 +39,7 @@ __global__ __launch_bounds__(256) void ff_fused_kernel(const FusedFFP p) {
   constexpr int BLK_B = 2 * KT * TILE_B;             // weights of one hidden block
   constexpr int CHUNKS = BLK_B / 16 / 256;           // 16-byte chunks per thread per block
   __shared__ __attribute__((aligned(16))) char wl[2 * BLK_B];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // (wave index in an SGPR: uniform index math stays scalar)
   const int g = lane >> 5, lr = lane & 31;
   const long tok = ((long)blockIdx.x * 4 + wave) * 32 + lr;
   const bool ok = tok < p.M;
@@ -117,7 +117,7 @@ __global__ __launch_bounds__(256) void attn_freq_fused_kernel(const FusedAttnP p
   constexpr int KT = C / 32;
   constexpr int H = C / 32;       // heads
   constexpr int F = 1024 / C;     // tokens per (b,t) row: 32, 16, 8
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int g = lane >> 5, lr = lane & 31;
   const long tok = ((long)blockIdx.x * 4 + wave) * 32 + lr;
   const bool ok = tok < p.M;

@@ -137,7 +137,7 @@ __global__ __launch_bounds__(256) void outff_fused_kernel(const FusedOutFFP p) {
   constexpr int TILE_B = WRing<T, C>::TILE_B, STEP_B = WRing<T, C>::STEP_B, NST = WRing<T, C>::NST;
   __shared__ __attribute__((aligned(16))) char wl[NST * STEP_B + 4 * C * 4];
   float* b1s = reinterpret_cast<float*>(wl + NST * STEP_B);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // (wave index in an SGPR: uniform index math stays scalar)
   const int g = lane >> 5, lr = lane & 31;
   const long tok = ((long)blockIdx.x * 4 + wave) * 32 + lr;
   const bool ok_st = tok < p.M && !(p.abl & 2);
@@ -198,7 +198,7 @@ __global__ __launch_bounds__(256) void attnff_fused_kernel(const FusedAttnFFP p)
   constexpr int TILE_B = WRing<T, C>::TILE_B, STEP_B = WRing<T, C>::STEP_B, NST = WRing<T, C>::NST;
   __shared__ __attribute__((aligned(16))) char wl[NST * STEP_B + 4 * C * 4];
   float* b1s = reinterpret_cast<float*>(wl + NST * STEP_B);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // (wave index in an SGPR: uniform index math stays scalar)
   const int g = lane >> 5, lr = lane & 31;
   const long tok = ((long)blockIdx.x * 4 + wave) * 32 + lr;
   const bool ok = tok < p.M;

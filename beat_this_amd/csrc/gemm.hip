@@ -95,7 +95,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
   char* Bs = smem + 128 * PITCH;
   float* rs = reinterpret_cast<float*>(smem + (128 + BN) * PITCH);
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // (wave index in an SGPR: uniform index math stays scalar)
   const int g = lane >> 5, lr = lane & 31;
   const int wm = wave / WN, wn = wave % WN;
   const long m0 = (long)blockIdx.y * 128;

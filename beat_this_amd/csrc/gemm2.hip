@@ -46,7 +46,7 @@ __global__ __launch_bounds__(256, 2) void gemm2_kernel(const GemmP p, int n_tile
   const long m0 = (long)m_tile * BM;
   const int n0 = n_tile * BN;
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // (wave index in an SGPR: uniform index math stays scalar)
   const int g = lane >> 5, lr = lane & 31;
   const int wm = wave >> 1, wn = wave & 1;
   const int nk = p.K / BK;

@@ -109,7 +109,7 @@ void gemm3_kernel(const Gemm3P p, int n_tiles, int total_tiles, int per_xcd) {
   if (tile >= total_tiles) return;
   const int m_tile = tile / n_tiles, n_tile = tile - m_tile * n_tiles;
   const int m0 = m_tile * BM, n0 = n_tile * BN;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // (wave index in an SGPR: uniform index math stays scalar)
   const int g = lane >> 5, lr = lane & 31;
   const int wm = wave / CFG::WGN, wn = wave % CFG::WGN;
   const int nk = p.K / BK;

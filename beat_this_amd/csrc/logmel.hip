@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256) void logmel_kernel(const LogmelP p) {
   __shared__ float sre[4][XPAD];
   __shared__ float sim[4][XPAD];
   __shared__ float smag[4][520];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const long frame = (long)blockIdx.x * 4 + wave;
   const bool active = frame < p.n_frames;
   float* re = sre[wave];

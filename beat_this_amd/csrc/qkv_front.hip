@@ -26,7 +26,7 @@ __global__ __launch_bounds__(256, (C == 32 ? 4 : C == 64 ? 3 : 2)) void qkv_fron
   constexpr int STEP_B = 3 * KT * TILE_B;  // q, k, v tiles of one head (the gate step uses the first KT)
   constexpr int NCH = STEP_B / 16;       // 16-byte chunks per step
   __shared__ __attribute__((aligned(16))) char wl[2 * STEP_B];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // (wave index in an SGPR: uniform index math stays scalar)
   const int g = lane >> 5, lr = lane & 31;
   const int nblk = (p.T + 31) >> 5;
   const long wb_id = (long)blockIdx.x * 4 + wave;          // global token-block index
