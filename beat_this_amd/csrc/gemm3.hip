@@ -381,16 +381,26 @@ void gemm3_kernel(const Gemm3P p, int n_tiles, int total_tiles, int per_xcd) {
             for (int i = 0; i < 4; ++i) acc[a][b][4 * q + i] += bb[i];
         }
     }
+    // Row-major phase addressing: lane (r4 = lane >> 4, cp = lane & 15) handles row 32 b + 4 ps + r4 and the 16-byte
+    // chunk cp ^ (row & 15) of its 256 B.  ONE per-lane multiply (32-bit element offsets: M * ldx < 2^31 is checked by the
+    // launcher); per access a wave-uniform term (32 b + 4 ps) * ldx and one of four column terms are added -- the
+    // straightforward `row * ldx` per access cost ~150 quarter-rate integer multiplies / 64-bit ops per wave.
+    const int r4 = lane >> 4, cp = lane & 15;
+    const unsigned ldx = (unsigned)p.ldx;
+    const unsigned off_lane = (unsigned)(row0 + r4) * ldx + (unsigned)nb0;
+    unsigned colq[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) colq[q] = (unsigned)((cp ^ (4 * q + r4)) << 2);  // (row & 15) = 4 (ps & 3) + r4
+    const int rows_left = p.M - row0 - r4;  // row (32 b + 4 ps + r4) exists iff 32 b + 4 ps < rows_left
 #pragma unroll
     for (int b = 0; b < TB; ++b) {
       f32x4 xv[8];  // (per token block: more at once -- all blocks, or a prefetch of the next one -- spills next to the
                     // accumulators and measured slower)
 #pragma unroll
       for (int ps = 0; ps < 8; ++ps) {
-        const int r = ps * 4 + (lane >> 4), cp = lane & 15;
-        const long row = (long)row0 + 32 * b + r;
-        xv[ps] = (row < p.M && !p.no_resid) ? *reinterpret_cast<const f32x4*>(p.x + row * p.ldx + nb0 + ((cp ^ (r & 15)) << 2))
-                                            : f32x4{0.f, 0.f, 0.f, 0.f};
+        const unsigned off = off_lane + (unsigned)(32 * b + 4 * ps) * ldx + colq[ps & 3];
+        xv[ps] = (32 * b + 4 * ps < rows_left && !p.no_resid) ? *reinterpret_cast<const f32x4*>(p.x + off)
+                                                               : f32x4{0.f, 0.f, 0.f, 0.f};
       }
 #pragma unroll
       for (int a = 0; a < FB; ++a)
@@ -400,30 +410,28 @@ void gemm3_kernel(const Gemm3P p, int n_tiles, int total_tiles, int per_xcd) {
               f32x4{acc[a][b][4 * q], acc[a][b][4 * q + 1], acc[a][b][4 * q + 2], acc[a][b][4 * q + 3]};
 #pragma unroll
       for (int ps = 0; ps < 8; ++ps) {  // 4 rows x 256 B per wave-instruction
-        const int r = ps * 4 + (lane >> 4), cp = lane & 15;
-        const int col = nb0 + ((cp ^ (r & 15)) << 2);
-        const long row = (long)row0 + 32 * b + r;
-        const bool ok = row < p.M;
+        const int r = ps * 4 + r4;
+        const unsigned off = off_lane + (unsigned)(32 * b + 4 * ps) * ldx + colq[ps & 3];
+        const bool ok = 32 * b + 4 * ps < rows_left;
         f32x4 v = *reinterpret_cast<const f32x4*>(wst + r * 256 + (cp << 4));
 #pragma unroll
         for (int i = 0; i < 4; ++i) v[i] = ES == 1 ? fmaf(v[i], wsc, xv[ps][i]) : v[i] + xv[ps][i];
         if (ok) {
-          *reinterpret_cast<f32x4*>(p.x + row * p.ldx + col) = v;
-          if (xb) *reinterpret_cast<u32x2*>(xb + row * p.ldx + col) = u32x2{pk2(v[0], v[1]), pk2(v[2], v[3])};
+          *reinterpret_cast<f32x4*>(p.x + off) = v;
+          if (xb) *reinterpret_cast<u32x2*>(xb + off) = u32x2{pk2(v[0], v[1]), pk2(v[2], v[3])};
         }
         if (p.x8) {  // e4m3 shadow x * c, c = RMSNorm factor of the OLD row (within a few % of the new one; the consumer
                      // divides it out again, so only the e4m3 range matters); c of row r lives in lane r of rs[b]
           const float c = __shfl(rs[b], r);
           if (ok) {
-            *reinterpret_cast<unsigned*>(reinterpret_cast<unsigned char*>(p.x8) + row * p.ldx + col) =
-                pk4_f8(v[0] * c, v[1] * c, v[2] * c, v[3] * c);
-            if (n0 == 0 && wn == 0 && cp == 0) p.ascale_out[row] = c;
+            *reinterpret_cast<unsigned*>(reinterpret_cast<unsigned char*>(p.x8) + off) = pk4_f8(v[0] * c, v[1] * c, v[2] * c, v[3] * c);
+            if (n0 == 0 && wn == 0 && cp == 0) p.ascale_out[row0 + 32 * b + r] = c;
           }
         }
         float ssq = ok ? fmaf(v[0], v[0], fmaf(v[1], v[1], fmaf(v[2], v[2], v[3] * v[3]))) : 0.f;
 #pragma unroll
         for (int o = 8; o > 0; o >>= 1) ssq += __shfl_xor(ssq, o);
-        if (p.ssq_out && ok && cp == 0) p.ssq_out[(long)(n0 / 64 + wn) * p.M + row] = ssq;
+        if (p.ssq_out && ok && cp == 0) p.ssq_out[(unsigned)(n0 / 64 + wn) * (unsigned)p.M + (unsigned)(row0 + 32 * b + r)] = ssq;
       }
     }
   } else {  // G3_QKV
@@ -521,7 +529,8 @@ bool gemm3_supported(const Gemm3P& p) {
   if (p.x8 && (p.epi != G3_RESID || !p.ssq_in || !p.ascale_out || p.ldx % 4 != 0)) return false;
   if (p.epi == G3_QKV) return p.inner % 128 == 0 && p.inner == p.heads * 32 && p.L > 0 && p.L <= 1536;
   if (p.epi == G3_FF1) return p.N % 128 == 0 && p.ldo % (p.f8 ? 16 : 8) == 0;
-  if (p.epi == G3_RESID) return p.N % 128 == 0 && p.ldx % 8 == 0;
+  if (p.epi == G3_RESID) return p.N % 128 == 0 && p.ldx % 8 == 0 && (long)(p.M + 256) * p.ldx < 0x7fffffffL &&
+                                (long)(p.N / 64) * p.M < 0x7fffffffL;  // (32-bit element offsets in the epilogue)
   return false;
 }
 
