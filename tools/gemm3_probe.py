@@ -76,7 +76,7 @@ if "out" in which:
 if "qkv" in which:
     from beat_this_amd.tables import rope_table
     a = _lib.Gemm3Args()
-    H, L, B = 16, 1500, 16
+    H, L, B = 16, 1500, int(os.environ.get('QKV_B', '16'))
     nbp = _lib.lib().bt_attn_frag_blocks(L)
     W = rnd(3 * D + 128, D, scale=0.05)
     rope = torch.from_numpy(rope_table(10000.0 ** (-torch.arange(0, 32, 2).float() / 32))).to(dev)
@@ -86,7 +86,8 @@ if "qkv" in which:
     a.A, a.lda, a.M, a.K, a.W, a.N, a.epi = x.data_ptr(), D, M, D, W.data_ptr(), 3 * D + H, 2
     a.ssq_in, a.ssq_parts, a.n_seq, a.L, a.nbp, a.heads = ssq.data_ptr(), D // 64, B, L, nbp, H
     a.rope, a.qf, a.kf, a.vf, a.gates, a.b_gates = rope.data_ptr(), qf.data_ptr(), kf.data_ptr(), vf.data_ptr(), gh.data_ptr(), bg.data_ptr()
-    timeit("qkv (N=1552,K=512)", a, 2.0 * M * D * (3 * D + H))
+    a.M = B * L
+    timeit(f"qkv (N=1552,K=512,B={B})", a, 2.0 * B * L * D * (3 * D + H))
 if "ff1_f8" in which or "ff2_f8" in which:
     F8 = torch.float8_e4m3fn
     x8 = (torch.randn((M, D), generator=g)).to(F8).view(torch.uint8).to(dev)
