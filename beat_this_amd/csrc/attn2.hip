@@ -78,11 +78,6 @@ struct QState {
   float m;         // running max (SAFE pass) / reference max (fast pass)
 };
 
-// One 32-key block against the QB query blocks of this wave: scores, probabilities, O^T += V^T . P^T.
-// ABL: development-only ablations selected by the BT_ATTN_ABL environment variable (timing experiments):
-//   bit 0: stage only the first two tiles (no global traffic afterwards)   bit 1: skip the exponentials
-//   bit 2: no row-sum MFMAs   bit 3: no bf16 conversion   bit 4: no P.V MFMAs   bit 5: no score MFMAs
-//   bit 7: dump shader-clock / wall-clock ticks of the pass   bit 10: unpipelined key loop (bits 0-5 need it)
 struct KFrag { bf16x8 k0, k1; };
 struct VFrag { bf16x8 v0, v1; };
 DEVI KFrag ld_k(const char* kb, int g, int lr) {
@@ -98,17 +93,14 @@ DEVI VFrag ld_v(const char* vb, int lane) {
   return f;
 }
 
-template <bool SAFE, bool MASK, int ABL, int QB>
+// One 32-key block against the QB query blocks of this wave: scores, probabilities, O^T += V^T . P^T (the plain,
+// unpipelined form: SAFE pass and the ragged / masked last tile of the fast pass).
+template <bool SAFE, bool MASK, int QB>
 DEVI void do_block(const KFrag& kf, const VFrag& vf, int g, QState (&st)[QB], int key0, int L) {
   const bf16x8 k0 = kf.k0, k1 = kf.k1, v0 = vf.v0, v1 = vf.v1;
   f32x16 sc[QB];
 #pragma unroll
   for (int j = 0; j < QB; ++j) {
-    if constexpr ((ABL & 32) != 0) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) sc[j][r] = st[j].negm[r] + (float)k0[r & 7];
-      continue;
-    }
     if constexpr (SAFE) {
       zero16(sc[j]);
       sc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, st[j].q0, sc[j], 0, 0, 0);
@@ -140,31 +132,18 @@ DEVI void do_block(const KFrag& kf, const VFrag& vf, int g, QState (&st)[QB], in
       for (int r = 0; r < 16; ++r) sc[j][r] = __builtin_amdgcn_exp2f(sc[j][r] - m_new);
     } else {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) sc[j][r] = (ABL & 2) ? sc[j][r] : __builtin_amdgcn_exp2f(sc[j][r]);
+      for (int r = 0; r < 16; ++r) sc[j][r] = __builtin_amdgcn_exp2f(sc[j][r]);
       if constexpr (MASK) {
 #pragma unroll
         for (int r = 0; r < 16; ++r)
           if (key0 + crow(r, g) >= L) sc[j][r] = 0.f;
       }
     }
-    u32x4 w0, w1;
-    if constexpr ((ABL & 8) != 0) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) { w0[r] = __builtin_bit_cast(unsigned, sc[j][r] + sc[j][r + 8]); w1[r] = __builtin_bit_cast(unsigned, sc[j][r + 4] + sc[j][r + 12]); }
-    } else {
-      w0 = pack8(sc[j], 0); w1 = pack8(sc[j], 1);
-    }
-    if constexpr ((ABL & 4) == 0) {
-      rowsum8(st[j].l, w0);
-      rowsum8(st[j].l, w1);
-    }
-    if constexpr ((ABL & 16) != 0) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) { st[j].acc[r] += __builtin_bit_cast(float, w0[r]); st[j].acc[r + 4] += __builtin_bit_cast(float, w1[r]); }
-    } else {
-      st[j].acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v0, __builtin_bit_cast(bf16x8, w0), st[j].acc, 0, 0, 0);
-      st[j].acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v1, __builtin_bit_cast(bf16x8, w1), st[j].acc, 0, 0, 0);
-    }
+    const u32x4 w0 = pack8(sc[j], 0), w1 = pack8(sc[j], 1);
+    rowsum8(st[j].l, w0);
+    rowsum8(st[j].l, w1);
+    st[j].acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v0, __builtin_bit_cast(bf16x8, w0), st[j].acc, 0, 0, 0);
+    st[j].acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v1, __builtin_bit_cast(bf16x8, w1), st[j].acc, 0, 0, 0);
   }
 }
 
@@ -184,7 +163,7 @@ DEVI void stage_tile(rsrc_t rk, rsrc_t rv, int tile, char* smem, int buf, int ti
   static_assert(TILE_BYTES == 8192, "stage_tile copies two 4 KB pieces per operand");
 }
 
-template <bool SAFE, int ABL, int QB>
+template <bool SAFE, int QB>
 DEVI void attn_pass(rsrc_t rk, rsrc_t rv, char* smem, int tid, int wave, int lane, int g, int lr, QState (&st)[QB],
                     int L, int nblk) {
   const int ntiles = (nblk + KB - 1) / KB;
@@ -221,7 +200,7 @@ DEVI void attn_pass(rsrc_t rk, rsrc_t rv, char* smem, int tid, int wave, int lan
   // just-in-time it was the largest stall of the loop).
   KFrag kf = ld_k(smem, g, lr);
   for (int t = 0; t < ntiles; ++t) {
-    if (t + 1 < ntiles && !((ABL & 1) && t >= 1)) stage_tile(rk, rv, t + 1, smem, (t + 1) & 1, tid, wave);
+    if (t + 1 < ntiles) stage_tile(rk, rv, t + 1, smem, (t + 1) & 1, tid, wave);
     const char* kb = smem + (t & 1) * 2 * TILE_BYTES;
     const char* vb = kb + TILE_BYTES;
     const int nb = min(KB, nblk - t * KB);
@@ -232,7 +211,7 @@ DEVI void attn_pass(rsrc_t rk, rsrc_t rv, char* smem, int tid, int wave, int lan
         KFrag kn = kf;
         if (c + 1 < KB) kn = ld_k(kb + (c + 1) * BLK_BYTES, g, lr);
         __builtin_amdgcn_sched_barrier(0);
-        do_block<SAFE, false, ABL, QB>(kf, vf, g, st, (t * KB + c) * 32, L);
+        do_block<SAFE, false, QB>(kf, vf, g, st, (t * KB + c) * 32, L);
         kf = kn;
       }
     } else {
@@ -241,9 +220,9 @@ DEVI void attn_pass(rsrc_t rk, rsrc_t rv, char* smem, int tid, int wave, int lan
         const VFrag vf = ld_v(vb + c * BLK_BYTES, lane);
         if (c > 0) kf = ld_k(kb + c * BLK_BYTES, g, lr);
         if (partial && blk == nblk - 1)
-          do_block<SAFE, true, 0, QB>(kf, vf, g, st, blk * 32, L);
+          do_block<SAFE, true, QB>(kf, vf, g, st, blk * 32, L);
         else
-          do_block<SAFE, false, 0, QB>(kf, vf, g, st, blk * 32, L);
+          do_block<SAFE, false, QB>(kf, vf, g, st, blk * 32, L);
       }
     }
     __syncthreads();  // tile t+1 has landed (every wave waited for its own copies), tile t is free
@@ -356,9 +335,9 @@ DEVI void attn_pass_pipe(rsrc_t rk, rsrc_t rv, char* smem, int tid, int wave, in
       const VFrag vf = ld_v(vb + c * BLK_BYTES, lane);
       const KFrag kf = ld_k(kb + c * BLK_BYTES, g, lr);
       if (partial && blk == nblk - 1)
-        do_block<false, true, 0, QB>(kf, vf, g, st, blk * 32, L);
+        do_block<false, true, QB>(kf, vf, g, st, blk * 32, L);
       else
-        do_block<false, false, 0, QB>(kf, vf, g, st, blk * 32, L);
+        do_block<false, false, QB>(kf, vf, g, st, blk * 32, L);
     }
   }
   __syncthreads();
@@ -399,10 +378,7 @@ __global__ __launch_bounds__(256, (QB == 1 ? 4 : 2)) void attn_frag_kernel(const
   const rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(vseq), 0, seq_bytes, 0x00020000);
   const long long tc0 = clock64(), tw0 = wall_clock64();
   long long t_loop = tw0;
-  if constexpr ((ABL & 1024) == 0 && QB == 1)  // (bit 10: the unpipelined loop, kept for comparisons)
-    attn_pass_pipe<QB>(rk, rv, smem, tid, wave, lane, g, lr, st, L, nblk, (ABL & 128) ? &t_loop : nullptr);
-  else
-    attn_pass<false, ABL, QB>(rk, rv, smem, tid, wave, lane, g, lr, st, L, nblk);
+  attn_pass_pipe<QB>(rk, rv, smem, tid, wave, lane, g, lr, st, L, nblk, (ABL & 128) ? &t_loop : nullptr);
   if constexpr ((ABL & 128) != 0) {  // development: shader-clock ticks vs 100 MHz wall ticks of the pass
     if (lane == 0) {
       long long* dbg = reinterpret_cast<long long*>(const_cast<float*>(p.gates));
@@ -424,7 +400,7 @@ __global__ __launch_bounds__(256, (QB == 1 ? 4 : 2)) void attn_frag_kernel(const
   __syncthreads();
   if (*flag) {  // workgroup-uniform
     __syncthreads();
-    attn_pass<true, 0, QB>(rk, rv, smem, tid, wave, lane, g, lr, st, L, nblk);
+    attn_pass<true, QB>(rk, rv, smem, tid, wave, lane, g, lr, st, L, nblk);
 #pragma unroll
     for (int j = 0; j < QB; ++j) l_tot[j] = st[j].l[0] + __shfl_xor(st[j].l[0], 32);
   }
@@ -482,19 +458,10 @@ static void launch_v(const AttnFragP& p, hipStream_t s) {
 int launch_attn_frag(const AttnFragP& p, hipStream_t s) {
   if (p.L <= 0 || p.n_seq <= 0 || p.heads <= 0 || p.inner != p.heads * 32 || p.nbp < attn_frag_blocks(p.L)) return -2;
   if ((long)p.n_seq * p.heads * ((p.L + 127) / 128) > 0x3fffffffL) return -3;
-  // development switches: BT_ATTN_ABL (ablations, see do_block), BT_ATTN_QB (query blocks per wave)
+  // development switch: BT_ATTN_ABL=128 dumps per-wave phase timings over the gates buffer (tools/attn_probe.py).
+  // (Two query blocks per wave -- QB = 2, half the fragment reads per MFMA at half the occupancy -- measured equal.)
   static const int abl = getenv("BT_ATTN_ABL") ? atoi(getenv("BT_ATTN_ABL")) : 0;
-  static const int qb = getenv("BT_ATTN_QB") ? atoi(getenv("BT_ATTN_QB")) : 1;
-  if (qb == 2) {
-    launch_v<0, 2>(p, s);
-  } else {
-    switch (abl) {
-      case 1025: launch_v<1025, 1>(p, s); break;
-      case 1027: launch_v<1027, 1>(p, s); break;
-      case 128: launch_v<128, 1>(p, s); break;
-      case 1024: launch_v<1024, 1>(p, s); break;
-      default: launch_v<0, 1>(p, s);
-    }
-  }
+  if (abl == 128) launch_v<128, 1>(p, s);
+  else launch_v<0, 1>(p, s);
   return (int)hipGetLastError();
 }

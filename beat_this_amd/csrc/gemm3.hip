@@ -85,8 +85,8 @@ DEVI void pack_row_bf16(const float (&v)[16], u32x4 (&piece)[2]) {
   }
 }
 
-// ABL (development, BT_G3_ABL): bit 0 = no LDS-DMA after the prologue, bit 1 = FF1 epilogue without GELU,
-// bit 2 = no fragment reads / MFMAs in the loop (staging + barriers only)
+// ABL (development, BT_G3_ABL = 8): per-wave timing dump (k-loop, waits, epilogue) read by tools/gemm3_probe.py;
+// bits 0 - 2 (no LDS-DMA after the prologue / no GELU / no MFMAs) are ablations that can be instantiated by hand
 template <int EPI, typename CFG, int ABL = 0>
 __global__ __launch_bounds__(64 * CFG::WGM * CFG::WGN, (CFG::OCC * CFG::WGM * CFG::WGN + 3) / 4)
 void gemm3_kernel(const Gemm3P p, int n_tiles, int total_tiles, int per_xcd) {
@@ -558,8 +558,6 @@ int launch_gemm3(const Gemm3P& p, hipStream_t s) {
   switch (p.epi) {
     case G3_FF1:
       if (big) launch_cfg<G3_FF1, CfgB>(p, s);
-      else if (abl == 1) launch_cfg<G3_FF1, CfgS, 1>(p, s);
-      else if (abl == 4) launch_cfg<G3_FF1, CfgS, 4>(p, s);
       else if (abl == 8) launch_cfg<G3_FF1, CfgS, 8>(p, s);
       else launch_cfg<G3_FF1, CfgS>(p, s);
       break;
