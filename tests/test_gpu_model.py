@@ -47,7 +47,7 @@ def test_forward_fp32_matches_reference_golden(case):
     assert eb < LOGIT_TOL_F32 and ed < LOGIT_TOL_F32
 
 
-@pytest.mark.parametrize("case", [0, 4])
+@pytest.mark.parametrize("case", [0, 2, 3, 4])
 def test_forward_bf16_close_and_reported(case):
     """bf16-MFMA path (float16=True): not under the 1e-3 gate (the reference's own autocast path
     is ~2e-2 off its fp32 path); bounded relative to the logit spread."""
@@ -66,7 +66,7 @@ def test_forward_bf16_close_and_reported(case):
     assert eb < 0.25 * max(float(ref.std()), 0.2)
 
 
-@pytest.mark.parametrize("case", [0, 4])
+@pytest.mark.parametrize("case", [0, 3, 4])
 def test_forward_fp8_close_and_reported(case):
     """BT_PREC_FP8 (model.fp8_weights under autocast; BASELINE config 5): the feed-forward GEMMs of the main layers on
     e4m3 weights / activations.  Report-only like bf16, bounded relative to the logit spread; beat / downbeat
@@ -313,3 +313,22 @@ def test_ablation_variants_against_oracle(variant, prec_half):
     report("ablation", variant=variant, half=prec_half, err_beat=eb, err_downbeat=ed, spread=float(ob.std()))
     tol = 0.25 * max(float(ob.std()), 0.2) if prec_half else 1e-3
     assert eb < tol and ed < tol
+
+
+@pytest.mark.parametrize("B,T", [(1, 37), (2, 1), (5, 333), (33, 64)])
+def test_forward_bf16_odd_batches_match_fp32_path(B, T):
+    """Ragged shapes through the bf16 kernels (partial 32-token blocks, partial GEMM tiles, more chunks than one tile
+    row): bounded against the exact-fp32 path of the same engine."""
+    from beat_this_amd import weights as W
+
+    m = _model("final0", 1, "lively")
+    x = torch.from_numpy(np.stack([W.synthetic_spect(T, seed=300 + i) for i in range(B)])).to(dev())
+    with torch.inference_mode():
+        ref = m(x)
+        with torch.autocast("cuda", enabled=True):
+            got = m(x)
+    assert got["beat"].shape == (B, T) and torch.isfinite(got["beat"]).all() and torch.isfinite(got["downbeat"]).all()
+    err = float((got["beat"] - ref["beat"]).abs().max())
+    spread = float(ref["beat"].std()) if B * T > 1 else 0.0
+    report("forward_bf16_odd", B=B, T=T, err_beat=err, spread=spread)
+    assert err < 0.25 * max(spread, 0.4)
