@@ -219,3 +219,22 @@ def test_gemm3_store_without_residual():
     errs = _rel(ssq, (ref ** 2).view(M, N // 64, 64).sum(-1).T)
     report("gemm3_store", M=M, K=K, N=N, rel=err, shadow=errb, ssq=errs)
     assert err < 1e-5 and errb < 5e-3 and errs < 1e-4
+
+
+def test_gemm3_f8_hidden_saturates_instead_of_overflowing():
+    """e4m3 has no infinity: hidden activations beyond +-448 must saturate (OCP e4m3fn 0x7e / 0xfe), never become NaN (0x7f)."""
+    M, K, N = 256, 128, 128
+    x = _mk((M, K), 61).float()
+    c = torch.ones(M, dtype=torch.float64)
+    A8, _ = _q8(x.double())
+    W8, _ = _q8(_mk((N, K), 62))
+    b = torch.full((N,), 1000.0)
+    b[::2] = -1000.0  # gelu(-1000) = -0: the negative side stays finite as well
+    out = torch.zeros((M, N), dtype=torch.uint8, device=dev())
+    _call(A=A8.view(torch.uint8).to(dev()), lda=K, M=M, K=K, W=pad_rows(W8.view(torch.uint8)).to(dev()), N=N, epi=0,
+          bias=b.float().to(dev()), ssq_in=_ssq_parts(x).to(dev()), ssq_parts=K // 64, out=out, ldo=N, f8=1,
+          wscale=torch.ones(N, device=dev()), ascale=c.float().to(dev()))
+    got = out.cpu()
+    assert not ((got & 0x7F) == 0x7F).any(), "NaN encoding in the e4m3 hidden activation"
+    dec = got.view(F8).float()
+    assert torch.all(dec[:, 1::2] == 448.0) and torch.all(dec[:, 0::2].abs() < 1e-3)
