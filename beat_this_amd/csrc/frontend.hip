@@ -59,11 +59,24 @@ __global__ __launch_bounds__(256) void head_kernel(const HeadP p) {
   if (row >= p.M) return;
   const float* x = p.x + row * p.D;
   float ss = 0.f, d0 = 0.f, d1 = 0.f;
-  for (int k = lane; k < p.D; k += 64) {
-    float v = x[k];
-    ss = fmaf(v, v, ss);
-    d0 = fmaf(v, p.w[k], d0);
-    d1 = fmaf(v, p.w[p.D + k], d1);
+  if ((p.D & 3) == 0) {  // 16 bytes per lane: one wave-instruction covers 1 KB of the row
+    for (int k = 4 * lane; k < p.D; k += 256) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(x + k);
+      const f32x4 w0 = *reinterpret_cast<const f32x4*>(p.w + k), w1 = *reinterpret_cast<const f32x4*>(p.w + p.D + k);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        ss = fmaf(v[i], v[i], ss);
+        d0 = fmaf(v[i], w0[i], d0);
+        d1 = fmaf(v[i], w1[i], d1);
+      }
+    }
+  } else {
+    for (int k = lane; k < p.D; k += 64) {
+      float v = x[k];
+      ss = fmaf(v, v, ss);
+      d0 = fmaf(v, p.w[k], d0);
+      d1 = fmaf(v, p.w[p.D + k], d1);
+    }
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
