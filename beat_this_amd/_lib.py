@@ -85,7 +85,8 @@ class Gemm3Args(C.Structure):
                 ("L", C.c_int32), ("nbp", C.c_int32), ("heads", C.c_int32), ("rope", C.c_void_p), ("qf", C.c_void_p),
                 ("kf", C.c_void_p), ("vf", C.c_void_p), ("gates", C.c_void_p), ("b_gates", C.c_void_p),
                 ("f8", C.c_int32), ("wscale", C.c_void_p), ("ascale", C.c_void_p), ("x8", C.c_void_p),
-                ("ascale_out", C.c_void_p), ("no_resid", C.c_int32)]
+                ("ascale_out", C.c_void_p), ("no_resid", C.c_int32), ("gelu", C.c_int32), ("conv_C2", C.c_int32),
+                ("conv_T", C.c_int32), ("conv_F", C.c_int32)]
 
 
 G3_FF1, G3_RESID, G3_QKV = 0, 1, 2

@@ -151,8 +151,14 @@ int run_layer_bf16(const bt_pair_weights& pw, const float* rope, const Workspace
   return BT_OK;
 }
 
+// bf16 shadow of the residual stream written by the fused out-projection + FF kernel (time-direction half; A operand of
+// the following frontend conv on gemm3)
+inline bool pair_fused2_ok(const bt_pair_weights& pw, int prec) {
+  return pw.dim <= 128 && pw.w_outp[prec] && pw.w_ff_frag[prec] && pw.w_outff_frag[prec] && pw.w_attnff_frag[prec];
+}
+
 int run_pair(const bt_pair_weights& pw, const float* rope, float* x, void* xshadow, const Workspace& ws, int B, int T,
-             int F, int mode, int prec, hipStream_t s) {
+             int F, int mode, int prec, hipStream_t s, void* out_shadow = nullptr) {
   const int C = pw.dim, H = pw.heads;
   const long M = (long)B * T * F;
   if (M > 0x7fffffffL) return bt_set_error(BT_ERR_ARG, "batch too large for one forward call");
@@ -164,7 +170,7 @@ int run_pair(const bt_pair_weights& pw, const float* rope, float* x, void* xshad
   auto outff = [&]() -> int {  // x += to_out(ws.ao); x += FF(x) in one launch
     FusedOutFFP f;
     f.x = x; f.M = M; f.C = C; f.ao = ws.ao; f.wfrag = pw.w_outff_frag[prec]; f.b1 = pw.b_ff1; f.b2 = pw.b_ff2;
-    f.xb = nullptr; f.abl = 0;
+    f.xb = out_shadow; f.abl = 0;
     LAUNCH_CAT(CAT_FF_FUSED, s, launch_outff_fused(f, prec, s), "fused out-projection + feed-forward");
     return BT_OK;
   };
@@ -313,7 +319,7 @@ int bt_forward(bt_engine* e, void* stream, int prec, const float* d_spect, int B
   if (fast_layers) {
     Gemm3P g;
     memset(&g, 0, sizeof g);
-    g.lda = 1024; g.M = B * T; g.K = 1024; g.N = D; g.epi = G3_RESID; g.ldx = D;
+    g.lda = 1024; g.M = B * T; g.K = 1024; g.N = D; g.epi = G3_RESID; g.ldx = D; g.x = ws.xm;
     lin3 = gemm3_supported(g);
   }
 
@@ -326,11 +332,25 @@ int bt_forward(bt_engine* e, void* stream, int prec, const float* d_spect, int B
   float* xn = ws.xb;
   for (int blk = 0; blk < 3; ++blk) {
     const int C = 32 << blk, F = 32 >> blk;
+    // conv of this block on gemm3 (LDS-DMA ring on the bf16 shadow of x that the time-direction half leaves in ws.hid)
+    Gemm3P cg;
+    memset(&cg, 0, sizeof cg);
+    cg.A = ws.hid; cg.lda = 2 * C; cg.M = B * T * (F / 2); cg.K = 6 * C; cg.W = d.conv_w[blk][BT_PREC_BF16]; cg.N = 2 * C;
+    cg.epi = G3_RESID; cg.no_resid = 1; cg.gelu = 1; cg.bias = d.conv_b[blk]; cg.ldx = 2 * C;
+    cg.conv_C2 = 2 * C; cg.conv_T = T; cg.conv_F = F / 2;
+    const bool to_bf16 = blk == 2 && lin3;  // the last block's output is read by frontend.linear (gemm3) only
+    cg.x = to_bf16 ? nullptr : xn; cg.xb = to_bf16 ? (void*)xn : nullptr;
+    const bool conv3 = fast_layers && d.partial_transformers && pair_fused2_ok(d.front[blk][1], prec) && gemm3_supported(cg);
     if (d.partial_transformers) {
       int rc = run_pair(d.front[blk][0], d.rope, x, nullptr, ws, B, T, F, 1, prec, s);
       if (rc) return rc;
-      rc = run_pair(d.front[blk][1], d.rope, x, nullptr, ws, B, T, F, 2, prec, s);
+      rc = run_pair(d.front[blk][1], d.rope, x, nullptr, ws, B, T, F, 2, prec, s, conv3 ? ws.hid : nullptr);
       if (rc) return rc;
+    }
+    if (conv3) {
+      LAUNCH_CAT(CAT_CONV, s, launch_gemm3(cg, s), "frontend conv gemm");
+      std::swap(x, xn);
+      continue;
     }
     GemmP g;
     memset(&g, 0, sizeof g);
@@ -562,7 +582,7 @@ int bt_gemm3(void* stream, const bt_gemm3_args* a) {
   g.heads = a->heads; g.inner = a->heads * 32; g.rope = a->rope; g.qf = a->qf; g.kf = a->kf; g.vf = a->vf;
   g.gates = a->gates; g.b_gates = a->b_gates;
   g.f8 = a->f8; g.wscale = a->wscale; g.ascale = a->ascale; g.x8 = a->x8; g.ascale_out = a->ascale_out;
-  g.no_resid = a->no_resid;
+  g.no_resid = a->no_resid; g.gelu = a->gelu; g.conv_C2 = a->conv_C2; g.conv_T = a->conv_T; g.conv_F = a->conv_F;
   if (!gemm3_supported(g)) return bt_set_error(BT_ERR_ARG, "shape not supported by bt_gemm3");
   LAUNCH(launch_gemm3(g, (hipStream_t)stream), "gemm3");
   return BT_OK;

@@ -25,6 +25,10 @@ namespace {
 
 typedef __amdgpu_buffer_rsrc_t rsrc_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
+DEVI unsigned pk2_bf16(float a, float b) {
+  const bf16x2 t = {(bf16)a, (bf16)b};
+  return __builtin_bit_cast(unsigned, t);
+}
 
 // Weight stream: uniform steps of STEP_B bytes (2 KT fragment-major tiles), copied global -> LDS by LDS-DMA
 // (buffer_load ... lds, no staging registers) into a ring of NST stages; step s + NST - 1 is issued while
@@ -114,19 +118,29 @@ DEVI void ff_tail(WRing<T, C>& ws, int step0, float (&xn)[C / 32][16], const flo
 #pragma unroll
     for (int mt = 0; mt < KT; ++mt) mma32(acc2[mt], lds_frag<T>(wb + (KT + mt) * TILE_B, lane), hf);
   }
-  if (ok) {
 #pragma unroll
-    for (int mt = 0; mt < KT; ++mt)
+  for (int mt = 0; mt < KT; ++mt) {
+    f32x4 v[4];
 #pragma unroll
-      for (int a = 0; a < 4; ++a) {
-        const int f0 = mt * 32 + 8 * a + 4 * g;
-        const f32x4 b = *reinterpret_cast<const f32x4*>(b2 + f0);
-        f32x4 v;
+    for (int a = 0; a < 4; ++a) {
+      const int f0 = mt * 32 + 8 * a + 4 * g;
+      const f32x4 b = *reinterpret_cast<const f32x4*>(b2 + f0);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = acc2[mt][4 * a + j] + b[j];
-        *reinterpret_cast<f32x4*>(xrow + f0) = v;
-        if (xbrow) *reinterpret_cast<bf16x4*>(xbrow + f0) = bf16x4{(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+      for (int j = 0; j < 4; ++j) v[a][j] = acc2[mt][4 * a + j] + b[j];
+      if (ok) *reinterpret_cast<f32x4*>(xrow + f0) = v[a];
+    }
+    if (xbrow) {  // bf16 shadow: the two halves of the wave exchange 4-feature runs so that a lane stores 16 bytes
+                  // (features 16 k + 8 g .. + 7); 8-byte row-strided stores cost 44 us per forward here.  Executed by all lanes.
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const unsigned x0 = pk2_bf16(v[2 * k][0], v[2 * k][1]), x1 = pk2_bf16(v[2 * k][2], v[2 * k][3]);
+        const unsigned y0 = pk2_bf16(v[2 * k + 1][0], v[2 * k + 1][1]), y1 = pk2_bf16(v[2 * k + 1][2], v[2 * k + 1][3]);
+        auto r0 = __builtin_amdgcn_permlane32_swap(x0, y0, false, false);
+        auto r1 = __builtin_amdgcn_permlane32_swap(x1, y1, false, false);
+        typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+        if (ok) *reinterpret_cast<u32x4*>(xbrow + mt * 32 + 16 * k + 8 * g) = u32x4{r0[0], r1[0], r0[1], r1[1]};
       }
+    }
   }
 }
 

@@ -128,6 +128,7 @@ void gemm3_kernel(const Gemm3P p, int n_tiles, int total_tiles, int per_xcd) {
   // builtin, is what makes the HOST pass drop the kernel stub)
   static_assert(APC <= 4 && WPC <= 4, "voffA / voffW hold at most 4 pieces");
   unsigned voffA[4], voffW[4];
+  int tapmask[4] = {0, 0, 0, 0};
 #pragma unroll
   for (int i = 0; i < APC; ++i) {
     const int r = (i * NW + wave) * RPI + lane / CPR;
@@ -140,6 +141,10 @@ void gemm3_kernel(const Gemm3P p, int n_tiles, int total_tiles, int per_xcd) {
       row = (long)seq * p.L + t;
     }
     voffA[i] = ok ? (unsigned)(row * p.lda * ES + c * 16) : OOB;
+    if constexpr (EPI == G3_RESID) {  // conv: which of the three time taps exist for this row
+      const int t = p.conv_C2 > 0 ? (int)((row / p.conv_F) % p.conv_T) : 1;
+      tapmask[i] = ok ? ((t >= 1 ? 1 : 0) | 2 | (t + 1 < p.conv_T ? 4 : 0)) : 0;
+    }
   }
 #pragma unroll
   for (int i = 0; i < WPC; ++i) {
@@ -150,14 +155,27 @@ void gemm3_kernel(const Gemm3P p, int n_tiles, int total_tiles, int per_xcd) {
   // LDS-DMA of one k-step: APC pieces of the A tile, WPC of the W tile (1 KB per wave-instruction; the pieces of a
   // thread are NW KB apart).  The instruction's immediate offset would also move the LDS address, so it stays 0 and
   // the k offset goes into the scalar offset.
-  const rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A), 0, a_bytes, 0x00020000);
+  // conv: the descriptor starts one time step (conv_F rows) BEFORE A so that the tap offset dt * conv_F rows is >= 0
+  const bool conv = EPI == G3_RESID && p.conv_C2 > 0;
+  const unsigned tap_bytes = conv ? (unsigned)(p.conv_F * p.conv_C2 * ES) : 0u;
+  const int c2_shift = conv ? __builtin_ctz((unsigned)p.conv_C2) : 0;
+  const rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(p.A)) - tap_bytes, 0,
+                                                      a_bytes + 2 * tap_bytes, 0x00020000);
   const rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.W), 0, w_bytes, 0x00020000);
 #define G3_ISSUE(kt, stage)                                                                                          \
   do {                                                                                                                \
     char* st_ = smem + (stage) * ST_BYTES + wave * 1024;                                                              \
     const int so_ = (kt) * ROWB;                                                                                      \
-    _Pragma("unroll") for (int i_ = 0; i_ < APC; ++i_)                                                                \
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lptr_t)(st_ + i_ * NW * 1024), 16, voffA[i_], so_, 0, 0);       \
+    if (conv) {                                                                                                       \
+      const int tap_ = ((kt) * BK) >> c2_shift;                                                                       \
+      const int soa_ = tap_ * (int)tap_bytes + (((kt) * BK) & (p.conv_C2 - 1)) * ES;                                  \
+      _Pragma("unroll") for (int i_ = 0; i_ < APC; ++i_)                                                              \
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lptr_t)(st_ + i_ * NW * 1024), 16,                            \
+                                                   ((tapmask[i_] >> tap_) & 1) ? voffA[i_] : OOB, soa_, 0, 0);        \
+    } else {                                                                                                          \
+      _Pragma("unroll") for (int i_ = 0; i_ < APC; ++i_)                                                              \
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lptr_t)(st_ + i_ * NW * 1024), 16, voffA[i_], so_, 0, 0);     \
+    }                                                                                                                 \
     _Pragma("unroll") for (int i_ = 0; i_ < WPC; ++i_)                                                                \
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (lptr_t)(st_ + A_BYTES + i_ * NW * 1024), 16, voffW[i_], so_, 0, 0); \
   } while (0)
@@ -392,6 +410,14 @@ void gemm3_kernel(const Gemm3P p, int n_tiles, int total_tiles, int per_xcd) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) colq[q] = (unsigned)((cp ^ (4 * q + r4)) << 2);  // (row & 15) = 4 (ps & 3) + r4
     const int rows_left = p.M - row0 - r4;  // row (32 b + 4 ps + r4) exists iff 32 b + 4 ps < rows_left
+    if (p.gelu) {  // frontend convs: BatchNorm is folded into W / bias, GELU in the tanh form of the bf16 path
+#pragma unroll
+      for (int a = 0; a < FB; ++a)
+#pragma unroll
+        for (int b = 0; b < TB; ++b)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[a][b][r] = gelu_tanh(acc[a][b][r]);
+    }
 #pragma unroll
     for (int b = 0; b < TB; ++b) {
       f32x4 xv[8];  // (per token block: more at once -- all blocks, or a prefetch of the next one -- spills next to the
@@ -399,7 +425,7 @@ void gemm3_kernel(const Gemm3P p, int n_tiles, int total_tiles, int per_xcd) {
 #pragma unroll
       for (int ps = 0; ps < 8; ++ps) {
         const unsigned off = off_lane + (unsigned)(32 * b + 4 * ps) * ldx + colq[ps & 3];
-        xv[ps] = (32 * b + 4 * ps < rows_left && !p.no_resid) ? *reinterpret_cast<const f32x4*>(p.x + off)
+        xv[ps] = (32 * b + 4 * ps < rows_left && !p.no_resid && p.x) ? *reinterpret_cast<const f32x4*>(p.x + off)
                                                                : f32x4{0.f, 0.f, 0.f, 0.f};
       }
 #pragma unroll
@@ -417,7 +443,7 @@ void gemm3_kernel(const Gemm3P p, int n_tiles, int total_tiles, int per_xcd) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) v[i] = ES == 1 ? fmaf(v[i], wsc, xv[ps][i]) : v[i] + xv[ps][i];
         if (ok) {
-          *reinterpret_cast<f32x4*>(p.x + off) = v;
+          if (p.x) *reinterpret_cast<f32x4*>(p.x + off) = v;
           if (xb) *reinterpret_cast<u32x2*>(xb + off) = u32x2{pk2(v[0], v[1]), pk2(v[2], v[3])};
         }
         if (p.x8) {  // e4m3 shadow x * c, c = RMSNorm factor of the OLD row (within a few % of the new one; the consumer
@@ -526,6 +552,10 @@ bool gemm3_supported(const Gemm3P& p) {
   if (p.M <= 0 || p.K % (p.f8 ? 128 : 64) != 0 || p.K < 128 || p.lda % (16 / es) != 0) return false;
   if ((long)p.M * p.lda * es >= 0x7fffffffL || (long)(p.N + 255) / 256 * 256 * p.K * es >= 0x7fffffffL) return false;
   if (p.f8 && (!p.wscale || p.epi == G3_QKV)) return false;
+  if (p.conv_C2 > 0 && (p.epi != G3_RESID || p.f8 || (p.conv_C2 & (p.conv_C2 - 1)) || p.conv_C2 % 32 != 0 || p.lda != p.conv_C2 ||
+                        p.K != 3 * p.conv_C2 || p.conv_F <= 0 || p.conv_T <= 0 || p.M % (p.conv_T * p.conv_F) != 0 || !p.no_resid))
+    return false;
+  if (p.epi == G3_RESID && !p.x && !p.xb) return false;
   if (p.x8 && (p.epi != G3_RESID || !p.ssq_in || !p.ascale_out || p.ldx % 4 != 0)) return false;
   if (p.epi == G3_QKV) return p.inner % 128 == 0 && p.inner == p.heads * 32 && p.L > 0 && p.L <= 1536;
   if (p.epi == G3_FF1) return p.N % 128 == 0 && p.ldo % (p.f8 ? 16 : 8) == 0;

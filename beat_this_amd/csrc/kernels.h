@@ -67,7 +67,12 @@ struct Gemm3P {
   // each W row; ascale[M] (FF1 / QKV) = factor the producer multiplied row m of x by before conversion; FF1 then
   // writes its output as e4m3 as well (unit scale).  RESID (any operand type) with x8 != null also writes the e4m3
   // shadow x8[m] = e4m3(x_new[m] * c[m]), c = RMSNorm factor of the OLD row from ssq_in, and ascale_out[m] = c[m].
-  int no_resid;  // RESID: x = A W^T + bias (x is only written: frontend.linear)
+  int no_resid;  // RESID: x = A W^T + bias (x is only written: frontend.linear, frontend convs)
+  int gelu;      // RESID: x = gelu(... + bias) (tanh form; frontend convs).  x may be null then (bf16 output xb only)
+  // RESID, implicit-GEMM convolution (frontend convs, beat_tracker.py:155-166): conv_C2 > 0 -> A is the bf16 shadow of the
+  // (b, t, f, c) activation seen as [M = B T F/2, C2 = 2 C]; K = 3 C2 = the rows m - conv_F, m, m + conv_F (time taps
+  // t-1, t, t+1; conv_F = F/2 rows per time step), rows outside 0 <= t < conv_T read as zeros
+  int conv_C2, conv_T, conv_F;
   int f8;
   const float* wscale; const float* ascale;
   void* x8; float* ascale_out;

@@ -216,6 +216,11 @@ typedef struct {
   int32_t n_seq, L, nbp, heads; const float* rope; void* qf; void* kf; void* vf; float* gates; const float* b_gates;
   int32_t f8; const float* wscale; const float* ascale; void* x8; float* ascale_out;
   int32_t no_resid; /* epi 1: x = A W^T + bias, x is only written (frontend.linear) */
+  /* epi 1 as the frontend convolution (beat_tracker.py:155-166, BatchNorm folded): gelu != 0 -> x = gelu(.. + bias) (tanh
+   * form), x may be NULL (bf16 output xb only); conv_C2 = 2 C > 0 -> A is the bf16 (b, t, f, c) activation seen as
+   * [M = B T F/2, conv_C2], lda = conv_C2, K = 3 conv_C2: the rows m - conv_F, m, m + conv_F (time taps t-1, t, t+1 with
+   * conv_F = F/2 rows per time step), rows with t outside [0, conv_T) read as zeros.  Needs no_resid. */
+  int32_t gelu, conv_C2, conv_T, conv_F;
 } bt_gemm3_args;
 int bt_gemm3(void* stream, const bt_gemm3_args* a);
 int bt_attn_frag_blocks(int L);

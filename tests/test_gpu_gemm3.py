@@ -238,3 +238,26 @@ def test_gemm3_f8_hidden_saturates_instead_of_overflowing():
     assert not ((got & 0x7F) == 0x7F).any(), "NaN encoding in the e4m3 hidden activation"
     dec = got.view(F8).float()
     assert torch.all(dec[:, 1::2] == 448.0) and torch.all(dec[:, 0::2].abs() < 1e-3)
+
+
+@pytest.mark.parametrize("B,T,Fp,C2,N,bf16_out", [(2, 50, 8, 128, 128, False), (1, 33, 4, 256, 256, True), (3, 7, 16, 64, 128, False)])
+def test_gemm3_frontend_conv(B, T, Fp, C2, N, bf16_out):
+    """epi 1 as the (2,3) / stride (2,1) frontend convolution on the bf16 (b, t, f, c) activation: three time taps gathered
+    by the LDS-DMA loader (zero rows outside 0 <= t < T), bias, tanh-form GELU; fp32 or bf16 output."""
+    M, K = B * T * Fp, 3 * C2
+    x = _mk((M, C2), 71).float().to(torch.bfloat16)               # row m = (b, t, f'), C2 = 2 C channels of the frequency pair
+    W = _mk((N, K), 72, 1 / math.sqrt(K)).float().to(torch.bfloat16)
+    b = _mk((N,), 73, 0.5)
+    out = torch.full((M, N), float("nan"), dtype=torch.float32, device=dev())
+    outb = torch.zeros((M, N), dtype=torch.bfloat16, device=dev())
+    _call(A=x.to(dev()), lda=C2, M=M, K=K, W=pad_rows(W).to(dev()), N=N, epi=1, bias=b.float().to(dev()),
+          x=0 if bf16_out else out, ldx=N, xb=outb if bf16_out else 0, no_resid=1, gelu=1, conv_C2=C2, conv_T=T, conv_F=Fp)
+    xd = x.double().view(B, T, Fp, C2)
+    xp = torch.zeros((B, T + 2, Fp, C2), dtype=torch.float64)
+    xp[:, 1:-1] = xd
+    Wd = W.double()
+    acc = sum(xp[:, dt:dt + T].reshape(M, C2) @ Wd[:, dt * C2:(dt + 1) * C2].T for dt in range(3))
+    ref = _gelu_tanh(acc + b)
+    err = _rel(outb if bf16_out else out, ref)
+    report("gemm3_frontend_conv", B=B, T=T, Fp=Fp, C2=C2, N=N, rel=err)
+    assert err < (5e-3 if bf16_out else 2e-5)
