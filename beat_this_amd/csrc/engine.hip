@@ -340,7 +340,9 @@ int bt_forward(bt_engine* e, void* stream, int prec, const float* d_spect, int B
     cg.conv_C2 = 2 * C; cg.conv_T = T; cg.conv_F = F / 2;
     const bool to_bf16 = blk == 2 && lin3;  // the last block's output is read by frontend.linear (gemm3) only
     cg.x = to_bf16 ? nullptr : xn; cg.xb = to_bf16 ? (void*)xn : nullptr;
-    const bool conv3 = fast_layers && d.partial_transformers && pair_fused2_ok(d.front[blk][1], prec) && gemm3_supported(cg);
+    // (the first conv, N = 64, works as well but only pays 4 us for the 12 us its shadow write costs: it stays on gemm.hip)
+    const bool conv3 = fast_layers && d.partial_transformers && pair_fused2_ok(d.front[blk][1], prec) && cg.N >= 128 &&
+                       gemm3_supported(cg);
     if (d.partial_transformers) {
       int rc = run_pair(d.front[blk][0], d.rope, x, nullptr, ws, B, T, F, 1, prec, s);
       if (rc) return rc;

@@ -382,6 +382,7 @@ void gemm3_kernel(const Gemm3P p, int n_tiles, int total_tiles, int per_xcd) {
   } else if constexpr (EPI == G3_RESID) {
     bf16* xb = reinterpret_cast<bf16*>(p.xb);
     const int nb0 = n0 + wn * 64;
+    if (nb0 < p.N) {  // (N = 64: the first frontend conv -- the upper column half of the tile is weight padding)
     // The x loads of a token block are all requested before the first is used: one at a time (load x, add, store,
     // next pass) they cost a memory round trip EACH -- 16 of them were 31 k of a 122 k-cycle wave life in FF2.
     // (e4m3 operands: ONE dequantisation factor for the whole weight matrix, applied with the residual add below;
@@ -459,6 +460,7 @@ void gemm3_kernel(const Gemm3P p, int n_tiles, int total_tiles, int per_xcd) {
         for (int o = 8; o > 0; o >>= 1) ssq += __shfl_xor(ssq, o);
         if (p.ssq_out && ok && cp == 0) p.ssq_out[(unsigned)(n0 / 64 + wn) * (unsigned)p.M + (unsigned)(row0 + 32 * b + r)] = ssq;
       }
+    }
     }
   } else {  // G3_QKV
     if (kind < 2) {  // q / k: RoPE, fragment-major [quarter][token][8 dims]
@@ -559,7 +561,7 @@ bool gemm3_supported(const Gemm3P& p) {
   if (p.x8 && (p.epi != G3_RESID || !p.ssq_in || !p.ascale_out || p.ldx % 4 != 0)) return false;
   if (p.epi == G3_QKV) return p.inner % 128 == 0 && p.inner == p.heads * 32 && p.L > 0 && p.L <= 1536;
   if (p.epi == G3_FF1) return p.N % 128 == 0 && p.ldo % (p.f8 ? 16 : 8) == 0;
-  if (p.epi == G3_RESID) return p.N % 128 == 0 && p.ldx % 8 == 0 && (long)(p.M + 256) * p.ldx < 0x7fffffffL &&
+  if (p.epi == G3_RESID) return p.N % 64 == 0 && p.ldx % 8 == 0 && (long)(p.M + 256) * p.ldx < 0x7fffffffL &&
                                 (long)(p.N / 64) * p.M < 0x7fffffffL;  // (32-bit element offsets in the epilogue)
   return false;
 }

@@ -240,7 +240,8 @@ def test_gemm3_f8_hidden_saturates_instead_of_overflowing():
     assert torch.all(dec[:, 1::2] == 448.0) and torch.all(dec[:, 0::2].abs() < 1e-3)
 
 
-@pytest.mark.parametrize("B,T,Fp,C2,N,bf16_out", [(2, 50, 8, 128, 128, False), (1, 33, 4, 256, 256, True), (3, 7, 16, 64, 128, False)])
+@pytest.mark.parametrize("B,T,Fp,C2,N,bf16_out", [(2, 50, 8, 128, 128, False), (1, 33, 4, 256, 256, True), (3, 7, 16, 64, 128, False),
+                                                   (2, 40, 16, 64, 64, False)])
 def test_gemm3_frontend_conv(B, T, Fp, C2, N, bf16_out):
     """epi 1 as the (2,3) / stride (2,1) frontend convolution on the bf16 (b, t, f, c) activation: three time taps gathered
     by the LDS-DMA loader (zero rows outside 0 <= t < T), bias, tanh-form GELU; fp32 or bf16 output."""
