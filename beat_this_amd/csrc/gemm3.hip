@@ -1,5 +1,6 @@
-// bf16 GEMM for the main transformer layers in BT_PREC_BF16:  C[M,N] = epilogue(A[M,K] . W[N,K]^T), A = bf16
-// activations (shadow of the residual stream / attention output / FF hidden), W = bf16 weights.
+// bf16 / e4m3 GEMM of the BT_PREC_BF16 / BT_PREC_FP8 forward:  C[M,N] = epilogue(A[M,K] . W[N,K]^T), A = bf16 (e4m3)
+// activations (shadow of the residual stream / attention output / FF hidden), W = bf16 (e4m3) weights.  Main-layer QKV,
+// out-projection, FF1, FF2; frontend.linear; the second and third frontend convolution (implicit-GEMM gather).
 //
 // Engine (differences from gemm2.hip):
 //   * 128 x 128 x 32 tiles, 4 waves as 2 x 2 (64 x 64 each = 2 x 2 MFMA 32x32 tiles);
@@ -9,11 +10,12 @@
 //   * LDS rows are 64 B; the 16-byte chunk c of row r is stored at chunk c ^ ((r >> 2) & 3) (the XOR goes
 //     on the per-lane SOURCE address, the LDS image stays lane-linear), which makes every ds_read_b128
 //     fragment read conflict free without padding;
-//   * no LDS staging in the epilogue.  The product is formed TRANSPOSED (C^T = W . A^T) so that a lane owns
-//     ONE output row (token) and its registers hold 4-feature runs of that row: RMSNorm factor, RoPE angle,
-//     bias runs, residual runs are all lane-local, and stores are 8/16-byte row pieces (bf16 pairs are
-//     widened to 16 B with v_permlane32_swap).  Only the V columns of the QKV projection use the normal
-//     orientation (lane = feature), which is exactly the V^T fragment layout of attn2.hip.
+//   * the product is formed TRANSPOSED (C^T = W . A^T) so that a lane owns ONE output row (token) and its registers
+//     hold 4-feature runs of that row: RMSNorm factor, RoPE angle, bias runs are all lane-local.  QKV results are
+//     stored straight from that layout (fragment-major attention operands: contiguous 512 B / 1 KB per instruction);
+//     FF1 / residual results leave through LDS (free after the k-loop) so that every global access covers whole
+//     lines.  Only the V columns of the QKV projection use the normal orientation (lane = feature), which is
+//     exactly the V^T fragment layout of attn2.hip.
 //   * RMSNorm: the producer of the residual stream (EPI_RESID here, gemm2's fp32 epilogues for
 //     frontend.linear) writes per-row partial sums of squares per 64 columns; the consumers (QKV, FF1)
 //     add the partials -- no pass over A for the statistics (LDS-DMA data never visits registers).
