@@ -10,12 +10,12 @@
 //                lane (token lr, half g) reads entries (2g, lr) and (2g+1, lr): dims [16g, 16g+16)
 //   V block    : [s = 0..1][lane = 32 g + d][8 tokens crow(8s+j, g), j = 0..7]
 //                i.e. V^T with the token order of MFMA C registers 8s..8s+7
-// so a K/V tile is copied global -> LDS linearly (global_load_lds, 16 B per lane, no VGPRs), every
+// so a K/V tile is copied global -> LDS linearly (buffer_load ... lds, 16 B per lane, no VGPRs), every
 // fragment is ONE conflict-free ds_read_b128, and nothing is transposed or shuffled anywhere.
 //
 // Softmax: S^T = K . Q^T puts one query per lane (16 of its 32 key scores per lane-half).  d = 32
 // makes this kernel VALU-bound (4 MFMAs per 512 exp), so the per-score work is cut to
-// exp + add + half a cvt_pk:
+// exp + half a cvt_pk (the row sums ride on v_mfma_f32_4x4x4_16b_bf16 with an all-ones A operand):
 //   * the running-max subtraction rides on the MFMA: the accumulator INPUT of the score MFMA is a
 //     register block holding -m (q is pre-scaled by log2(e)/sqrt(32), RoPE applied by the producer);
 //   * m is fixed per query from the first key block; later scores may exceed it, which is exact in
