@@ -14,7 +14,9 @@ import subprocess
 import torch  # noqa: F401  (must precede loading the HIP library)
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("BT_LIB_PATH") or os.path.join(PKG_DIR, "libbeat_this_amd.so")  # (BT_LIB_PATH: development override, an alternative build)
+LIB_PATH = os.path.join(PKG_DIR, "libbeat_this_amd.so")
+if os.environ.get("BT_DEV") == "1" and os.environ.get("BT_LIB_PATH"):  # development only (tools/ab.sh: A/B of two builds)
+    LIB_PATH = os.environ["BT_LIB_PATH"]
 SOURCES = ["gemm.hip", "gemm2.hip", "gemm3.hip", "attn.hip", "attn2.hip", "fused.hip", "fused2.hip", "qkv_front.hip", "frontend.hip", "logmel.hip",
            "engine.hip"]
 HEADERS = ["common.h", "chain.h", "kernels.h", os.path.join("..", "..", "include", "beat_this_amd.h")]
@@ -47,7 +49,7 @@ class ModelDesc(C.Structure):
                 ("conv_w", (C.c_void_p * 2) * 3), ("conv_b", C.c_void_p * 3),
                 ("lin_w", C.c_void_p * 2), ("lin_b", C.c_void_p),
                 ("layers", PairWeights * MAX_LAYERS),
-                ("head_w", C.c_void_p), ("head_b", C.c_float * 2), ("rope", C.c_void_p)]
+                ("head_w", C.c_void_p), ("head_b", C.c_float * 2), ("rope", C.c_void_p), ("ff_mult", C.c_int32)]
 
 
 class LogmelTables(C.Structure):
@@ -109,8 +111,16 @@ EXPORTS = {
     "bt_peaks": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]),
     "bt_postprocess_host": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_double, C.c_void_p,
                                       C.POINTER(C.c_int32), C.c_void_p, C.POINTER(C.c_int32)]),
-    "bt_profile_begin": (None, []),
-    "bt_profile_end": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
+    "bt_profile_begin": (None, [C.c_void_p]),
+    "bt_profile_end": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
+    "bt_resample_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_int,
+                                    C.c_void_p]),
+    "bt_logmel_batch": (C.c_int, [C.c_void_p, C.POINTER(LogmelTables), C.c_void_p, C.c_int, C.c_int64, C.c_void_p]),
+    "bt_split_chunks_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "bt_aggregate_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int64,
+                                     C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "bt_peaks_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "bt_peaks_host": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.POINTER(C.c_int32)]),
     "bt_gemm": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(GemmArgs)]),
     "bt_attention": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(AttnArgs), C.c_int]),
     "bt_gemm3": (C.c_int, [C.c_void_p, C.POINTER(Gemm3Args)]),
@@ -129,23 +139,53 @@ EXPORTS = {
 # frontend kernels in AGPRs and moves them with v_accvgpr_read / _write: 2900 such moves in fused2.hip, 32 per FF step);
 # frequency-direction halves 0.315 -> 0.287 ms.  (-fgpu-flush-denormals-to-zero: no effect; max-ilp scheduling: slower.)
 HIPCC_FLAGS = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops", "-mllvm", "-amdgpu-mfma-vgpr-form"]
+# compile-time switches: BT_DEV_BUILD=1 in the environment of build() compiles the development instrumentation (per-wave timing
+# dumps, ablation variants read by tools/*_probe.py) into the kernels; release builds contain none of it
+EXTRA_DEFINES = ["-DBT_DEV"] if os.environ.get("BT_DEV_BUILD") == "1" else []
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
-    """Compile the HIP sources for gfx950 into libbeat_this_amd.so (in tree)."""
+    """Compile the HIP sources for gfx950 into libbeat_this_amd.so (in tree): one object per source file under
+    beat_this_amd/build/ (rebuilt only when the file, a header or the flags changed; compiled in parallel), then one link."""
+    from concurrent.futures import ThreadPoolExecutor
+
     src_dir = os.path.join(PKG_DIR, "csrc")
-    srcs = [os.path.join(src_dir, s) for s in SOURCES]
-    deps = srcs + [os.path.join(src_dir, h) for h in HEADERS] + [os.path.abspath(__file__)]  # (this file: HIPCC_FLAGS)
-    if not force and os.path.exists(LIB_PATH) and all(
-            os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
-        return LIB_PATH
+    obj_dir = os.path.join(PKG_DIR, "build")
+    hdrs = [os.path.join(src_dir, h) for h in HEADERS] + [os.path.abspath(__file__)]  # (this file: HIPCC_FLAGS)
+    hdr_time = max(os.path.getmtime(h) for h in hdrs)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     # -packed-fp32-ops: hipcc pairs independent fp32 multiplies / adds / fmas into v_pk_*_f32, which issue at 5.5 clk per
     # instruction on gfx950 against 2 x 1.8 for the scalar forms (tools/ubench/valu_rates.hip); without the pairing the
     # forward is 3.7 % faster (frequency-direction fused halves 0.43 -> 0.32 ms), A/B on one box with tools/ab.sh
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", *HIPCC_FLAGS, *srcs, "-o", LIB_PATH]
+    base = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", *HIPCC_FLAGS, *EXTRA_DEFINES]
+    todo, objs = [], []
+    for name in SOURCES:
+        src = os.path.join(src_dir, name)
+        obj = os.path.join(obj_dir, name.replace(".hip", ".o"))
+        objs.append(obj)
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_time):
+            todo.append((src, obj))
+    if not todo and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(o) for o in objs):
+        return LIB_PATH
+    os.makedirs(obj_dir, exist_ok=True)
+
+    def compile_one(job):
+        cmd = [*base, "-c", job[0], "-o", job[1]]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, stderr=subprocess.PIPE, text=True)
+        # (the host pass of hipcc does not know the device feature switch and says so once per file: not a diagnostic)
+        err = "\n".join(l for l in r.stderr.splitlines() if "-packed-fp32-ops' is not a recognized feature" not in l)
+        if err.strip():
+            print(err, flush=True)
+        if r.returncode:
+            raise subprocess.CalledProcessError(r.returncode, cmd)
+
+    with ThreadPoolExecutor(max_workers=min(len(todo), os.cpu_count() or 4) or 1) as pool:
+        list(pool.map(compile_one, todo))
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB_PATH]
     if verbose:
-        print(" ".join(cmd))
+        print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)
     return LIB_PATH
 

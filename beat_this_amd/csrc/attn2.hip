@@ -458,10 +458,12 @@ static void launch_v(const AttnFragP& p, hipStream_t s) {
 int launch_attn_frag(const AttnFragP& p, hipStream_t s) {
   if (p.L <= 0 || p.n_seq <= 0 || p.heads <= 0 || p.inner != p.heads * 32 || p.nbp < attn_frag_blocks(p.L)) return -2;
   if ((long)p.n_seq * p.heads * ((p.L + 127) / 128) > 0x3fffffffL) return -3;
-  // development switch: BT_ATTN_ABL=128 dumps per-wave phase timings over the gates buffer (tools/attn_probe.py).
   // (Two query blocks per wave -- QB = 2, half the fragment reads per MFMA at half the occupancy -- measured equal.)
+#ifdef BT_DEV
+  // development builds only: BT_ATTN_ABL=128 dumps per-wave phase timings over the gates buffer (tools/attn_probe.py)
   static const int abl = getenv("BT_ATTN_ABL") ? atoi(getenv("BT_ATTN_ABL")) : 0;
-  if (abl == 128) launch_v<128, 1>(p, s);
-  else launch_v<0, 1>(p, s);
+  if (abl == 128) { launch_v<128, 1>(p, s); return (int)hipGetLastError(); }
+#endif
+  launch_v<0, 1>(p, s);
   return (int)hipGetLastError();
 }

@@ -20,28 +20,29 @@ static int bt_set_error(int code, const std::string& msg) {
   return code;
 }
 
-struct bt_engine {
-  bt_model_desc d;
-};
-
-// Optional per-launch timing with HIP events on the caller's stream (bench.py roofline leg).
-// Off by default: a normal bt_forward records nothing and never synchronises.
+// Optional per-launch timing with HIP events on the caller's stream (bench.py roofline leg); state lives in the engine
+// handle (reentrant per handle, like everything else).  Off by default: a normal bt_forward records nothing and never
+// synchronises.
 namespace prof {
 struct Rec { int cat; hipEvent_t a, b; };
-static bool on = false;
-static std::vector<Rec> recs;
+struct State { bool on = false; std::vector<Rec> recs; };
 struct Scope {
-  bool live; size_t idx; hipStream_t s;
-  Scope(int cat, hipStream_t st) : live(on), idx(0), s(st) {
-    if (!live) return;
+  State* st; size_t idx; hipStream_t s;
+  Scope(State* state, int cat, hipStream_t stream) : st(state && state->on ? state : nullptr), idx(0), s(stream) {
+    if (!st) return;
     Rec r; r.cat = cat;
     (void)hipEventCreate(&r.a); (void)hipEventCreate(&r.b);
     (void)hipEventRecord(r.a, s);
-    idx = recs.size(); recs.push_back(r);
+    idx = st->recs.size(); st->recs.push_back(r);
   }
-  ~Scope() { if (live) (void)hipEventRecord(recs[idx].b, s); }
+  ~Scope() { if (st) (void)hipEventRecord(st->recs[idx].b, s); }
 };
 }  // namespace prof
+
+struct bt_engine {
+  bt_model_desc d;
+  prof::State prof;
+};
 enum { CAT_STEM = 0, CAT_QKV, CAT_ATTN_SMALL, CAT_ATTN_FLASH, CAT_OUT, CAT_FF1, CAT_FF2, CAT_CONV, CAT_LINEAR,
        CAT_HEAD, CAT_FF_FUSED, CAT_ATTN_FREQ_FUSED, CAT_COUNT };
 
@@ -58,7 +59,7 @@ struct Workspace {
   size_t total;
 };
 
-Workspace carve(char* base, int B, int T, int D, int prec) {
+Workspace carve(char* base, int B, int T, int D, int ff_mult, int prec) {
   const bool fp8 = prec == BT_PREC_FP8;
   if (fp8) prec = BT_PREC_BF16;
   const size_t es = prec == BT_PREC_F32 ? 4 : 2;
@@ -74,7 +75,7 @@ Workspace carve(char* base, int B, int T, int D, int prec) {
   w.gates = (float*)take(bt * std::max(32, D / 32) * 4);
   w.qkv = take(bt * 3 * dmax * es);
   w.ao = take(bt * dmax * es);
-  w.hid = take(bt * 4 * dmax * es);
+  w.hid = take(bt * std::max<size_t>(4 * 1024, (size_t)ff_mult * D) * es);  // FF hidden activation / conv shadow
   w.nbp = attn_frag_blocks(T);
   w.qf = w.kf = w.vf = nullptr; w.gates_h = nullptr;
   if (prec == BT_PREC_BF16) {  // (sequences x heads) = 32 B in the frontend, (D / 32) B in the main layers
@@ -105,7 +106,7 @@ Workspace carve(char* base, int B, int T, int D, int prec) {
 #define LAUNCH(expr, what) \
   do { int _rc = (expr); CHECK_RC(what) } while (0)
 #define LAUNCH_CAT(cat, st, expr, what) \
-  do { int _rc; { prof::Scope _ps(cat, st); _rc = (expr); } CHECK_RC(what) } while (0)
+  do { int _rc; { prof::Scope _ps(pf, cat, st); _rc = (expr); } CHECK_RC(what) } while (0)
 
 // mode 0: main transformer (sequences = chunks, tokens = frames)
 // mode 1: frequency direction (sequences = (b,t), tokens = f)      -- attn_small
@@ -115,9 +116,9 @@ Workspace carve(char* base, int B, int T, int D, int prec) {
 // those of x after the attention half.
 // fp8: the GEMMs whose e4m3 weights are present run on e4m3 operands (FF1 reads the e4m3 shadow of x written by the
 // out-projection's epilogue and writes an e4m3 hidden activation; FF2 reads that).
-int run_layer_bf16(const bt_pair_weights& pw, const float* rope, const Workspace& ws, int B, int T, bool fp8,
-                   hipStream_t s) {
-  const int D = pw.dim, H = pw.heads;
+int run_layer_bf16(prof::State* pf, const bt_pair_weights& pw, const float* rope, const Workspace& ws, int B, int T,
+                   int ff_mult, bool fp8, hipStream_t s) {
+  const int D = pw.dim, H = pw.heads, HID = ff_mult * D;
   const int M = B * T;
   const int parts = D / 64;
   Gemm3P g;
@@ -139,12 +140,12 @@ int run_layer_bf16(const bt_pair_weights& pw, const float* rope, const Workspace
   if (ff8) { g.ssq_in = ws.ssq[0]; g.ssq_parts = parts; g.x8 = ws.x8; g.ascale_out = ws.ascale; }
   LAUNCH_CAT(CAT_OUT, s, launch_gemm3(g, s), "out-proj gemm");
   memset(&g, 0, sizeof g);
-  g.A = ws.xmb; g.lda = D; g.M = M; g.K = D; g.W = pw.w_ff1[BT_PREC_BF16]; g.N = 4 * D; g.epi = G3_FF1;
-  g.bias = pw.b_ff1; g.ssq_in = ws.ssq[1]; g.ssq_parts = parts; g.out = ws.hid; g.ldo = 4 * D;
+  g.A = ws.xmb; g.lda = D; g.M = M; g.K = D; g.W = pw.w_ff1[BT_PREC_BF16]; g.N = HID; g.epi = G3_FF1;
+  g.bias = pw.b_ff1; g.ssq_in = ws.ssq[1]; g.ssq_parts = parts; g.out = ws.hid; g.ldo = HID;
   if (ff8) { g.A = ws.x8; g.W = pw.w_ff1_f8; g.f8 = 1; g.wscale = pw.s_ff1; g.ascale = ws.ascale; }
   LAUNCH_CAT(CAT_FF1, s, launch_gemm3(g, s), "ff1 gemm");
   memset(&g, 0, sizeof g);
-  g.A = ws.hid; g.lda = 4 * D; g.M = M; g.K = 4 * D; g.W = pw.w_ff2[BT_PREC_BF16]; g.N = D; g.epi = G3_RESID;
+  g.A = ws.hid; g.lda = HID; g.M = M; g.K = HID; g.W = pw.w_ff2[BT_PREC_BF16]; g.N = D; g.epi = G3_RESID;
   g.bias = pw.b_ff2; g.x = ws.xm; g.ldx = D; g.xb = ws.xmb; g.ssq_out = ws.ssq[0];
   if (ff8) { g.W = pw.w_ff2_f8; g.f8 = 1; g.wscale = pw.s_ff2; g.bias = pw.b_ff2_f8; }
   LAUNCH_CAT(CAT_FF2, s, launch_gemm3(g, s), "ff2 gemm");
@@ -157,9 +158,9 @@ inline bool pair_fused2_ok(const bt_pair_weights& pw, int prec) {
   return pw.dim <= 128 && pw.w_outp[prec] && pw.w_ff_frag[prec] && pw.w_outff_frag[prec] && pw.w_attnff_frag[prec];
 }
 
-int run_pair(const bt_pair_weights& pw, const float* rope, float* x, void* xshadow, const Workspace& ws, int B, int T,
-             int F, int mode, int prec, hipStream_t s, void* out_shadow = nullptr) {
-  const int C = pw.dim, H = pw.heads;
+int run_pair(prof::State* pf, const bt_pair_weights& pw, const float* rope, float* x, void* xshadow, const Workspace& ws,
+             int B, int T, int F, int mode, int prec, hipStream_t s, void* out_shadow = nullptr, int ff_mult = 4) {
+  const int C = pw.dim, H = pw.heads, HID = ff_mult * C;
   const long M = (long)B * T * F;
   if (M > 0x7fffffffL) return bt_set_error(BT_ERR_ARG, "batch too large for one forward call");
   GemmP g;
@@ -244,13 +245,13 @@ int run_pair(const bt_pair_weights& pw, const float* rope, float* x, void* xshad
   }
   // ---- h = gelu(RMSNorm(x) . W1^T + b1) ------------------------------------------------------
   memset(&g, 0, sizeof g);
-  g.A = shadow ? xshadow : (const void*)x; g.lda = C; g.W = pw.w_ff1[prec]; g.M = (int)M; g.N = 4 * C; g.K = C;
+  g.A = shadow ? xshadow : (const void*)x; g.lda = C; g.W = pw.w_ff1[prec]; g.M = (int)M; g.N = HID; g.K = C;
   g.epi = GEMM_EPI_STORE; g.flags = GEMM_F_RMS | (shadow ? 0 : GEMM_F_A_F32) | GEMM_F_BIAS | GEMM_F_GELU;
-  g.bias = pw.b_ff1; g.out = ws.hid; g.ldo = 4 * C;
+  g.bias = pw.b_ff1; g.out = ws.hid; g.ldo = HID;
   LAUNCH_CAT(CAT_FF1, s, launch_gemm(g, prec, s), "ff1 gemm");
   // ---- x += h . W2^T + b2 ---------------------------------------------------------------------
   memset(&g, 0, sizeof g);
-  g.A = ws.hid; g.lda = 4 * C; g.W = pw.w_ff2[prec]; g.M = (int)M; g.N = C; g.K = 4 * C;
+  g.A = ws.hid; g.lda = HID; g.W = pw.w_ff2[prec]; g.M = (int)M; g.N = C; g.K = HID;
   g.epi = GEMM_EPI_RESID; g.flags = GEMM_F_BIAS; g.bias = pw.b_ff2; g.x = x; g.ldx = C; g.xb = shadow ? xshadow : nullptr;
   LAUNCH_CAT(CAT_FF2, s, launch_gemm(g, prec, s), "ff2 gemm");
   return BT_OK;
@@ -274,18 +275,22 @@ void bt_struct_sizes(int32_t* out) {
 int bt_engine_create(const bt_model_desc* desc, bt_engine** out) {
   if (!desc || !out) return bt_set_error(BT_ERR_ARG, "null argument");
   if (desc->transformer_dim % 32 || desc->transformer_dim < 32 || desc->transformer_dim > 1024 ||
-      desc->n_layers < 0 || desc->n_layers > BT_MAX_LAYERS)
-    return bt_set_error(BT_ERR_ARG, "unsupported transformer_dim / n_layers");
+      desc->n_layers < 0 || desc->n_layers > BT_MAX_LAYERS || desc->ff_mult < 1 || desc->ff_mult > 16)
+    return bt_set_error(BT_ERR_ARG, "unsupported transformer_dim / n_layers / ff_mult");
   bt_engine* e = new bt_engine;
   e->d = *desc;
   *out = e;
   return BT_OK;
 }
-void bt_engine_destroy(bt_engine* e) { delete e; }
+void bt_engine_destroy(bt_engine* e) {
+  if (!e) return;
+  for (auto& r : e->prof.recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+  delete e;
+}
 
 size_t bt_workspace_bytes(const bt_engine* e, int B, int T, int prec) {
   if (!e || B <= 0 || T <= 0) return 0;
-  return carve(nullptr, B, T, e->d.transformer_dim, prec).total;
+  return carve(nullptr, B, T, e->d.transformer_dim, e->d.ff_mult, prec).total;
 }
 
 int bt_forward(bt_engine* e, void* stream, int prec, const float* d_spect, int B, int T, void* d_ws, size_t ws_bytes,
@@ -294,14 +299,15 @@ int bt_forward(bt_engine* e, void* stream, int prec, const float* d_spect, int B
   if (B <= 0 || T <= 0 || T > 1536) return bt_set_error(BT_ERR_ARG, "need B >= 1 and 1 <= T <= 1536");
   if (prec != BT_PREC_F32 && prec != BT_PREC_BF16 && prec != BT_PREC_FP8) return bt_set_error(BT_ERR_ARG, "unknown precision");
   const bt_model_desc& d = e->d;
+  prof::State* pf = &e->prof;
   const int D = d.transformer_dim;
-  Workspace ws = carve((char*)d_ws, B, T, D, prec);
+  Workspace ws = carve((char*)d_ws, B, T, D, d.ff_mult, prec);
   if (ws.total > ws_bytes) return bt_set_error(BT_ERR_WORKSPACE, "workspace too small");
   hipStream_t s = (hipStream_t)stream;
   const bool fp8 = prec == BT_PREC_FP8;
   if (fp8) {  // everything but the e4m3 GEMMs of the main layers is the bf16 path
     prec = BT_PREC_BF16;
-    if (D % 128 != 0 || (long)B * T * 4 * D * 2 >= 0x7fffffffL)
+    if (D % 128 != 0 || (long)B * T * d.ff_mult * D * 2 >= 0x7fffffffL)
       return bt_set_error(BT_ERR_ARG, "BT_PREC_FP8 needs transformer_dim % 128 == 0 (gemm3 main layers)");
     for (int l = 0; l < d.n_layers; ++l)
       if (!d.layers[l].w_ff1_f8 || !d.layers[l].w_ff2_f8 || !d.layers[l].s_ff1 || !d.layers[l].s_ff2 ||
@@ -312,7 +318,7 @@ int bt_forward(bt_engine* e, void* stream, int prec, const float* d_spect, int B
   // the bf16 shadow of the main residual stream is maintained by the gemm2 / gemm3 epilogues only
   const bool use_shadow = prec == BT_PREC_BF16 && D >= 128 && D % 64 == 0;
   // main layers on gemm3 + fragment-major attention (needs q | k | v column blocks that are whole 128-tiles)
-  const bool fast_layers = use_shadow && D % 128 == 0 && (long)B * T * 4 * D * 2 < 0x7fffffffL;
+  const bool fast_layers = use_shadow && D % 128 == 0 && (long)B * T * d.ff_mult * D * 2 < 0x7fffffffL;
 
   // frontend.linear on gemm3 (bf16 A written by the last conv block) when its shape fits
   bool lin3 = false;
@@ -344,9 +350,9 @@ int bt_forward(bt_engine* e, void* stream, int prec, const float* d_spect, int B
     const bool conv3 = fast_layers && d.partial_transformers && pair_fused2_ok(d.front[blk][1], prec) && cg.N >= 128 &&
                        gemm3_supported(cg);
     if (d.partial_transformers) {
-      int rc = run_pair(d.front[blk][0], d.rope, x, nullptr, ws, B, T, F, 1, prec, s);
+      int rc = run_pair(pf, d.front[blk][0], d.rope, x, nullptr, ws, B, T, F, 1, prec, s);
       if (rc) return rc;
-      rc = run_pair(d.front[blk][1], d.rope, x, nullptr, ws, B, T, F, 2, prec, s, conv3 ? ws.hid : nullptr);
+      rc = run_pair(pf, d.front[blk][1], d.rope, x, nullptr, ws, B, T, F, 2, prec, s, conv3 ? ws.hid : nullptr);
       if (rc) return rc;
     }
     if (conv3) {
@@ -382,8 +388,9 @@ int bt_forward(bt_engine* e, void* stream, int prec, const float* d_spect, int B
     LAUNCH_CAT(CAT_LINEAR, s, launch_gemm(g, prec, s), "frontend linear gemm");
   }
   for (int l = 0; l < d.n_layers; ++l) {
-    int rc = fast_layers ? run_layer_bf16(d.layers[l], d.rope, ws, B, T, fp8, s)
-                         : run_pair(d.layers[l], d.rope, ws.xm, use_shadow ? ws.xmb : nullptr, ws, B, T, 1, 0, prec, s);
+    int rc = fast_layers ? run_layer_bf16(pf, d.layers[l], d.rope, ws, B, T, d.ff_mult, fp8, s)
+                         : run_pair(pf, d.layers[l], d.rope, ws.xm, use_shadow ? ws.xmb : nullptr, ws, B, T, 1, 0, prec, s, nullptr,
+                                    d.ff_mult);
     if (rc) return rc;
   }
   HeadP hp;
@@ -397,7 +404,14 @@ int bt_split_chunks(void* stream, const float* d_spect, int64_t n_frames, const 
                     float* d_chunks) {
   if (!d_spect || !d_starts || !d_chunks || B <= 0 || T <= 0 || n_frames <= 0)
     return bt_set_error(BT_ERR_ARG, "bad argument to bt_split_chunks");
-  LAUNCH(launch_split(d_spect, n_frames, d_starts, B, T, d_chunks, (hipStream_t)stream), "split");
+  LAUNCH(launch_split(d_spect, n_frames, d_starts, nullptr, B, T, d_chunks, (hipStream_t)stream), "split");
+  return BT_OK;
+}
+
+int bt_split_chunks_batch(void* stream, const float* d_spect, const int32_t* d_chunk_table, int B, int T, float* d_chunks) {
+  if (!d_spect || !d_chunk_table || !d_chunks || B <= 0 || T <= 0)
+    return bt_set_error(BT_ERR_ARG, "bad argument to bt_split_chunks_batch");
+  LAUNCH(launch_split(d_spect, 0, nullptr, d_chunk_table, B, T, d_chunks, (hipStream_t)stream), "split (batch)");
   return BT_OK;
 }
 
@@ -405,19 +419,47 @@ int bt_aggregate(void* stream, const float* cb, const float* cd, const int32_t* 
                  int64_t n_frames, float* d_beat, float* d_downbeat) {
   if (!cb || !cd || !d_starts || !d_beat || !d_downbeat || B <= 0 || T <= 0 || n_frames <= 0 || border < 0)
     return bt_set_error(BT_ERR_ARG, "bad argument to bt_aggregate");
-  LAUNCH(launch_aggregate(cb, cd, d_starts, B, T, border, n_frames, d_beat, d_downbeat, (hipStream_t)stream),
-         "aggregate");
+  LAUNCH(launch_aggregate(cb, cd, d_starts, nullptr, nullptr, 1, B, T, border, n_frames, d_beat, d_downbeat,
+                          (hipStream_t)stream), "aggregate");
   return BT_OK;
+}
+
+int bt_aggregate_batch(void* stream, const float* cb, const float* cd, const int32_t* d_chunk_table, const int32_t* d_pieces,
+                       int n_pieces, int64_t max_frames, int T, int border, float* d_beat, float* d_downbeat) {
+  if (!cb || !cd || !d_chunk_table || !d_pieces || !d_beat || !d_downbeat || n_pieces <= 0 || T <= 0 || max_frames <= 0 ||
+      border < 0)
+    return bt_set_error(BT_ERR_ARG, "bad argument to bt_aggregate_batch");
+  LAUNCH(launch_aggregate(cb, cd, nullptr, d_chunk_table, d_pieces, n_pieces, 0, T, border, max_frames, d_beat, d_downbeat,
+                          (hipStream_t)stream), "aggregate (batch)");
+  return BT_OK;
+}
+
+static void fill_logmel(LogmelP& p, const bt_logmel_tables* t, float* d_spect) {
+  p.window = t->window; p.twiddle = t->twiddle; p.mel_start = t->mel_start; p.mel_len = t->mel_len; p.mel_w = t->mel_w;
+  p.spect = d_spect;
 }
 
 int bt_logmel(void* stream, const bt_logmel_tables* t, const float* d_audio, int64_t n_samples, float* d_spect) {
   if (!t || !d_audio || !d_spect) return bt_set_error(BT_ERR_ARG, "null argument");
   if (n_samples <= 512) return bt_set_error(BT_ERR_ARG, "signal too short: reflect padding needs more than 512 samples");
   LogmelP p;
-  p.audio = d_audio; p.n_samples = n_samples; p.window = t->window; p.twiddle = t->twiddle;
-  p.mel_start = t->mel_start; p.mel_len = t->mel_len; p.mel_w = t->mel_w; p.spect = d_spect;
-  p.n_frames = 1 + n_samples / 441;
+  fill_logmel(p, t, d_spect);
+  p.one = bt_span_t{d_audio, (long)n_samples, 0, (long)(1 + n_samples / 441)};
+  p.tracks = nullptr; p.n_tracks = 1; p.max_frames = p.one.n_out;
   LAUNCH(launch_logmel(p, (hipStream_t)stream), "logmel");
+  return BT_OK;
+}
+
+int bt_logmel_batch(void* stream, const bt_logmel_tables* t, const bt_span* d_tracks, int n_tracks, int64_t max_frames,
+                    float* d_spect) {
+  if (!t || !d_tracks || !d_spect || n_tracks <= 0 || max_frames <= 0)
+    return bt_set_error(BT_ERR_ARG, "bad argument to bt_logmel_batch");
+  static_assert(sizeof(bt_span) == sizeof(bt_span_t), "bt_span layout");
+  LogmelP p;
+  fill_logmel(p, t, d_spect);
+  p.one = bt_span_t{nullptr, 0, 0, 0};
+  p.tracks = reinterpret_cast<const bt_span_t*>(d_tracks); p.n_tracks = n_tracks; p.max_frames = (long)max_frames;
+  LAUNCH(launch_logmel(p, (hipStream_t)stream), "logmel (batch)");
   return BT_OK;
 }
 
@@ -426,13 +468,48 @@ int bt_resample(void* stream, const float* d_in, int64_t n_in, int up, int down,
   if (!d_in || !d_filter || !d_out || n_in <= 0 || n_out <= 0 || up <= 0 || down <= 0 || half_len < 0)
     return bt_set_error(BT_ERR_ARG, "bad argument to bt_resample");
   if (n_out > (n_in * up + down - 1) / down) return bt_set_error(BT_ERR_ARG, "n_out exceeds ceil(n_in * up / down)");
-  LAUNCH(launch_resample(d_in, n_in, up, down, d_filter, half_len, d_out, n_out, (hipStream_t)stream), "resample");
+  const bt_span_t one{d_in, (long)n_in, 0, (long)n_out};
+  LAUNCH(launch_resample(one, nullptr, 1, (long)n_out, up, down, d_filter, half_len, d_out, (hipStream_t)stream), "resample");
+  return BT_OK;
+}
+
+int bt_resample_batch(void* stream, const bt_span* d_tracks, int n_tracks, int64_t max_n_out, int up, int down,
+                      const float* d_filter, int half_len, float* d_out) {
+  if (!d_tracks || !d_filter || !d_out || n_tracks <= 0 || max_n_out <= 0 || up <= 0 || down <= 0 || half_len < 0)
+    return bt_set_error(BT_ERR_ARG, "bad argument to bt_resample_batch");
+  const bt_span_t none{nullptr, 0, 0, 0};
+  LAUNCH(launch_resample(none, reinterpret_cast<const bt_span_t*>(d_tracks), n_tracks, (long)max_n_out, up, down, d_filter,
+                         half_len, d_out, (hipStream_t)stream), "resample (batch)");
   return BT_OK;
 }
 
 int bt_peaks(void* stream, const float* d_logits, int64_t n, int n_arrays, int32_t* d_idx, int32_t* d_count) {
   if (!d_logits || !d_idx || !d_count || n <= 0 || n_arrays <= 0) return bt_set_error(BT_ERR_ARG, "bad argument");
-  LAUNCH(launch_peaks(d_logits, n, n_arrays, d_idx, d_count, (hipStream_t)stream), "peaks");
+  LAUNCH(launch_peaks(d_logits, n, nullptr, n_arrays, d_idx, d_count, (hipStream_t)stream), "peaks");
+  return BT_OK;
+}
+
+int bt_peaks_batch(void* stream, const float* d_logits, const int32_t* d_spans, int n_arrays, int32_t* d_idx,
+                   int32_t* d_count) {
+  if (!d_logits || !d_spans || !d_idx || !d_count || n_arrays <= 0)
+    return bt_set_error(BT_ERR_ARG, "bad argument to bt_peaks_batch");
+  LAUNCH(launch_peaks(d_logits, 0, d_spans, n_arrays, d_idx, d_count, (hipStream_t)stream), "peaks (batch)");
+  return BT_OK;
+}
+
+int bt_peaks_host(const float* logits, int64_t n, int32_t* idx, int32_t* count) {
+  // x == max_pool1d(x, 7, 1, 3) (implicit -inf padding) and x > 0 (postprocessor.py:93-99) for logits in HOST memory
+  if (!logits || !idx || !count || n < 0) return bt_set_error(BT_ERR_ARG, "bad argument to bt_peaks_host");
+  int32_t m = 0;
+  for (int64_t i = 0; i < n; ++i) {
+    const float v = logits[i];
+    if (!(v > 0.0f)) continue;
+    bool peak = true;
+    for (int64_t j = std::max<int64_t>(0, i - 3); j <= std::min<int64_t>(n - 1, i + 3); ++j)
+      if (logits[j] > v) { peak = false; break; }
+    if (peak) idx[m++] = (int32_t)i;
+  }
+  *count = m;
   return BT_OK;
 }
 
@@ -484,18 +561,20 @@ int bt_postprocess_host(const int32_t* beat_idx, int nb, const int32_t* down_idx
   return BT_OK;
 }
 
-void bt_profile_begin(void) {
-  for (auto& r : prof::recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
-  prof::recs.clear();
-  prof::on = true;
+void bt_profile_begin(bt_engine* e) {
+  if (!e) return;
+  for (auto& r : e->prof.recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+  e->prof.recs.clear();
+  e->prof.on = true;
 }
 
-int bt_profile_end(double* ms_by_category, int32_t* launches_by_category, int n_categories) {
-  prof::on = false;
+int bt_profile_end(bt_engine* e, double* ms_by_category, int32_t* launches_by_category, int n_categories) {
+  if (!e) return bt_set_error(BT_ERR_ARG, "null engine");
+  e->prof.on = false;
   if (!ms_by_category || !launches_by_category || n_categories < CAT_COUNT)
     return bt_set_error(BT_ERR_ARG, "need room for BT_PROFILE_CATEGORIES entries");
   for (int i = 0; i < n_categories; ++i) { ms_by_category[i] = 0.0; launches_by_category[i] = 0; }
-  for (auto& r : prof::recs) {
+  for (auto& r : e->prof.recs) {
     hipError_t e = hipEventSynchronize(r.b);
     float ms = 0.f;
     if (e == hipSuccess) e = hipEventElapsedTime(&ms, r.a, r.b);
@@ -504,7 +583,7 @@ int bt_profile_end(double* ms_by_category, int32_t* launches_by_category, int n_
     launches_by_category[r.cat] += 1;
     (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b);
   }
-  prof::recs.clear();
+  e->prof.recs.clear();
   return BT_OK;
 }
 

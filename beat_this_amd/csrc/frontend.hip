@@ -92,27 +92,42 @@ __global__ __launch_bounds__(256) void head_kernel(const HeadP p) {
   }
 }
 
-__global__ void split_kernel(const float* __restrict__ spect, long n_frames, const int* __restrict__ starts, int B,
-                             int T, float* __restrict__ chunks) {
+// chunk table row (int32 x 4): {first source frame (may be negative / before the piece), first frame of the piece,
+// end frame of the piece, unused}, all ABSOLUTE frame indices of the (concatenated) spectrogram buffer; frames of a
+// chunk outside [lo, hi) read as zeros (split_piece / zeropad, inference.py:90-135).
+__global__ void split_kernel(const float* __restrict__ spect, const int* __restrict__ table, const int* __restrict__ starts,
+                             long n_frames, int B, int T, float* __restrict__ chunks) {
   const long total = (long)B * T * 32;  // float4 units
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     long row = i >> 5;
     int c4 = (int)(i & 31);
     int b = (int)(row / T), t = (int)(row - (long)b * T);
-    long src = (long)starts[b] + t;
+    long src, lo = 0, hi = n_frames;
+    if (table) { src = (long)table[4 * b] + t; lo = table[4 * b + 1]; hi = table[4 * b + 2]; }
+    else src = (long)starts[b] + t;
     f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (src >= 0 && src < n_frames) v = reinterpret_cast<const f32x4*>(spect + src * 128)[c4];
+    if (src >= lo && src < hi) v = reinterpret_cast<const f32x4*>(spect + src * 128)[c4];
     reinterpret_cast<f32x4*>(chunks + row * 128)[c4] = v;
   }
 }
 
+// aggregate_prediction, keep_first (inference.py:138-185).  Single piece: `starts` + n_frames.  Batch (blockIdx.y = piece):
+// pieces[4 k ..] = {first frame, end frame (absolute, of the concatenated outputs), first chunk, end chunk}, chunk starts
+// from the chunk table of split_kernel.
 __global__ void aggregate_kernel(const float* __restrict__ cb, const float* __restrict__ cd,
-                                 const int* __restrict__ starts, int B, int T, int border, long n_frames,
+                                 const int* __restrict__ starts, const int* __restrict__ table,
+                                 const int* __restrict__ pieces, int B, int T, int border, long n_frames,
                                  float* __restrict__ beat, float* __restrict__ downbeat) {
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n_frames; i += (long)gridDim.x * blockDim.x) {
+  long f_lo = 0, f_hi = n_frames;
+  int c_lo = 0, c_hi = B;
+  if (pieces) {
+    const int* pc = pieces + 4 * blockIdx.y;
+    f_lo = pc[0]; f_hi = pc[1]; c_lo = pc[2]; c_hi = pc[3];
+  }
+  for (long i = f_lo + (long)blockIdx.x * blockDim.x + threadIdx.x; i < f_hi; i += (long)gridDim.x * blockDim.x) {
     float vb = -1000.0f, vd = -1000.0f;
-    for (int c = 0; c < B; ++c) {  // first (earliest) chunk whose kept span covers frame i wins
-      long s = starts[c];
+    for (int c = c_lo; c < c_hi; ++c) {  // first (earliest) chunk whose kept span covers frame i wins
+      long s = table ? table[4 * c] : starts[c];
       if (i >= s + border && i < s + T - border) {
         vb = cb[(long)c * T + (i - s)];
         vd = cd[(long)c * T + (i - s)];
@@ -124,13 +139,17 @@ __global__ void aggregate_kernel(const float* __restrict__ cb, const float* __re
   }
 }
 
-// grid.x = number of logit arrays (stride n); one workgroup scans one array in order.
-__global__ __launch_bounds__(1024) void peaks_kernel(const float* __restrict__ logits, long n, int* __restrict__ idx,
+// grid.x = number of logit arrays; one workgroup scans one array in order.  spans == nullptr: array a = logits + a n
+// (n frames); else array a = logits + spans[2 a] with spans[2 a + 1] frames, indices written at idx + spans[2 a].
+__global__ __launch_bounds__(1024) void peaks_kernel(const float* __restrict__ logits, long n_uniform,
+                                                     const int* __restrict__ spans, int* __restrict__ idx,
                                                      int* __restrict__ count) {
   __shared__ int wave_tot[16];
   __shared__ int base_s;
-  const float* x = logits + (long)blockIdx.x * n;
-  int* out = idx + (long)blockIdx.x * n;
+  const long off = spans ? (long)spans[2 * blockIdx.x] : (long)blockIdx.x * n_uniform;
+  const long n = spans ? (long)spans[2 * blockIdx.x + 1] : n_uniform;
+  const float* x = logits + off;
+  int* out = idx + off;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // (wave index in an SGPR: uniform index math stays scalar)
   if (tid == 0) base_s = 0;
   __syncthreads();
@@ -168,32 +187,64 @@ __global__ __launch_bounds__(1024) void peaks_kernel(const float* __restrict__ l
 }
 
 // Rational resampler (replaces the host soxr.resample call of inference.py:274-275):
-//   y[m] = sum_k x[k] * h[m * down + half - k * up],   h = up * firwin(2 half + 1, 1 / max(up, down), kaiser 5.0),
-// i.e. upsample by `up`, zero-phase FIR low-pass, keep every `down`-th sample (the polyphase form of
-// scipy.signal.resample_poly, zero extension at the ends).  One thread per output sample, ~20 max(up,down)/up + 1
-// taps; x and h reads of neighbouring threads overlap and stay in L1/L2, so the kernel is bound by its
-// 4 B/sample in + 4 B/sample out of HBM traffic.
-__global__ __launch_bounds__(256) void resample_kernel(const float* __restrict__ x, long n_in, int up, int down,
-                                                         const float* __restrict__ h, int half, float* __restrict__ y,
-                                                         long n_out) {
-  const long m = (long)blockIdx.x * 256 + threadIdx.x;
+//   y[m] = sum_k x[k] * h[m * down + half - k * up],   h = up * (Kaiser-windowed sinc, beat_this_amd/tables.py),
+// i.e. upsample by `up`, zero-phase FIR low-pass, keep every `down`-th sample (polyphase form, zero extension at the
+// ends).  A workgroup produces 256 consecutive outputs of one track (blockIdx.y): the input window they need
+// (256 down / up + 2 half / up samples) is staged in LDS once with coalesced loads, and -- for up == 1, the
+// 44.1 -> 22.05 kHz case -- so is the filter; a thread then runs its taps out of LDS.  HBM traffic = the input once +
+// the output once.
+constexpr int RS_XMAX = 4096;  // staged input samples (floats)
+constexpr int RS_HMAX = 1024;  // staged filter taps (up == 1 only)
+__global__ __launch_bounds__(256) void resample_kernel(const bt_span_t one, const bt_span_t* __restrict__ tracks, int up,
+                                                         int down, const float* __restrict__ h, int half,
+                                                         float* __restrict__ y) {
+  __shared__ float xs[RS_XMAX];
+  __shared__ float hs[RS_HMAX];
+  const bt_span_t tr = tracks ? tracks[blockIdx.y] : one;
+  const float* __restrict__ x = tr.data;
+  const long n_in = tr.n, n_out = tr.n_out;
+  const long m0 = (long)blockIdx.x * 256;
+  if (m0 >= n_out) return;
+  const int tid = threadIdx.x;
+  // inputs needed by outputs m0 .. m0 + 255: k in [ceil((m0 down - half) / up), floor(((m0 + 255) down + half) / up)]
+  const long c_first = m0 * down - half, c_last = (m0 + 255) * down + half;
+  long k0 = c_first <= 0 ? 0 : (c_first + up - 1) / up;
+  long k1 = c_last / up;
+  if (k1 > n_in - 1) k1 = n_in - 1;
+  const int nx = (int)(k1 - k0 + 1);
+  const bool staged = nx <= RS_XMAX;
+  if (staged)
+    for (int i = tid; i < nx; i += 256) xs[i] = x[k0 + i];
+  const bool hstaged = up == 1 && 2 * half + 1 <= RS_HMAX;
+  if (hstaged)
+    for (int i = tid; i <= 2 * half; i += 256) hs[i] = h[i];
+  __syncthreads();
+  const long m = m0 + tid;
   if (m >= n_out) return;
   const long c = m * down + half;                 // h index of x[0]'s tap
-  long k_lo = (c - 2L * half + up - 1) / up;      // smallest k with c - k up <= 2 half (c - 2 half may be negative)
-  if (c - 2L * half < 0) k_lo = 0;
+  long k_lo = c - 2L * half <= 0 ? 0 : (c - 2L * half + up - 1) / up;  // smallest k with c - k up <= 2 half
   long k_hi = c / up;                             // largest k with c - k up >= 0
   if (k_hi > n_in - 1) k_hi = n_in - 1;
   float acc = 0.f;
-  for (long k = k_lo; k <= k_hi; ++k) acc = fmaf(x[k], h[c - k * up], acc);
-  y[m] = acc;
+  if (staged && hstaged) {
+    const float* xp = xs + (k_lo - k0);
+    const float* hp = hs + (c - k_lo);            // tap index falls by 1 per input sample
+    const int nt = (int)(k_hi - k_lo + 1);
+    for (int i = 0; i < nt; ++i) acc = fmaf(xp[i], hp[-i], acc);
+  } else if (staged) {
+    for (long k = k_lo; k <= k_hi; ++k) acc = fmaf(xs[k - k0], h[c - k * up], acc);
+  } else {
+    for (long k = k_lo; k <= k_hi; ++k) acc = fmaf(x[k], h[c - k * up], acc);
+  }
+  y[tr.out_off + m] = acc;
 }
 
 }  // namespace
 
-int launch_resample(const float* x, long n_in, int up, int down, const float* h, int half, float* y, long n_out,
-                    hipStream_t s) {
-  hipLaunchKernelGGL(resample_kernel, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, s, x, n_in, up, down, h, half,
-                     y, n_out);
+int launch_resample(const bt_span_t& one, const bt_span_t* tracks, int n_tracks, long max_n_out, int up, int down,
+                    const float* h, int half, float* y, hipStream_t s) {
+  hipLaunchKernelGGL(resample_kernel, dim3((unsigned)((max_n_out + 255) / 256), (unsigned)n_tracks), dim3(256), 0, s, one,
+                     tracks, up, down, h, half, y);
   return (int)hipGetLastError();
 }
 
@@ -206,20 +257,21 @@ int launch_head(const HeadP& p, hipStream_t s) {
   hipLaunchKernelGGL(head_kernel, dim3((unsigned)((p.M + 3) / 4)), dim3(256), 0, s, p);
   return (int)hipGetLastError();
 }
-int launch_split(const float* spect, long n_frames, const int* starts, int B, int T, float* chunks, hipStream_t s) {
+int launch_split(const float* spect, long n_frames, const int* starts, const int* table, int B, int T, float* chunks,
+                 hipStream_t s) {
   long total = (long)B * T * 32;
-  unsigned grid = (unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-  hipLaunchKernelGGL(split_kernel, dim3(grid), dim3(256), 0, s, spect, n_frames, starts, B, T, chunks);
+  unsigned grid = (unsigned)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  hipLaunchKernelGGL(split_kernel, dim3(grid), dim3(256), 0, s, spect, table, starts, n_frames, B, T, chunks);
   return (int)hipGetLastError();
 }
-int launch_aggregate(const float* cb, const float* cd, const int* starts, int B, int T, int border, long n_frames,
-                     float* beat, float* downbeat, hipStream_t s) {
+int launch_aggregate(const float* cb, const float* cd, const int* starts, const int* table, const int* pieces, int n_pieces,
+                     int B, int T, int border, long n_frames, float* beat, float* downbeat, hipStream_t s) {
   unsigned grid = (unsigned)((n_frames + 255) / 256 < 2048 ? (n_frames + 255) / 256 : 2048);
-  hipLaunchKernelGGL(aggregate_kernel, dim3(grid), dim3(256), 0, s, cb, cd, starts, B, T, border, n_frames, beat,
-                     downbeat);
+  hipLaunchKernelGGL(aggregate_kernel, dim3(grid, (unsigned)(pieces ? n_pieces : 1)), dim3(256), 0, s, cb, cd, starts, table,
+                     pieces, B, T, border, n_frames, beat, downbeat);
   return (int)hipGetLastError();
 }
-int launch_peaks(const float* logits, long n, int n_arrays, int* idx, int* count, hipStream_t s) {
-  hipLaunchKernelGGL(peaks_kernel, dim3((unsigned)n_arrays), dim3(1024), 0, s, logits, n, idx, count);
+int launch_peaks(const float* logits, long n, const int* spans, int n_arrays, int* idx, int* count, hipStream_t s) {
+  hipLaunchKernelGGL(peaks_kernel, dim3((unsigned)n_arrays), dim3(1024), 0, s, logits, n, spans, idx, count);
   return (int)hipGetLastError();
 }

@@ -21,7 +21,8 @@
 
 namespace {
 
-// development switch BT_F2_ABL (timing experiments only): bit 0 = x / ao are not loaded, bit 1 = x is not stored
+// Development instrumentation (per-wave phase timing, load / store ablations) is compiled in with -DBT_DEV only
+// (BT_DEV_BUILD=1 for beat_this_amd._lib.build): release builds read no environment variables and carry no debug hooks.
 
 typedef __amdgpu_buffer_rsrc_t rsrc_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
@@ -34,8 +35,15 @@ DEVI unsigned pk2_bf16(float a, float b) {
 // (buffer_load ... lds, no staging registers) into a ring of NST stages; step s + NST - 1 is issued while
 // step s is consumed, so three steps of L2 latency are covered instead of none (the register-staged
 // version waited for every step's load inside the step: ~2 k cycles x 25 steps per workgroup).
+#ifdef BT_DEV
 // development: per-wave phase timing of attnff_fused_kernel (bt_debug_fused2_buffer; null = off)
 __device__ long long* g_f2_dbg = nullptr;
+#define F2_DBG g_f2_dbg
+#define F2_ABL(p) ((p).abl)
+#else
+#define F2_DBG ((long long*)nullptr)
+#define F2_ABL(p) 0
+#endif
 
 template <typename T, int C>
 struct WRing {
@@ -154,8 +162,8 @@ __global__ __launch_bounds__(256) void outff_fused_kernel(const FusedOutFFP p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // (wave index in an SGPR: uniform index math stays scalar)
   const int g = lane >> 5, lr = lane & 31;
   const long tok = ((long)blockIdx.x * 4 + wave) * 32 + lr;
-  const bool ok_st = tok < p.M && !(p.abl & 2);
-  const bool ok = tok < p.M && !(p.abl & 1);
+  const bool ok_st = tok < p.M && !(F2_ABL(p) & 2);
+  const bool ok = tok < p.M && !(F2_ABL(p) & 1);
   float* xrow = p.x + (tok < p.M ? tok : 0) * C;
   for (int i = tid; i < 4 * C; i += 256) b1s[i] = p.b1[i];
 
@@ -217,7 +225,7 @@ __global__ __launch_bounds__(256) void attnff_fused_kernel(const FusedAttnFFP p)
   const long tok = ((long)blockIdx.x * 4 + wave) * 32 + lr;
   const bool ok = tok < p.M;
   float* xrow = p.x + (ok ? tok : 0) * C;
-  long long* dbg = g_f2_dbg;
+  long long* dbg = F2_DBG;
   const long long t_in = dbg ? clock64() : 0;
   for (int i = tid; i < 4 * C; i += 256) b1s[i] = p.b1[i];
 
@@ -387,15 +395,20 @@ int launch_attnff_t(const FusedAttnFFP& p, hipStream_t s) {
 
 }  // namespace
 
+#ifdef BT_DEV
 extern "C" int bt_debug_fused2_buffer(void* buf) {
   return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_f2_dbg), &buf, sizeof buf);
 }
+#endif
 
 int launch_outff_fused(const FusedOutFFP& p0, int prec, hipStream_t s) {
   if (p0.M <= 0) return -2;
-  static const int abl = getenv("BT_F2_ABL") ? atoi(getenv("BT_F2_ABL")) : 0;
   FusedOutFFP p = p0;
+  p.abl = 0;
+#ifdef BT_DEV
+  static const int abl = getenv("BT_F2_ABL") ? atoi(getenv("BT_F2_ABL")) : 0;
   p.abl = abl;
+#endif
   return prec == BT_PREC_F32 ? launch_outff_t<float>(p, s) : launch_outff_t<bf16>(p, s);
 }
 int launch_attnff_fused(const FusedAttnFFP& p, int prec, hipStream_t s) {

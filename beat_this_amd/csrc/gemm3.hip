@@ -570,9 +570,13 @@ bool gemm3_supported(const Gemm3P& p) {
 
 int launch_gemm3(const Gemm3P& p, hipStream_t s) {
   if (!gemm3_supported(p)) return -2;
-  // development switches: BT_G3_ABL (ablations), BT_G3_BIG = 0 / 1 forces the tile configuration
+#ifdef BT_DEV
+  // development builds only: BT_G3_ABL (timing dump), BT_G3_BIG = 0 / 1 forces the tile configuration
   static const int abl = getenv("BT_G3_ABL") ? atoi(getenv("BT_G3_ABL")) : 0;
   static const int force_big = getenv("BT_G3_BIG") ? atoi(getenv("BT_G3_BIG")) : -1;
+#else
+  constexpr int abl = 0, force_big = -1;
+#endif
   // Measured on the final0 shapes (M = 24000): for K = 512 the 256^2 configuration is no faster in isolation (FF1 85 vs
   // 86 us) and slower inside the forward (one workgroup per CU cannot hide its epilogue behind another workgroup's
   // k-loop); for the long-K residual GEMM (FF2, K = 4 D: half the operand traffic per flop, epilogue amortised over 32
@@ -592,14 +596,18 @@ int launch_gemm3(const Gemm3P& p, hipStream_t s) {
   switch (p.epi) {
     case G3_FF1:
       if (big) launch_cfg<G3_FF1, CfgB>(p, s);
+#ifdef BT_DEV
       else if (abl == 8) launch_cfg<G3_FF1, CfgS, 8>(p, s);
+#endif
       else launch_cfg<G3_FF1, CfgS>(p, s);
       break;
     case G3_RESID:
-      if (big && abl == 8) launch_cfg<G3_RESID, CfgB, 8>(p, s);
-      else if (rows192) launch_cfg<G3_RESID, G3CfgT>(p, s);
+#ifdef BT_DEV
+      if (big && abl == 8) { launch_cfg<G3_RESID, CfgB, 8>(p, s); break; }
+      if (!big && abl == 8) { launch_cfg<G3_RESID, CfgS, 8>(p, s); break; }
+#endif
+      if (rows192) launch_cfg<G3_RESID, G3CfgT>(p, s);
       else if (big) launch_cfg<G3_RESID, CfgB>(p, s);
-      else if (abl == 8) launch_cfg<G3_RESID, CfgS, 8>(p, s);
       else launch_cfg<G3_RESID, CfgS>(p, s);
       break;
     case G3_QKV: launch_cfg<G3_QKV, CfgS>(p, s); break;

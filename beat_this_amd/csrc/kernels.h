@@ -173,23 +173,32 @@ struct HeadP {
 };
 int launch_head(const HeadP& p, hipStream_t s);
 
-int launch_split(const float* spect, long n_frames, const int* starts, int B, int T, float* chunks, hipStream_t s);
-int launch_aggregate(const float* cb, const float* cd, const int* starts, int B, int T, int border, long n_frames,
-                     float* beat, float* downbeat, hipStream_t s);
-int launch_resample(const float* x, long n_in, int up, int down, const float* h, int half, float* y, long n_out,
-                    hipStream_t s);
-// logits: [n_arrays][n]; idx: [n_arrays][n] ascending frame indices; count: [n_arrays]
-int launch_peaks(const float* logits, long n, int n_arrays, int* idx, int* count, hipStream_t s);
+// One track of a batched front-end launch: input samples, their count, and where the track's output starts in the
+// concatenated output buffer (samples for the resampler, frames for the log-mel kernel) / how many outputs it has.
+// Same layout as bt_span of include/beat_this_amd.h.
+struct bt_span_t { const float* data; long n; long out_off; long n_out; };
+
+// starts (one piece, frames relative to spect) or table ([B][4] absolute chunk table, see frontend.hip)
+int launch_split(const float* spect, long n_frames, const int* starts, const int* table, int B, int T, float* chunks,
+                 hipStream_t s);
+int launch_aggregate(const float* cb, const float* cd, const int* starts, const int* table, const int* pieces, int n_pieces,
+                     int B, int T, int border, long n_frames, float* beat, float* downbeat, hipStream_t s);
+int launch_resample(const bt_span_t& one, const bt_span_t* tracks, int n_tracks, long max_n_out, int up, int down,
+                    const float* h, int half, float* y, hipStream_t s);
+// logits: n_arrays arrays of n frames (spans == nullptr) or arrays (offset, length) = spans[2 a], spans[2 a + 1];
+// idx: ascending frame indices at the array's offset; count: [n_arrays]
+int launch_peaks(const float* logits, long n, const int* spans, int n_arrays, int* idx, int* count, hipStream_t s);
 
 // ---- log-mel -----------------------------------------------------------------------
 struct LogmelP {
-  const float* audio; long n_samples;
+  bt_span_t one;               // single track: {audio, n_samples, 0, n_frames}
+  const bt_span_t* tracks;     // batch: device table, blockIdx.y = track (one unused then)
+  int n_tracks; long max_frames;
   const float* window;    // [1024]
   const float* twiddle;   // see logmel.hip
   const int* mel_start;   // [128]
   const int* mel_len;     // [128]
   const float* mel_w;     // [128][32]
-  float* spect;           // [n_frames, 128]
-  long n_frames;
+  float* spect;           // [sum of n_frames, 128]: track k starts at row tracks[k].out_off
 };
 int launch_logmel(const LogmelP& p, hipStream_t s);

@@ -50,13 +50,16 @@ __global__ __launch_bounds__(256) void logmel_kernel(const LogmelP p) {
   __shared__ float sim[4][XPAD];
   __shared__ float smag[4][520];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const bt_span_t tr = p.tracks ? p.tracks[blockIdx.y] : p.one;
+  const float* __restrict__ audio = tr.data;
+  if ((long)blockIdx.x * 4 >= tr.n_out) return;  // (workgroup-uniform: a shorter track of the batch)
   const long frame = (long)blockIdx.x * 4 + wave;
-  const bool active = frame < p.n_frames;
+  const bool active = frame < tr.n_out;
   float* re = sre[wave];
   float* im = sim[wave];
   float* mag = smag[wave];
   const f32x2* tw = reinterpret_cast<const f32x2*>(p.twiddle);
-  const long N = p.n_samples;
+  const long N = tr.n;
   const long s0 = (active ? frame : 0) * 441 - 512;
 
   // ---- load + window: lane holds z[64 a + lane], z[n] = x[2n] + i x[2n+1] -------------
@@ -68,8 +71,8 @@ __global__ __launch_bounds__(256) void logmel_kernel(const LogmelP p) {
     j0 = j0 < 0 ? -j0 : (j0 >= N ? 2 * (N - 1) - j0 : j0);
     j1 = j1 < 0 ? -j1 : (j1 >= N ? 2 * (N - 1) - j1 : j1);
     const f32x2 w = *reinterpret_cast<const f32x2*>(p.window + 2 * n);
-    x[a].re = p.audio[j0] * w.x;
-    x[a].im = p.audio[j1] * w.y;
+    x[a].re = audio[j0] * w.x;
+    x[a].im = audio[j1] * w.y;
   }
   // ---- stage 1: DFT over a; lane = (b, c) = (lane >> 3, lane & 7) -----------------------
   dft8(x);
@@ -150,7 +153,7 @@ __global__ __launch_bounds__(256) void logmel_kernel(const LogmelP p) {
       const int st = p.mel_start[m], len = p.mel_len[m];
       float acc = 0.f;
       for (int i = 0; i < len; ++i) acc = fmaf(mag[st + i], p.mel_w[m * 32 + i], acc);
-      p.spect[frame * 128 + m] = log1pf(1000.0f * acc);
+      p.spect[(tr.out_off + frame) * 128 + m] = log1pf(1000.0f * acc);
     }
   }
 }
@@ -158,7 +161,7 @@ __global__ __launch_bounds__(256) void logmel_kernel(const LogmelP p) {
 }  // namespace
 
 int launch_logmel(const LogmelP& p, hipStream_t s) {
-  if (p.n_samples <= 512 || p.n_frames <= 0) return -2;
-  hipLaunchKernelGGL(logmel_kernel, dim3((unsigned)((p.n_frames + 3) / 4)), dim3(256), 0, s, p);
+  if (p.max_frames <= 0 || p.n_tracks <= 0 || (!p.tracks && p.one.n <= 512)) return -2;
+  hipLaunchKernelGGL(logmel_kernel, dim3((unsigned)((p.max_frames + 3) / 4), (unsigned)p.n_tracks), dim3(256), 0, s, p);
   return (int)hipGetLastError();
 }

@@ -6,6 +6,15 @@ Differences that matter for speed, not for results:
     batch-1, inference.py:215); chunk gathering and keep_first aggregation are GPU kernels.
   * ``Spect2Frames.spect2frames_many`` (extension) batches the chunks of several pieces, and
     shards them over torch.distributed ranks (RCCL) when a process group is initialised.
+  * ``Audio2Beats.many`` / ``Audio2Frames.signal2spect_many`` / ``Spect2Frames.spect2frames_batch`` (extensions):
+    a whole list of tracks per call -- ONE launch per stage (resample, log-mel, chunk gather, forward slices,
+    aggregation, peak picking) and ONE device-to-host copy for all tracks.
+
+Limits of the drop-in (there is no CPU implementation in this package):
+  * ``device`` must be a ROCm GPU; the default is "cuda" (the reference's default "cpu" raises here, in ``__init__``);
+  * ``BeatThis.forward`` takes at most 1536 frames per item (the reference's chunk length is 1500; its module accepts any
+    length); longer spectrograms go through ``split_predict_aggregate`` like in the reference's own inference classes;
+  * the resampler is a Kaiser-windowed-sinc polyphase FIR built to libsoxr's HQ specification, not libsoxr.
 """
 from __future__ import annotations
 
@@ -37,6 +46,16 @@ def load_checkpoint(checkpoint_path, device="cpu") -> dict:
             return torch.hub.load_state_dict_from_url(url, file_name=file_name, map_location=device)
         except Exception:
             raise ValueError("Could not load the checkpoint given the provided name", checkpoint_path)
+
+
+def _gpu_device(device) -> torch.device:
+    """The device argument of the inference classes: a ROCm GPU, or a clear error right away."""
+    dev = torch.device("cuda" if device is None else device)
+    if dev.type != "cuda":
+        raise RuntimeError(
+            f"beat_this_amd runs on ROCm GPUs only (got device='{dev}'): this package has no CPU implementation. "
+            "Pass device='cuda' (the default here) or 'cuda:N'.")
+    return dev
 
 
 def load_model(checkpoint_path="final0", device="cpu") -> BeatThis:
@@ -124,6 +143,9 @@ def split_predict_aggregate(spect: torch.Tensor, chunk_size: int, border_size: i
         raise ValueError(f"expected a (frames, 128) spectrogram, got {tuple(spect.shape)}")
     spect = spect.to(torch.float32).contiguous()
     n = spect.shape[0]
+    if n == 0:  # no chunks: the reference returns empty (full_size = 0) tensors, inference.py:172-173
+        empty = torch.empty((0,), dtype=torch.float32, device=spect.device)
+        return {"beat": empty, "downbeat": empty.clone()}
     starts = chunk_starts(n, chunk_size, border_size)
     T = chunk_length(n, chunk_size, border_size)
     chunks, d_starts = _gather_chunks(spect, starts, T)
@@ -145,9 +167,9 @@ def split_predict_aggregate(spect: torch.Tensor, chunk_size: int, border_size: i
 class Spect2Frames:
     """Framewise beat/downbeat logits from a spectrogram (inference.py:233-257)."""
 
-    def __init__(self, checkpoint_path="final0", device="cpu", float16=False):
+    def __init__(self, checkpoint_path="final0", device="cuda", float16=False):
         super().__init__()
-        self.device = torch.device(device)
+        self.device = _gpu_device(device)
         self.float16 = bool(float16)
         self.model = load_model(checkpoint_path, self.device)
         if float16 == "fp8":  # extension: float16="fp8" -> autocast + e4m3 feed-forward GEMMs (BT_PREC_FP8)
@@ -171,6 +193,14 @@ class Spect2Frames:
             with torch.autocast(enabled=self.float16, device_type=self.device.type):
                 return forward_chunks_sharded(self.model, spects, 1500, 6, group)
 
+    def spect2frames_batch(self, spect: torch.Tensor, frame_off):
+        """Extension: the pieces ``spect[frame_off[k]:frame_off[k+1]]`` of one concatenated (frames, 128) spectrogram
+        -> (beat, downbeat) logits concatenated the same way.  One chunk-gather launch per forward slice, one aggregation
+        launch for all pieces (same chunking / keep_first arithmetic as ``spect2frames``, inference.py:188-230)."""
+        with torch.inference_mode():
+            with torch.autocast(enabled=self.float16, device_type=self.device.type):
+                return batch_predict_aggregate(spect, frame_off, 1500, 6, self.model)
+
     def __call__(self, spect):
         return self.spect2frames(spect)
 
@@ -178,7 +208,7 @@ class Spect2Frames:
 class Audio2Frames(Spect2Frames):
     """Framewise logits from an audio signal (inference.py:260-281)."""
 
-    def __init__(self, checkpoint_path="final0", device="cpu", float16=False):
+    def __init__(self, checkpoint_path="final0", device="cuda", float16=False):
         super().__init__(checkpoint_path, device, float16)
         self.spect = LogMelSpect(device=self.device)
 
@@ -192,6 +222,72 @@ class Audio2Frames(Spect2Frames):
             signal = resample_gpu(signal, sr, 22050)
         return self.spect(signal)
 
+    def signal2spect_many(self, signals, sr):
+        """Extension: a list of waveforms (numpy (N,) / (N, C) or torch tensors, all at sample rate ``sr``) ->
+        (spect, frame_off): ONE (sum of frames, 128) spectrogram tensor with the tracks back to back and the int64 numpy
+        array of their first rows (length n + 1).  Mono mix as in ``signal2spect``; resampling and the log-mel run as one
+        launch each for all tracks (bt_resample_batch / bt_logmel_batch)."""
+        import ctypes as C
+        from math import gcd
+
+        dev = self.device
+        waves = []
+        for sig in signals:
+            if isinstance(sig, torch.Tensor):
+                w = sig.to(dev, torch.float32)
+                if w.dim() == 2:
+                    w = w.mean(1)
+                elif w.dim() != 1:
+                    raise ValueError(f"Expected 1D or 2D signal, got shape {tuple(sig.shape)}")
+            else:
+                if sig.ndim == 2:
+                    sig = sig.mean(1)
+                elif sig.ndim != 1:
+                    raise ValueError(f"Expected 1D or 2D signal, got shape {sig.shape}")
+                w = torch.tensor(sig, dtype=torch.float32, device=dev)
+            waves.append(w.contiguous())
+        n = len(waves)
+        if n == 0:
+            return torch.empty((0, 128), dtype=torch.float32, device=dev), np.zeros(1, dtype=np.int64)
+        sr = int(sr)
+        g = gcd(sr, 22050)
+        up, down = 22050 // g, sr // g
+        n_in = np.array([w.shape[0] for w in waves], dtype=np.int64)
+        n22 = n_in if up == down else -(-n_in * up // down)
+        if int(n22.min()) <= 512:
+            raise ValueError("signal too short: reflect padding needs more than 512 samples")
+        n_fr = 1 + n22 // 441
+        s_off = np.concatenate([[0], np.cumsum(n22)]).astype(np.int64)
+        frame_off = np.concatenate([[0], np.cumsum(n_fr)]).astype(np.int64)
+        lib, st = _lib.lib(), _lib.stream_ptr(dev)
+        table = np.zeros((2, n, 4), dtype=np.int64)
+        with torch.cuda.device(dev):
+            if up != down:
+                buf22 = torch.empty(int(s_off[-1]), dtype=torch.float32, device=dev)
+                table[0, :, 0] = [w.data_ptr() for w in waves]
+                table[0, :, 1], table[0, :, 2], table[0, :, 3] = n_in, s_off[:-1], n22
+                table[1, :, 0] = buf22.data_ptr() + 4 * s_off[:-1]
+            else:
+                table[1, :, 0] = [w.data_ptr() for w in waves]
+            table[1, :, 1], table[1, :, 2], table[1, :, 3] = n22, frame_off[:-1], n_fr
+            d_table = torch.from_numpy(table).to(dev)
+            if up != down:
+                h, half = _resample_filter(up, down, dev)
+                _lib.check(lib.bt_resample_batch(st, d_table[0].data_ptr(), n, int(n22.max()), up, down, h.data_ptr(), half,
+                                                 buf22.data_ptr()))
+            spect = torch.empty((int(frame_off[-1]), 128), dtype=torch.float32, device=dev)
+            if self.spect.device != dev:
+                self.spect.to(dev)
+            _lib.check(lib.bt_logmel_batch(st, C.byref(self.spect._get_tables()), d_table[1].data_ptr(), n, int(n_fr.max()),
+                                           spect.data_ptr()))
+        return spect, frame_off
+
+    def many(self, signals, sr):
+        """Extension: [(beat_logits, downbeat_logits)] for a list of waveforms, batched per stage."""
+        spect, frame_off = self.signal2spect_many(signals, sr)
+        beat, down = self.spect2frames_batch(spect, frame_off)
+        return [(beat[frame_off[k]: frame_off[k + 1]], down[frame_off[k]: frame_off[k + 1]]) for k in range(len(signals))]
+
     def __call__(self, signal, sr):
         return self.spect2frames(self.signal2spect(signal, sr))
 
@@ -199,13 +295,24 @@ class Audio2Frames(Spect2Frames):
 class Audio2Beats(Audio2Frames):
     """Beat and downbeat times in seconds from an audio signal (inference.py:284-303)."""
 
-    def __init__(self, checkpoint_path="final0", device="cpu", float16=False, dbn=False):
+    def __init__(self, checkpoint_path="final0", device="cuda", float16=False, dbn=False):
         super().__init__(checkpoint_path, device, float16)
         self.frames2beats = Postprocessor(type="dbn" if dbn else "minimal")
 
     def __call__(self, signal, sr):
         beat_logits, downbeat_logits = super().__call__(signal, sr)
         return self.frames2beats(beat_logits, downbeat_logits)
+
+    def many(self, signals, sr):
+        """Extension: [(beats, downbeats)] (seconds, float64 arrays as ``__call__`` returns them) for a list of waveforms
+        at sample rate ``sr``: every GPU stage is one launch for all tracks and the peak indices of all tracks come back in
+        one device-to-host copy (``Postprocessor.ragged``)."""
+        spect, frame_off = self.signal2spect_many(signals, sr)
+        beat, down = self.spect2frames_batch(spect, frame_off)
+        if self.frames2beats.type != "minimal":
+            return [self.frames2beats(beat[frame_off[k]: frame_off[k + 1]], down[frame_off[k]: frame_off[k + 1]])
+                    for k in range(len(signals))]
+        return self.frames2beats.ragged(beat, down, frame_off)
 
 
 class File2Beats(Audio2Beats):
@@ -223,15 +330,78 @@ class File2File(File2Beats):
 _RESAMPLE_FILTERS: dict = {}
 
 
+def _resample_filter(up: int, down: int, device):
+    from . import tables
+
+    key = (up, down, torch.device(device))
+    if key not in _RESAMPLE_FILTERS:
+        h, half = tables.resample_filter(up, down)
+        _RESAMPLE_FILTERS[key] = (torch.from_numpy(h.astype(np.float32)).to(device), half)
+    return _RESAMPLE_FILTERS[key]
+
+
+def batch_predict_aggregate(spect: torch.Tensor, frame_off, chunk_size: int, border_size: int, model):
+    """``split_predict_aggregate`` (keep_first) for several pieces stored back to back in ``spect`` (rows
+    ``frame_off[k]:frame_off[k+1]``): -> (beat, downbeat), concatenated like the input.  Pieces longer than
+    ``chunk_size - 2 border_size`` frames share one chunk table: their chunks are gathered slice by slice
+    (MAX_CHUNKS_PER_LAUNCH) straight into the model and aggregated by one launch; shorter pieces (one odd-length chunk
+    each) go through ``split_predict_aggregate`` one by one."""
+    _lib.require_gpu(spect, "spectrogram")
+    if spect.dim() != 2 or spect.shape[1] != 128:
+        raise ValueError(f"expected a (frames, 128) spectrogram, got {tuple(spect.shape)}")
+    spect = spect.to(torch.float32).contiguous()
+    dev = spect.device
+    frame_off = np.asarray(frame_off, dtype=np.int64)
+    total = int(frame_off[-1])
+    beat = torch.empty((total,), dtype=torch.float32, device=dev)
+    down = torch.empty((total,), dtype=torch.float32, device=dev)
+    rows, pieces = [], []
+    for k in range(len(frame_off) - 1):
+        lo, hi = int(frame_off[k]), int(frame_off[k + 1])
+        n = hi - lo
+        if n == 0:
+            continue
+        if n <= chunk_size - 2 * border_size:  # a single (n + 2 border)-frame chunk
+            r = split_predict_aggregate(spect[lo:hi], chunk_size, border_size, "keep_first", model)
+            beat[lo:hi], down[lo:hi] = r["beat"], r["downbeat"]
+            continue
+        c0 = len(rows)
+        rows += [(lo + int(st), lo, hi, 0) for st in chunk_starts(n, chunk_size, border_size)]
+        pieces.append((lo, hi, c0, len(rows)))
+    if not rows:
+        return beat, down
+    if total + chunk_size >= 2 ** 31:
+        raise ValueError("batch too long for 32-bit frame indices: split the track list")
+    B = len(rows)
+    tab = torch.from_numpy(np.concatenate([np.asarray(rows, dtype=np.int32).reshape(-1),
+                                           np.asarray(pieces, dtype=np.int32).reshape(-1)])).to(dev)
+    d_rows, d_pieces = tab[: 4 * B], tab[4 * B:]
+    cb = torch.empty((B, chunk_size), dtype=torch.float32, device=dev)
+    cd = torch.empty((B, chunk_size), dtype=torch.float32, device=dev)
+    lib, st = _lib.lib(), _lib.stream_ptr(dev)
+    step = MAX_CHUNKS_PER_LAUNCH
+    chunks = torch.empty((min(step, B), chunk_size, 128), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        for i in range(0, B, step):
+            nb = min(step, B - i)
+            _lib.check(lib.bt_split_chunks_batch(st, spect.data_ptr(), d_rows[4 * i:].data_ptr(), nb, chunk_size,
+                                                 chunks.data_ptr()))
+            r = model(chunks[:nb])
+            cb[i: i + nb], cd[i: i + nb] = r["beat"], r["downbeat"]
+        max_frames = max(hi - lo for lo, hi, _, _ in pieces)
+        _lib.check(lib.bt_aggregate_batch(st, cb.data_ptr(), cd.data_ptr(), d_rows.data_ptr(), d_pieces.data_ptr(),
+                                          len(pieces), max_frames, chunk_size, border_size, beat.data_ptr(),
+                                          down.data_ptr()))
+    return beat, down
+
+
 def resample_gpu(signal: torch.Tensor, in_rate: int, out_rate: int) -> torch.Tensor:
     """1-D fp32 device waveform at ``in_rate`` -> ``out_rate`` on the GPU (csrc/frontend.hip: resample_kernel), the
     MI355X replacement of the reference's host ``soxr.resample`` (inference.py:274-275).  Polyphase
-    Kaiser-windowed-sinc FIR with scipy.signal.resample_poly's filter design; like every non-libsoxr resampler it is
-    not bit-compatible with soxr: parity is defined from the 22.05 kHz waveform onwards."""
-    import ctypes as C
+    Kaiser-windowed-sinc FIR designed to libsoxr's HQ specification (tables.resample_filter: flat to 91.3 % of the lower
+    Nyquist frequency, 125 dB rejection from 100 %); like every non-libsoxr resampler it is not bit-compatible with soxr:
+    parity is defined from the 22.05 kHz waveform onwards."""
     from math import gcd
-
-    from . import tables
 
     _lib.require_gpu(signal, "waveform")
     if signal.dim() != 1:
@@ -241,11 +411,7 @@ def resample_gpu(signal: torch.Tensor, in_rate: int, out_rate: int) -> torch.Ten
     up, down = out_rate // g, in_rate // g
     if up == down:
         return signal
-    key = (up, down, signal.device)
-    if key not in _RESAMPLE_FILTERS:
-        h, half = tables.resample_filter(up, down)
-        _RESAMPLE_FILTERS[key] = (torch.from_numpy(h.astype(np.float32)).to(signal.device), half)
-    h, half = _RESAMPLE_FILTERS[key]
+    h, half = _resample_filter(up, down, signal.device)
     x = signal.to(torch.float32).contiguous()
     n_in = x.shape[0]
     n_out = -(-n_in * up // down)
@@ -254,20 +420,3 @@ def resample_gpu(signal: torch.Tensor, in_rate: int, out_rate: int) -> torch.Ten
         _lib.check(_lib.lib().bt_resample(_lib.stream_ptr(x.device), x.data_ptr(), n_in, up, down, h.data_ptr(), half,
                                           y.data_ptr(), n_out))
     return y
-
-
-def resample(signal: np.ndarray, in_rate: int, out_rate: int) -> np.ndarray:
-    """Host resampler for sr != 22050 (reference: soxr.resample, inference.py:274-275).
-    soxr (libsoxr) if installed, else a polyphase FIR (scipy).  Not bit-compatible with each
-    other: parity is defined from the 22.05 kHz waveform onwards."""
-    try:
-        import soxr
-
-        return soxr.resample(signal, in_rate=in_rate, out_rate=out_rate)
-    except ImportError:
-        from math import gcd
-
-        from scipy.signal import resample_poly
-
-        g = gcd(int(in_rate), int(out_rate))
-        return resample_poly(np.asarray(signal), int(out_rate) // g, int(in_rate) // g, axis=0)

@@ -83,6 +83,14 @@ class BeatThis(nn.Module):
         if x.dim() != 3:
             raise ValueError(f"expected (batch, time, {self.hparams['spect_dim']}) input, got {tuple(x.shape)}")
         _lib.require_gpu(x, "model input")
+        if x.shape[1] > 1536:
+            raise ValueError(
+                f"beat_this_amd.BeatThis.forward takes at most 1536 frames per item (got {x.shape[1]}): the kernels are "
+                "built for the reference's 1500-frame chunks.  Feed longer spectrograms through "
+                "beat_this_amd.inference.split_predict_aggregate / Spect2Frames, as the reference's inference classes do.")
+        if x.shape[0] == 0 or x.shape[1] == 0:
+            empty = torch.empty((x.shape[0], x.shape[1]), dtype=torch.float32, device=x.device)
+            return {"beat": empty, "downbeat": empty.clone()}
         half = torch.is_autocast_enabled("cuda") if hasattr(torch, "is_autocast_enabled") else False
         prec = _lib.PREC_F32 if not half else (_lib.PREC_FP8 if self.fp8_weights else _lib.PREC_BF16)
         beat, down = self.engine().forward(x, prec)

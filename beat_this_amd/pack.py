@@ -82,8 +82,13 @@ class PackedModel:
         D = int(hparams["transformer_dim"])
         L = int(hparams["n_layers"])
         if int(hparams.get("head_dim", 32)) != 32 or int(hparams.get("stem_dim", 32)) != 32 or \
-                int(hparams.get("spect_dim", 128)) != 128 or int(hparams.get("ff_mult", 4)) != 4:
-            raise ValueError("beat_this_amd kernels are built for head_dim=32, stem_dim=32, spect_dim=128, ff_mult=4")
+                int(hparams.get("spect_dim", 128)) != 128:
+            raise ValueError("beat_this_amd kernels are built for head_dim=32, stem_dim=32, spect_dim=128")
+        mult = int(hparams.get("ff_mult", 4))
+        if not 1 <= mult <= 16 or (mult * D) % 128:
+            raise ValueError(f"unsupported ff_mult={mult} for transformer_dim={D} (ff_mult * transformer_dim must be a "
+                             "multiple of 128)")
+        d.ff_mult = mult
         if L > _lib.MAX_LAYERS or D % 32:
             raise ValueError(f"unsupported transformer_dim={D} / n_layers={L}")
         d.transformer_dim, d.n_layers = D, L

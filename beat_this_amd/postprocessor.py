@@ -2,8 +2,11 @@
 (postprocessor.py:9-173).  "minimal": the peak mask (x == maxpool7(x) and x > 0) and the
 ordered index compaction run in one HIP kernel per call; the handful of surviving indices
 go to the host where deduplicate_peaks / nearest-beat snapping / unique run in C++
-(bt_postprocess_host, float64 like numpy).  No thread pool.  "dbn" defers to madmom exactly
-like the reference (not installed here; out of scope, SURVEY.md 2 #5)."""
+(bt_postprocess_host, float64 like numpy).  No thread pool.  Logits that live in host memory (the
+reference accepts CPU tensors, postprocessor.py:58-83) get the same peak mask from the library's host entry
+point (bt_peaks_host).  ``ragged`` (extension) post-processes many tracks stored back to back with one launch
+and one device-to-host copy.  "dbn" defers to madmom exactly like the reference (not installed here; out of
+scope, SURVEY.md 2 #5)."""
 from __future__ import annotations
 
 import ctypes as C
@@ -48,20 +51,27 @@ class Postprocessor:
         return (pb, pd) if batched else (pb[0], pd[0])
 
     def postp_minimal(self, beat, downbeat, padding_mask=None):
-        _lib.require_gpu(beat, "beat logits")
         B, T = beat.shape
         logits = torch.stack([beat, downbeat], 1).to(torch.float32)  # (B, 2, T)
         if padding_mask is not None:
             logits = logits.masked_fill(~padding_mask.bool().unsqueeze(1), -1000.0)
         logits = logits.contiguous()
-        idx = torch.empty((B * 2, T), dtype=torch.int32, device=beat.device)
-        cnt = torch.empty((B * 2,), dtype=torch.int32, device=beat.device)
-        with torch.cuda.device(beat.device):
-            _lib.check(_lib.lib().bt_peaks(_lib.stream_ptr(beat.device), logits.data_ptr(), T, B * 2, idx.data_ptr(),
-                                           cnt.data_ptr()))
-        cnt_h = cnt.cpu().numpy()
-        width = int(cnt_h.max()) if len(cnt_h) else 0
-        idx_h = idx[:, : max(width, 1)].cpu().numpy()
+        if not logits.is_cuda:  # host logits: the library's host peak mask, same definition
+            idx_h = np.zeros((B * 2, max(T, 1)), dtype=np.int32)
+            cnt_h = np.zeros(B * 2, dtype=np.int32)
+            flat = logits.view(B * 2, T).numpy()
+            for a in range(B * 2):
+                c = C.c_int32(0)
+                _lib.check(_lib.lib().bt_peaks_host(flat[a].ctypes.data, T, idx_h[a].ctypes.data, C.byref(c)))
+                cnt_h[a] = c.value
+        else:
+            # indices and counts travel in ONE buffer -> one device-to-host copy, one synchronisation
+            buf = torch.empty((B * 2 * T + B * 2,), dtype=torch.int32, device=beat.device)
+            with torch.cuda.device(beat.device):
+                _lib.check(_lib.lib().bt_peaks(_lib.stream_ptr(beat.device), logits.data_ptr(), T, B * 2, buf.data_ptr(),
+                                               buf[B * 2 * T:].data_ptr()))
+            host = buf.cpu().numpy()
+            cnt_h, idx_h = host[B * 2 * T:], host[: B * 2 * T].reshape(B * 2, T)
         out_b, out_d = [], []
         for b in range(B):
             frames_b = idx_h[2 * b, : cnt_h[2 * b]]
@@ -75,6 +85,36 @@ class Postprocessor:
             out_b.append(bt)
             out_d.append(dt)
         return tuple(out_b), tuple(out_d)
+
+    def ragged(self, beat: torch.Tensor, downbeat: torch.Tensor, frame_off):
+        """Extension: "minimal" post-processing of many tracks stored back to back (track k = frames
+        ``frame_off[k]:frame_off[k+1]`` of the 1-D ``beat`` / ``downbeat`` device tensors) -> [(beats, downbeats)]:
+        one peak-picking launch and one device-to-host copy for all tracks, then the C++ host step per track."""
+        assert self.type == "minimal"
+        _lib.require_gpu(beat, "beat logits")
+        frame_off = np.asarray(frame_off, dtype=np.int64)
+        n = len(frame_off) - 1
+        total = int(frame_off[-1])
+        if n == 0:
+            return []
+        dev = beat.device
+        logits = torch.cat([beat.reshape(-1).float(), downbeat.reshape(-1).float()])   # [2 * total]
+        lens = (frame_off[1:] - frame_off[:-1]).astype(np.int32)
+        spans = np.empty((2 * n, 2), dtype=np.int32)     # array 2 k = beat of track k, 2 k + 1 = its downbeat
+        spans[0::2, 0], spans[1::2, 0] = frame_off[:-1], total + frame_off[:-1]
+        spans[0::2, 1] = spans[1::2, 1] = lens
+        buf = torch.empty((2 * total + 2 * n,), dtype=torch.int32, device=dev)   # [indices | counts]
+        with torch.cuda.device(dev):
+            d_spans = torch.from_numpy(spans).to(dev)
+            _lib.check(_lib.lib().bt_peaks_batch(_lib.stream_ptr(dev), logits.data_ptr(), d_spans.data_ptr(), 2 * n,
+                                                 buf.data_ptr(), buf[2 * total:].data_ptr()))
+        host = buf.cpu().numpy()
+        cnt = host[2 * total:]
+        out = []
+        for k in range(n):
+            lo = int(frame_off[k])
+            out.append(_host_post(host[lo: lo + cnt[2 * k]], host[total + lo: total + lo + cnt[2 * k + 1]], self.fps))
+        return out
 
     def postp_dbn(self, beat, downbeat, padding_mask=None):
         if padding_mask is None:

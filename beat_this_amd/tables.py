@@ -67,14 +67,26 @@ def rope_table(freqs: torch.Tensor, n_pos: int = 1536) -> np.ndarray:
     return torch.stack((ang.cos(), ang.sin()), dim=-1).numpy().astype(np.float32)
 
 
+# Resampler design (replaces soxr.resample(..., quality="HQ") of inference.py:274-275; libsoxr itself is unavailable, so
+# this follows its published HQ specification rather than its code): linear phase, pass band flat up to 91.3 % of the
+# lower Nyquist frequency, stop band from 100 % of it (no aliasing into the pass band), >= 120 dB rejection (soxr HQ =
+# 20 bit).  Kaiser-windowed sinc: beta from the attenuation, length from the transition width (Kaiser's formulas).
+RESAMPLE_PASSBAND_END = 0.913
+RESAMPLE_ATTENUATION_DB = 125.0
+
+
 def resample_filter(up: int, down: int):
-    """(h float64 [2 half + 1], half): the low-pass of scipy.signal.resample_poly(x, up, down) with its default
-    window -- firwin(2 half + 1, 1 / max(up, down), window=("kaiser", 5.0)) * up, half = 10 max(up, down) --
-    restated with numpy only (sinc * symmetric Kaiser window, unit DC gain)."""
+    """(h float64 [2 half + 1], half): low-pass of the rational resampler x[up/down], designed at the upsampled rate
+    (in_rate * up): -6 dB point in the middle of the transition band [0.913, 1.0] x the lower Nyquist frequency,
+    Kaiser window for 125 dB, unit DC gain, multiplied by ``up`` (the interpolation gain)."""
     max_rate = max(up, down)
-    half = 10 * max_rate
+    att = RESAMPLE_ATTENUATION_DB
+    beta = 0.1102 * (att - 8.7)
+    width = (1.0 - RESAMPLE_PASSBAND_END) * 0.5 / max_rate            # transition width, cycles / sample (upsampled rate)
+    n_taps = int(math.ceil((att - 7.95) / (2.285 * 2.0 * math.pi * width))) + 1
+    half = (n_taps + 1) // 2
+    fc = 0.5 * (1.0 + RESAMPLE_PASSBAND_END) * 0.5 / max_rate          # -6 dB point, cycles / sample
     n = np.arange(-half, half + 1, dtype=np.float64)
-    fc = 1.0 / max_rate
-    h = fc * np.sinc(fc * n) * np.kaiser(2 * half + 1, 5.0)
+    h = 2.0 * fc * np.sinc(2.0 * fc * n) * np.kaiser(2 * half + 1, beta)
     h /= h.sum()
     return h * up, half

@@ -53,7 +53,7 @@ def state_dict_shapes(hp: dict) -> "OrderedDict[str, tuple]":
         out[p + "to_gates.bias"] = (h,)
         out[p + "to_out.0.weight"] = (dim, dim)
 
-    def ff(p, dim):
+    def ff(p, dim, mult=4):  # (the frontend's FeedForward(dim) is always mult = 4: beat_tracker.py:279,288)
         out[p + "net.0.gamma"] = (dim,)
         out[p + "net.1.weight"] = (mult * dim, dim)
         out[p + "net.1.bias"] = (mult * dim,)
@@ -78,7 +78,7 @@ def state_dict_shapes(hp: dict) -> "OrderedDict[str, tuple]":
     out["frontend.linear.bias"] = (D,)
     for l in range(L):
         attn(f"transformer_blocks.layers.{l}.0.", D)
-        ff(f"transformer_blocks.layers.{l}.1.", D)
+        ff(f"transformer_blocks.layers.{l}.1.", D, mult)
     out["transformer_blocks.norm.gamma"] = (D,)
     out["task_heads.beat_downbeat_lin.weight"] = (2, D)
     out["task_heads.beat_downbeat_lin.bias"] = (2,)

@@ -7,7 +7,8 @@
  * `stream` is a hipStream_t (torch.cuda.current_stream().cuda_stream).  No call
  * allocates device memory, synchronises the device, or starts threads.  Return
  * value: BT_OK or a negative BT_ERR_* code; bt_last_error() gives the text.
- * The library is reentrant per engine handle, not concurrently on one handle.
+ * The library is reentrant per engine handle, not concurrently on one handle; the caller's workspace belongs to ONE
+ * stream at a time (two streams running one engine need two workspaces).
  */
 #ifndef BEAT_THIS_AMD_H
 #define BEAT_THIS_AMD_H
@@ -100,6 +101,8 @@ typedef struct {
   const float* head_w; /* [2][D] task_heads weight * final RMSNorm gamma */
   float head_b[2];
   const float* rope;   /* [1536][16][2] cos/sin of pos * freqs (rotary-embedding-torch) */
+  int32_t ff_mult;     /* hidden width of the main layers' FeedForward = ff_mult * transformer_dim (the frontend's partial
+                        * transformers always use 4, beat_tracker.py:279,288) */
 } bt_model_desc;
 
 typedef struct {
@@ -140,6 +143,27 @@ int bt_aggregate(void* stream, const float* d_chunk_beat, const float* d_chunk_d
 int bt_logmel(void* stream, const bt_logmel_tables* tables, const float* d_audio, int64_t n_samples,
               float* d_spect);
 
+/* ---- several tracks per launch (the batch form of Audio2Beats.__call__, inference.py:269-303: one launch per stage for
+ * a whole list of tracks instead of a Python loop of per-track calls; same arithmetic as the single-track entry points).
+ * A DEVICE table of bt_span describes the tracks: input samples, their count, the offset of the track's output in the
+ * concatenated output buffer (samples for the resampler, spectrogram rows for the log-mel), and its output count. */
+typedef struct { const float* d_in; int64_t n_in; int64_t out_off; int64_t n_out; } bt_span;
+/* resample every track (all at the same up / down), max_n_out = the largest n_out */
+int bt_resample_batch(void* stream, const bt_span* d_tracks, int n_tracks, int64_t max_n_out, int up, int down,
+                      const float* d_filter, int half_len, float* d_out);
+/* log-mel of every track: n_out = 1 + n_in / 441 frames written at row out_off of d_spect; every n_in > 512 */
+int bt_logmel_batch(void* stream, const bt_logmel_tables* tables, const bt_span* d_tracks, int n_tracks,
+                    int64_t max_frames, float* d_spect);
+/* split_piece over the concatenated spectrogram: d_chunk_table [B][4] int32 = {first source row of the chunk (may lie
+ * before the piece), first row of its piece, end row of its piece, unused}, ABSOLUTE rows of d_spect; rows outside the
+ * piece read as zeros */
+int bt_split_chunks_batch(void* stream, const float* d_spect, const int32_t* d_chunk_table, int B, int T, float* d_chunks);
+/* keep_first aggregation of all pieces: d_pieces [n_pieces][4] int32 = {first frame, end frame (absolute, of the
+ * concatenated d_beat / d_downbeat), first chunk, end chunk}; chunk starts from d_chunk_table */
+int bt_aggregate_batch(void* stream, const float* d_chunk_beat, const float* d_chunk_downbeat, const int32_t* d_chunk_table,
+                       const int32_t* d_pieces, int n_pieces, int64_t max_frames, int T, int border, float* d_beat,
+                       float* d_downbeat);
+
 /* Audio2Frames.signal2spect's resampling step (inference.py:274-275, soxr.resample on the host in the reference):
  * rational polyphase FIR on the GPU, y[m] = sum_k x[k] h[m down + half_len - k up], d_filter = 2 half_len + 1 taps
  * (beat_this_amd/tables.py: resample_filter = up * firwin(.., 1/max(up,down), kaiser 5.0), scipy.signal.resample_poly's
@@ -150,6 +174,12 @@ int bt_resample(void* stream, const float* d_in, int64_t n_in, int up, int down,
 /* Postprocessor.postp_minimal peak mask (postprocessor.py:93-99) + nonzero (:119-120):
  * d_logits [n_arrays][n] -> d_idx [n_arrays][n] ascending frame indices, d_count [n_arrays]. */
 int bt_peaks(void* stream, const float* d_logits, int64_t n, int n_arrays, int32_t* d_idx, int32_t* d_count);
+/* ragged form: array a = d_logits + d_spans[2 a], d_spans[2 a + 1] frames; its indices are written at d_idx + d_spans[2 a] */
+int bt_peaks_batch(void* stream, const float* d_logits, const int32_t* d_spans, int n_arrays, int32_t* d_idx,
+                   int32_t* d_count);
+/* HOST: the same peak mask for logits in host memory (the reference's Postprocessor accepts CPU tensors,
+ * postprocessor.py:58-83); idx must hold n entries */
+int bt_peaks_host(const float* logits, int64_t n, int32_t* idx, int32_t* count);
 
 /* HOST: deduplicate_peaks(width=1) (postprocessor.py:176-197), frame/fps, snap every
  * downbeat to the nearest beat, np.unique (postprocessor.py:121-136).  Output buffers
@@ -158,8 +188,8 @@ int bt_postprocess_host(const int32_t* beat_idx, int n_beat_idx, const int32_t* 
                         double fps, double* beats, int32_t* n_beats, double* downbeats, int32_t* n_downbeats);
 
 /* Per-launch timing of bt_forward with HIP events recorded on the caller's stream (bench.py's
- * roofline leg).  bt_profile_begin() arms it; every bt_forward until bt_profile_end() records one
- * event pair per kernel launch; bt_profile_end() synchronises on the events and returns summed
+ * roofline leg); per engine handle.  bt_profile_begin(e) arms it; every bt_forward(e, ...) until bt_profile_end(e, ...)
+ * records one event pair per kernel launch; bt_profile_end() synchronises on the events and returns summed
  * milliseconds and launch counts per category (index = BT_CAT_*). */
 #define BT_CAT_STEM 0
 #define BT_CAT_QKV_GEMM 1
@@ -174,8 +204,8 @@ int bt_postprocess_host(const int32_t* beat_idx, int n_beat_idx, const int32_t* 
 #define BT_CAT_FF_FUSED 10        /* ff_fused_kernel (frontend FF blocks) */
 #define BT_CAT_ATTN_FREQ_FUSED 11 /* attn_freq_fused_kernel (QKV + attention + out-proj) */
 #define BT_PROFILE_CATEGORIES 12
-void bt_profile_begin(void);
-int bt_profile_end(double* ms_by_category, int32_t* launches_by_category, int n_categories);
+void bt_profile_begin(bt_engine* e);
+int bt_profile_end(bt_engine* e, double* ms_by_category, int32_t* launches_by_category, int n_categories);
 
 /* Single-operator entry points (used by the parity tests; same kernels bt_forward launches). */
 typedef struct {

@@ -91,6 +91,36 @@ def test_package_fails_loudly_without_gpu():
         BeatThis()(torch.zeros(1, 50, 128))
     with pytest.raises(RuntimeError):
         LogMelSpect()(torch.zeros(4000))
-    s2f = Spect2Frames(checkpoint_path=None, device="cpu")
-    with pytest.raises(RuntimeError):
-        s2f(torch.zeros(100, 128))
+    with pytest.raises(RuntimeError, match="no CPU implementation"):
+        Spect2Frames(checkpoint_path=None, device="cpu")  # refused in __init__, not at the first call
+
+
+def test_host_peak_mask_and_cpu_logits_postprocessor():
+    """Postprocessor on CPU logits (the reference accepts them, postprocessor.py:58-83): bt_peaks_host + bt_postprocess_host
+    through the C ABI, bit-exact against the oracle and the reference's golden edge cases."""
+    from beat_this_amd.postprocessor import Postprocessor
+
+    post = json.load(open(os.path.join(GOLDEN, "postp_minimal.json")))
+    pp = Postprocessor("minimal", fps=50)
+    for name, (bs, ds) in POSTP_CASES.items():
+        b = torch.full((100,), -5.0)
+        d = torch.full((100,), -5.0)
+        for f, v in bs:
+            b[f] = v
+        for f, v in ds:
+            d[f] = v
+        bt, dt = pp(b, d)
+        assert bt.tolist() == post[name]["beats"] and dt.tolist() == post[name]["downbeats"], name
+    rng = np.random.default_rng(post["random3000"]["seed"])
+    rb = torch.from_numpy(rng.normal(-1.0, 1.5, 3000).astype(np.float32))
+    rd = torch.from_numpy(rng.normal(-2.0, 1.5, 3000).astype(np.float32))
+    bt, dt = pp(rb, rd)
+    assert bt.tolist() == post["random3000"]["beats"] and dt.tolist() == post["random3000"]["downbeats"]
+    bb, dd = pp(torch.stack([rb, rb]), torch.stack([rd, rd]))
+    assert isinstance(bb, tuple) and bb[1].tolist() == post["random3000"]["beats"]
+    # padding mask path (postprocessor.py:100-104,119-120)
+    mask = torch.ones(3000, dtype=torch.bool)
+    mask[2500:] = False
+    mb, md = pp(rb, rd, mask)
+    ob, od = O.postp_minimal(rb[:2500].clone().masked_fill(~mask[:2500], -1000.0), rd[:2500])
+    assert np.array_equal(mb, ob) and np.array_equal(md, od)

@@ -3,6 +3,7 @@
 #   tools/ab.sh tools/bin/lib_a.so [tools/bin/lib_b.so ...]     (the in-tree build is always the last candidate)     [extra bench args via AB_ARGS]
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $R
+export BT_DEV=1
 for i in 1 2 3; do
   for l in "$@" ""; do
     if [ -n "$l" ]; then export BT_LIB_PATH=$R/$l; else unset BT_LIB_PATH; fi
