@@ -22,3 +22,42 @@ POSTP_CASES = {
     "edges": ([(0, 1.0), (99, 1.0)], [(0, 2.0), (99, 0.5)]),
     "dense": ([(i, 1.0 + 0.01 * (i % 7)) for i in range(3, 97, 2)], [(i, 1.0) for i in range(5, 95, 9)]),
 }
+
+
+# ---- fixtures regenerated from seeds on both sides (generator: oracle/make_golden.py, consumers: tests/) --------------------
+AUTOCAST_CASES = ["small0_lively_T1500", "small0_lively_T1012", "final0_lively_T1500"]  # names of MODEL_CASES
+CLI_CASE = dict(hparams="small0", weight_seed=1, style="lively", seconds=41.0, audio_seed=17, sr=22050)
+
+
+def lightning_checkpoint(hp_name, seed, style, compiled=False):
+    """A checkpoint dict in the layout the reference's training writes and ``load_checkpoint`` / ``load_model`` read
+    (inference.py:16-87, launch_scripts/clean_checkpoints.py:18-28): ``state_dict`` keys prefixed ``model.`` (plus
+    ``_orig_mod.`` when the module was torch.compile'd, beat_tracker.py:194-203), ``hyper_parameters`` holding the model's
+    constructor arguments next to training-only entries, and Lightning bookkeeping."""
+    from beat_this_amd import weights as W
+
+    hp = W.resolve_hparams(hp_name)
+    sd = W.random_state_dict(hp, seed=seed, style=style)
+    prefix = "model._orig_mod." if compiled else "model."
+    hyper = {k: hp[k] for k in ("spect_dim", "transformer_dim", "ff_mult", "n_layers", "head_dim", "stem_dim")}
+    hyper.update(dropout={"frontend": 0.1, "transformer": 0.2}, sum_head=True, partial_transformers=True,
+                 lr=0.0008, weight_decay=0.01, pos_weights={"beat": 1, "downbeat": 1}, max_epochs=100,
+                 use_dbn=False, eval_trim_beats=5, fps=50, loss_type="shift_tolerant_weighted_bce", warmup_steps=1000)
+    return {"epoch": 99, "global_step": 123456, "pytorch-lightning_version": "2.1.3",
+            "state_dict": {prefix + k: v for k, v in sd.items()}, "hyper_parameters": hyper,
+            "datamodule_hyper_parameters": {"batch_size": 8, "train_length": 1500}}
+
+
+def pcm16_wav(path, seconds, seed, sr=22050, channels=1):
+    """Write the seeded synthetic click-track (beat_this_amd.weights.synthetic_audio) as 16-bit PCM; returns the int16 data."""
+    import numpy as np
+    from scipy.io import wavfile
+
+    from beat_this_amd import weights as W
+
+    x = W.synthetic_audio(seconds, seed=seed, sr=sr)
+    pcm = np.clip(np.round(x / 2.5 * 32767.0), -32768, 32767).astype(np.int16)
+    if channels == 2:
+        pcm = np.stack([pcm, (pcm // 2).astype(np.int16)], 1)
+    wavfile.write(str(path), sr, pcm)
+    return pcm

@@ -28,7 +28,7 @@ from beat_this.model.postprocessor import Postprocessor  # noqa: E402
 from beat_this.preprocessing import LogMelSpect  # noqa: E402
 
 from beat_this_amd import weights as W  # noqa: E402
-from oracle.cases import MODEL_CASES, POSTP_CASES  # noqa: E402
+from oracle.cases import AUTOCAST_CASES, CLI_CASE, MODEL_CASES, POSTP_CASES, lightning_checkpoint, pcm16_wav  # noqa: E402
 
 OUT = os.path.join(ROOT, "tests", "golden")
 MODEL_KEYS = ("spect_dim", "transformer_dim", "ff_mult", "n_layers", "head_dim", "stem_dim")
@@ -120,6 +120,59 @@ def main():
     np.savez_compressed(os.path.join(OUT, "e2e_small0.npz"), beats=beats, downbeats=downbeats,
                         beat_logits=bl.numpy(), downbeat_logits=dl.numpy())
     print("e2e beats", len(beats), "downbeats", len(downbeats))
+
+    # 7. the reference's OWN reduced-precision path on the same inputs: BeatThis.forward under torch.autocast, which is what
+    # Spect2Frames(float16=True) enters (inference.py:245-246): bfloat16 is what that gives on a CPU device, float16 what it
+    # gives on a GPU (cli.py:82).  Logits + the reference's own error / beat flips against its fp32 forward: the yardstick
+    # for our half-precision path.
+    auto = {}
+    report = {}
+    for name, hpn, wseed, style, T, iseed in MODEL_CASES:
+        if name not in AUTOCAST_CASES:
+            continue
+        m = reference_model(hpn, wseed, style)
+        x = torch.from_numpy(W.synthetic_spect(T, seed=iseed))[None]
+        with torch.inference_mode():
+            r = m(x)
+            rb, rd = pp(r["beat"][0], r["downbeat"][0])
+            for tag, dt in (("bf16", torch.bfloat16), ("f16", torch.float16)):
+                with torch.autocast("cpu", dtype=dt):
+                    a = m(x)
+                ab_, ad_ = a["beat"][0].float(), a["downbeat"][0].float()
+                auto[f"{name}_{tag}_beat"] = ab_.numpy()
+                auto[f"{name}_{tag}_downbeat"] = ad_.numpy()
+                bt, dt_ = pp(ab_, ad_)
+                report[f"{name}_{tag}"] = {
+                    "max_abs_beat": float((ab_ - r["beat"][0]).abs().max()),
+                    "max_abs_downbeat": float((ad_ - r["downbeat"][0]).abs().max()),
+                    "rms_beat": float((ab_ - r["beat"][0]).pow(2).mean().sqrt()),
+                    "flips_beat": len(set(np.round(bt * 50, 1)) ^ set(np.round(rb * 50, 1))),
+                    "flips_downbeat": len(set(np.round(dt_ * 50, 1)) ^ set(np.round(rd * 50, 1))),
+                    "n_beats_fp32": len(rb), "n_downbeats_fp32": len(rd)}
+                print(name, tag, report[f"{name}_{tag}"])
+    np.savez_compressed(os.path.join(OUT, "model_logits_autocast.npz"), **auto)
+    json.dump(report, open(os.path.join(OUT, "reference_autocast_report.json"), "w"), indent=1)
+
+    # 8. the reference's command line (cli.py:114-191) on a PCM WAV with a Lightning-layout checkpoint FILE
+    # (inference.py:16-87): the .beats TSV (utils.py:79-102) and the --activations .npy it writes
+    import tempfile
+
+    from beat_this import cli as ref_cli
+
+    with tempfile.TemporaryDirectory() as tmp:
+        ck = os.path.join(tmp, "cli_case.ckpt")
+        torch.save(lightning_checkpoint(CLI_CASE["hparams"], CLI_CASE["weight_seed"], CLI_CASE["style"]), ck)
+        wav = os.path.join(tmp, "clicks.wav")
+        pcm16_wav(wav, CLI_CASE["seconds"], CLI_CASE["audio_seed"], CLI_CASE["sr"])
+        out = os.path.join(tmp, "out", "clicks.beats")
+        os.makedirs(os.path.dirname(out))
+        ref_cli.run(inputs=[wav], model=ck, output=out, suffix=".beats", append=False, skip_existing=False,
+                    touch_first=False, dbn=False, gpu=-1, float16=False, activations=True)
+        text = open(out).read()
+        act = np.load(out[: -len(".beats")] + ".npy")
+    open(os.path.join(OUT, "cli_small0.beats"), "w").write(text)
+    np.savez_compressed(os.path.join(OUT, "cli_small0_activations.npz"), activations=act)
+    print("cli:", len(text.splitlines()), "beat lines, activations", act.shape)
 
 
 if __name__ == "__main__":
