@@ -96,6 +96,7 @@ G3_FF1, G3_RESID, G3_QKV = 0, 1, 2
 EXPORTS = {
     "bt_last_error": (C.c_char_p, []),
     "bt_version": (C.c_int, []),
+    "bt_half_is_bf16": (C.c_int, []),
     "bt_struct_sizes": (None, [C.POINTER(C.c_int32)]),
     "bt_engine_create": (C.c_int, [C.POINTER(ModelDesc), C.POINTER(C.c_void_p)]),
     "bt_engine_destroy": (None, [C.c_void_p]),
@@ -208,6 +209,15 @@ def lib():
             fn.argtypes = args
         _lib = handle
     return _lib
+
+
+def half_dtype_name() -> str:
+    """Operand type of the half-precision path this library was built with ("f16" or "bf16")."""
+    return "bf16" if lib().bt_half_is_bf16() else "f16"
+
+
+def half_torch_dtype():
+    return torch.bfloat16 if lib().bt_half_is_bf16() else torch.float16
 
 
 def check(rc: int) -> None:

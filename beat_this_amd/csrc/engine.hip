@@ -262,7 +262,8 @@ int run_pair(prof::State* pf, const bt_pair_weights& pw, const float* rope, floa
 extern "C" {
 
 const char* bt_last_error(void) { return g_err.c_str(); }
-int bt_version(void) { return 100; }
+int bt_version(void) { return 200; }
+int bt_half_is_bf16(void) { return 1; }
 void bt_struct_sizes(int32_t* out) {
   out[0] = (int32_t)sizeof(bt_pair_weights); out[1] = (int32_t)sizeof(bt_model_desc);
   out[2] = (int32_t)sizeof(bt_logmel_tables); out[3] = (int32_t)sizeof(bt_gemm_args);

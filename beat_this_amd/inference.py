@@ -30,7 +30,7 @@ from .preprocessing import LogMelSpect, load_audio
 from .utils import replace_state_dict_key, save_beat_tsv
 
 CHECKPOINT_URL = "https://cloud.cp.jku.at/public.php/dav/files/7ik4RrBKTS273gp"
-MAX_CHUNKS_PER_LAUNCH = 64  # workspace is ~70 MB (fp32) per chunk; larger batches are split
+MAX_CHUNKS_PER_LAUNCH = 96  # workspace is ~70 MB (fp32) / ~45 MB (half) per chunk; larger batches are split into equal slices
 
 
 def load_checkpoint(checkpoint_path, device="cpu") -> dict:
@@ -127,8 +127,10 @@ def _gather_chunks(spect: torch.Tensor, starts: np.ndarray, T: int):
 
 
 def _run_batched(model, chunks: torch.Tensor):
-    """model over (B,T,128) in slices of MAX_CHUNKS_PER_LAUNCH -> beat, downbeat (B,T)."""
-    outs = [model(chunks[i: i + MAX_CHUNKS_PER_LAUNCH]) for i in range(0, chunks.shape[0], MAX_CHUNKS_PER_LAUNCH)]
+    """model over (B,T,128) in equal slices of at most MAX_CHUNKS_PER_LAUNCH -> beat, downbeat (B,T)."""
+    B = chunks.shape[0]
+    step = -(-B // max(1, -(-B // MAX_CHUNKS_PER_LAUNCH)))
+    outs = [model(chunks[i: i + step]) for i in range(0, B, step)]
     if len(outs) == 1:
         return outs[0]["beat"], outs[0]["downbeat"]
     return torch.cat([o["beat"] for o in outs]), torch.cat([o["downbeat"] for o in outs])
@@ -307,12 +309,23 @@ class Audio2Beats(Audio2Frames):
         """Extension: [(beats, downbeats)] (seconds, float64 arrays as ``__call__`` returns them) for a list of waveforms
         at sample rate ``sr``: every GPU stage is one launch for all tracks and the peak indices of all tracks come back in
         one device-to-host copy (``Postprocessor.ragged``)."""
+        return self.many_async(signals, sr).result()
+
+    def many_async(self, signals, sr):
+        """``many`` without the final wait: all GPU work and the device-to-host copy of the peak indices are enqueued;
+        ``.result()`` of the returned handle waits for the copy and runs the host step.  Submitting batch i + 1 before
+        collecting batch i keeps the GPU busy during the host step (bench.py does)."""
         spect, frame_off = self.signal2spect_many(signals, sr)
         beat, down = self.spect2frames_batch(spect, frame_off)
         if self.frames2beats.type != "minimal":
-            return [self.frames2beats(beat[frame_off[k]: frame_off[k + 1]], down[frame_off[k]: frame_off[k + 1]])
-                    for k in range(len(signals))]
-        return self.frames2beats.ragged(beat, down, frame_off)
+            class _Done:  # the DBN runs on the host right away (madmom)
+                def __init__(s, out): s.out = out
+                def result(s): return s.out
+            return _Done([self.frames2beats(beat[frame_off[k]: frame_off[k + 1]], down[frame_off[k]: frame_off[k + 1]])
+                          for k in range(len(signals))])
+        pending = self.frames2beats.ragged_async(beat, down, frame_off)
+        pending.logits = (beat, down, frame_off)   # framewise logits of the batch (concatenated), for callers that want them
+        return pending
 
 
 class File2Beats(Audio2Beats):
@@ -379,8 +392,9 @@ def batch_predict_aggregate(spect: torch.Tensor, frame_off, chunk_size: int, bor
     cb = torch.empty((B, chunk_size), dtype=torch.float32, device=dev)
     cd = torch.empty((B, chunk_size), dtype=torch.float32, device=dev)
     lib, st = _lib.lib(), _lib.stream_ptr(dev)
-    step = MAX_CHUNKS_PER_LAUNCH
-    chunks = torch.empty((min(step, B), chunk_size, 128), dtype=torch.float32, device=dev)
+    n_slices = -(-B // MAX_CHUNKS_PER_LAUNCH)
+    step = -(-B // n_slices)                 # equal slices (66 chunks -> 33 + 33, not 64 + 2)
+    chunks = torch.empty((step, chunk_size, 128), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
         for i in range(0, B, step):
             nb = min(step, B - i)

@@ -96,3 +96,52 @@ def forward_chunks_sharded(model, spects, chunk_size=1500, border=6, group=None,
                 results[i] = aggregate(seg[:, 0].contiguous(), seg[:, 1].contiguous(), starts, T, border, n)
                 pos += len(starts)
     return results
+
+
+def track_frames(n_samples: int, sr: int) -> int:
+    """Spectrogram rows of an ``n_samples`` track at sample rate ``sr`` (resampled to 22.05 kHz, hop 441, centred)."""
+    from math import gcd
+
+    g = gcd(int(sr), 22050)
+    up, down = 22050 // g, int(sr) // g
+    n22 = n_samples if up == down else -(-n_samples * up // down)
+    return 1 + n22 // 441
+
+
+def audio2frames_sharded(signals, sr, frames_fn, group=None, device=None):
+    """Track-level sharding of ``Audio2Frames.many`` (README.md:53-56 runs N independent CLI processes over a file set; this
+    is the in-process form): every rank holds the same list of waveforms, computes the block ``partition`` gives it with
+    ``frames_fn(sub_list) -> (beat_cat, downbeat_cat, frame_off)`` (e.g. ``lambda s: a2f.spect2frames_batch(
+    *a2f.signal2spect_many(s, sr))`` plus the offsets), and ONE ``all_gather_into_tensor`` of the zero-padded framewise
+    logits (2 x frames fp32 per rank: 120 KB per 5-minute track) returns every track's logits to every rank.
+    -> [(beat, downbeat)] in the order of ``signals``."""
+    distributed = dist.is_available() and dist.is_initialized()
+    world = dist.get_world_size(group) if distributed else 1
+    rank = dist.get_rank(group) if distributed else 0
+    n = len(signals)
+    frames = [track_frames(s.shape[0], sr) for s in signals]
+    lo, hi, per = partition(n, world, rank)
+    blocks = [partition(n, world, r)[:2] for r in range(world)]
+    width = max([sum(frames[a:b]) for a, b in blocks] + [1])
+    mine = signals[lo:hi]
+    if mine:
+        beat, down, off = frames_fn(mine)
+        dev = beat.device
+    else:
+        dev = torch.device(device) if device is not None else torch.device("cpu")
+        beat = down = torch.zeros(0, device=dev)
+    local = torch.zeros((2, width), dtype=torch.float32, device=dev)
+    local[0, : beat.shape[0]], local[1, : down.shape[0]] = beat.float(), down.float()
+    if world > 1:
+        full = torch.empty((world * 2, width), dtype=torch.float32, device=dev)  # (concatenation along dim 0)
+        dist.all_gather_into_tensor(full, local, group=group)
+        full = full.view(world, 2, width)
+    else:
+        full = local[None]
+    out = []
+    for r, (a, b) in enumerate(blocks):
+        pos = 0
+        for k in range(a, b):
+            out.append((full[r, 0, pos: pos + frames[k]], full[r, 1, pos: pos + frames[k]]))
+            pos += frames[k]
+    return out

@@ -28,6 +28,34 @@ def _host_post(bidx: np.ndarray, didx: np.ndarray, fps: float):
     return beats[: nb.value].copy(), downs[: nd.value].copy()
 
 
+class PendingBeats:
+    """Handle of an enqueued ``Postprocessor.ragged_async`` call; ``result()`` -> [(beats, downbeats)] per track."""
+
+    def __init__(self, host, done, frame_off, total, fps, owner=None, keep=None):
+        self._host, self._done, self._frame_off, self._total, self._fps = host, done, frame_off, total, fps
+        self._owner, self._keep, self._out = owner, keep, None
+
+    def result(self):
+        if self._out is not None:
+            return self._out
+        n = len(self._frame_off) - 1
+        if self._host is None:
+            self._out = [(np.zeros(0), np.zeros(0)) for _ in range(n)]
+            return self._out
+        self._done.synchronize()
+        host, total = self._host.numpy(), self._total
+        cnt = host[2 * total:]
+        out = []
+        for k in range(n):
+            lo = int(self._frame_off[k])
+            out.append(_host_post(host[lo: lo + cnt[2 * k]], host[total + lo: total + lo + cnt[2 * k + 1]], self._fps))
+        if self._owner is not None:  # hand the pinned buffer back
+            self._owner.__dict__.setdefault("_pin_pool", []).append(self._host._base if self._host._base is not None else self._host)
+        self._host = self._keep = None
+        self._out = out
+        return out
+
+
 class Postprocessor:
     def __init__(self, type: str = "minimal", fps: int = 50):
         assert type in ["minimal", "dbn"]
@@ -90,31 +118,44 @@ class Postprocessor:
         """Extension: "minimal" post-processing of many tracks stored back to back (track k = frames
         ``frame_off[k]:frame_off[k+1]`` of the 1-D ``beat`` / ``downbeat`` device tensors) -> [(beats, downbeats)]:
         one peak-picking launch and one device-to-host copy for all tracks, then the C++ host step per track."""
+        return self.ragged_async(beat, downbeat, frame_off).result()
+
+    def ragged_async(self, beat: torch.Tensor, downbeat: torch.Tensor, frame_off) -> "PendingBeats":
+        """``ragged`` split in two: everything up to the (asynchronous, pinned-memory) device-to-host copy is enqueued
+        now; ``.result()`` waits for that copy and runs the host step.  A caller with several batches enqueues batch
+        i + 1 before collecting batch i, so the GPU never idles during the host step."""
         assert self.type == "minimal"
         _lib.require_gpu(beat, "beat logits")
         frame_off = np.asarray(frame_off, dtype=np.int64)
         n = len(frame_off) - 1
         total = int(frame_off[-1])
-        if n == 0:
-            return []
+        if n == 0 or total == 0:
+            return PendingBeats(None, None, frame_off, 0, self.fps)
         dev = beat.device
         logits = torch.cat([beat.reshape(-1).float(), downbeat.reshape(-1).float()])   # [2 * total]
         lens = (frame_off[1:] - frame_off[:-1]).astype(np.int32)
         spans = np.empty((2 * n, 2), dtype=np.int32)     # array 2 k = beat of track k, 2 k + 1 = its downbeat
         spans[0::2, 0], spans[1::2, 0] = frame_off[:-1], total + frame_off[:-1]
         spans[0::2, 1] = spans[1::2, 1] = lens
-        buf = torch.empty((2 * total + 2 * n,), dtype=torch.int32, device=dev)   # [indices | counts]
+        size = 2 * total + 2 * n
+        buf = torch.empty((size,), dtype=torch.int32, device=dev)   # [indices | counts]
         with torch.cuda.device(dev):
             d_spans = torch.from_numpy(spans).to(dev)
             _lib.check(_lib.lib().bt_peaks_batch(_lib.stream_ptr(dev), logits.data_ptr(), d_spans.data_ptr(), 2 * n,
                                                  buf.data_ptr(), buf[2 * total:].data_ptr()))
-        host = buf.cpu().numpy()
-        cnt = host[2 * total:]
-        out = []
-        for k in range(n):
-            lo = int(frame_off[k])
-            out.append(_host_post(host[lo: lo + cnt[2 * k]], host[total + lo: total + lo + cnt[2 * k + 1]], self.fps))
-        return out
+            host = self._pinned(size)
+            host[:size].copy_(buf, non_blocking=True)
+            done = torch.cuda.Event()
+            done.record(torch.cuda.current_stream(dev))
+        return PendingBeats(host[:size], done, frame_off, total, self.fps, owner=self, keep=(buf, logits, d_spans))
+
+    def _pinned(self, size: int) -> torch.Tensor:
+        """A pinned host buffer of at least ``size`` int32 (pool of returned buffers: page-locking costs ~a millisecond)."""
+        pool = self.__dict__.setdefault("_pin_pool", [])
+        for i, t in enumerate(pool):
+            if t.numel() >= size:
+                return pool.pop(i)
+        return torch.empty((max(size, 1 << 16),), dtype=torch.int32, pin_memory=True)
 
     def postp_dbn(self, beat, downbeat, padding_mask=None):
         if padding_mask is None:

@@ -1,45 +1,54 @@
 #!/usr/bin/env python
-"""Benchmark of the beat_this inference hot path on MI355X (driver contract, see DESIGN.md 6).
+"""Benchmark of the beat_this inference hot path on MI355X (driver contract, DESIGN.md section 6).
 
-    python bench.py --gpus N --steps K --warmup W
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py --gpus N --steps K --warmup W        (N > 1 re-launches itself under torch.distributed.run)
 
-Workload (BASELINE.json configs[1]): final0-shaped BeatThis, bf16 MFMA operands / fp32
-accumulate, a batch of 16 synthetic 30 s chunks (1500 frames x 128 mels) PER GPU through
-BeatThis.forward -- the model invocation of the Spect2Frames path -- with the inputs resident
-in HBM.  One step = one such batch on every rank; for N > 1 the per-chunk logits are
-all-gathered (RCCL) inside the step, so every rank ends with all logits (weak scaling).
-value = N * 16 * 30 audio-seconds / step time (max over ranks).
+Headline workload = BASELINE.json's metric: final0-shaped BeatThis, 5-minute (300 s) synthetic 44.1 kHz mono tracks
+through ``Audio2Beats`` -- GPU resampler -> log-mel -> chunk gather -> BeatThis.forward (half-precision MFMA operands,
+fp32 accumulate) -> keep_first aggregation -> peak picking -> device-to-host copy of the peak indices -> C++ host
+post-processing -- audio in, beat / downbeat times out.  One step = one batch of TRACKS_PER_GPU = 6 tracks (66 chunks of
+1500 frames; BASELINE config 4's per-GPU share is 64) on every rank, waveforms resident in HBM when the timed region
+starts; step i + 1 is enqueued before the host part of step i is collected (Audio2Beats.many_async).  For N > 1 every
+rank processes its own tracks and the framewise logits are all-gathered (RCCL) inside the step -- weak scaling.
+value = N * 6 * 300 audio-seconds / step time (max over ranks).
 
 Extra objects on the JSON line:
-  roofline      dominant launch category (attention: attn_frag_kernel, MFMA bound): algorithmic FLOP of
-                its launches in one forward / their summed duration, HIP events on the launch stream
-                (a separate profiled pass of the same workload after the timed region).
-  cpu_baseline  the CPU oracle (torch fp32 restatement of the reference, kind "port") timed on
-                this host on a bounded sample (a few single-chunk forwards), rank 0, N = 1 only.
+  parity        GPU logits / beats of track 0 against the CPU oracle run on the same waveform (the run cpu_baseline times):
+                max |logit difference|, beat / downbeat frame flips.
+  roofline      dominant launch category of the forward (attention, MFMA bound): algorithmic FLOP per launch / average
+                launch duration from HIP events on the launch stream (bt_profile_*, a profiled pass of the same workload
+                right after the timed region); traffic = HBM bytes per launch from the committed PMC passes (labelled).
+  frontend      the HBM-bound stages (resample, log-mel, chunk gather, aggregation, peak picking): ms per step and GB/s of
+                ALGORITHMIC bytes (3.41 MB per chunk for the log-mel).
+  forward_only  BASELINE config 2 (16 chunks through BeatThis.forward, spectrograms resident), for continuity with round 1.
+  fp32_path     the same headline workload on the exact-fp32 MFMA path (the one under the 1e-3 gate), fewer steps.
+  cpu_baseline  the CPU oracle's Audio2Beats (torch fp32, SDPA attention like the reference) on ONE 300 s track on this
+                host, thread count probed and stated (rank 0, N = 1 only).
 """
 import argparse
 import ctypes as C
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
-
 CHUNK_FRAMES = 1500
-CHUNK_SECONDS = 30.0
-PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3, "fp8": 5000.0}  # MI355X_MICROARCH.md: dense MFMA peaks
+FRESH_SECONDS_PER_CHUNK = 29.76   # 1488 fresh frames at 50 fps
+TRACK_SECONDS = 300.0
+TRACK_SR = 44100
+TRACKS_PER_GPU = 6
+PEAK_TFLOPS = {"half": 2500.0, "f32": 157.3, "fp8": 5000.0}  # MI355X_MICROARCH.md: dense MFMA peaks
+PEAK_HBM_GBS = 8000.0
 
 
-def flops_per_chunk(D: int, T: int = CHUNK_FRAMES):
+def flops_per_chunk(D: int, T: int = CHUNK_FRAMES, ff_mult: int = 4):
     """Algorithmic MACs*2 per chunk, by launch category of csrc/engine.hip (recomputed;
-    the sum is the 134.71 GFLOP / chunk of SURVEY.md section 8d for final0).  bf16 path:
+    the sum is the 134.71 GFLOP / chunk of SURVEY.md section 8d for final0).  Half path:
       attn_freq_fused = attnff_fused_kernel   frequency direction: QKV+gates, attention, out-proj AND its FF
       ff_fused        = outff_fused_kernel    time direction: out-proj and its FF
       qkv_gemm        = gemm3 QKV (main layers) + qkv_front_kernel (time-direction QKV of the frontend)
@@ -63,30 +72,53 @@ def flops_per_chunk(D: int, T: int = CHUNK_FRAMES):
     for _ in range(6):
         cat["qkv_gemm"] += 2 * T * D * (3 * D + H)
         cat["out_gemm"] += 2 * T * D * D
-        cat["ff1_gemm"] += 2 * T * D * 4 * D
-        cat["ff2_gemm"] += 2 * T * D * 4 * D
+        cat["ff1_gemm"] += 2 * T * D * ff_mult * D
+        cat["ff2_gemm"] += 2 * T * D * ff_mult * D
         cat["attn_flash"] += 2 * 2 * H * T * T * 32
     return cat
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--model", default="final0")
-    ap.add_argument("--prec", default="bf16", choices=["bf16", "f32", "fp8"],
-                    help="fp8 = BT_PREC_FP8: bf16 path with the main layers' feed-forward GEMMs on e4m3 (BASELINE config 5)")
-    ap.add_argument("--chunks", type=int, default=16, help="chunks per GPU per step")
+    ap.add_argument("--prec", default="half", choices=["half", "f32", "fp8"],
+                    help="half = half-precision MFMA operands (float16=True of the Python API); fp8 = EXPERIMENTAL: half path "
+                         "with the main layers' feed-forward GEMMs on e4m3 (BASELINE config 5)")
+    ap.add_argument("--tracks", type=int, default=TRACKS_PER_GPU, help="5-minute tracks per GPU per step")
+    ap.add_argument("--workload", default="tracks", choices=["tracks", "forward"],
+                    help="tracks = Audio2Beats on 300 s 44.1 kHz tracks (BASELINE metric); forward = BeatThis.forward on "
+                         "--chunks resident spectrogram chunks (BASELINE configs 2 / 3 / 5)")
+    ap.add_argument("--chunks", type=int, default=16, help="--workload forward: chunks per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the forward_only / fp32_path / frontend legs")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # self-launch: one process per GPU under torch.distributed.run (RCCL rendezvous on 127.0.0.1)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__), *sys.argv[1:]]
+        raise SystemExit(subprocess.run(cmd).returncode)
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
@@ -95,45 +127,94 @@ def main():
 
     from beat_this_amd import _lib
     from beat_this_amd import weights as W
+    from beat_this_amd.inference import Audio2Beats
     from beat_this_amd.model import BeatThis
 
     hp = W.resolve_hparams(args.model)
-    sd = W.random_state_dict(hp, seed=0, style="init")
-    model = BeatThis(**{k: hp[k] for k in ("spect_dim", "transformer_dim", "ff_mult", "n_layers", "head_dim",
-                                           "stem_dim")})
+    # "lively" seeded weights (O(1) logits, sharp softmaxes, beats to pick): same FLOPs as any other weights of this
+    # architecture, but the post-processor has real work and the parity figures mean something
+    sd = W.random_state_dict(hp, seed=1, style="lively")
+    model = BeatThis(**{k: hp[k] for k in ("spect_dim", "transformer_dim", "ff_mult", "n_layers", "head_dim", "stem_dim")})
     model.load_state_dict(sd)
-    model = model.to(dev)
-    B = args.chunks
-    x = torch.from_numpy(np.stack([W.synthetic_spect(CHUNK_FRAMES, seed=1000 * rank + i) for i in range(B)])).to(dev)
+    a2b = Audio2Beats(checkpoint_path=None, device=dev, float16=args.prec != "f32", dbn=False)
+    a2b.model = model.to(dev)
+    a2b.model.fp8_weights = args.prec == "fp8"
     half = args.prec != "f32"
-    model.fp8_weights = args.prec == "fp8"
-    gathered = torch.empty((world * B, 2, CHUNK_FRAMES), dtype=torch.float32, device=dev) if world > 1 else None
-
-    def step():
-        with torch.inference_mode(), torch.autocast("cuda", enabled=half):
-            r = model(x)
-        if world > 1:
-            local = torch.stack((r["beat"], r["downbeat"]), 1)
-            dist.all_gather_into_tensor(gathered, local)
-        return r
+    half_name = _lib.half_dtype_name()
 
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    # ---- workload -------------------------------------------------------------------------------------------------
+    if args.workload == "tracks":
+        n_tr = args.tracks
+        tracks = [torch.from_numpy(W.synthetic_audio(TRACK_SECONDS, seed=100 * rank + i, sr=TRACK_SR)).to(dev)
+                  for i in range(n_tr)]
+        from beat_this_amd.parallel import track_frames
+
+        frames_per_track = track_frames(tracks[0].shape[0], TRACK_SR)
+        gathered = torch.empty((world * 2, n_tr * frames_per_track), dtype=torch.float32, device=dev) if world > 1 else None
+        pending = []
+
+        def step():
+            h = a2b.many_async(tracks, TRACK_SR)
+            if world > 1:
+                beat, down, _ = h.logits
+                dist.all_gather_into_tensor(gathered, torch.stack((beat, down)))
+            pending.append(h)
+            if len(pending) > 1:
+                return pending.pop(0).result()
+            return None
+
+        def drain():
+            out = None
+            while pending:
+                out = pending.pop(0).result()
+            return out
+
+        units_per_step = world * n_tr * TRACK_SECONDS
+        chunks_per_step = n_tr * 11
+        n_settle = 4
+        workload = (f"{args.model} Audio2Beats on {n_tr} x {TRACK_SECONDS:.0f} s synthetic {TRACK_SR / 1000:.1f} kHz mono tracks per GPU "
+                    f"(resample, log-mel, {chunks_per_step} chunks through BeatThis.forward, aggregation, peak picking, host "
+                    f"post-processing), seeded random weights")
+    else:
+        B = args.chunks
+        x = torch.from_numpy(np.stack([W.synthetic_spect(CHUNK_FRAMES, seed=1000 * rank + i) for i in range(B)])).to(dev)
+        gathered = torch.empty((world * B, 2, CHUNK_FRAMES), dtype=torch.float32, device=dev) if world > 1 else None
+
+        def step():
+            with torch.inference_mode(), torch.autocast("cuda", enabled=half):
+                r = a2b.model(x)
+            if world > 1:
+                dist.all_gather_into_tensor(gathered, torch.stack((r["beat"], r["downbeat"]), 1))
+            return r
+
+        def drain():
+            return None
+
+        units_per_step = world * B * FRESH_SECONDS_PER_CHUNK
+        chunks_per_step = B
+        n_settle = max(5, -(-1600 // B))
+        workload = (f"{args.model} BeatThis.forward (Spect2Frames path), {B} chunks of 1500 frames x 128 mels per GPU resident in "
+                    f"HBM (29.76 s of fresh audio each), seeded random weights")
+
     # Untimed settling before the W warm-up steps: a fresh process on a fresh box needs a few hundred ms of GPU work
-    # before clocks, page tables and RCCL channels are in their steady state (a 15 ms timed region right after start-up
-    # once measured 7x slow); part of the set-up, not of the W / K steps of the contract.
-    for _ in range(max(5, -(-1600 // B))):  # a fixed count (every rank issues the same collectives): ~0.35 s at 16 chunks
+    # before clocks, page tables and RCCL channels are in their steady state; part of the set-up, not of the W / K steps.
+    for _ in range(n_settle):
         step()
+    drain()
     fence()
     for _ in range(args.warmup):
         step()
+    drain()
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    last = drain()
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -141,95 +222,181 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ms_per_step = 1e3 * elapsed / args.steps
-    value = world * B * CHUNK_SECONDS / (elapsed / args.steps)
+    value = units_per_step / (elapsed / args.steps)
 
-    # ---- roofline leg: per-kernel HIP-event timing of the same workload (rank 0) ---------------
-    roofline = None
-    breakdown = None
+    out = None
     if rank == 0:
         lib = _lib.lib()
-        n_prof = 3
-        lib.bt_profile_begin()
-        for _ in range(n_prof):
-            with torch.inference_mode(), torch.autocast("cuda", enabled=half):
-                model(x)
-        ncat = len(_lib.PROFILE_CATEGORIES)
-        ms = (C.c_double * ncat)()
-        cnt = (C.c_int32 * ncat)()
-        _lib.check(lib.bt_profile_end(ms, cnt, ncat))
-        fl = flops_per_chunk(hp["transformer_dim"])
-        breakdown = {}
-        for i, name in enumerate(_lib.PROFILE_CATEGORIES):
-            if cnt[i]:
-                t_fwd = ms[i] / n_prof  # ms per forward spent in this category
-                breakdown[name] = {"ms_per_step": round(t_fwd, 4), "launches_per_step": cnt[i] // n_prof,
-                                   "tflops": round(fl[name] * B / (t_fwd * 1e-3) / 1e12, 2)}
+        fl = flops_per_chunk(hp["transformer_dim"], ff_mult=hp["ff_mult"])
+        eng = a2b.model.engine()
+
+        def profile_forward(run, n_prof, chunks):
+            lib.bt_profile_begin(eng._h)
+            for _ in range(n_prof):
+                run()
+            ncat = len(_lib.PROFILE_CATEGORIES)
+            ms = (C.c_double * ncat)()
+            cnt = (C.c_int32 * ncat)()
+            _lib.check(lib.bt_profile_end(eng._h, ms, cnt, ncat))
+            bd = {}
+            for i, name in enumerate(_lib.PROFILE_CATEGORIES):
+                if cnt[i]:
+                    t_step = ms[i] / n_prof
+                    bd[name] = {"ms_per_step": round(t_step, 4), "launches_per_step": cnt[i] // n_prof,
+                                "tflops": round(fl[name] * chunks / (t_step * 1e-3) / 1e12, 2)}
+            return bd
+
+        # ---- roofline leg: per-kernel HIP-event timing of the same workload ------------------------------------------
+        if args.workload == "tracks":
+            breakdown = profile_forward(lambda: a2b.many(tracks, TRACK_SR), 2, chunks_per_step)
+        else:
+            breakdown = profile_forward(step, 3, chunks_per_step)
         dom = max(breakdown, key=lambda k: breakdown[k]["ms_per_step"])
         d = breakdown[dom]
-        # (fp8 mode: only the feed-forward GEMMs run on e4m3 operands, the other launch categories are the bf16 kernels)
         peak = PEAK_TFLOPS["fp8" if args.prec == "fp8" and dom in ("ff1_gemm", "ff2_gemm") else
-                           ("f32" if args.prec == "f32" else "bf16")]
-        # HBM bytes per launch of the dominant category: PMC counters collected in separate rocprofv3 passes
-        # (tools/pmc_traffic.sh) for exactly this workload, committed under profiles/; null for any other workload
-        traffic = None
-        try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-            if tj["workload"] == {"model": args.model, "prec": args.prec, "chunks": B} and dom in tj:
-                traffic = tj[dom]["bytes_per_launch"]
-        except (OSError, ValueError, KeyError):
+                           ("f32" if args.prec == "f32" else "half")]
+        traffic, traffic_src = None, None
+        try:  # HBM bytes per launch of the dominant category: PMC counters of separate rocprofv3 passes, committed
+            tj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+            if tj["workload"]["model"] == args.model and tj["workload"]["prec"] == args.prec and dom in tj:
+                traffic = tj[dom]["bytes_per_launch"] * chunks_per_step / tj["workload"]["chunks"] / (
+                    d["launches_per_step"] / tj[dom]["launches_per_forward"])
+                traffic_src = f"profiles/pmc_traffic.json ({tj['workload']['chunks']}-chunk forward, scaled per launch)"
+        except (OSError, ValueError, KeyError, ZeroDivisionError):
             pass
         roofline = {"kernel": dom, "bound": "mfma", "achieved": d["tflops"], "peak": peak, "unit": "TFLOP/s",
-                    "frac": round(d["tflops"] / peak, 4), "traffic": traffic,
+                    "frac": round(d["tflops"] / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
                     "avg_launch_ms": round(d["ms_per_step"] / d["launches_per_step"], 4),
-                    "flop_per_launch": fl[dom] * B / d["launches_per_step"],
-                    "whole_forward_tflops": round(sum(fl.values()) * B / (ms_per_step * 1e-3) / 1e12, 2)}
+                    "flop_per_launch": fl[dom] * chunks_per_step / d["launches_per_step"],
+                    "forward_ms_per_step": round(sum(v["ms_per_step"] for v in breakdown.values()), 3),
+                    "whole_forward_tflops": round(sum(fl.values()) * chunks_per_step /
+                                                  (sum(v["ms_per_step"] for v in breakdown.values()) * 1e-3) / 1e12, 2)}
 
-    # ---- CPU baseline: the oracle on this host, bounded sample, rank 0 at N = 1 only ------------
-    cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        from oracle import beat_this_oracle as O
+        frontend = forward_only = fp32_path = None
+        if args.workload == "tracks" and not args.no_extras:
+            # ---- HBM-bound stages: events around each stage on torch's current stream (the launch stream) -------------
+            def timed(fn, reps=5):
+                fn()
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                for _ in range(reps):
+                    r = fn()
+                b.record()
+                b.synchronize()
+                return a.elapsed_time(b) / reps, r
 
-        xc = x[:1].cpu()
-        with torch.inference_mode():
-            # torch's default (one thread per logical core) oversubscribes big hosts badly
-            # (128 threads: 12-23 s per chunk vs 1.2 s with 16 on the 2 x EPYC 9575F box): probe.
-            best = None
-            for nt in (8, 16, 32):
-                if nt > (os.cpu_count() or 1):
-                    continue
-                torch.set_num_threads(nt)
-                O.model_forward(sd, xc)  # warm-up at this thread count
-                tp = time.perf_counter()
-                O.model_forward(sd, xc)
-                tp = time.perf_counter() - tp
-                if best is None or tp < best[1]:
-                    best = (nt, tp)
-            torch.set_num_threads(best[0])
-            reps = 0
-            t1 = time.perf_counter()
-            while True:
-                O.model_forward(sd, xc)
-                reps += 1
-                if time.perf_counter() - t1 > 12.0 or reps >= 20:
-                    break
-            tc = (time.perf_counter() - t1) / reps
-        cpu = {"value": round(CHUNK_SECONDS / tc, 2), "unit": "audio-seconds/s", "cores": torch.get_num_threads(),
-               "kind": "port", "sample": f"{reps} x BeatThis.forward of one 1500-frame chunk (30 s), fp32, "
-                                          f"oracle/beat_this_oracle.py, {tc * 1e3:.0f} ms each"}
+            n_samp = sum(int(t.shape[0]) for t in tracks)
+            t_front, (spect, foff) = timed(lambda: a2b.signal2spect_many(tracks, TRACK_SR))
+            tr22 = [torch.from_numpy(W.synthetic_audio(TRACK_SECONDS, seed=i)).to(dev) for i in range(n_tr)]
+            t_mel, _ = timed(lambda: a2b.signal2spect_many(tr22, 22050))
+            n22 = sum(int(t.shape[0]) for t in tr22)
+            beat, down = a2b.spect2frames_batch(spect, foff)
+            t_post, _ = timed(lambda: a2b.frames2beats.ragged(beat, down, foff))
+            mel_bytes = 4 * n22 + 4 * 128 * int(foff[-1])
+            res_bytes = 4 * n_samp + 4 * n22
+            frontend = {
+                "resample+logmel_ms": round(t_front, 4), "logmel_ms": round(t_mel, 4),
+                "logmel_GBps_algorithmic": round(mel_bytes / (t_mel * 1e-3) / 1e9, 1),
+                "logmel_frac_of_hbm_peak": round(mel_bytes / (t_mel * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
+                "resample_ms": round(max(t_front - t_mel, 0.0), 4),
+                "resample_GBps_algorithmic": round(res_bytes / (max(t_front - t_mel, 1e-6) * 1e-3) / 1e9, 1),
+                "peaks+d2h+host_post_ms": round(t_post, 4),
+                "note": "python launch overhead included (stage wall time between stream events); bytes = SURVEY 8d algorithmic"}
+            # ---- BASELINE config 2: forward only, 16 resident chunks --------------------------------------------------
+            x16 = torch.from_numpy(np.stack([W.synthetic_spect(CHUNK_FRAMES, seed=1000 + i) for i in range(16)])).to(dev)
 
-    if rank == 0:
+            def fwd():
+                with torch.inference_mode(), torch.autocast("cuda", enabled=half):
+                    return a2b.model(x16)
+            for _ in range(20):
+                fwd()
+            torch.cuda.synchronize(dev)
+            tf = time.perf_counter()
+            for _ in range(30):
+                fwd()
+            torch.cuda.synchronize(dev)
+            tf = (time.perf_counter() - tf) / 30
+            forward_only = {"workload": "BASELINE config 2: 16 chunks x 1500 frames, BeatThis.forward, spectrograms resident",
+                            "ms_per_step": round(tf * 1e3, 3), "audio_seconds_per_s": round(16 * FRESH_SECONDS_PER_CHUNK / tf, 1),
+                            "whole_forward_tflops": round(sum(fl.values()) * 16 / tf / 1e12, 1)}
+
+        # ---- CPU baseline + in-run parity: the oracle's Audio2Beats on track 0, bounded sample ------------------------
+        cpu = parity = None
+        if world == 1 and not args.no_cpu_baseline and args.workload == "tracks":
+            from oracle import beat_this_oracle as O
+
+            sig = tracks[0].cpu().numpy()
+            with torch.inference_mode():
+                # torch's default (one thread per logical core) oversubscribes big hosts badly: probe on one chunk
+                xc = torch.from_numpy(W.synthetic_spect(CHUNK_FRAMES, seed=5))[None]
+                best = None
+                for nt in sorted({8, 16, 32, os.cpu_count() or 1}):
+                    if nt > (os.cpu_count() or 1):
+                        continue
+                    torch.set_num_threads(nt)
+                    O.model_forward(sd, xc)
+                    tp = time.perf_counter()
+                    O.model_forward(sd, xc)
+                    tp = time.perf_counter() - tp
+                    if best is None or tp < best[1]:
+                        best = (nt, tp)
+                torch.set_num_threads(best[0])
+                t1 = time.perf_counter()
+                ob, od = O.audio2frames(sd, sig, TRACK_SR)
+                obeats, odown = O.postp_minimal(ob, od)
+                tc = time.perf_counter() - t1
+            cpu = {"value": round(TRACK_SECONDS / tc, 2), "unit": "audio-seconds/s", "cores": best[0],
+                   "host_logical_cores": os.cpu_count(), "kind": "port",
+                   "sample": f"1 x Audio2Beats of one {TRACK_SECONDS:.0f} s {TRACK_SR} Hz track (resample, log-mel, 11 chunks batch-1 "
+                             f"like the reference, SDPA attention, fp32, post-processing), oracle/beat_this_oracle.py, {tc:.1f} s; "
+                             f"thread count = fastest of 8/16/32/all on one chunk ({best[1] * 1e3:.0f} ms per chunk)"}
+
+            def flips(a, b):
+                return len(set(np.round(np.asarray(a) * 100).astype(np.int64)) ^ set(np.round(np.asarray(b) * 100).astype(np.int64)))
+
+            def parity_of(a2b_):
+                res = a2b_.many_async(tracks[:1], TRACK_SR)
+                beats, downbeats = res.result()[0]
+                gb, gd, _ = res.logits
+                return {"max_abs_logit": round(max(float((gb.cpu() - ob).abs().max()), float((gd.cpu() - od).abs().max())), 6),
+                        "flips_beat": flips(beats, obeats), "flips_downbeat": flips(downbeats, odown),
+                        "n_beats": len(obeats), "n_downbeats": len(odown), "logit_spread": round(float(ob.std()), 3),
+                        "against": "CPU oracle (fp32) on the same 300 s waveform, 15001 frames"}
+            parity = parity_of(a2b)
+            if half and not args.no_extras:
+                # the exact-fp32 path on the SAME workload: the path under north_star's 1e-3 / identical-beats gate
+                a2b.float16 = False
+                for _ in range(2):
+                    a2b.many(tracks, TRACK_SR)
+                torch.cuda.synchronize(dev)
+                t32 = time.perf_counter()
+                for _ in range(3):
+                    step()
+                drain()
+                torch.cuda.synchronize(dev)
+                t32 = (time.perf_counter() - t32) / 3
+                fp32_path = {"ms_per_step": round(t32 * 1e3, 2), "audio_seconds_per_s": round(units_per_step / t32, 1),
+                             "dtype": "f32 (v_mfma_f32_32x32x2_f32)", "parity": parity_of(a2b)}
+                a2b.float16 = True
+
         out = {
             "metric": "audio-seconds processed/sec", "value": round(value, 1), "unit": "audio-seconds/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": {"bf16": "bf16", "f32": "f32", "fp8": "bf16+fp8(e4m3 feed-forward GEMMs)"}[args.prec], "data": "synthetic",
-            "config": {"workload": f"{args.model} BeatThis.forward (Spect2Frames path), {B} x 30 s chunks "
-                                   f"(1500 frames x 128 mels) per GPU, random-init weights, logits all-gathered",
-                       "chunks_per_gpu": B, "global_chunks": world * B, "parallelism": f"chunk-sharded x{world}"},
-            "roofline": roofline, "cpu_baseline": cpu, "breakdown": breakdown,
+            "dtype": {"half": half_name, "f32": "f32", "fp8": f"{half_name}+fp8(e4m3 feed-forward GEMMs, experimental)"}[args.prec],
+            "data": "synthetic",
+            "config": {"workload": workload, "tracks_per_gpu": args.tracks if args.workload == "tracks" else None,
+                       "chunks_per_gpu": chunks_per_step, "global_chunks": world * chunks_per_step,
+                       "parallelism": f"track-sharded x{world}, framewise logits all-gathered" if args.workload == "tracks"
+                       else f"chunk-sharded x{world}, logits all-gathered"},
+            "parity": parity, "roofline": roofline, "cpu_baseline": cpu, "frontend": frontend, "forward_only": forward_only,
+            "fp32_path": fp32_path, "breakdown": breakdown,
         }
+        if last is not None and args.workload == "tracks":
+            out["config"]["beats_in_last_track"] = int(len(last[-1][0]))
         print(json.dumps(out))
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -115,6 +115,9 @@ typedef struct {
 
 const char* bt_last_error(void);
 int bt_version(void);
+/* operand type of the half-precision path (BT_PREC_BF16 / BT_PREC_FP8 slots of the weight arrays) this library was built
+ * with: 0 = IEEE fp16 (default), 1 = bfloat16 (-DBT_HALF_BF16) */
+int bt_half_is_bf16(void);
 /* sizeof/offsetof of the structs above as this library was compiled (binding self-check):
  * out[9] = {pair_weights, model_desc, logmel_tables, gemm_args, attn_args, offsetof layers, offsetof rope,
  * attn_frag_args, gemm3_args} */

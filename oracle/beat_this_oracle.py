@@ -161,8 +161,13 @@ def attention(x, sd, pfx, heads):
     q, k, v = qkv[0], qkv[1], qkv[2]
     fr = sd[pfx + "rotary_embed.freqs"]
     q, k = rope(q, fr), rope(k, fr)
-    att = torch.softmax((q @ k.transpose(-1, -2)) * (d ** -0.5), dim=-1)  # Attend, roformer.py:67-80
-    out = att @ v
+    if q.dtype == torch.float32:
+        # Attend.forward (roformer.py:67-80) calls F.scaled_dot_product_attention (default scale d^-0.5, no mask): the same
+        # fused CPU kernel the reference runs, so that the cpu_baseline timing of bench.py is the reference's own cost
+        out = F.scaled_dot_product_attention(q, k, v)
+    else:  # float64 evaluation (accuracy reference): the explicit definition of the same operator
+        att = torch.softmax((q @ k.transpose(-1, -2)) * (d ** -0.5), dim=-1)
+        out = att @ v
     gates = xn @ sd[pfx + "to_gates.weight"].T + sd[pfx + "to_gates.bias"]  # (b,n,h)
     out = out * torch.sigmoid(gates).permute(0, 2, 1)[..., None]
     out = out.permute(0, 2, 1, 3).reshape(b, n, heads * d)
@@ -313,3 +318,27 @@ def audio2beats(sd, signal22k: np.ndarray, dtype=torch.float32):
     spect = logmel(torch.as_tensor(signal22k, dtype=torch.float32))
     b, d = spect2frames(sd, spect, dtype)
     return postp_minimal(b, d)
+
+
+def signal2spect(signal: np.ndarray, sr: int):
+    """Audio2Frames.signal2spect (inference.py:269-277): mono mix, resample to 22.05 kHz (the soxr stand-in of
+    oracle/shims -- parity with libsoxr itself is unpinned), float32, log-mel."""
+    import importlib.util
+    import os
+
+    if signal.ndim == 2:
+        signal = signal.mean(1)
+    elif signal.ndim != 1:
+        raise ValueError(f"Expected 1D or 2D signal, got shape {signal.shape}")
+    if sr != SAMPLE_RATE:
+        spec = importlib.util.spec_from_file_location(
+            "_oracle_soxr_shim", os.path.join(os.path.dirname(os.path.abspath(__file__)), "shims", "soxr", "__init__.py"))
+        shim = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(shim)
+        signal = shim.resample(signal, in_rate=sr, out_rate=SAMPLE_RATE)
+    return logmel(torch.tensor(signal, dtype=torch.float32))
+
+
+def audio2frames(sd, signal: np.ndarray, sr: int, dtype=torch.float32):
+    """Audio2Frames.__call__ (inference.py:279-281)."""
+    return spect2frames(sd, signal2spect(signal, sr), dtype)

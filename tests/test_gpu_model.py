@@ -332,3 +332,90 @@ def test_forward_bf16_odd_batches_match_fp32_path(B, T):
     spread = float(ref["beat"].std()) if B * T > 1 else 0.0
     report("forward_bf16_odd", B=B, T=T, err_beat=err, spread=spread)
     assert err < 0.25 * max(spread, 0.4)
+
+
+def test_audio2beats_many_matches_single_track_calls_and_oracle():
+    """The batched track API (one launch per stage for a list of tracks, async device-to-host copy) against one
+    Audio2Beats.__call__ per track: identical logits and beats; ragged lengths incl. a short piece (one odd-length chunk),
+    a piece of exactly 1488 frames + 1, 44.1 kHz stereo input through the batched resampler; and against the oracle."""
+    from beat_this_amd import weights as W
+    from beat_this_amd.inference import Audio2Beats
+    from oracle import beat_this_oracle as O
+
+    hp = W.resolve_hparams("small0")
+    sd = W.random_state_dict(hp, seed=4, style="lively")
+    a2b = Audio2Beats(checkpoint_path=None, device=dev(), float16=False, dbn=False)
+    a2b.model = _model("small0", 4, "lively")
+    secs = (7.0, 29.77, 65.3, 31.0, 2.0)
+    sigs = [W.synthetic_audio(s, seed=40 + i) for i, s in enumerate(secs)]
+    many = a2b.many(sigs, 22050)
+    assert len(many) == len(sigs)
+    spect, foff = a2b.signal2spect_many(sigs, 22050)
+    bl, dl = a2b.spect2frames_batch(spect, foff)
+    worst = 0.0
+    for i, sig in enumerate(sigs):
+        b1, d1 = a2b(sig, 22050)
+        assert np.array_equal(many[i][0], b1) and np.array_equal(many[i][1], d1), i
+        s1 = a2b.signal2spect(sig, 22050)
+        assert torch.equal(spect[foff[i]: foff[i + 1]], s1), i
+        lb, ld = a2b.spect2frames(s1)
+        worst = max(worst, float((bl[foff[i]: foff[i + 1]] - lb).abs().max()))
+    assert worst <= 1e-5
+    with torch.inference_mode():
+        ob, od = O.spect2frames(sd, O.logmel(torch.from_numpy(sigs[2])))
+    err = float((bl[foff[2]: foff[3]].cpu() - ob).abs().max())
+    obeats, odown = O.postp_minimal(ob, od)
+    report("a2b_many", worst_vs_single=worst, err_vs_oracle=err, beats=len(obeats))
+    assert err < LOGIT_TOL_F32 and np.array_equal(many[2][0], obeats) and np.array_equal(many[2][1], odown)
+    # 44.1 kHz stereo numpy + torch device tensors, mixed in one batch
+    s44 = [np.stack([W.synthetic_audio(9.0, seed=60, sr=44100)] * 2, 1).astype(np.float64),
+           torch.from_numpy(W.synthetic_audio(40.0, seed=61, sr=44100)).to(dev())]
+    m44 = a2b.many(s44, 44100)
+    for i, sig in enumerate(s44):
+        ref = a2b(sig.cpu().numpy() if isinstance(sig, torch.Tensor) else sig, 44100)
+        assert np.array_equal(m44[i][0], ref[0]) and np.array_equal(m44[i][1], ref[1]), i
+    ob, od = O.audio2frames(sd, s44[1].cpu().numpy(), 44100)
+    fr = a2b.many_async(s44[1:], 44100)
+    fr.result()
+    e44 = float((fr.logits[0].cpu() - ob).abs().max())
+    report("a2b_many_44k1", err_vs_oracle=e44)
+    assert e44 < LOGIT_TOL_F32
+    assert a2b.many([], 22050) == []
+
+
+def test_empty_and_oversize_inputs():
+    from beat_this_amd.inference import Spect2Frames
+
+    s2f = Spect2Frames(checkpoint_path=None, device="cuda:0")
+    b, d = s2f(torch.zeros((0, 128), device=dev()))
+    assert b.shape == (0,) and d.shape == (0,) and b.dtype == torch.float32
+    with pytest.raises(ValueError, match="at most 1536 frames"):
+        s2f.model(torch.zeros((1, 2000, 128), device=dev()))
+    with pytest.raises(RuntimeError, match="no CPU implementation"):
+        Spect2Frames(checkpoint_path=None, device="cpu")
+
+
+def test_ff_mult_other_than_four_loads_and_matches_oracle():
+    """A checkpoint with ff_mult != 4: the frontend's FeedForward stays at 4 x dim (beat_tracker.py:279,288),
+    the main layers use ff_mult."""
+    from beat_this_amd import weights as W
+    from beat_this_amd.model import BeatThis
+    from oracle import beat_this_oracle as O
+
+    hp = dict(W.resolve_hparams("small0"), ff_mult=2)
+    sd = W.random_state_dict(hp, seed=9, style="lively")
+    assert sd["transformer_blocks.layers.0.1.net.1.weight"].shape == (256, 128)
+    assert sd["frontend.blocks.0.partial.ffF.net.1.weight"].shape == (128, 32)
+    m = BeatThis(**{k: hp[k] for k in ("spect_dim", "transformer_dim", "ff_mult", "n_layers", "head_dim", "stem_dim")})
+    m.load_state_dict(sd)
+    m = m.to(dev())
+    x = torch.from_numpy(W.synthetic_spect(600, seed=2))[None]
+    with torch.inference_mode():
+        r = m(x.to(dev()))
+        ob, od = O.model_forward(sd, x)
+        with torch.autocast("cuda", enabled=True):
+            rh = m(x.to(dev()))
+    err = float((r["beat"].cpu() - ob).abs().max())
+    errh = float((rh["beat"].cpu() - ob).abs().max())
+    report("ff_mult2", err_f32=err, err_half=errh)
+    assert err < LOGIT_TOL_F32 and errh < 0.1

@@ -68,6 +68,56 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
+def _fake_frames(tracks):
+    """(beat_cat, downbeat_cat, frame_off) of a list of fake 22.05 kHz tracks: frame value = f(track content, frame index)"""
+    from beat_this_amd.parallel import track_frames
+
+    n = [track_frames(t.shape[0], 22050) for t in tracks]
+    beat = torch.cat([t[:1].float() + 0.01 * torch.arange(k) for t, k in zip(tracks, n)])
+    return beat, -beat, np.concatenate([[0], np.cumsum(n)])
+
+
+def _tracks():
+    return [torch.full((m,), float(i + 1)) for i, m in enumerate((22050 * 7, 441 * 30 + 5, 22050 * 3, 5000, 22050 * 11))]
+
+
+def _track_worker(rank, world, port, q):
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from beat_this_amd.parallel import audio2frames_sharded
+
+    res = audio2frames_sharded(_tracks(), 22050, _fake_frames)
+    q.put((rank, [(b.numpy(), d.numpy()) for b, d in res]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_track_sharding_two_ranks_matches_single_process():
+    from beat_this_amd.parallel import audio2frames_sharded, track_frames
+
+    single = audio2frames_sharded(_tracks(), 22050, _fake_frames)
+    for t, (b, d) in zip(_tracks(), single):
+        assert b.shape[0] == track_frames(t.shape[0], 22050) and float(b[0]) == float(t[0]) and torch.equal(d, -b)
+    assert track_frames(13230000, 44100) == 15001 and track_frames(661500, 22050) == 1501
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_track_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=100) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in range(2):
+        for (b, d), (sb, sd_) in zip(got[r], single):
+            assert np.array_equal(b, sb.numpy()) and np.array_equal(d, sd_.numpy())
+
+
 def test_partition_covers_everything():
     from beat_this_amd.parallel import partition
 
