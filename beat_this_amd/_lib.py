@@ -18,14 +18,14 @@ LIB_PATH = os.path.join(PKG_DIR, "libbeat_this_amd.so")
 if os.environ.get("BT_DEV") == "1" and os.environ.get("BT_LIB_PATH"):  # development only (tools/ab.sh: A/B of two builds)
     LIB_PATH = os.environ["BT_LIB_PATH"]
 SOURCES = ["gemm.hip", "gemm2.hip", "gemm3.hip", "attn.hip", "attn2.hip", "fused.hip", "fused2.hip", "qkv_front.hip", "frontend.hip", "logmel.hip",
-           "engine.hip"]
+           "tail.hip", "engine.hip"]
 HEADERS = ["common.h", "chain.h", "kernels.h", os.path.join("..", "..", "include", "beat_this_amd.h")]
 
 BT_OK, BT_ERR_ARG, BT_ERR_HIP, BT_ERR_WORKSPACE = 0, -1, -2, -3
-PREC_F32, PREC_BF16, PREC_FP8 = 0, 1, 2
+PREC_F32, PREC_HALF, PREC_FP8 = 0, 1, 2
 MAX_LAYERS = 32
 PROFILE_CATEGORIES = ["stem", "qkv_gemm", "attn_freq", "attn_flash", "out_gemm", "ff1_gemm", "ff2_gemm", "conv_gemm",
-                      "linear_gemm", "head", "ff_fused", "attn_freq_fused"]
+                      "linear_gemm", "head", "ff_fused", "attn_freq_fused", "layer_tail"]
 
 GEMM_EPI_STORE, GEMM_EPI_RESID, GEMM_EPI_QKV = 0, 1, 2
 GEMM_F_RMS, GEMM_F_BIAS, GEMM_F_GELU, GEMM_F_OUT_F32, GEMM_F_A_F32, GEMM_F_CONV, GEMM_F_ROWMAP = 1, 2, 4, 8, 16, 32, 64
@@ -38,7 +38,7 @@ class PairWeights(C.Structure):
                 ("w_ff_frag", C.c_void_p * 2), ("w_qkv_frag", C.c_void_p),
                 ("w_outff_frag", C.c_void_p * 2), ("w_attnff_frag", C.c_void_p * 2),
                 ("w_ff1_f8", C.c_void_p), ("s_ff1", C.c_void_p), ("w_ff2_f8", C.c_void_p), ("s_ff2", C.c_void_p),
-                ("b_ff2_f8", C.c_void_p)]
+                ("b_ff2_f8", C.c_void_p), ("w_tail_frag", C.c_void_p)]
 
 
 class ModelDesc(C.Structure):
@@ -131,6 +131,8 @@ EXPORTS = {
                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     "bt_outff_fused": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(PairWeights), C.c_void_p, C.c_void_p, C.c_int64]),
     "bt_attnff_fused": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(PairWeights), C.c_void_p, C.c_void_p, C.c_int64]),
+    "bt_layer_tail": (C.c_int, [C.c_void_p, C.POINTER(PairWeights), C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
+                                C.c_void_p]),
     "bt_ff_fused": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(PairWeights), C.c_void_p, C.c_int64]),
     "bt_attn_freq_fused": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(PairWeights), C.c_void_p, C.c_void_p, C.c_int64]),
 }
@@ -140,25 +142,31 @@ EXPORTS = {
 # frontend kernels in AGPRs and moves them with v_accvgpr_read / _write: 2900 such moves in fused2.hip, 32 per FF step);
 # frequency-direction halves 0.315 -> 0.287 ms.  (-fgpu-flush-denormals-to-zero: no effect; max-ilp scheduling: slower.)
 HIPCC_FLAGS = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops", "-mllvm", "-amdgpu-mfma-vgpr-form"]
+# tail.hip keeps 256 accumulator registers per lane next to 128 operand registers: its accumulators MUST live in AGPRs
+# (a wave has 256 architectural VGPRs + 256 AGPRs), so it is compiled without -amdgpu-mfma-vgpr-form
+FLAGS_BY_SOURCE = {"tail.hip": ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]}
 # compile-time switches: BT_DEV_BUILD=1 in the environment of build() compiles the development instrumentation (per-wave timing
 # dumps, ablation variants read by tools/*_probe.py) into the kernels; release builds contain none of it
-EXTRA_DEFINES = ["-DBT_DEV"] if os.environ.get("BT_DEV_BUILD") == "1" else []
+EXTRA_DEFINES = (["-DBT_DEV"] if os.environ.get("BT_DEV_BUILD") == "1" else []) + os.environ.get("BT_DEFINES", "").split()
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
+def build(force: bool = False, verbose: bool = False, lib_path: str | None = None, obj_dir: str | None = None,
+          defines=()) -> str:
     """Compile the HIP sources for gfx950 into libbeat_this_amd.so (in tree): one object per source file under
-    beat_this_amd/build/ (rebuilt only when the file, a header or the flags changed; compiled in parallel), then one link."""
+    beat_this_amd/build/ (rebuilt only when the file, a header or the flags changed; compiled in parallel), then one link.
+    ``lib_path`` / ``obj_dir`` / ``defines``: a variant build elsewhere (tools/build_variant.py, A/B measurements)."""
     from concurrent.futures import ThreadPoolExecutor
 
     src_dir = os.path.join(PKG_DIR, "csrc")
-    obj_dir = os.path.join(PKG_DIR, "build")
+    obj_dir = obj_dir or os.path.join(PKG_DIR, "build")
+    LIB_PATH = lib_path or os.path.join(PKG_DIR, "libbeat_this_amd.so")
     hdrs = [os.path.join(src_dir, h) for h in HEADERS] + [os.path.abspath(__file__)]  # (this file: HIPCC_FLAGS)
     hdr_time = max(os.path.getmtime(h) for h in hdrs)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     # -packed-fp32-ops: hipcc pairs independent fp32 multiplies / adds / fmas into v_pk_*_f32, which issue at 5.5 clk per
     # instruction on gfx950 against 2 x 1.8 for the scalar forms (tools/ubench/valu_rates.hip); without the pairing the
     # forward is 3.7 % faster (frequency-direction fused halves 0.43 -> 0.32 ms), A/B on one box with tools/ab.sh
-    base = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", *HIPCC_FLAGS, *EXTRA_DEFINES]
+    common = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
     todo, objs = [], []
     for name in SOURCES:
         src = os.path.join(src_dir, name)
@@ -171,7 +179,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(obj_dir, exist_ok=True)
 
     def compile_one(job):
-        cmd = [*base, "-c", job[0], "-o", job[1]]
+        flags = FLAGS_BY_SOURCE.get(os.path.basename(job[0]), HIPCC_FLAGS)
+        cmd = [*common, *flags, *EXTRA_DEFINES, *defines, "-c", job[0], "-o", job[1]]
         if verbose:
             print(" ".join(cmd), flush=True)
         r = subprocess.run(cmd, stderr=subprocess.PIPE, text=True)

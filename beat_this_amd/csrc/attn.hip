@@ -9,7 +9,7 @@
 // LDS in tiles of 64.  Scores are computed TRANSPOSED (S^T = K . Q^T) so that a lane holds
 // 16 of the 32 key-scores of ONE query: row max / row sum are lane-local plus a single
 // exchange with lane^32, and the probabilities are already in the B-operand layout of the
-// second MFMA (O^T = V^T . P^T) -- no cross-lane traffic for P at all.  For bf16 the V tile
+// second MFMA (O^T = V^T . P^T) -- no cross-lane traffic for P at all.  For half the V tile
 // is transposed on its way into LDS so the A operand (V^T) is read with two ds_read_b64;
 // for fp32 (k = 2 MFMA) V is read row-major.
 //
@@ -23,11 +23,11 @@
 namespace {
 
 constexpr int KT = 64;          // keys per tile
-constexpr int VT_PITCH = 136;   // bytes per d-row of the transposed bf16 V tile (64 keys * 2 + 8)
+constexpr int VT_PITCH = 136;   // bytes per d-row of the transposed half V tile (64 keys * 2 + 8)
 
 template <typename T> struct KV8;  // 8 contiguous elements staged in registers
 template <> struct KV8<float> { f32x4 v[2]; };
-template <> struct KV8<bf16> { bf16x8 v; };
+template <> struct KV8<hf> { hfx8 v; };
 
 template <typename T> DEVI KV8<T> ldg8(const T* p, bool ok);
 template <> DEVI KV8<float> ldg8<float>(const float* p, bool ok) {
@@ -41,22 +41,22 @@ template <> DEVI KV8<float> ldg8<float>(const float* p, bool ok) {
   }
   return r;
 }
-template <> DEVI KV8<bf16> ldg8<bf16>(const bf16* p, bool ok) {
-  KV8<bf16> r;
+template <> DEVI KV8<hf> ldg8<hf>(const hf* p, bool ok) {
+  KV8<hf> r;
   typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
   u32x4 z = {0, 0, 0, 0};
-  r.v = ok ? *reinterpret_cast<const bf16x8*>(p) : __builtin_bit_cast(bf16x8, z);
+  r.v = ok ? *reinterpret_cast<const hfx8*>(p) : __builtin_bit_cast(hfx8, z);
   return r;
 }
 DEVI void sts8(char* dst, const KV8<float>& r) {
   reinterpret_cast<f32x4*>(dst)[0] = r.v[0];
   reinterpret_cast<f32x4*>(dst)[1] = r.v[1];
 }
-DEVI void sts8(char* dst, const KV8<bf16>& r) { *reinterpret_cast<bf16x8*>(dst) = r.v; }
+DEVI void sts8(char* dst, const KV8<hf>& r) { *reinterpret_cast<hfx8*>(dst) = r.v; }
 
 template <typename T> struct VSize;
 template <> struct VSize<float> { static constexpr int BYTES = KT * Tile<float>::PITCH; };
-template <> struct VSize<bf16> { static constexpr int BYTES = 32 * VT_PITCH; };
+template <> struct VSize<hf> { static constexpr int BYTES = 32 * VT_PITCH; };
 
 template <typename T>
 __global__ __launch_bounds__(256) void attn_flash_kernel(const AttnP p) {
@@ -83,8 +83,8 @@ __global__ __launch_bounds__(256) void attn_flash_kernel(const AttnP p) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) fq.v[i] = reinterpret_cast<const f32x4*>(qp)[i];
     } else {
-      fq.v[0] = reinterpret_cast<const bf16x8*>(qp)[0];
-      fq.v[1] = reinterpret_cast<const bf16x8*>(qp)[1];
+      fq.v[0] = reinterpret_cast<const hfx8*>(qp)[0];
+      fq.v[1] = reinterpret_cast<const hfx8*>(qp)[1];
     }
   }
 
@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256) void attn_flash_kernel(const AttnP p) {
       sts8(Vs + skey * PITCH + spart * 8 * (int)sizeof(T), rv);
     } else {
 #pragma unroll
-      for (int i = 0; i < 8; ++i) *reinterpret_cast<bf16*>(Vs + (spart * 8 + i) * VT_PITCH + skey * 2) = rv.v[i];
+      for (int i = 0; i < 8; ++i) *reinterpret_cast<hf*>(Vs + (spart * 8 + i) * VT_PITCH + skey * 2) = rv.v[i];
     }
     __syncthreads();
     if (kt + 1 < ntiles) loadKV(kt + 1, rk, rv);
@@ -173,13 +173,13 @@ __global__ __launch_bounds__(256) void attn_flash_kernel(const AttnP p) {
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
           const char* vp = Vs + lr * VT_PITCH + (c * 32 + s * 16 + 4 * g) * 2;
-          bf16x4 v0 = *reinterpret_cast<const bf16x4*>(vp);
-          bf16x4 v1 = *reinterpret_cast<const bf16x4*>(vp + 16);
-          bf16x8 va = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-          bf16x8 pb;
+          hfx4 v0 = *reinterpret_cast<const hfx4*>(vp);
+          hfx4 v1 = *reinterpret_cast<const hfx4*>(vp + 16);
+          hfx8 va = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+          hfx8 pb;
 #pragma unroll
-          for (int j = 0; j < 8; ++j) pb[j] = (bf16)sc[c][s * 8 + j];
-          acc_o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va, pb, acc_o, 0, 0, 0);
+          for (int j = 0; j < 8; ++j) pb[j] = (hf)sc[c][s * 8 + j];
+          acc_o = MFMA32_H(va, pb, acc_o);
         }
     }
   }
@@ -197,9 +197,9 @@ __global__ __launch_bounds__(256) void attn_flash_kernel(const AttnP p) {
         *reinterpret_cast<f32x4*>(op + 8 * a) = f32x4{acc_o[4 * a] * scale, acc_o[4 * a + 1] * scale,
                                                        acc_o[4 * a + 2] * scale, acc_o[4 * a + 3] * scale};
       } else {
-        bf16x4 o = {(bf16)(acc_o[4 * a] * scale), (bf16)(acc_o[4 * a + 1] * scale),
-                    (bf16)(acc_o[4 * a + 2] * scale), (bf16)(acc_o[4 * a + 3] * scale)};
-        *reinterpret_cast<bf16x4*>(op + 8 * a) = o;
+        hfx4 o = {(hf)(acc_o[4 * a] * scale), (hf)(acc_o[4 * a + 1] * scale),
+                    (hf)(acc_o[4 * a + 2] * scale), (hf)(acc_o[4 * a + 3] * scale)};
+        *reinterpret_cast<hfx4*>(op + 8 * a) = o;
       }
     }
   }
@@ -208,8 +208,8 @@ __global__ __launch_bounds__(256) void attn_flash_kernel(const AttnP p) {
 // ---------------------------------------------------------------------------------------
 template <typename T> DEVI f32x4 ldg4f(const T* p);
 template <> DEVI f32x4 ldg4f<float>(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
-template <> DEVI f32x4 ldg4f<bf16>(const bf16* p) {
-  bf16x4 v = *reinterpret_cast<const bf16x4*>(p);
+template <> DEVI f32x4 ldg4f<hf>(const hf* p) {
+  hfx4 v = *reinterpret_cast<const hfx4*>(p);
   return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
 }
 
@@ -301,9 +301,9 @@ __global__ __launch_bounds__(256) void attn_small_kernel(const AttnP p) {
         *reinterpret_cast<f32x4*>(op + 4 * i) =
             f32x4{o[4 * i] * scale, o[4 * i + 1] * scale, o[4 * i + 2] * scale, o[4 * i + 3] * scale};
       } else {
-        bf16x4 ov = {(bf16)(o[4 * i] * scale), (bf16)(o[4 * i + 1] * scale), (bf16)(o[4 * i + 2] * scale),
-                     (bf16)(o[4 * i + 3] * scale)};
-        *reinterpret_cast<bf16x4*>(op + 4 * i) = ov;
+        hfx4 ov = {(hf)(o[4 * i] * scale), (hf)(o[4 * i + 1] * scale), (hf)(o[4 * i + 2] * scale),
+                     (hf)(o[4 * i + 3] * scale)};
+        *reinterpret_cast<hfx4*>(op + 4 * i) = ov;
       }
     }
   }
@@ -330,11 +330,11 @@ int launch_attn_flash(const AttnP& p, int prec, hipStream_t s) {
   if (prec == BT_PREC_F32)
     hipLaunchKernelGGL((attn_flash_kernel<float>), grid, block, 0, s, p);
   else
-    hipLaunchKernelGGL((attn_flash_kernel<bf16>), grid, block, 0, s, p);
+    hipLaunchKernelGGL((attn_flash_kernel<hf>), grid, block, 0, s, p);
   return (int)hipGetLastError();
 }
 
 int launch_attn_small(const AttnP& p, int prec, hipStream_t s) {
   if (p.heads * p.L != 32 || p.inner != p.heads * 32) return -2;
-  return prec == BT_PREC_F32 ? launch_small_t<float>(p, s) : launch_small_t<bf16>(p, s);
+  return prec == BT_PREC_F32 ? launch_small_t<float>(p, s) : launch_small_t<hf>(p, s);
 }

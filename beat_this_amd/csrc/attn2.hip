@@ -1,5 +1,5 @@
-// bf16 flash attention on FRAGMENT-MAJOR operands (head_dim = 32, non-causal, no mask), the
-// BT_PREC_BF16 replacement of attn_flash_kernel for the time-direction and main-transformer
+// half flash attention on FRAGMENT-MAJOR operands (head_dim = 32, non-causal, no mask), the
+// BT_PREC_HALF replacement of attn_flash_kernel for the time-direction and main-transformer
 // attention (roformer.py:67-80,125-131).
 //
 // Operand layout (written by the QKV producers, csrc/qkv_front.hip and the QKV epilogue of
@@ -19,7 +19,7 @@
 //   * the running-max subtraction rides on the MFMA: the accumulator INPUT of the score MFMA is a
 //     register block holding -m (q is pre-scaled by log2(e)/sqrt(32), RoPE applied by the producer);
 //   * m is fixed per query from the first key block; later scores may exceed it, which is exact in
-//     fp32/bf16 (common factor 2^-m cancels in O / l) unless exp2 overflows.  Overflow or a sum
+//     fp32/half (common factor 2^-m cancels in O / l) unless exp2 overflows.  Overflow or a sum
 //     >= 1e30 is detected on l at the end and the whole workgroup then re-runs the classic
 //     online-softmax loop (SAFE pass), so the result is always the exact softmax.
 #include <cstdlib>
@@ -38,7 +38,7 @@ typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
 DEVI unsigned pk2(float a, float b) {
-  const bf16x2 t = {(bf16)a, (bf16)b};
+  const hfx2 t = {(hf)a, (hf)b};
   return __builtin_bit_cast(unsigned, t);
 }
 DEVI void zero16(f32x16& a) {
@@ -48,48 +48,81 @@ DEVI void zero16(f32x16& a) {
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
-// 8 probabilities -> 4 dwords of packed bf16 (one v_cvt_pk_bf16_f32 each).  Operands are assembled from
-// these dwords by bit casts only: bf16-vector shuffles make hipcc (ROCm 7.2) emit 3x the conversions.
+// 8 probabilities -> 4 dwords of packed half (one v_cvt_pk_bf16_f32 each).  Operands are assembled from
+// these dwords by bit casts only: half-vector shuffles make hipcc (ROCm 7.2) emit 3x the conversions.
 DEVI u32x4 pack8(const f32x16& p, int s) {
   u32x4 w;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    const bf16x2 t = {(bf16)p[8 * s + 2 * j], (bf16)p[8 * s + 2 * j + 1]};
+    const hfx2 t = {(hf)p[8 * s + 2 * j], (hf)p[8 * s + 2 * j + 1]};
     w[j] = __builtin_bit_cast(unsigned int, t);
   }
   return w;
 }
-// l += sum of this lane's 8 bf16 probabilities: D = ones(4x4) . B puts, in every output register of a
+// l += sum of this lane's 8 half probabilities: D = ones(4x4) . B puts, in every output register of a
 // lane, the sum of the 4 k-values that lane supplied as B (16 independent 4x4x4 blocks, column j of
 // block b lives in lane 4b + j for B and D alike; checked by tools/ubench/mfma444_probe.hip), so the
 // row sums cost no VALU issue slots.
+// BT_ATTN_ROWSUM selects where the row sums run: 0 = matrix pipe (4x4x4 MFMAs, below), 1 = VALU adds of the fp32
+// probabilities, 2 = v_dot2_f32_f16 on the packed words (A/B-measured on the MI355X).
+#ifndef BT_ATTN_ROWSUM
+#define BT_ATTN_ROWSUM 0
+#endif
 DEVI void rowsum8(f32x4& l, const u32x4& w) {
+#if BT_ATTN_ROWSUM == 2
+  const hfx2 one2 = {(hf)1.0f, (hf)1.0f};
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#if BT_HALF_IS_BF16
+    l[0] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(hfx2, w[i]), one2, l[0], false);
+#else
+    l[0] = __builtin_amdgcn_fdot2(__builtin_bit_cast(hfx2, w[i]), one2, l[0], false);
+#endif
+#elif BT_HALF_IS_BF16
   const s16x4 ones = {0x3f80, 0x3f80, 0x3f80, 0x3f80};
   l = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(ones, __builtin_bit_cast(s16x4, u32x2{w[0], w[1]}), l, 0, 0, 0);
   l = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(ones, __builtin_bit_cast(s16x4, u32x2{w[2], w[3]}), l, 0, 0, 0);
+#else
+  const hfx4 ones = {(hf)1.0f, (hf)1.0f, (hf)1.0f, (hf)1.0f};
+  l = __builtin_amdgcn_mfma_f32_4x4x4f16(ones, __builtin_bit_cast(hfx4, u32x2{w[0], w[1]}), l, 0, 0, 0);
+  l = __builtin_amdgcn_mfma_f32_4x4x4f16(ones, __builtin_bit_cast(hfx4, u32x2{w[2], w[3]}), l, 0, 0, 0);
+#endif
 }
+// 16 fp32 probabilities of one lane added as a tree (BT_ATTN_ROWSUM == 1)
+DEVI void rowsum16_valu(f32x4& l, const f32x16& p) {
+  const float a = (p[0] + p[1]) + (p[2] + p[3]), b = (p[4] + p[5]) + (p[6] + p[7]);
+  const float c = (p[8] + p[9]) + (p[10] + p[11]), d = (p[12] + p[13]) + (p[14] + p[15]);
+  l[0] += (a + b) + (c + d);
+}
+// Fast pass: P = exp2(s - m_ref - P_SHIFT) with m_ref the query's maximum over the FIRST key block.  fp16 probabilities
+// overflow at 2^16, so the reference point sits P_SHIFT octaves below 1: later keys may score up to 16 + P_SHIFT octaves
+// (13.9 nats) above the first block's maximum before the SAFE pass has to re-run the workgroup; the price is that keys
+// more than 14 - P_SHIFT octaves below the reference point are rounded as fp16 subnormals (absolute 2^-25: a relative
+// error of 2^-10 in the row sum only if ALL 1500 keys sit there).  The common factor cancels in O / l.  bfloat16 has
+// the fp32 exponent range and needs no shift.
+constexpr float P_SHIFT = BT_HALF_IS_BF16 ? 0.f : 4.f;
 
 // Per-query-block softmax state of a wave (QB query blocks of 32 queries share every K / V fragment read).
 struct QState {
-  bf16x8 q0, q1;   // Q^T operand: dims [16g, 16g+8) and [16g+8, 16g+16) of this lane's query
+  hfx8 q0, q1;   // Q^T operand: dims [16g, 16g+8) and [16g+8, 16g+16) of this lane's query
   f32x16 negm;     // -m splat: accumulator input of the score MFMA (fast pass)
   f32x16 acc;      // O^T accumulator
   f32x4 l;         // row sum (all four registers equal)
   float m;         // running max (SAFE pass) / reference max (fast pass)
 };
 
-struct KFrag { bf16x8 k0, k1; };
-struct VFrag { bf16x8 v0, v1; };
+struct KFrag { hfx8 k0, k1; };
+struct VFrag { hfx8 v0, v1; };
 DEVI KFrag ld_k(const char* kb, int g, int lr) {
   KFrag f;
-  f.k0 = *reinterpret_cast<const bf16x8*>(kb + ((2 * g) * 32 + lr) * 16);
-  f.k1 = *reinterpret_cast<const bf16x8*>(kb + ((2 * g + 1) * 32 + lr) * 16);
+  f.k0 = *reinterpret_cast<const hfx8*>(kb + ((2 * g) * 32 + lr) * 16);
+  f.k1 = *reinterpret_cast<const hfx8*>(kb + ((2 * g + 1) * 32 + lr) * 16);
   return f;
 }
 DEVI VFrag ld_v(const char* vb, int lane) {
   VFrag f;
-  f.v0 = *reinterpret_cast<const bf16x8*>(vb + lane * 16);
-  f.v1 = *reinterpret_cast<const bf16x8*>(vb + 1024 + lane * 16);
+  f.v0 = *reinterpret_cast<const hfx8*>(vb + lane * 16);
+  f.v1 = *reinterpret_cast<const hfx8*>(vb + 1024 + lane * 16);
   return f;
 }
 
@@ -97,17 +130,17 @@ DEVI VFrag ld_v(const char* vb, int lane) {
 // unpipelined form: SAFE pass and the ragged / masked last tile of the fast pass).
 template <bool SAFE, bool MASK, int QB>
 DEVI void do_block(const KFrag& kf, const VFrag& vf, int g, QState (&st)[QB], int key0, int L) {
-  const bf16x8 k0 = kf.k0, k1 = kf.k1, v0 = vf.v0, v1 = vf.v1;
+  const hfx8 k0 = kf.k0, k1 = kf.k1, v0 = vf.v0, v1 = vf.v1;
   f32x16 sc[QB];
 #pragma unroll
   for (int j = 0; j < QB; ++j) {
     if constexpr (SAFE) {
       zero16(sc[j]);
-      sc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, st[j].q0, sc[j], 0, 0, 0);
+      sc[j] = MFMA32_H(k0, st[j].q0, sc[j]);
     } else {
-      sc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, st[j].q0, st[j].negm, 0, 0, 0);
+      sc[j] = MFMA32_H(k0, st[j].q0, st[j].negm);
     }
-    sc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, st[j].q1, sc[j], 0, 0, 0);
+    sc[j] = MFMA32_H(k1, st[j].q1, sc[j]);
   }
 #pragma unroll
   for (int j = 0; j < QB; ++j) {
@@ -140,10 +173,14 @@ DEVI void do_block(const KFrag& kf, const VFrag& vf, int g, QState (&st)[QB], in
       }
     }
     const u32x4 w0 = pack8(sc[j], 0), w1 = pack8(sc[j], 1);
+#if BT_ATTN_ROWSUM == 1
+    rowsum16_valu(st[j].l, sc[j]);
+#else
     rowsum8(st[j].l, w0);
     rowsum8(st[j].l, w1);
-    st[j].acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v0, __builtin_bit_cast(bf16x8, w0), st[j].acc, 0, 0, 0);
-    st[j].acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v1, __builtin_bit_cast(bf16x8, w1), st[j].acc, 0, 0, 0);
+#endif
+    st[j].acc = MFMA32_H(v0, __builtin_bit_cast(hfx8, w0), st[j].acc);
+    st[j].acc = MFMA32_H(v1, __builtin_bit_cast(hfx8, w1), st[j].acc);
   }
 }
 
@@ -179,20 +216,20 @@ DEVI void attn_pass(rsrc_t rk, rsrc_t rv, char* smem, int tid, int wave, int lan
   }
   if constexpr (!SAFE) {  // reference max of each query: its scores against key block 0
     const KFrag k00 = ld_k(smem, g, lr);
-    const bf16x8 k0 = k00.k0, k1 = k00.k1;
+    const hfx8 k0 = k00.k0, k1 = k00.k1;
 #pragma unroll
     for (int j = 0; j < QB; ++j) {
       f32x16 sc;
       zero16(sc);
-      sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, st[j].q0, sc, 0, 0, 0);
-      sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, st[j].q1, sc, 0, 0, 0);
+      sc = MFMA32_H(k0, st[j].q0, sc);
+      sc = MFMA32_H(k1, st[j].q1, sc);
       float bm = -1e30f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) bm = fmaxf(bm, (crow(r, g) < L) ? sc[r] : -1e30f);
       bm = fmaxf(bm, __shfl_xor(bm, 32));
       st[j].m = bm;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) st[j].negm[r] = -bm;
+      for (int r = 0; r < 16; ++r) st[j].negm[r] = -bm - P_SHIFT;
     }
   }
   // Fragment reads are software pipelined by hand: V of block c and K of block c+1 are issued before the
@@ -239,8 +276,8 @@ template <int QB>
 DEVI void score_fast(const KFrag& kf, const QState (&st)[QB], f32x16 (&sc)[QB]) {
 #pragma unroll
   for (int j = 0; j < QB; ++j) {
-    sc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf.k0, st[j].q0, st[j].negm, 0, 0, 0);
-    sc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf.k1, st[j].q1, sc[j], 0, 0, 0);
+    sc[j] = MFMA32_H(kf.k0, st[j].q0, st[j].negm);
+    sc[j] = MFMA32_H(kf.k1, st[j].q1, sc[j]);
   }
 }
 template <int QB>
@@ -250,10 +287,14 @@ DEVI void finish_fast(f32x16 (&sc)[QB], const VFrag& vf, QState (&st)[QB]) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) sc[j][r] = __builtin_amdgcn_exp2f(sc[j][r]);
     const u32x4 w0 = pack8(sc[j], 0), w1 = pack8(sc[j], 1);
+#if BT_ATTN_ROWSUM == 1
+    rowsum16_valu(st[j].l, sc[j]);
+#else
     rowsum8(st[j].l, w0);
     rowsum8(st[j].l, w1);
-    st[j].acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf.v0, __builtin_bit_cast(bf16x8, w0), st[j].acc, 0, 0, 0);
-    st[j].acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf.v1, __builtin_bit_cast(bf16x8, w1), st[j].acc, 0, 0, 0);
+#endif
+    st[j].acc = MFMA32_H(vf.v0, __builtin_bit_cast(hfx8, w0), st[j].acc);
+    st[j].acc = MFMA32_H(vf.v1, __builtin_bit_cast(hfx8, w1), st[j].acc);
   }
 }
 
@@ -278,15 +319,15 @@ DEVI void attn_pass_pipe(rsrc_t rk, rsrc_t rv, char* smem, int tid, int wave, in
     for (int j = 0; j < QB; ++j) {
       f32x16 sc;
       zero16(sc);
-      sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k00.k0, st[j].q0, sc, 0, 0, 0);
-      sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k00.k1, st[j].q1, sc, 0, 0, 0);
+      sc = MFMA32_H(k00.k0, st[j].q0, sc);
+      sc = MFMA32_H(k00.k1, st[j].q1, sc);
       float bm = -1e30f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) bm = fmaxf(bm, (crow(r, g) < L) ? sc[r] : -1e30f);
       bm = fmaxf(bm, __shfl_xor(bm, 32));
       st[j].m = bm;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) st[j].negm[r] = -bm;
+      for (int r = 0; r < 16; ++r) st[j].negm[r] = -bm - P_SHIFT;
     }
   }
   if (t_loop) *t_loop = wall_clock64();
@@ -370,8 +411,8 @@ __global__ __launch_bounds__(256, (QB == 1 ? 4 : 2)) void attn_frag_kernel(const
   for (int j = 0; j < QB; ++j) {
     const int qbc = min(qb0 + j, nblk - 1);
     const char* qblk = reinterpret_cast<const char*>(p.q) + seq_off + (long)qbc * BLK_BYTES;
-    st[j].q0 = *reinterpret_cast<const bf16x8*>(qblk + ((2 * g) * 32 + lr) * 16);
-    st[j].q1 = *reinterpret_cast<const bf16x8*>(qblk + ((2 * g + 1) * 32 + lr) * 16);
+    st[j].q0 = *reinterpret_cast<const hfx8*>(qblk + ((2 * g) * 32 + lr) * 16);
+    st[j].q1 = *reinterpret_cast<const hfx8*>(qblk + ((2 * g + 1) * 32 + lr) * 16);
   }
   const unsigned seq_bytes = (unsigned)p.nbp * BLK_BYTES;
   const rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(kseq), 0, seq_bytes, 0x00020000);
@@ -406,7 +447,7 @@ __global__ __launch_bounds__(256, (QB == 1 ? 4 : 2)) void attn_frag_kernel(const
   }
 
   const int seq = sh / p.heads, head = sh - seq * p.heads;
-  bf16* st16[QB][2];
+  hf* st16[QB][2];
   bool okq[QB];
   float gatev[QB];
 #pragma unroll
@@ -418,7 +459,7 @@ __global__ __launch_bounds__(256, (QB == 1 ? 4 : 2)) void attn_frag_kernel(const
     if (okq[j]) {
       gatev[j] = p.gates[(long)sh * p.nbp * 32 + qi];
       const long orow = (long)(seq / p.o_div) * p.o_outer + (long)(seq % p.o_div) * p.o_inner + (long)qi * p.o_tok;
-      bf16* op = reinterpret_cast<bf16*>(p.out) + orow * p.inner + head * 32 + 8 * g;
+      hf* op = reinterpret_cast<hf*>(p.out) + orow * p.inner + head * 32 + 8 * g;
 #pragma unroll
       for (int k = 0; k < 2; ++k) st16[j][k] = op + 16 * k;
     }

@@ -11,10 +11,10 @@ template <> DEVI Frag<float> ldg_frag<float>(const float* p) {
   for (int i = 0; i < 4; ++i) f.v[i] = reinterpret_cast<const f32x4*>(p)[i];
   return f;
 }
-template <> DEVI Frag<bf16> ldg_frag<bf16>(const bf16* p) {
-  Frag<bf16> f;
-  f.v[0] = reinterpret_cast<const bf16x8*>(p)[0];
-  f.v[1] = reinterpret_cast<const bf16x8*>(p)[1];
+template <> DEVI Frag<hf> ldg_frag<hf>(const hf* p) {
+  Frag<hf> f;
+  f.v[0] = reinterpret_cast<const hfx8*>(p)[0];
+  f.v[1] = reinterpret_cast<const hfx8*>(p)[1];
   return f;
 }
 
@@ -31,8 +31,8 @@ template <> DEVI Frag<float> ldx_frag<float>(const float* p, bool ok, float& ss)
   }
   return f;
 }
-template <> DEVI Frag<bf16> ldx_frag<bf16>(const float* p, bool ok, float& ss) {
-  Frag<bf16> f;
+template <> DEVI Frag<hf> ldx_frag<hf>(const float* p, bool ok, float& ss) {
+  Frag<hf> f;
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
 #pragma unroll
@@ -41,7 +41,7 @@ template <> DEVI Frag<bf16> ldx_frag<bf16>(const float* p, bool ok, float& ss) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         ss = fmaf(v[j], v[j], ss);
-        f.v[h][4 * i + j] = (bf16)v[j];
+        f.v[h][4 * i + j] = (hf)v[j];
       }
     }
   }
@@ -56,12 +56,12 @@ template <> DEVI Frag<float> pack_frag<float>(const float (&h)[16]) {
   for (int i = 0; i < 4; ++i) f.v[i] = f32x4{h[4 * i], h[4 * i + 1], h[4 * i + 2], h[4 * i + 3]};
   return f;
 }
-template <> DEVI Frag<bf16> pack_frag<bf16>(const float (&h)[16]) {
-  Frag<bf16> f;
+template <> DEVI Frag<hf> pack_frag<hf>(const float (&h)[16]) {
+  Frag<hf> f;
 #pragma unroll
   for (int s = 0; s < 2; ++s)
 #pragma unroll
-    for (int j = 0; j < 8; ++j) f.v[s][j] = (bf16)h[8 * s + j];
+    for (int j = 0; j < 8; ++j) f.v[s][j] = (hf)h[8 * s + j];
   return f;
 }
 
@@ -70,13 +70,13 @@ DEVI void zero16(f32x16& a) {
   for (int r = 0; r < 16; ++r) a[r] = 0.f;
 }
 
-// Operand tile staged FRAGMENT-MAJOR in LDS: [piece][lane 0..63][8 bf16 | 4 fp32]; lane l reads its
+// Operand tile staged FRAGMENT-MAJOR in LDS: [piece][lane 0..63][8 half | 4 fp32]; lane l reads its
 // 16 k-values as 16-byte pieces at tile + piece * 1024 + l * 16 (conflict-free, no padding).
 template <typename T> DEVI Frag<T> lds_frag(const char* tile, int lane);
-template <> DEVI Frag<bf16> lds_frag<bf16>(const char* tile, int lane) {
-  Frag<bf16> f;
-  f.v[0] = *reinterpret_cast<const bf16x8*>(tile + lane * 16);
-  f.v[1] = *reinterpret_cast<const bf16x8*>(tile + 1024 + lane * 16);
+template <> DEVI Frag<hf> lds_frag<hf>(const char* tile, int lane) {
+  Frag<hf> f;
+  f.v[0] = *reinterpret_cast<const hfx8*>(tile + lane * 16);
+  f.v[1] = *reinterpret_cast<const hfx8*>(tile + 1024 + lane * 16);
   return f;
 }
 template <> DEVI Frag<float> lds_frag<float>(const char* tile, int lane) {

@@ -1,7 +1,7 @@
 // Shared device helpers for the beat_this MI355X (gfx950 / CDNA4) kernels.
 //
 // Everything is written for wave64 + the 32x32 MFMA shapes:
-//   bf16 operands : v_mfma_f32_32x32x16_bf16  (2 issues per 32-deep k-tile)
+//   half operands : v_mfma_f32_32x32x16_bf16  (2 issues per 32-deep k-tile)
 //   fp32 operands : v_mfma_f32_32x32x2_f32    (16 issues per 32-deep k-tile, exact fp32)
 // C/D layout of both (MI355X guide, "Fragment layout"):
 //   col = lane & 31,  row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5),  reg in [0,16)
@@ -14,10 +14,23 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-typedef __bf16 bf16;
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
-typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+// Half-precision operand type of the BT_PREC_HALF path.  Default: IEEE fp16 (11-bit significand) -- what the reference's
+// float16=True means on a GPU (inference.py:245-246, cli.py:82) and 8x finer than bfloat16 at the same MFMA rate; the
+// logit error against the fp32 path drops from ~5e-2 to ~6e-3 (tools/prec_study.py, tests/test_gpu_scale.py).
+// -DBT_HALF_BF16 builds the bfloat16 variant (8-bit significand, fp32 exponent range) for A/B comparisons.
+// Accumulation is fp32 in both; the residual stream, RMSNorm statistics and softmax sums stay fp32.
+#ifdef BT_HALF_BF16
+typedef __bf16 hf;
+#define BT_HALF_IS_BF16 1
+#define MFMA32_H(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
+#else
+typedef _Float16 hf;
+#define BT_HALF_IS_BF16 0
+#define MFMA32_H(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0)
+#endif
+typedef __attribute__((ext_vector_type(8))) hf hfx8;
+typedef __attribute__((ext_vector_type(4))) hf hfx4;
+typedef __attribute__((ext_vector_type(2))) hf hfx2;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
@@ -27,7 +40,7 @@ typedef __attribute__((ext_vector_type(2))) float f32x2;
 // One lane's share of a [32 rows] x [32 k] operand tile: 16 contiguous k values.
 template <typename T> struct Frag;
 template <> struct Frag<float> { f32x4 v[4]; };
-template <> struct Frag<bf16> { bf16x8 v[2]; };
+template <> struct Frag<hf> { hfx8 v[2]; };
 
 // LDS row pitch (bytes) of a 32-deep k-tile: +16 B pad makes the 16 B column slots of any
 // 16 rows distinct (pitch/16 is odd), i.e. ds_read_b128 fragment reads are conflict free.
@@ -41,9 +54,9 @@ template <> DEVI Frag<float> ld_frag<float>(const char* row_ptr, int g) {
   for (int i = 0; i < 4; ++i) f.v[i] = p[i];
   return f;
 }
-template <> DEVI Frag<bf16> ld_frag<bf16>(const char* row_ptr, int g) {
-  Frag<bf16> f;
-  const bf16x8* p = reinterpret_cast<const bf16x8*>(row_ptr + g * 32);
+template <> DEVI Frag<hf> ld_frag<hf>(const char* row_ptr, int g) {
+  Frag<hf> f;
+  const hfx8* p = reinterpret_cast<const hfx8*>(row_ptr + g * 32);
   f.v[0] = p[0];
   f.v[1] = p[1];
   return f;
@@ -55,9 +68,9 @@ DEVI void mma32(f32x16& acc, const Frag<float>& a, const Frag<float>& b) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.v[i][j], b.v[i][j], acc, 0, 0, 0);
 }
-DEVI void mma32(f32x16& acc, const Frag<bf16>& a, const Frag<bf16>& b) {
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v[0], b.v[0], acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v[1], b.v[1], acc, 0, 0, 0);
+DEVI void mma32(f32x16& acc, const Frag<hf>& a, const Frag<hf>& b) {
+  acc = MFMA32_H(a.v[0], b.v[0], acc);
+  acc = MFMA32_H(a.v[1], b.v[1], acc);
 }
 
 // row of C/D register r for lane-half g
@@ -75,24 +88,26 @@ DEVI float gelu_erf(float x) {
   const float e = 0.5f * p * t * __builtin_amdgcn_exp2f(-0.7213475204f * x * x);  // exp(-x^2 / 2)
   return x * (x < 0.f ? e : 1.0f - e);
 }
-// GELU for the bf16 path: x * sigmoid(1.5957691 x (1 + 0.044715 x^2))  (the tanh form), 7 VALU ops (2 transcendental)
-// instead of 14.  |gelu_tanh - gelu_erf| <= 4.8e-4 absolute for all x (1.2e-4 relative to max(|x|, 1)), i.e. an order of
-// magnitude below the bf16 rounding (2^-9 relative) the result gets anyway; the fp32 path keeps gelu_erf.  The FF1
-// epilogue of the main layers spent as many VALU cycles on gelu_erf as the MFMA pipe spent on the K = 512 product.
+// GELU for the half path: x * sigmoid(x (a + b x^2 + c x^4)) with a, b, c fitted (minimax over [-9, 9]) to the exact
+// x Phi(x): |error| <= 2.6e-5 absolute for all x -- below fp16 operand rounding (2^-12 relative) -- in 9 VALU ops
+// (2 transcendental) instead of gelu_erf's 14.  (The textbook tanh form, c = 0, is 4.8e-4 off: visible next to fp16.)
+// x^2 is clamped at 49: beyond |x| = 7 the sigmoid is saturated to 1 - 2e-11 and the quartic would eventually change
+// sign.  The FF1 epilogue of the main layers spends as many VALU cycles on the activation as the MFMA pipe spends on the
+// K = 512 product, hence the care.  The fp32 path keeps gelu_erf.
 DEVI float gelu_tanh(float x) {
-  const float x2 = x * x;
-  const float z = x * fmaf(x2, -0.1029432f, -2.3022082f);   // -log2(e) * 1.5957691 * (1 + 0.044715 x^2)
-  const float e = __builtin_amdgcn_exp2f(z);                 // exp(-u), u = 1.5957691 x (1 + 0.044715 x^2)
+  const float x2 = fminf(x * x, 49.0f);
+  const float pol = fmaf(fmaf(x2, 0.001014263f, -0.106775716f), x2, -2.3011212f);  // -log2(e) (a + b x^2 + c x^4)
+  const float e = __builtin_amdgcn_exp2f(x * pol);           // exp(-u), u = x (a + b x^2 + c x^4)
   return x * __builtin_amdgcn_rcpf(1.0f + e);                // inf -> 0, 0 -> x: both limits are exact
 }
 template <typename T> DEVI float gelu_t(float x);
 template <> DEVI float gelu_t<float>(float x) { return gelu_erf(x); }
-template <> DEVI float gelu_t<bf16>(float x) { return gelu_tanh(x); }
+template <> DEVI float gelu_t<hf>(float x) { return gelu_tanh(x); }
 DEVI float sigmoidf(float x) { return 1.0f / (1.0f + __expf(-x)); }
 
 template <typename T> DEVI T from_f32(float x);
 template <> DEVI float from_f32<float>(float x) { return x; }
-template <> DEVI bf16 from_f32<bf16>(float x) { return (bf16)x; }
+template <> DEVI hf from_f32<hf>(float x) { return (hf)x; }
 
 DEVI void st16(float* dst, const float* v) {  // 16 floats, 64 B aligned enough for 16 B stores
   f32x4* d = reinterpret_cast<f32x4*>(dst);

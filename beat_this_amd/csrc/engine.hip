@@ -44,7 +44,7 @@ struct bt_engine {
   prof::State prof;
 };
 enum { CAT_STEM = 0, CAT_QKV, CAT_ATTN_SMALL, CAT_ATTN_FLASH, CAT_OUT, CAT_FF1, CAT_FF2, CAT_CONV, CAT_LINEAR,
-       CAT_HEAD, CAT_FF_FUSED, CAT_ATTN_FREQ_FUSED, CAT_COUNT };
+       CAT_HEAD, CAT_FF_FUSED, CAT_ATTN_FREQ_FUSED, CAT_LAYER_TAIL, CAT_COUNT };
 
 namespace {
 
@@ -53,7 +53,7 @@ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 struct Workspace {
   float* xa; float* xb; float* xm; float* gates; void* xmb;
   void* qkv; void* ao; void* hid;
-  void* qf; void* kf; void* vf; float* gates_h; int nbp;  // fragment-major attention operands (bf16 path)
+  void* qf; void* kf; void* vf; float* gates_h; int nbp;  // fragment-major attention operands (half path)
   float* ssq[2];  // [D / 64][B T] partial row sums of squares of the main residual stream (ping-pong)
   void* x8; float* ascale;  // BT_PREC_FP8: e4m3 shadow of the residual stream [B T][D] and its row factors [B T]
   size_t total;
@@ -61,7 +61,7 @@ struct Workspace {
 
 Workspace carve(char* base, int B, int T, int D, int ff_mult, int prec) {
   const bool fp8 = prec == BT_PREC_FP8;
-  if (fp8) prec = BT_PREC_BF16;
+  if (fp8) prec = BT_PREC_HALF;
   const size_t es = prec == BT_PREC_F32 ? 4 : 2;
   const size_t bt = (size_t)B * T;
   const size_t dmax = std::max<size_t>(1024, D);
@@ -71,14 +71,14 @@ Workspace carve(char* base, int B, int T, int D, int ff_mult, int prec) {
   w.xa = (float*)take(bt * 1024 * 4);
   w.xb = (float*)take(bt * 1024 * 4);
   w.xm = (float*)take(bt * D * 4);
-  w.xmb = take(bt * D * 2);  // bf16 shadow of the main residual stream (A operand of the wide GEMMs)
+  w.xmb = take(bt * D * 2);  // half shadow of the main residual stream (A operand of the wide GEMMs)
   w.gates = (float*)take(bt * std::max(32, D / 32) * 4);
   w.qkv = take(bt * 3 * dmax * es);
   w.ao = take(bt * dmax * es);
   w.hid = take(bt * std::max<size_t>(4 * 1024, (size_t)ff_mult * D) * es);  // FF hidden activation / conv shadow
   w.nbp = attn_frag_blocks(T);
   w.qf = w.kf = w.vf = nullptr; w.gates_h = nullptr;
-  if (prec == BT_PREC_BF16) {  // (sequences x heads) = 32 B in the frontend, (D / 32) B in the main layers
+  if (prec == BT_PREC_HALF) {  // (sequences x heads) = 32 B in the frontend, (D / 32) B in the main layers
     const size_t sh = (size_t)B * std::max(32, D / 32);
     w.qf = take(sh * w.nbp * 2048); w.kf = take(sh * w.nbp * 2048); w.vf = take(sh * w.nbp * 2048);
     w.gates_h = (float*)take(sh * w.nbp * 32 * 4);
@@ -111,19 +111,19 @@ Workspace carve(char* base, int B, int T, int D, int ff_mult, int prec) {
 // mode 0: main transformer (sequences = chunks, tokens = frames)
 // mode 1: frequency direction (sequences = (b,t), tokens = f)      -- attn_small
 // mode 2: time direction      (sequences = (b,f), tokens = t)      -- rows permuted around attn_flash
-// Main transformer layer in BT_PREC_BF16 on the gemm3 / attn2 kernels.  ws.ssq[0] holds the partial row sums of
+// Main transformer layer in BT_PREC_HALF on the gemm3 / attn2 kernels.  ws.ssq[0] holds the partial row sums of
 // squares of x on entry and on exit (written by the producer of x: frontend.linear or the previous FF2), ws.ssq[1]
 // those of x after the attention half.
 // fp8: the GEMMs whose e4m3 weights are present run on e4m3 operands (FF1 reads the e4m3 shadow of x written by the
 // out-projection's epilogue and writes an e4m3 hidden activation; FF2 reads that).
-int run_layer_bf16(prof::State* pf, const bt_pair_weights& pw, const float* rope, const Workspace& ws, int B, int T,
+int run_layer_half(prof::State* pf, const bt_pair_weights& pw, const float* rope, const Workspace& ws, int B, int T,
                    int ff_mult, bool fp8, hipStream_t s) {
   const int D = pw.dim, H = pw.heads, HID = ff_mult * D;
   const int M = B * T;
   const int parts = D / 64;
   Gemm3P g;
   memset(&g, 0, sizeof g);
-  g.A = ws.xmb; g.lda = D; g.M = M; g.K = D; g.W = pw.w_qkvg[BT_PREC_BF16]; g.N = 3 * D + H; g.epi = G3_QKV;
+  g.A = ws.xmb; g.lda = D; g.M = M; g.K = D; g.W = pw.w_qkvg[BT_PREC_HALF]; g.N = 3 * D + H; g.epi = G3_QKV;
   g.ssq_in = ws.ssq[0]; g.ssq_parts = parts;
   g.n_seq = B; g.L = T; g.nblk = (T + 31) / 32; g.nbp = ws.nbp; g.heads = H; g.inner = D; g.rope = rope;
   g.qf = ws.qf; g.kf = ws.kf; g.vf = ws.vf; g.gates = ws.gates_h; g.b_gates = pw.b_gates;
@@ -133,26 +133,34 @@ int run_layer_bf16(prof::State* pf, const bt_pair_weights& pw, const float* rope
   a.q = ws.qf; a.k = ws.kf; a.v = ws.vf; a.gates = ws.gates_h; a.out = ws.ao; a.n_seq = B; a.L = T; a.heads = H;
   a.inner = D; a.nbp = ws.nbp; a.o_div = 1; a.o_outer = T; a.o_inner = 0; a.o_tok = 1;
   LAUNCH_CAT(CAT_ATTN_FLASH, s, launch_attn_frag(a, s), "attention");
+  if (!fp8 && pw.w_tail_frag && layer_tail_supported(D, HID)) {
+    // out-projection + FF1 + FF2 in ONE launch: x, its half shadow and the statistics of the new x written once
+    LayerTailP t;
+    t.x = ws.xm; t.M = M; t.C = D; t.hidden = HID; t.ao = ws.ao; t.wfrag = pw.w_tail_frag; t.b1 = pw.b_ff1; t.b2 = pw.b_ff2;
+    t.xb = ws.xmb; t.ssq_out = ws.ssq[0];
+    LAUNCH_CAT(CAT_LAYER_TAIL, s, launch_layer_tail(t, s), "layer tail (out-projection + feed-forward)");
+    return BT_OK;
+  }
   memset(&g, 0, sizeof g);
-  g.A = ws.ao; g.lda = D; g.M = M; g.K = D; g.W = pw.w_out[BT_PREC_BF16]; g.N = D; g.epi = G3_RESID;
+  g.A = ws.ao; g.lda = D; g.M = M; g.K = D; g.W = pw.w_out[BT_PREC_HALF]; g.N = D; g.epi = G3_RESID;
   g.x = ws.xm; g.ldx = D; g.xb = ws.xmb; g.ssq_out = ws.ssq[1];
   const bool ff8 = fp8 && pw.w_ff1_f8 && pw.w_ff2_f8;
   if (ff8) { g.ssq_in = ws.ssq[0]; g.ssq_parts = parts; g.x8 = ws.x8; g.ascale_out = ws.ascale; }
   LAUNCH_CAT(CAT_OUT, s, launch_gemm3(g, s), "out-proj gemm");
   memset(&g, 0, sizeof g);
-  g.A = ws.xmb; g.lda = D; g.M = M; g.K = D; g.W = pw.w_ff1[BT_PREC_BF16]; g.N = HID; g.epi = G3_FF1;
+  g.A = ws.xmb; g.lda = D; g.M = M; g.K = D; g.W = pw.w_ff1[BT_PREC_HALF]; g.N = HID; g.epi = G3_FF1;
   g.bias = pw.b_ff1; g.ssq_in = ws.ssq[1]; g.ssq_parts = parts; g.out = ws.hid; g.ldo = HID;
   if (ff8) { g.A = ws.x8; g.W = pw.w_ff1_f8; g.f8 = 1; g.wscale = pw.s_ff1; g.ascale = ws.ascale; }
   LAUNCH_CAT(CAT_FF1, s, launch_gemm3(g, s), "ff1 gemm");
   memset(&g, 0, sizeof g);
-  g.A = ws.hid; g.lda = HID; g.M = M; g.K = HID; g.W = pw.w_ff2[BT_PREC_BF16]; g.N = D; g.epi = G3_RESID;
+  g.A = ws.hid; g.lda = HID; g.M = M; g.K = HID; g.W = pw.w_ff2[BT_PREC_HALF]; g.N = D; g.epi = G3_RESID;
   g.bias = pw.b_ff2; g.x = ws.xm; g.ldx = D; g.xb = ws.xmb; g.ssq_out = ws.ssq[0];
   if (ff8) { g.W = pw.w_ff2_f8; g.f8 = 1; g.wscale = pw.s_ff2; g.bias = pw.b_ff2_f8; }
   LAUNCH_CAT(CAT_FF2, s, launch_gemm3(g, s), "ff2 gemm");
   return BT_OK;
 }
 
-// bf16 shadow of the residual stream written by the fused out-projection + FF kernel (time-direction half; A operand of
+// half shadow of the residual stream written by the fused out-projection + FF kernel (time-direction half; A operand of
 // the following frontend conv on gemm3)
 inline bool pair_fused2_ok(const bt_pair_weights& pw, int prec) {
   return pw.dim <= 128 && pw.w_outp[prec] && pw.w_ff_frag[prec] && pw.w_outff_frag[prec] && pw.w_attnff_frag[prec];
@@ -164,8 +172,8 @@ int run_pair(prof::State* pf, const bt_pair_weights& pw, const float* rope, floa
   const long M = (long)B * T * F;
   if (M > 0x7fffffffL) return bt_set_error(BT_ERR_ARG, "batch too large for one forward call");
   GemmP g;
-  // main layers in bf16 mode read the bf16 shadow of x (half the operand bytes, no conversion in the k-loop)
-  const bool shadow = xshadow != nullptr && prec == BT_PREC_BF16;
+  // main layers in half mode read the half shadow of x (half the operand bytes, no conversion in the k-loop)
+  const bool shadow = xshadow != nullptr && prec == BT_PREC_HALF;
   const bool fused_ok = C <= 128 && pw.w_outp[prec] && pw.w_ff_frag[prec];
   const bool fused2_ok = fused_ok && pw.w_outff_frag[prec] && pw.w_attnff_frag[prec];
   auto outff = [&]() -> int {  // x += to_out(ws.ao); x += FF(x) in one launch
@@ -187,8 +195,8 @@ int run_pair(prof::State* pf, const bt_pair_weights& pw, const float* rope, floa
     fa.x = x; fa.M = M; fa.C = C; fa.w_qkvg = pw.w_qkvg[prec]; fa.b_gates = pw.b_gates; fa.w_outp = pw.w_outp[prec];
     fa.rope = rope;
     LAUNCH_CAT(CAT_ATTN_FREQ_FUSED, s, launch_attn_freq_fused(fa, prec, s), "fused frequency attention");
-  } else if (mode == 2 && fused_ok && prec == BT_PREC_BF16 && pw.w_qkv_frag) {
-    // bf16 time direction: fragment-major QKV straight from the projection, flash attention on it
+  } else if (mode == 2 && fused_ok && prec == BT_PREC_HALF && pw.w_qkv_frag) {
+    // half time direction: fragment-major QKV straight from the projection, flash attention on it
     QkvFrontP qp;
     memset(&qp, 0, sizeof qp);
     qp.x = x; qp.B = B; qp.T = T; qp.F = F; qp.C = C; qp.wfrag = pw.w_qkv_frag; qp.b_gates = pw.b_gates; qp.rope = rope;
@@ -263,7 +271,7 @@ extern "C" {
 
 const char* bt_last_error(void) { return g_err.c_str(); }
 int bt_version(void) { return 200; }
-int bt_half_is_bf16(void) { return 1; }
+int bt_half_is_bf16(void) { return BT_HALF_IS_BF16; }
 void bt_struct_sizes(int32_t* out) {
   out[0] = (int32_t)sizeof(bt_pair_weights); out[1] = (int32_t)sizeof(bt_model_desc);
   out[2] = (int32_t)sizeof(bt_logmel_tables); out[3] = (int32_t)sizeof(bt_gemm_args);
@@ -298,7 +306,7 @@ int bt_forward(bt_engine* e, void* stream, int prec, const float* d_spect, int B
                float* d_beat, float* d_downbeat) {
   if (!e || !d_spect || !d_ws || !d_beat || !d_downbeat) return bt_set_error(BT_ERR_ARG, "null argument");
   if (B <= 0 || T <= 0 || T > 1536) return bt_set_error(BT_ERR_ARG, "need B >= 1 and 1 <= T <= 1536");
-  if (prec != BT_PREC_F32 && prec != BT_PREC_BF16 && prec != BT_PREC_FP8) return bt_set_error(BT_ERR_ARG, "unknown precision");
+  if (prec != BT_PREC_F32 && prec != BT_PREC_HALF && prec != BT_PREC_FP8) return bt_set_error(BT_ERR_ARG, "unknown precision");
   const bt_model_desc& d = e->d;
   prof::State* pf = &e->prof;
   const int D = d.transformer_dim;
@@ -306,8 +314,8 @@ int bt_forward(bt_engine* e, void* stream, int prec, const float* d_spect, int B
   if (ws.total > ws_bytes) return bt_set_error(BT_ERR_WORKSPACE, "workspace too small");
   hipStream_t s = (hipStream_t)stream;
   const bool fp8 = prec == BT_PREC_FP8;
-  if (fp8) {  // everything but the e4m3 GEMMs of the main layers is the bf16 path
-    prec = BT_PREC_BF16;
+  if (fp8) {  // everything but the e4m3 GEMMs of the main layers is the half path
+    prec = BT_PREC_HALF;
     if (D % 128 != 0 || (long)B * T * d.ff_mult * D * 2 >= 0x7fffffffL)
       return bt_set_error(BT_ERR_ARG, "BT_PREC_FP8 needs transformer_dim % 128 == 0 (gemm3 main layers)");
     for (int l = 0; l < d.n_layers; ++l)
@@ -316,12 +324,12 @@ int bt_forward(bt_engine* e, void* stream, int prec, const float* d_spect, int B
         return bt_set_error(BT_ERR_ARG, "BT_PREC_FP8 needs the e4m3 feed-forward weights of every layer");
   }
 
-  // the bf16 shadow of the main residual stream is maintained by the gemm2 / gemm3 epilogues only
-  const bool use_shadow = prec == BT_PREC_BF16 && D >= 128 && D % 64 == 0;
+  // the half shadow of the main residual stream is maintained by the gemm2 / gemm3 epilogues only
+  const bool use_shadow = prec == BT_PREC_HALF && D >= 128 && D % 64 == 0;
   // main layers on gemm3 + fragment-major attention (needs q | k | v column blocks that are whole 128-tiles)
   const bool fast_layers = use_shadow && D % 128 == 0 && (long)B * T * d.ff_mult * D * 2 < 0x7fffffffL;
 
-  // frontend.linear on gemm3 (bf16 A written by the last conv block) when its shape fits
+  // frontend.linear on gemm3 (half A written by the last conv block) when its shape fits
   bool lin3 = false;
   if (fast_layers) {
     Gemm3P g;
@@ -339,10 +347,10 @@ int bt_forward(bt_engine* e, void* stream, int prec, const float* d_spect, int B
   float* xn = ws.xb;
   for (int blk = 0; blk < 3; ++blk) {
     const int C = 32 << blk, F = 32 >> blk;
-    // conv of this block on gemm3 (LDS-DMA ring on the bf16 shadow of x that the time-direction half leaves in ws.hid)
+    // conv of this block on gemm3 (LDS-DMA ring on the half shadow of x that the time-direction half leaves in ws.hid)
     Gemm3P cg;
     memset(&cg, 0, sizeof cg);
-    cg.A = ws.hid; cg.lda = 2 * C; cg.M = B * T * (F / 2); cg.K = 6 * C; cg.W = d.conv_w[blk][BT_PREC_BF16]; cg.N = 2 * C;
+    cg.A = ws.hid; cg.lda = 2 * C; cg.M = B * T * (F / 2); cg.K = 6 * C; cg.W = d.conv_w[blk][BT_PREC_HALF]; cg.N = 2 * C;
     cg.epi = G3_RESID; cg.no_resid = 1; cg.gelu = 1; cg.bias = d.conv_b[blk]; cg.ldx = 2 * C;
     cg.conv_C2 = 2 * C; cg.conv_T = T; cg.conv_F = F / 2;
     const bool to_bf16 = blk == 2 && lin3;  // the last block's output is read by frontend.linear (gemm3) only
@@ -365,8 +373,8 @@ int bt_forward(bt_engine* e, void* stream, int prec, const float* d_spect, int B
     memset(&g, 0, sizeof g);
     g.A = x; g.W = d.conv_w[blk][prec]; g.M = B * T * (F / 2); g.N = 2 * C; g.K = 6 * C;
     g.epi = GEMM_EPI_STORE; g.flags = GEMM_F_CONV | GEMM_F_A_F32 | GEMM_F_BIAS | GEMM_F_GELU | GEMM_F_OUT_F32;
-    // the last block's output is read by frontend.linear only: bf16 when that runs on gemm3 (same rounding point as
-    // the fp32 -> bf16 conversion of its A operand, half the bytes both ways)
+    // the last block's output is read by frontend.linear only: half when that runs on gemm3 (same rounding point as
+    // the fp32 -> half conversion of its A operand, half the bytes both ways)
     if (blk == 2 && lin3) g.flags &= ~GEMM_F_OUT_F32;
     g.bias = d.conv_b[blk]; g.out = xn; g.ldo = 2 * C;
     g.conv_C2 = 2 * C; g.conv_T = T; g.conv_F = F / 2;
@@ -376,7 +384,7 @@ int bt_forward(bt_engine* e, void* stream, int prec, const float* d_spect, int B
   if (lin3) {
     Gemm3P g;
     memset(&g, 0, sizeof g);
-    g.A = x; g.lda = 1024; g.M = B * T; g.K = 1024; g.W = d.lin_w[BT_PREC_BF16]; g.N = D; g.epi = G3_RESID;
+    g.A = x; g.lda = 1024; g.M = B * T; g.K = 1024; g.W = d.lin_w[BT_PREC_HALF]; g.N = D; g.epi = G3_RESID;
     g.no_resid = 1; g.bias = d.lin_b; g.x = ws.xm; g.ldx = D; g.xb = ws.xmb; g.ssq_out = ws.ssq[0];
     LAUNCH_CAT(CAT_LINEAR, s, launch_gemm3(g, s), "frontend linear gemm");
   } else {
@@ -389,7 +397,7 @@ int bt_forward(bt_engine* e, void* stream, int prec, const float* d_spect, int B
     LAUNCH_CAT(CAT_LINEAR, s, launch_gemm(g, prec, s), "frontend linear gemm");
   }
   for (int l = 0; l < d.n_layers; ++l) {
-    int rc = fast_layers ? run_layer_bf16(pf, d.layers[l], d.rope, ws, B, T, d.ff_mult, fp8, s)
+    int rc = fast_layers ? run_layer_half(pf, d.layers[l], d.rope, ws, B, T, d.ff_mult, fp8, s)
                          : run_pair(pf, d.layers[l], d.rope, ws.xm, use_shadow ? ws.xmb : nullptr, ws, B, T, 1, 0, prec, s, nullptr,
                                     d.ff_mult);
     if (rc) return rc;
@@ -651,6 +659,17 @@ int bt_attnff_fused(void* stream, int prec, const bt_pair_weights* w, const floa
   f.x = d_x; f.M = M; f.C = w->dim; f.b_gates = w->b_gates; f.rope = d_rope; f.wfrag = w->w_attnff_frag[prec];
   f.b1 = w->b_ff1; f.b2 = w->b_ff2;
   LAUNCH(launch_attnff_fused(f, prec, (hipStream_t)stream), "fused frequency attention + feed-forward");
+  return BT_OK;
+}
+
+int bt_layer_tail(void* stream, const bt_pair_weights* w, int hidden, const void* d_ao, float* d_x, int64_t M, void* d_xb,
+                  float* d_ssq_out) {
+  if (!w || !w->w_tail_frag || !d_ao || !d_x || M <= 0 || !layer_tail_supported(w->dim, hidden))
+    return bt_set_error(BT_ERR_ARG, "bad argument to bt_layer_tail");
+  LayerTailP t;
+  t.x = d_x; t.M = M; t.C = w->dim; t.hidden = hidden; t.ao = d_ao; t.wfrag = w->w_tail_frag; t.b1 = w->b_ff1;
+  t.b2 = w->b_ff2; t.xb = d_xb; t.ssq_out = d_ssq_out;
+  LAUNCH(launch_layer_tail(t, (hipStream_t)stream), "layer tail");
   return BT_OK;
 }
 

@@ -28,7 +28,7 @@ namespace {
 // operand tiles [W1 rows hb*32.. x k-tile kt | W2p rows mt*32.. x cols hb*32..] are stored as
 // [tile][half h][lane][8 elements], i.e. one contiguous block of 2*KT*32*32 elements per hb whose
 // LDS image is exactly what the lanes read (lane l, half h: 16 B at tile + h*1024 B + l*16 B for
-// bf16).  One workgroup (4 waves = 128 tokens) copies that block global -> LDS once per hb
+// half).  One workgroup (4 waves = 128 tokens) copies that block global -> LDS once per hb
 // (coalesced 16-byte chunks, double buffered, one barrier per hb) and all four waves read their
 // A fragments from LDS conflict-free.  L2 -> CU weight traffic drops 4x versus per-wave streaming.
 template <typename T, int C>
@@ -105,8 +105,8 @@ __global__ __launch_bounds__(256) void ff_fused_kernel(const FusedFFP p) {
         for (int j = 0; j < 4; ++j) v[j] += acc2[mt][4 * a + j] + b[j];
         *xp = v;
         if (p.xb)
-          *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16*>(p.xb) + tok * C + f0) =
-              bf16x4{(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+          *reinterpret_cast<hfx4*>(reinterpret_cast<hf*>(p.xb) + tok * C + f0) =
+              hfx4{(hf)v[0], (hf)v[1], (hf)v[2], (hf)v[3]};
       }
   }
 }
@@ -263,9 +263,9 @@ int launch_af_t(const FusedAttnP& p, hipStream_t s) {
 
 int launch_ff_fused(const FusedFFP& p, int prec, hipStream_t s) {
   if (p.M <= 0) return -2;
-  return prec == BT_PREC_F32 ? launch_ff_t<float>(p, s) : launch_ff_t<bf16>(p, s);
+  return prec == BT_PREC_F32 ? launch_ff_t<float>(p, s) : launch_ff_t<hf>(p, s);
 }
 int launch_attn_freq_fused(const FusedAttnP& p, int prec, hipStream_t s) {
   if (p.M <= 0) return -2;
-  return prec == BT_PREC_F32 ? launch_af_t<float>(p, s) : launch_af_t<bf16>(p, s);
+  return prec == BT_PREC_F32 ? launch_af_t<float>(p, s) : launch_af_t<hf>(p, s);
 }

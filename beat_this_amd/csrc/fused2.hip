@@ -26,8 +26,8 @@ namespace {
 
 typedef __amdgpu_buffer_rsrc_t rsrc_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
-DEVI unsigned pk2_bf16(float a, float b) {
-  const bf16x2 t = {(bf16)a, (bf16)b};
+DEVI unsigned pk2_hf(float a, float b) {
+  const hfx2 t = {(hf)a, (hf)b};
   return __builtin_bit_cast(unsigned, t);
 }
 
@@ -90,7 +90,7 @@ struct WRing {
 // vmcnt accounting).
 template <typename T, int C>
 DEVI void ff_tail(WRing<T, C>& ws, int step0, float (&xn)[C / 32][16], const float* b1s, const float* b2,
-                  float* xrow, bf16* xbrow, bool ok, int lane, int g) {
+                  float* xrow, hf* xbrow, bool ok, int lane, int g) {
   constexpr int KT = C / 32, HB = 4 * C / 32;
   constexpr int TILE_B = WRing<T, C>::TILE_B;
   float ss = 0.f;
@@ -137,12 +137,12 @@ DEVI void ff_tail(WRing<T, C>& ws, int step0, float (&xn)[C / 32][16], const flo
       for (int j = 0; j < 4; ++j) v[a][j] = acc2[mt][4 * a + j] + b[j];
       if (ok) *reinterpret_cast<f32x4*>(xrow + f0) = v[a];
     }
-    if (xbrow) {  // bf16 shadow: the two halves of the wave exchange 4-feature runs so that a lane stores 16 bytes
+    if (xbrow) {  // half shadow: the two halves of the wave exchange 4-feature runs so that a lane stores 16 bytes
                   // (features 16 k + 8 g .. + 7); 8-byte row-strided stores cost 44 us per forward here.  Executed by all lanes.
 #pragma unroll
       for (int k = 0; k < 2; ++k) {
-        const unsigned x0 = pk2_bf16(v[2 * k][0], v[2 * k][1]), x1 = pk2_bf16(v[2 * k][2], v[2 * k][3]);
-        const unsigned y0 = pk2_bf16(v[2 * k + 1][0], v[2 * k + 1][1]), y1 = pk2_bf16(v[2 * k + 1][2], v[2 * k + 1][3]);
+        const unsigned x0 = pk2_hf(v[2 * k][0], v[2 * k][1]), x1 = pk2_hf(v[2 * k][2], v[2 * k][3]);
+        const unsigned y0 = pk2_hf(v[2 * k + 1][0], v[2 * k + 1][1]), y1 = pk2_hf(v[2 * k + 1][2], v[2 * k + 1][3]);
         auto r0 = __builtin_amdgcn_permlane32_swap(x0, y0, false, false);
         auto r1 = __builtin_amdgcn_permlane32_swap(x1, y1, false, false);
         typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
@@ -202,7 +202,7 @@ __global__ __launch_bounds__(256) void outff_fused_kernel(const FusedOutFFP p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) xn[mt][r] += acc[r];
   }
-  bf16* xbrow = p.xb ? reinterpret_cast<bf16*>(p.xb) + tok * C : nullptr;
+  hf* xbrow = p.xb ? reinterpret_cast<hf*>(p.xb) + tok * C : nullptr;
   ff_tail<T, C>(ws, KT, xn, b1s, p.b2, xrow, xbrow, ok_st, lane, g);
 }
 
@@ -409,9 +409,9 @@ int launch_outff_fused(const FusedOutFFP& p0, int prec, hipStream_t s) {
   static const int abl = getenv("BT_F2_ABL") ? atoi(getenv("BT_F2_ABL")) : 0;
   p.abl = abl;
 #endif
-  return prec == BT_PREC_F32 ? launch_outff_t<float>(p, s) : launch_outff_t<bf16>(p, s);
+  return prec == BT_PREC_F32 ? launch_outff_t<float>(p, s) : launch_outff_t<hf>(p, s);
 }
 int launch_attnff_fused(const FusedAttnFFP& p, int prec, hipStream_t s) {
   if (p.M <= 0) return -2;
-  return prec == BT_PREC_F32 ? launch_attnff_t<float>(p, s) : launch_attnff_t<bf16>(p, s);
+  return prec == BT_PREC_F32 ? launch_attnff_t<float>(p, s) : launch_attnff_t<hf>(p, s);
 }

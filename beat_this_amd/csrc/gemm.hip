@@ -11,7 +11,7 @@
 //   * QKV epilogue: RoPE on the q and k column blocks (interleaved pairs, table lookup),
 //     sigmoid(+bias) on the appended gate columns (roformer.py:117-129), optional
 //     (b,t,f)->(b,f,t) row permutation of the store for the time-direction attention.
-//   * bias / exact-erf GELU / residual add / fp32 or bf16 output.
+//   * bias / exact-erf GELU / residual add / fp32 or half output.
 //   * implicit-GEMM A gather for the (2,3)/(2,1) frontend convolutions in (b,t,f,c) layout.
 #include <type_traits>
 
@@ -22,7 +22,7 @@ namespace {
 
 template <typename E> struct Stg;
 template <> struct Stg<float> { f32x4 v[4]; };
-template <> struct Stg<bf16> { bf16x8 v[2]; };
+template <> struct Stg<hf> { hfx8 v[2]; };
 
 template <typename E> DEVI Stg<E> ldg16(const E* p, bool ok);
 template <> DEVI Stg<float> ldg16<float>(const float* p, bool ok) {
@@ -37,16 +37,16 @@ template <> DEVI Stg<float> ldg16<float>(const float* p, bool ok) {
   }
   return s;
 }
-template <> DEVI Stg<bf16> ldg16<bf16>(const bf16* p, bool ok) {
-  Stg<bf16> s;
+template <> DEVI Stg<hf> ldg16<hf>(const hf* p, bool ok) {
+  Stg<hf> s;
   if (ok) {
-    const bf16x8* q = reinterpret_cast<const bf16x8*>(p);
+    const hfx8* q = reinterpret_cast<const hfx8*>(p);
     s.v[0] = q[0];
     s.v[1] = q[1];
   } else {
     typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
     u32x4 z = {0, 0, 0, 0};
-    s.v[0] = __builtin_bit_cast(bf16x8, z);
+    s.v[0] = __builtin_bit_cast(hfx8, z);
     s.v[1] = s.v[0];
   }
   return s;
@@ -60,7 +60,7 @@ DEVI float sumsq(const Stg<float>& s) {
     for (int j = 0; j < 4; ++j) a = fmaf(s.v[i][j], s.v[i][j], a);
   return a;
 }
-DEVI float sumsq(const Stg<bf16>&) { return 0.f; }
+DEVI float sumsq(const Stg<hf>&) { return 0.f; }
 
 // write 16 staged elements to an LDS tile row as compute dtype T
 DEVI void sts16(char* dst, const Stg<float>& s, float) {
@@ -68,18 +68,18 @@ DEVI void sts16(char* dst, const Stg<float>& s, float) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) d[i] = s.v[i];
 }
-DEVI void sts16(char* dst, const Stg<bf16>& s, bf16) {
-  bf16x8* d = reinterpret_cast<bf16x8*>(dst);
+DEVI void sts16(char* dst, const Stg<hf>& s, hf) {
+  hfx8* d = reinterpret_cast<hfx8*>(dst);
   d[0] = s.v[0];
   d[1] = s.v[1];
 }
-DEVI void sts16(char* dst, const Stg<float>& s, bf16) {
-  bf16x8* d = reinterpret_cast<bf16x8*>(dst);
+DEVI void sts16(char* dst, const Stg<float>& s, hf) {
+  hfx8* d = reinterpret_cast<hfx8*>(dst);
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
-    bf16x8 o;
+    hfx8 o;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) o[j] = (bf16)s.v[2 * h + (j >> 2)][j & 3];
+    for (int j = 0; j < 8; ++j) o[j] = (hf)s.v[2 * h + (j >> 2)][j & 3];
     d[h] = o;
   }
 }
@@ -271,6 +271,6 @@ int launch_gemm(const GemmP& p, int prec, hipStream_t s) {
   if ((p.flags & GEMM_F_CONV) && (p.conv_C2 % 32 != 0 || p.K != 3 * p.conv_C2)) return -2;
   if (p.epi == GEMM_EPI_QKV && (p.inner % 32 != 0)) return -2;
   if (prec == BT_PREC_F32) return launch_epi<float, true>(p, s);
-  if (p.flags & GEMM_F_A_F32) return launch_epi<bf16, true>(p, s);
-  return launch_epi<bf16, false>(p, s);
+  if (p.flags & GEMM_F_A_F32) return launch_epi<hf, true>(p, s);
+  return launch_epi<hf, false>(p, s);
 }

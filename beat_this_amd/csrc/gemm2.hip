@@ -1,5 +1,5 @@
-// bf16 GEMM for the wide layers (N >= 128, K % 64 == 0): main-transformer QKV / out / FF,
-// frontend.linear and the frontend convolutions in BT_PREC_BF16.  Same contract and epilogues as
+// half GEMM for the wide layers (N >= 128, K % 64 == 0): main-transformer QKV / out / FF,
+// frontend.linear and the frontend convolutions in BT_PREC_HALF.  Same contract and epilogues as
 // gemm.hip (GemmP), different engine:
 //   * 128 x 128 x 64 tiles, 4 waves as 2 x 2 (64 x 64 each = 2 x 2 MFMA 32x32 tiles, 16 MFMAs per
 //     k-step between barriers);
@@ -8,8 +8,8 @@
 //   * XCD-aware tile order: the 1-D grid is remapped so that the (N/128) tiles sharing one
 //     128-row A panel run on the same XCD (block b -> XCD b % 8), i.e. the panel is fetched into
 //     one L2 instead of eight;
-//   * bf16 outputs leave through LDS: accumulators -> bf16 tile in LDS -> 16-byte row-contiguous
-//     stores (a 128-wide bf16 row is 256 B = two full lines) instead of 2-byte scattered stores.
+//   * half outputs leave through LDS: accumulators -> half tile in LDS -> 16-byte row-contiguous
+//     stores (a 128-wide half row is 256 B = two full lines) instead of 2-byte scattered stores.
 #include <type_traits>
 
 #include "common.h"
@@ -18,20 +18,20 @@
 namespace {
 
 constexpr int BM = 128, BN = 128, BK = 64;
-constexpr int PITCH2 = BK * 2 + 16;         // bytes per LDS tile row (bf16) -> conflict-free b128 reads
+constexpr int PITCH2 = BK * 2 + 16;         // bytes per LDS tile row (half) -> conflict-free b128 reads
 constexpr int OPITCH = BN * 2 + 16;         // bytes per staged output row
 constexpr int BUF_BYTES = (BM + BN) * PITCH2;
 
 // Staging is chunk-coalesced: consecutive lanes fetch consecutive 16-byte chunks of a row, so one
 // wave-instruction covers whole 128-byte lines (fp32 A: 16 chunks = 256 B per row and k-step,
-// 4 rows per instruction; bf16: 8 chunks = 128 B per row, 8 rows per instruction).  A
+// 4 rows per instruction; half: 8 chunks = 128 B per row, 8 rows per instruction).  A
 // row-per-lane mapping re-requests every line 8 times and is TA-bound at a quarter of the rate.
 struct AF { f32x4 v[8]; };    // fp32 A: rows r0 + 16 p, p = 0..7, chunk c = tid % 16 (4 floats)
-struct AH { bf16x8 v[4]; };   // bf16 A or W: rows r0 + 32 p, p = 0..3, chunk c = tid % 8 (8 bf16)
+struct AH { hfx8 v[4]; };   // half A or W: rows r0 + 32 p, p = 0..3, chunk c = tid % 8 (8 half)
 
 template <bool A_F32, int EPI>
 __global__ __launch_bounds__(256, 2) void gemm2_kernel(const GemmP p, int n_tiles, int total_tiles, int per_xcd) {
-  using EA = typename std::conditional<A_F32, float, bf16>::type;
+  using EA = typename std::conditional<A_F32, float, hf>::type;
   constexpr int APASS = A_F32 ? 8 : 4;        // row passes of the A staging
   constexpr int AROWS = A_F32 ? 16 : 32;      // rows covered per pass
   constexpr int ACH = A_F32 ? 16 : 8;         // 16-byte chunks per row and k-step
@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256, 2) void gemm2_kernel(const GemmP p, int n_tile
       a_off[ps] = ((b * p.conv_T + t) * p.conv_F + f) * (long)p.conv_C2 + ac * AEL;
     }
   }
-  const bf16* Wb = reinterpret_cast<const bf16*>(p.W) + (long)(n0 + (tid >> 3)) * p.K + (tid & 7) * 8;
+  const hf* Wb = reinterpret_cast<const hf*>(p.W) + (long)(n0 + (tid >> 3)) * p.K + (tid & 7) * 8;
   using AReg = typename std::conditional<A_F32, AF, AH>::type;
   auto loadA = [&](int kt, AReg& ra) {
     long koff = (long)kt * BK;
@@ -96,13 +96,13 @@ __global__ __launch_bounds__(256, 2) void gemm2_kernel(const GemmP p, int n_tile
       else {
         typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
         const u32x4 z = {0, 0, 0, 0};
-        ra.v[ps] = ok ? *reinterpret_cast<const bf16x8*>(src) : __builtin_bit_cast(bf16x8, z);
+        ra.v[ps] = ok ? *reinterpret_cast<const hfx8*>(src) : __builtin_bit_cast(hfx8, z);
       }
     }
   };
   auto loadB = [&](int kt, AH& rb) {
 #pragma unroll
-    for (int ps = 0; ps < 4; ++ps) rb.v[ps] = *reinterpret_cast<const bf16x8*>(Wb + (long)ps * 32 * p.K + (long)kt * BK);
+    for (int ps = 0; ps < 4; ++ps) rb.v[ps] = *reinterpret_cast<const hfx8*>(Wb + (long)ps * 32 * p.K + (long)kt * BK);
   };
   const bool rms_on = (p.flags & GEMM_F_RMS) != 0;
   float ssq[APASS];
@@ -115,24 +115,28 @@ __global__ __launch_bounds__(256, 2) void gemm2_kernel(const GemmP p, int n_tile
       if constexpr (A_F32) {
         const f32x4 v = ra.v[ps];
         ssq[ps] = fmaf(v[0], v[0], fmaf(v[1], v[1], fmaf(v[2], v[2], fmaf(v[3], v[3], ssq[ps]))));
-        *reinterpret_cast<bf16x4*>(dst) = bf16x4{(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+        *reinterpret_cast<hfx4*>(dst) = hfx4{(hf)v[0], (hf)v[1], (hf)v[2], (hf)v[3]};
       } else {
-        if (rms_on) {  // sum of squares of the bf16 operands themselves (v_dot2c_f32_bf16)
-          const bf16x8 v = ra.v[ps];
+        if (rms_on) {  // sum of squares of the half operands themselves (v_dot2c_f32_bf16)
+          const hfx8 v = ra.v[ps];
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            const bf16x2 pr = {v[2 * q], v[2 * q + 1]};
+            const hfx2 pr = {v[2 * q], v[2 * q + 1]};
+            #if BT_HALF_IS_BF16
             ssq[ps] = __builtin_amdgcn_fdot2_f32_bf16(pr, pr, ssq[ps], false);
+#else
+            ssq[ps] = __builtin_amdgcn_fdot2(pr, pr, ssq[ps], false);
+#endif
           }
         }
-        *reinterpret_cast<bf16x8*>(dst) = ra.v[ps];
+        *reinterpret_cast<hfx8*>(dst) = ra.v[ps];
       }
     }
   };
   auto storeB = [&](char* buf, const AH& rb) {
 #pragma unroll
     for (int ps = 0; ps < 4; ++ps)
-      *reinterpret_cast<bf16x8*>(buf + BM * PITCH2 + ((tid >> 3) + 32 * ps) * PITCH2 + (tid & 7) * 16) = rb.v[ps];
+      *reinterpret_cast<hfx8*>(buf + BM * PITCH2 + ((tid >> 3) + 32 * ps) * PITCH2 + (tid & 7) * 16) = rb.v[ps];
   };
 
   f32x16 acc[2][2];
@@ -166,11 +170,11 @@ __global__ __launch_bounds__(256, 2) void gemm2_kernel(const GemmP p, int n_tile
     const char* b_src = cur + BM * PITCH2 + (wn * 64 + lr) * PITCH2;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      Frag<bf16> fa[2], fb[2];
+      Frag<hf> fa[2], fb[2];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) fa[i] = ld_frag<bf16>(a_src + i * 32 * PITCH2 + ks * 64, g);
+      for (int i = 0; i < 2; ++i) fa[i] = ld_frag<hf>(a_src + i * 32 * PITCH2 + ks * 64, g);
 #pragma unroll
-      for (int j = 0; j < 2; ++j) fb[j] = ld_frag<bf16>(b_src + j * 32 * PITCH2 + ks * 64, g);
+      for (int j = 0; j < 2; ++j) fb[j] = ld_frag<hf>(b_src + j * 32 * PITCH2 + ks * 64, g);
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -213,7 +217,7 @@ __global__ __launch_bounds__(256, 2) void gemm2_kernel(const GemmP p, int n_tile
   __syncthreads();
 
   if (EPI == GEMM_EPI_QKV || (EPI == GEMM_EPI_STORE && !(p.flags & GEMM_F_OUT_F32))) {
-    // ---- bf16 output: 16 chunks of 8 columns per row ----------------------------------------------
+    // ---- half output: 16 chunks of 8 columns per row ----------------------------------------------
     const int ch = tid & 15;
     const int col = n0 + ch * 8;
     float bias8[8];
@@ -269,10 +273,10 @@ __global__ __launch_bounds__(256, 2) void gemm2_kernel(const GemmP p, int n_tile
         }
       }
       if (col < ncols_store) {
-        bf16x8 o;
+        hfx8 o;
 #pragma unroll
-        for (int q = 0; q < 8; ++q) o[q] = (bf16)v[q];
-        *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(p.out) + orow * p.ldo + col) = o;
+        for (int q = 0; q < 8; ++q) o[q] = (hf)v[q];
+        *reinterpret_cast<hfx8*>(reinterpret_cast<hf*>(p.out) + orow * p.ldo + col) = o;
       }
     }
   } else {
@@ -282,7 +286,7 @@ __global__ __launch_bounds__(256, 2) void gemm2_kernel(const GemmP p, int n_tile
     const bool col_ok = col < p.N;
     f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
     if ((p.flags & GEMM_F_BIAS) && col_ok) b4 = *reinterpret_cast<const f32x4*>(p.bias + col);
-    bf16* xb = reinterpret_cast<bf16*>(p.xb);
+    hf* xb = reinterpret_cast<hf*>(p.xb);
 #pragma unroll
     for (int half8 = 0; half8 < 2; ++half8) {
       f32x4 xv[8];
@@ -317,7 +321,7 @@ __global__ __launch_bounds__(256, 2) void gemm2_kernel(const GemmP p, int n_tile
         }
         if (ok) {
           *reinterpret_cast<f32x4*>(dst + gm * ld + col) = v;
-          if (xb) *reinterpret_cast<bf16x4*>(xb + gm * ld + col) = bf16x4{(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+          if (xb) *reinterpret_cast<hfx4*>(xb + gm * ld + col) = hfx4{(hf)v[0], (hf)v[1], (hf)v[2], (hf)v[3]};
         }
         if (p.ssq_out) {  // partial sums of squares per 64 columns (16 consecutive lanes), for the consumer's RMSNorm
           float ss = ok ? fmaf(v[0], v[0], fmaf(v[1], v[1], fmaf(v[2], v[2], v[3] * v[3]))) : 0.f;
@@ -358,7 +362,7 @@ int launch2(const GemmP& p, hipStream_t s) {
 }  // namespace
 
 bool gemm2_supported(const GemmP& p, int prec) {
-  if (prec != BT_PREC_BF16 || p.N < 128 || p.K % 64 != 0 || p.M <= 0) return false;
+  if (prec != BT_PREC_HALF || p.N < 128 || p.K % 64 != 0 || p.M <= 0) return false;
   if ((p.flags & GEMM_F_CONV) && p.conv_C2 % 64 != 0) return false;
   if (p.epi == GEMM_EPI_QKV && ((3 * p.inner) % 8 != 0 || p.ldo % 8 != 0)) return false;
   if (p.epi == GEMM_EPI_STORE && !(p.flags & GEMM_F_OUT_F32) && (p.N % 8 != 0 || p.ldo % 8 != 0)) return false;

@@ -1,5 +1,5 @@
-// bf16 / e4m3 GEMM of the BT_PREC_BF16 / BT_PREC_FP8 forward:  C[M,N] = epilogue(A[M,K] . W[N,K]^T), A = bf16 (e4m3)
-// activations (shadow of the residual stream / attention output / FF hidden), W = bf16 (e4m3) weights.  Main-layer QKV,
+// half / e4m3 GEMM of the BT_PREC_HALF / BT_PREC_FP8 forward:  C[M,N] = epilogue(A[M,K] . W[N,K]^T), A = half (e4m3)
+// activations (shadow of the residual stream / attention output / FF hidden), W = half (e4m3) weights.  Main-layer QKV,
 // out-projection, FF1, FF2; frontend.linear; the second and third frontend convolution (implicit-GEMM gather).
 //
 // Engine (differences from gemm2.hip):
@@ -33,7 +33,7 @@ struct G3CfgS { static constexpr int BM = 128, BN = 128, BK = 32, WGM = 2, WGN =
 struct G3CfgB { static constexpr int BM = 256, BN = 256, BK = 64, WGM = 2, WGN = 4, NST = 2, OCC = 1, ES = 2; };
 // e4m3 operands (BT_PREC_FP8, ES = 1 byte per element): the same LDS images (64- / 128-byte rows) hold twice the k
 // range; one v_mfma_scale_f32_32x32x64_f8f6f4 with unit block scales per 64-byte row group (lane = row, 32
-// consecutive k bytes at 32 (lane >> 5); layout and rate -- 4.15 PFLOP/s vs 2.3 for bf16 -- checked by
+// consecutive k bytes at 32 (lane >> 5); layout and rate -- 4.15 PFLOP/s vs 2.3 for half -- checked by
 // tools/ubench/mfma_f8_probe.hip), so the k-loop is half as long for the same LDS-DMA bytes per step.
 // T = B with 192 token rows (waves of 96 x 64): picked when it covers M in fewer CU-rounds x rows -- final0's FF2 at
 // M = 24000 is 125 x 2 = 250 tiles = one round on 98 % of the CUs instead of 188 tiles on 73 % (72 -> 65 us).
@@ -70,13 +70,13 @@ DEVI unsigned pk4_f8(float a, float b, float c, float d) {
 }
 
 DEVI unsigned pk2(float a, float b) {
-  const bf16x2 t = {(bf16)a, (bf16)b};
+  const hfx2 t = {(hf)a, (hf)b};
   return __builtin_bit_cast(unsigned, t);
 }
 
 // 16 values of one lane (features crow(r, g) of its row) -> two 16-byte pieces of 8 consecutive features each:
 // after the half exchange lane g = 0 holds features 16k .. 16k+7, lane g = 1 features 16k+8 .. 16k+15 (k = 0, 1).
-DEVI void pack_row_bf16(const float (&v)[16], u32x4 (&piece)[2]) {
+DEVI void pack_row_hf(const float (&v)[16], u32x4 (&piece)[2]) {
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
     unsigned x0 = pk2(v[8 * k], v[8 * k + 1]), x1 = pk2(v[8 * k + 2], v[8 * k + 3]);
@@ -96,7 +96,7 @@ void gemm3_kernel(const Gemm3P p, int n_tiles, int total_tiles, int per_xcd) {
   constexpr int NW = CFG::WGM * CFG::WGN, NT = 64 * NW;
   constexpr int TB = BM / CFG::WGM / 32;       // 32-token blocks per wave
   constexpr int FB = BN / CFG::WGN / 32;       // 32-feature blocks per wave
-  constexpr int ES = CFG::ES;                  // bytes per operand element: 2 = bf16, 1 = e4m3
+  constexpr int ES = CFG::ES;                  // bytes per operand element: 2 = half, 1 = e4m3
   constexpr int ROWB = BK * ES;                // bytes per LDS row
   constexpr int CPR = ROWB / 16;               // 16-byte chunks per row (4 or 8)
   constexpr int RPI = 64 / CPR;                // rows covered by one wave-instruction (1 KB)
@@ -188,10 +188,10 @@ void gemm3_kernel(const Gemm3P p, int n_tiles, int total_tiles, int per_xcd) {
   const int pofs = (normal ? wm * (TB * 32) * ROWB : A_BYTES + wn * (FB * 32) * ROWB) + lr * ROWB;
   const int qofs = (normal ? A_BYTES + wn * (FB * 32) * ROWB : wm * (TB * 32) * ROWB) + lr * ROWB;
   const int sw = swz(lr);
-  constexpr int MS = ES == 2 ? ROWB / 32 : ROWB / 64;  // MFMA steps per k-step: 32 B (bf16 k16) / 64 B (e4m3 k64) of a row
+  constexpr int MS = ES == 2 ? ROWB / 32 : ROWB / 64;  // MFMA steps per k-step: 32 B (half k16) / 64 B (e4m3 k64) of a row
   int kc[ROWB / 32];
 #pragma unroll
-  for (int m = 0; m < ROWB / 32; ++m)  // bf16 step m: chunk 2 m + g;  e4m3 step m: chunks 4 m + 2 g, + 1 (kc[2m], kc[2m+1])
+  for (int m = 0; m < ROWB / 32; ++m)  // half step m: chunk 2 m + g;  e4m3 step m: chunks 4 m + 2 g, + 1 (kc[2m], kc[2m+1])
     kc[m] = ((ES == 2 ? 2 * m + g : 4 * (m >> 1) + 2 * g + (m & 1)) ^ sw) * 16;
 
   f32x16 acc[NP][NQ];
@@ -269,15 +269,15 @@ void gemm3_kernel(const Gemm3P p, int n_tiles, int total_tiles, int per_xcd) {
     if constexpr (ES == 2) {
 #pragma unroll
       for (int m = 0; m < ((ABL & 4) ? 0 : MS); ++m) {
-        bf16x8 fp[NP], fq[NQ];
+        hfx8 fp[NP], fq[NQ];
 #pragma unroll
-        for (int a = 0; a < NP; ++a) fp[a] = *reinterpret_cast<const bf16x8*>(st + pofs + a * 32 * ROWB + kc[m]);
+        for (int a = 0; a < NP; ++a) fp[a] = *reinterpret_cast<const hfx8*>(st + pofs + a * 32 * ROWB + kc[m]);
 #pragma unroll
-        for (int b = 0; b < NQ; ++b) fq[b] = *reinterpret_cast<const bf16x8*>(st + qofs + b * 32 * ROWB + kc[m]);
+        for (int b = 0; b < NQ; ++b) fq[b] = *reinterpret_cast<const hfx8*>(st + qofs + b * 32 * ROWB + kc[m]);
 #pragma unroll
         for (int a = 0; a < NP; ++a)
 #pragma unroll
-          for (int b = 0; b < NQ; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fp[a], fq[b], acc[a][b], 0, 0, 0);
+          for (int b = 0; b < NQ; ++b) acc[a][b] = MFMA32_H(fp[a], fq[b], acc[a][b]);
       }
     } else {
 #pragma unroll
@@ -351,7 +351,7 @@ void gemm3_kernel(const Gemm3P p, int n_tiles, int total_tiles, int per_xcd) {
       }
     }
   } else if constexpr (EPI == G3_FF1) {
-    bf16* out = reinterpret_cast<bf16*>(p.out);
+    hf* out = reinterpret_cast<hf*>(p.out);
     const int nb0 = n0 + wn * 64;  // first feature of this wave
 #pragma unroll
     for (int b = 0; b < TB; ++b) {
@@ -367,7 +367,7 @@ void gemm3_kernel(const Gemm3P p, int n_tiles, int total_tiles, int per_xcd) {
           v[r] = (ABL & 2) ? u : gelu_tanh(u);
         }
         u32x4 piece[2];
-        pack_row_bf16(v, piece);
+        pack_row_hf(v, piece);
 #pragma unroll
         for (int k = 0; k < 2; ++k)  // 128 B per token row: chunk c = 4 a + 2 k + g, stored at chunk c ^ (row & 7)
           *reinterpret_cast<u32x4*>(wst + lr * 128 + (((4 * a + 2 * k + g) ^ (lr & 7)) << 4)) = piece[k];
@@ -382,7 +382,7 @@ void gemm3_kernel(const Gemm3P p, int n_tiles, int total_tiles, int per_xcd) {
       }
     }
   } else if constexpr (EPI == G3_RESID) {
-    bf16* xb = reinterpret_cast<bf16*>(p.xb);
+    hf* xb = reinterpret_cast<hf*>(p.xb);
     const int nb0 = n0 + wn * 64;
     if (nb0 < p.N) {  // (N = 64: the first frontend conv -- the upper column half of the tile is weight padding)
     // The x loads of a token block are all requested before the first is used: one at a time (load x, add, store,
@@ -413,7 +413,7 @@ void gemm3_kernel(const Gemm3P p, int n_tiles, int total_tiles, int per_xcd) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) colq[q] = (unsigned)((cp ^ (4 * q + r4)) << 2);  // (row & 15) = 4 (ps & 3) + r4
     const int rows_left = p.M - row0 - r4;  // row (32 b + 4 ps + r4) exists iff 32 b + 4 ps < rows_left
-    if (p.gelu) {  // frontend convs: BatchNorm is folded into W / bias, GELU in the tanh form of the bf16 path
+    if (p.gelu) {  // frontend convs: BatchNorm is folded into W / bias, GELU in the tanh form of the half path
 #pragma unroll
       for (int a = 0; a < FB; ++a)
 #pragma unroll
@@ -466,7 +466,7 @@ void gemm3_kernel(const Gemm3P p, int n_tiles, int total_tiles, int per_xcd) {
     }
   } else {  // G3_QKV
     if (kind < 2) {  // q / k: RoPE, fragment-major [quarter][token][8 dims]
-      bf16* dst = reinterpret_cast<bf16*>(kind == 0 ? p.qf : p.kf);
+      hf* dst = reinterpret_cast<hf*>(kind == 0 ? p.qf : p.kf);
 #pragma unroll
       for (int b = 0; b < TB; ++b) {
         if (tseq[b] >= p.n_seq) continue;  // wave-uniform
@@ -477,7 +477,7 @@ void gemm3_kernel(const Gemm3P p, int n_tiles, int total_tiles, int per_xcd) {
 #pragma unroll
         for (int a = 0; a < FB; ++a) {
           const int head = (n0 - kind * p.inner + wn * 64 + a * 32) >> 5;
-          bf16* blk = dst + (((long)tseq[b] * p.heads + head) * p.nbp + tblk[b]) * 1024;
+          hf* blk = dst + (((long)tseq[b] * p.heads + head) * p.nbp + tblk[b]) * 1024;
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             const float e0 = acc[a][b][4 * q] * rs[b], o0 = acc[a][b][4 * q + 1] * rs[b];
@@ -489,7 +489,7 @@ void gemm3_kernel(const Gemm3P p, int n_tiles, int total_tiles, int per_xcd) {
         }
       }
     } else if (kind == 2) {  // v: lane = feature (dim), registers = tokens -> V^T fragments
-      bf16* dst = reinterpret_cast<bf16*>(p.vf);
+      hf* dst = reinterpret_cast<hf*>(p.vf);
 #pragma unroll
       for (int a = 0; a < TB; ++a) {  // token block a of this wave (accumulator rows)
         if (tseq[a] >= p.n_seq) continue;
@@ -499,7 +499,7 @@ void gemm3_kernel(const Gemm3P p, int n_tiles, int total_tiles, int per_xcd) {
 #pragma unroll
         for (int b = 0; b < FB; ++b) {  // feature block b (lanes)
           const int head = (n0 - 2 * p.inner + wn * 64 + b * 32) >> 5;
-          bf16* blk = dst + (((long)tseq[a] * p.heads + head) * p.nbp + tblk[a]) * 1024;
+          hf* blk = dst + (((long)tseq[a] * p.heads + head) * p.nbp + tblk[a]) * 1024;
 #pragma unroll
           for (int s = 0; s < 2; ++s) {
             u32x4 w;

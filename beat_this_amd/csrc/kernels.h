@@ -5,7 +5,7 @@
 
 #ifndef BT_PREC_F32
 #define BT_PREC_F32 0
-#define BT_PREC_BF16 1
+#define BT_PREC_HALF 1
 #endif
 
 // ---- GEMM: C[M,N] = epilogue( A[M,K] . W[N,K]^T ) ------------------------------------
@@ -18,8 +18,8 @@ enum {
   GEMM_F_RMS = 1,      // accumulate row sum-of-squares of A while staging, scale rows in the epilogue
   GEMM_F_BIAS = 2,
   GEMM_F_GELU = 4,
-  GEMM_F_OUT_F32 = 8,  // EPI_STORE writes fp32 even in bf16 mode
-  GEMM_F_A_F32 = 16,   // A is fp32 in memory even in bf16 mode (residual stream)
+  GEMM_F_OUT_F32 = 8,  // EPI_STORE writes fp32 even in half mode
+  GEMM_F_A_F32 = 16,   // A is fp32 in memory even in half mode (residual stream)
   GEMM_F_CONV = 32,    // A rows are gathered: 3 time taps x C2 contiguous channels (implicit GEMM conv)
   GEMM_F_ROWMAP = 64   // QKV: store rows in (b,f,t) order instead of (b,t,f)
 };
@@ -35,7 +35,7 @@ struct GemmP {
   long ldo;
   float* x;        // EPI_RESID: residual stream, ld = ldx
   long ldx;
-  void* xb;        // optional bf16 shadow of the fp32 result (EPI_RESID: of x; OUT_F32: of out), same ld
+  void* xb;        // optional half shadow of the fp32 result (EPI_RESID: of x; OUT_F32: of out), same ld
   float* ssq_out;  // optional (gemm2 fp32 epilogues): [N / 64][M] partial row sums of squares of the fp32 result
   // conv gather (GEMM_F_CONV): output row m = (b, t, f'), A = x[b, t-1..t+1, f', 0..C2)
   int conv_C2, conv_T, conv_F;
@@ -49,16 +49,16 @@ struct GemmP {
 };
 int launch_gemm(const GemmP& p, int prec, hipStream_t s);
 
-// ---- bf16 GEMM of the main layers (gemm3.hip): LDS-DMA ring, transposed product, register epilogues --------
+// ---- half GEMM of the main layers (gemm3.hip): LDS-DMA ring, transposed product, register epilogues --------
 enum { G3_FF1 = 0, G3_RESID = 1, G3_QKV = 2 };
 struct Gemm3P {
-  const void* A; long lda; int M, K;   // bf16 [M, lda]
-  const void* W; int N;                // bf16 [N padded to 128, K]
+  const void* A; long lda; int M, K;   // half [M, lda]
+  const void* W; int N;                // half [N padded to 128, K]
   int epi;
   const float* bias;                   // FF1: [N]; RESID: [N] or null
   const float* ssq_in; int ssq_parts;  // RMSNorm of A: [parts][M] partial row sums of squares, or null
-  void* out; long ldo;                 // FF1: bf16 [M, ldo] = gelu(rms(A) W^T + bias)
-  float* x; long ldx; void* xb;        // RESID: x += A W^T + bias (fp32, in place), xb = bf16 shadow (or null)
+  void* out; long ldo;                 // FF1: half [M, ldo] = gelu(rms(A) W^T + bias)
+  float* x; long ldx; void* xb;        // RESID: x += A W^T + bias (fp32, in place), xb = half shadow (or null)
   float* ssq_out;                      // RESID: [N / 64][M] partial sums of squares of the new x (or null)
   // QKV: rows are (sequence, token) with n_seq sequences of L tokens (M = n_seq * L); columns q | k | v | gates
   int n_seq, L, nblk, nbp, heads, inner;
@@ -68,8 +68,8 @@ struct Gemm3P {
   // writes its output as e4m3 as well (unit scale).  RESID (any operand type) with x8 != null also writes the e4m3
   // shadow x8[m] = e4m3(x_new[m] * c[m]), c = RMSNorm factor of the OLD row from ssq_in, and ascale_out[m] = c[m].
   int no_resid;  // RESID: x = A W^T + bias (x is only written: frontend.linear, frontend convs)
-  int gelu;      // RESID: x = gelu(... + bias) (tanh form; frontend convs).  x may be null then (bf16 output xb only)
-  // RESID, implicit-GEMM convolution (frontend convs, beat_tracker.py:155-166): conv_C2 > 0 -> A is the bf16 shadow of the
+  int gelu;      // RESID: x = gelu(... + bias) (tanh form; frontend convs).  x may be null then (half output xb only)
+  // RESID, implicit-GEMM convolution (frontend convs, beat_tracker.py:155-166): conv_C2 > 0 -> A is the half shadow of the
   // (b, t, f, c) activation seen as [M = B T F/2, C2 = 2 C]; K = 3 C2 = the rows m - conv_F, m, m + conv_F (time taps
   // t-1, t, t+1; conv_F = F/2 rows per time step), rows outside 0 <= t < conv_T read as zeros
   int conv_C2, conv_T, conv_F;
@@ -93,11 +93,11 @@ struct AttnP {
 };
 int launch_attn_flash(const AttnP& p, int prec, hipStream_t s);
 
-// bf16 attention on fragment-major operands (attn2.hip; layout described there)
+// half attention on fragment-major operands (attn2.hip; layout described there)
 struct AttnFragP {
-  const void* q; const void* k; const void* v;  // [n_seq * heads][nbp][1024] bf16
+  const void* q; const void* k; const void* v;  // [n_seq * heads][nbp][1024] half
   const float* gates;                            // [n_seq * heads][nbp * 32] fp32
-  void* out;                                     // bf16 [rows, inner], row mapping as AttnP
+  void* out;                                     // half [rows, inner], row mapping as AttnP
   int n_seq, L, heads, inner, nbp;
   int o_div;
   long o_outer, o_inner, o_tok;
@@ -105,14 +105,14 @@ struct AttnFragP {
 int attn_frag_blocks(int L);  // 32-token blocks to allocate per (sequence, head): ceil(L/32) rounded up to a tile
 int launch_attn_frag(const AttnFragP& p, hipStream_t s);
 
-// time-direction QKV projection of the frontend (qkv_front.hip), bf16, fragment-major outputs
+// time-direction QKV projection of the frontend (qkv_front.hip), half, fragment-major outputs
 struct QkvFrontP {
   const float* x;        // residual stream [B, T, F, C] fp32
   int B, T, F, C;
   const void* wfrag;     // bt_pair_weights.w_qkv_frag
   const float* b_gates;  // [C / 32]
   const float* rope;     // [pos][16][2]
-  void* q; void* k; void* v;  // [B * F * heads][nbp][1024] bf16
+  void* q; void* k; void* v;  // [B * F * heads][nbp][1024] half
   float* gates;          // [B * F * heads][nbp * 32]
   int nbp;
 };
@@ -124,7 +124,7 @@ struct FusedFFP {
   float* x; long M; int C;           // residual stream [M, C] fp32, updated in place
   const void* wfrag;                 // W1 (gamma folded) and PERM32'd W2 in fragment-major order (fused.hip)
   const float* b1; const float* b2;  // [4C], [C]
-  void* xb;                          // optional bf16 shadow of the updated x (same layout), may be null
+  void* xb;                          // optional half shadow of the updated x (same layout), may be null
 };
 int launch_ff_fused(const FusedFFP& p, int prec, hipStream_t s);
 struct FusedAttnP {
@@ -141,7 +141,7 @@ struct FusedOutFFP {  // x += Wout . ao ; x += FF(x)      (time direction, after
   const void* ao;                    // attention output [M, C], compute dtype
   const void* wfrag;                 // bt_pair_weights.w_outff_frag
   const float* b1; const float* b2;
-  void* xb;                          // optional bf16 shadow of the new x
+  void* xb;                          // optional half shadow of the new x
   int abl;                           // development (BT_F2_ABL)
 };
 int launch_outff_fused(const FusedOutFFP& p, int prec, hipStream_t s);
@@ -152,6 +152,18 @@ struct FusedAttnFFP {  // x += AttnF(x) ; x += FF(x)      (frequency direction)
   const float* b1; const float* b2;
 };
 int launch_attnff_fused(const FusedAttnFFP& p, int prec, hipStream_t s);
+
+// ---- tail of a main layer (tail.hip): x += to_out(ao); x += FF(x) in one launch, C = 256 / 512, half operands ------
+struct LayerTailP {
+  float* x; long M; int C; int hidden;   // residual stream [M, C] fp32 (in place); hidden = ff_mult * C
+  const void* ao;                        // attention output [M, C], half
+  const void* wfrag;                     // bt_pair_weights.w_tail_frag (stream layout: tail.hip header)
+  const float* b1; const float* b2;      // [hidden], [C]
+  void* xb;                              // half shadow of the new x [M, C] (or null)
+  float* ssq_out;                        // [C / 64][M] partial row sums of squares of the new x (or null)
+};
+bool layer_tail_supported(int C, int hidden);
+int launch_layer_tail(const LayerTailP& p, hipStream_t s);
 
 // ---- small model kernels (frontend.hip) ---------------------------------------------
 struct StemP {

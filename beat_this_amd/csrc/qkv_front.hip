@@ -1,5 +1,5 @@
 // Time-direction QKV projection of the frontend's partial transformers (C = 32 / 64 / 128) for the
-// bf16 path: q|k|v|gates = RMSNorm(x) . W^T, RoPE over the time index, sigmoid gates
+// half path: q|k|v|gates = RMSNorm(x) . W^T, RoPE over the time index, sigmoid gates
 // (roformer.py:99-124 on the "(b f) t c" view of beat_tracker.py:297-299), written directly in the
 // fragment-major block layout attn_frag_kernel consumes (csrc/attn2.hip).
 //
@@ -22,7 +22,7 @@ template <int C>
 __global__ __launch_bounds__(256, (C == 32 ? 4 : C == 64 ? 3 : 2)) void qkv_front_kernel(const QkvFrontP p) {
   constexpr int KT = C / 32;             // k-tiles
   constexpr int H = C / 32;              // heads
-  constexpr int TILE_B = 2048;           // one 32x32 bf16 operand tile, fragment-major
+  constexpr int TILE_B = 2048;           // one 32x32 half operand tile, fragment-major
   constexpr int STEP_B = 3 * KT * TILE_B;  // q, k, v tiles of one head (the gate step uses the first KT)
   constexpr int NCH = STEP_B / 16;       // 16-byte chunks per step
   __shared__ __attribute__((aligned(16))) char wl[2 * STEP_B];
@@ -53,9 +53,9 @@ __global__ __launch_bounds__(256, (C == 32 ? 4 : C == 64 ? 3 : 2)) void qkv_fron
   stage(0, 0);
 
   float ss = 0.f;
-  Frag<bf16> xf[KT];
+  Frag<hf> xf[KT];
 #pragma unroll
-  for (int kt = 0; kt < KT; ++kt) xf[kt] = ldx_frag<bf16>(xrow + kt * 32 + 16 * g, ok, ss);
+  for (int kt = 0; kt < KT; ++kt) xf[kt] = ldx_frag<hf>(xrow + kt * 32 + 16 * g, ok, ss);
   ss += __shfl_xor(ss, 32);
   const float scale = sqrtf((float)C) / fmaxf(sqrtf(ss), 1e-12f);
   // RMSNorm factors of the 16 tokens whose V values this lane holds (register r <-> token crow(r,g))
@@ -70,9 +70,9 @@ __global__ __launch_bounds__(256, (C == 32 ? 4 : C == 64 ? 3 : 2)) void qkv_fron
     for (int bb = 0; bb < 2; ++bb)
       cs[2 * a + bb] = *reinterpret_cast<const f32x2*>(p.rope + ((long)(ok ? t : 0) * 16 + 4 * a + 2 * g + bb) * 2);
 
-  bf16* qf = reinterpret_cast<bf16*>(p.q);
-  bf16* kf = reinterpret_cast<bf16*>(p.k);
-  bf16* vf = reinterpret_cast<bf16*>(p.v);
+  hf* qf = reinterpret_cast<hf*>(p.q);
+  hf* kf = reinterpret_cast<hf*>(p.k);
+  hf* vf = reinterpret_cast<hf*>(p.v);
   __syncthreads();
 #pragma unroll 1
   for (int step = 0; step <= H; ++step) {
@@ -84,9 +84,9 @@ __global__ __launch_bounds__(256, (C == 32 ? 4 : C == 64 ? 3 : 2)) void qkv_fron
       zero16(aq); zero16(ak); zero16(av);
 #pragma unroll
       for (int kt = 0; kt < KT; ++kt) {
-        mma32(aq, lds_frag<bf16>(wb + kt * TILE_B, lane), xf[kt]);
-        mma32(ak, lds_frag<bf16>(wb + (KT + kt) * TILE_B, lane), xf[kt]);
-        mma32(av, xf[kt], lds_frag<bf16>(wb + (2 * KT + kt) * TILE_B, lane));  // roles swapped: [token][feature]
+        mma32(aq, lds_frag<hf>(wb + kt * TILE_B, lane), xf[kt]);
+        mma32(ak, lds_frag<hf>(wb + (KT + kt) * TILE_B, lane), xf[kt]);
+        mma32(av, xf[kt], lds_frag<hf>(wb + (2 * KT + kt) * TILE_B, lane));  // roles swapped: [token][feature]
       }
       if (wave_ok) {
         const long base = (((long)sq * H + hd) * p.nbp + blk) * 1024;  // elements
@@ -102,22 +102,22 @@ __global__ __launch_bounds__(256, (C == 32 ? 4 : C == 64 ? 3 : 2)) void qkv_fron
             k[2 * bb] = k0 * cth.x - k1 * cth.y; k[2 * bb + 1] = k1 * cth.x + k0 * cth.y;
           }
           const long off = base + (a * 32 + lr) * 8 + 4 * g;
-          *reinterpret_cast<bf16x4*>(qf + off) = bf16x4{(bf16)q[0], (bf16)q[1], (bf16)q[2], (bf16)q[3]};
-          *reinterpret_cast<bf16x4*>(kf + off) = bf16x4{(bf16)k[0], (bf16)k[1], (bf16)k[2], (bf16)k[3]};
+          *reinterpret_cast<hfx4*>(qf + off) = hfx4{(hf)q[0], (hf)q[1], (hf)q[2], (hf)q[3]};
+          *reinterpret_cast<hfx4*>(kf + off) = hfx4{(hf)k[0], (hf)k[1], (hf)k[2], (hf)k[3]};
         }
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-          bf16x8 o;
+          hfx8 o;
 #pragma unroll
-          for (int j = 0; j < 8; ++j) o[j] = (bf16)(av[8 * s + j] * sk[8 * s + j]);
-          *reinterpret_cast<bf16x8*>(vf + base + (s * 64 + lane) * 8) = o;
+          for (int j = 0; j < 8; ++j) o[j] = (hf)(av[8 * s + j] * sk[8 * s + j]);
+          *reinterpret_cast<hfx8*>(vf + base + (s * 64 + lane) * 8) = o;
         }
       }
     } else {  // gate rows: one padded tile row block, gate hd = register hd of the g = 0 half
       f32x16 ag;
       zero16(ag);
 #pragma unroll
-      for (int kt = 0; kt < KT; ++kt) mma32(ag, lds_frag<bf16>(wb + kt * TILE_B, lane), xf[kt]);
+      for (int kt = 0; kt < KT; ++kt) mma32(ag, lds_frag<hf>(wb + kt * TILE_B, lane), xf[kt]);
       if (wave_ok && g == 0) {
 #pragma unroll
         for (int hd = 0; hd < H; ++hd)

@@ -92,6 +92,6 @@ class BeatThis(nn.Module):
             empty = torch.empty((x.shape[0], x.shape[1]), dtype=torch.float32, device=x.device)
             return {"beat": empty, "downbeat": empty.clone()}
         half = torch.is_autocast_enabled("cuda") if hasattr(torch, "is_autocast_enabled") else False
-        prec = _lib.PREC_F32 if not half else (_lib.PREC_FP8 if self.fp8_weights else _lib.PREC_BF16)
+        prec = _lib.PREC_F32 if not half else (_lib.PREC_FP8 if self.fp8_weights else _lib.PREC_HALF)
         beat, down = self.engine().forward(x, prec)
         return {"beat": beat, "downbeat": down}

@@ -2,7 +2,7 @@
 layouts of include/beat_this_amd.h: fold RMSNorm gammas / BatchNorm statistics into the
 adjacent weights, append the gate rows to the QKV projection, permute the conv and the
 frontend.linear weights to the (b, t, f, c) activation layout, pad N to 128 rows and keep an
-fp32 and a bf16 device copy of every matrix.  One-time host work (torch CPU ops)."""
+fp32 and a half-precision (fp16, or bf16 in a -DBT_HALF_BF16 build) device copy of every matrix.  One-time host work (torch CPU ops)."""
 from __future__ import annotations
 
 import ctypes as C
@@ -57,6 +57,27 @@ def qkv_fragment_major(w: torch.Tensor, dim: int) -> torch.Tensor:
     t = t[order]                                               # [(hd, q|k|v)..., gate][KT][64][16]
     t = t.reshape(t.shape[0], t.shape[1], 64, 2, 8).permute(0, 1, 3, 2, 4)
     return t.contiguous().reshape(-1)
+
+
+def tail_fragment_major(wo: torch.Tensor, w1p: torch.Tensor, w2p: torch.Tensor) -> torch.Tensor:
+    """Weight stream of csrc/tail.hip (layout: bt_pair_weights.w_tail_frag): ``wo`` = to_out weight [C, C] (natural k
+    order), ``w1p`` = gamma-folded net.1.weight [H, C] with PERM32'd columns, ``w2p`` = net.4.weight [C, H] with PERM32'd
+    columns.  Every step is 2 C/32 fragment-major tiles ([half][lane][8])."""
+    C = wo.shape[0]
+    kt, hb = C // 32, w1p.shape[0] // 32
+
+    def pieces(tiles):  # [..., 64, 16] -> [..., 2, 64, 8]
+        return tiles.reshape(*tiles.shape[:-2], 64, 2, 8).transpose(-3, -2)
+
+    ot = pieces(fragment_tiles(wo))       # [mt, kt, 2, 64, 8]
+    t1 = pieces(fragment_tiles(w1p))      # [hb, kt, ...]
+    t2 = pieces(fragment_tiles(w2p))      # [mt, hb, ...]
+    zero = torch.zeros(kt * 1024, dtype=wo.dtype)
+    steps = [ot[2 * st: 2 * st + 2].reshape(-1) for st in range(kt // 2)]
+    for i in range(-1, hb + 1):
+        steps.append(t1[i + 1].reshape(-1) if i + 1 < hb else zero)
+        steps.append(t2[:, i - 1].reshape(-1) if i >= 1 else zero)
+    return torch.cat(steps)
 
 
 def _pad_rows(w: torch.Tensor, mult: int = 128) -> torch.Tensor:
@@ -147,7 +168,7 @@ class PackedModel:
     def _mat(self, w: torch.Tensor):
         w = _pad_rows(w.to(torch.float32))
         a = w.to(self.device)
-        b = w.to(torch.bfloat16).to(self.device)
+        b = w.to(_lib.half_torch_dtype()).to(self.device)
         self._keep += [a, b]
         return a.data_ptr(), b.data_ptr()
 
@@ -161,7 +182,7 @@ class PackedModel:
         w = torch.cat([wqkv, wg], 0) * ga[None, :]
         pw.w_qkvg[0], pw.w_qkvg[1] = self._mat(w)
         if dim <= 128:
-            qf = qkv_fragment_major(_pad_rows(w.to(torch.float32)), dim).to(torch.bfloat16).to(self.device)
+            qf = qkv_fragment_major(_pad_rows(w.to(torch.float32)), dim).to(_lib.half_torch_dtype()).to(self.device)
             self._keep.append(qf)
             pw.w_qkv_frag = qf.data_ptr()
         pw.b_gates = self._f32(sd[pa + "to_gates.bias"])
@@ -171,13 +192,13 @@ class PackedModel:
             w1 = (sd[pf + "net.1.weight"] * sd[pf + "net.0.gamma"][None, :]).to(torch.float32)
             w2p = perm32(sd[pf + "net.4.weight"].to(torch.float32))
             f32 = ff_fragment_major(w1, w2p, 4).to(self.device)
-            b16 = ff_fragment_major(w1, w2p, 8).to(torch.bfloat16).to(self.device)
+            b16 = ff_fragment_major(w1, w2p, 8).to(_lib.half_torch_dtype()).to(self.device)
             self._keep += [f32, b16]
             pw.w_ff_frag[0], pw.w_ff_frag[1] = f32.data_ptr(), b16.data_ptr()
             # fused2.hip: out-projection tiles (natural k order), then the FF stream with PERM32'd W1 columns
             wo = sd[pa + "to_out.0.weight"].to(torch.float32)
             w1p = perm32(w1)
-            for i, (epp, dt) in enumerate(((4, torch.float32), (8, torch.bfloat16))):
+            for i, (epp, dt) in enumerate(((4, torch.float32), (8, _lib.half_torch_dtype()))):
                 ot = fragment_tiles(wo)                                   # [mt, kt, 64, 16]
                 ot = ot.reshape(ot.shape[0], ot.shape[1], 64, 16 // epp, epp).permute(0, 1, 3, 2, 4)
                 ot = torch.cat([ot, torch.zeros_like(ot)], 1).reshape(-1)  # every step is 2 KT tiles: pad with zeros
@@ -204,6 +225,14 @@ class PackedModel:
         pw.b_ff1 = self._f32(sd[pf + "net.1.bias"])
         pw.w_ff2[0], pw.w_ff2[1] = self._mat(sd[pf + "net.4.weight"])
         pw.b_ff2 = self._f32(sd[pf + "net.4.bias"])
+        hidden = sd[pf + "net.1.weight"].shape[0]
+        if dim in (256, 512) and hidden % 64 == 0 and 128 <= hidden <= 4096:  # fused layer tail (csrc/tail.hip)
+            w1 = (sd[pf + "net.1.weight"] * gf[None, :]).to(torch.float32)
+            t = tail_fragment_major(sd[pa + "to_out.0.weight"].to(torch.float32), perm32(w1),
+                                    perm32(sd[pf + "net.4.weight"].to(torch.float32)))
+            t = t.to(_lib.half_torch_dtype()).to(self.device)
+            self._keep.append(t)
+            pw.w_tail_frag = t.data_ptr()
         if fp8 and dim % 128 == 0:  # BT_PREC_FP8: e4m3 copies for the main layers' feed-forward GEMMs
             w1 = _pad_rows((sd[pf + "net.1.weight"] * gf[None, :]).to(torch.float32), 256)
             s1 = (w1.abs().amax(dim=1) / E4M3_MAX).clamp_min(1e-30)            # one factor per hidden unit

@@ -25,10 +25,11 @@ extern "C" {
 #define BT_ERR_WORKSPACE (-3)/* workspace too small               -> RuntimeError */
 
 #define BT_PREC_F32 0  /* exact fp32 MFMA (v_mfma_f32_32x32x2_f32), fp32 activations: float16=False */
-#define BT_PREC_BF16 1 /* bf16 MFMA operands, fp32 accumulate + fp32 residual stream: float16=True */
-#define BT_PREC_FP8 2  /* BT_PREC_BF16 with the main-layer GEMMs that have e4m3 weights (bt_pair_weights *_f8) on OCP e4m3
+#define BT_PREC_HALF 1 /* half-precision MFMA operands (IEEE fp16; bfloat16 in a -DBT_HALF_BF16 build, see bt_half_is_bf16),
+                        * fp32 accumulate + fp32 residual stream: float16=True */
+#define BT_PREC_FP8 2  /* BT_PREC_HALF with the main-layer GEMMs that have e4m3 weights (bt_pair_weights *_f8) on OCP e4m3
                         * operands (2x the bf16 MFMA rate), fp32 accumulate + fp32 residual stream; attention, frontend
-                        * and head as in BT_PREC_BF16 */
+                        * and head as in BT_PREC_HALF */
 
 #define BT_MAX_LAYERS 32
 
@@ -36,7 +37,7 @@ typedef struct bt_engine bt_engine;
 
 /* One [RMSNorm -> gated RoPE attention -> +x ; RMSNorm -> FF -> +x] pair
  * (roformer.py:38-61,83-132,176-179).  Weight matrices come in two device copies,
- * index BT_PREC_F32 / BT_PREC_BF16, row-major [N padded to a multiple of 128][K]:
+ * index BT_PREC_F32 / BT_PREC_HALF, row-major [N padded to a multiple of 128][K]:
  *   w_qkvg : rows = q (heads*32, scaled by log2(e)/sqrt(32)) | k | v | gate rows (heads),
  *            every row multiplied by the attention RMSNorm gamma;
  *   w_out  : to_out.0.weight;  w_ff1 : net.1.weight * FF gamma;  w_ff2 : net.4.weight. */
@@ -78,6 +79,13 @@ typedef struct {
    *   w_ff2_f8 / s_ff2[0] (ONE factor for the matrix), b_ff2_f8 = b_ff2 / s_ff2[0]. */
   const void* w_ff1_f8; const float* s_ff1;
   const void* w_ff2_f8; const float* s_ff2; const float* b_ff2_f8;
+  /* Weights of the fused layer tail (csrc/tail.hip: x += to_out(ao); x += FF(x) in one launch; main layers with
+   * dim = 256 / 512, half precision only; NULL elsewhere): fragment-major tiles [half h][lane][8] as above, steps of
+   * 2 dim/32 tiles: for st = 0 .. dim/64 - 1 the dim/32 k-tiles of to_out.0.weight's row block 2 st, then of row block
+   * 2 st + 1 (natural k order); then for i = -1 .. hidden/32 the step [A(i + 1) | B(i - 1)], A(j) = the dim/32 k-tiles of
+   * (net.1.weight * FF gamma) rows 32 j .. (k columns PERM32-ordered), B(j) = the dim/32 row tiles of net.4.weight's
+   * columns 32 j .. (PERM32-ordered inside the block); halves that do not exist (j < 0, j >= hidden/32) are zero tiles. */
+  const void* w_tail_frag;
 } bt_pair_weights;
 
 /* Packed BeatThis weights (beat_tracker.py:38-106).  Host-side packing is done by
@@ -115,7 +123,7 @@ typedef struct {
 
 const char* bt_last_error(void);
 int bt_version(void);
-/* operand type of the half-precision path (BT_PREC_BF16 / BT_PREC_FP8 slots of the weight arrays) this library was built
+/* operand type of the half-precision path (BT_PREC_HALF / BT_PREC_FP8 slots of the weight arrays) this library was built
  * with: 0 = IEEE fp16 (default), 1 = bfloat16 (-DBT_HALF_BF16) */
 int bt_half_is_bf16(void);
 /* sizeof/offsetof of the structs above as this library was compiled (binding self-check):
@@ -206,7 +214,8 @@ int bt_postprocess_host(const int32_t* beat_idx, int n_beat_idx, const int32_t* 
 #define BT_CAT_HEAD 9
 #define BT_CAT_FF_FUSED 10        /* ff_fused_kernel (frontend FF blocks) */
 #define BT_CAT_ATTN_FREQ_FUSED 11 /* attn_freq_fused_kernel (QKV + attention + out-proj) */
-#define BT_PROFILE_CATEGORIES 12
+#define BT_CAT_LAYER_TAIL 12      /* layer_tail_kernel (main layers: out-projection + FF1 + FF2 in one launch) */
+#define BT_PROFILE_CATEGORIES 13
 void bt_profile_begin(bt_engine* e);
 int bt_profile_end(bt_engine* e, double* ms_by_category, int32_t* launches_by_category, int n_categories);
 
@@ -267,6 +276,11 @@ int bt_attn_freq_fused(void* stream, int prec, const bt_pair_weights* w, const f
 /* fused halves (csrc/fused2.hip): x += to_out(ao) then x += FF(x);  x += AttnF(x) then x += FF(x) */
 int bt_outff_fused(void* stream, int prec, const bt_pair_weights* w, const void* d_ao, float* d_x, int64_t M);
 int bt_attnff_fused(void* stream, int prec, const bt_pair_weights* w, const float* d_rope, float* d_x, int64_t M);
+/* fused tail of a main layer (csrc/tail.hip, BT_PREC_HALF, w->dim = 256 / 512, w->w_tail_frag set): d_x [M, dim] fp32
+ * += to_out(d_ao [M, dim] half), then += FF(x); optional outputs: d_xb = half copy of the new x, d_ssq_out [dim/64][M] =
+ * partial row sums of squares of the new x (what the next layer's QKV projection consumes) */
+int bt_layer_tail(void* stream, const bt_pair_weights* w, int hidden, const void* d_ao, float* d_x, int64_t M, void* d_xb,
+                  float* d_ssq_out);
 
 #ifdef __cplusplus
 }

@@ -19,12 +19,19 @@ def report(name, **vals):
         f.write(json.dumps(dict(test=name, **clean)) + "\n")
 
 
+def HALF():
+    """torch dtype of the library's half-precision operands (float16, or bfloat16 in a -DBT_HALF_BF16 build)"""
+    from beat_this_amd import _lib
+
+    return _lib.half_torch_dtype()
+
+
 def dev():
     return torch.device("cuda:0")
 
 
 def tdtype(prec):
-    return torch.float32 if prec == 0 else torch.bfloat16
+    return torch.float32 if prec == 0 else HALF()
 
 
 def run_gemm(prec, A, W, N, epi, flags, bias=None, out=None, ldo=0, x=None, conv=None, qkv=None, sync=True):
@@ -77,7 +84,7 @@ def frag_qk(x, nbp):
     SH, L, _ = x.shape
     pad = torch.zeros((SH, nbp * 32, 32), dtype=x.dtype)
     pad[:, :L] = x
-    return pad.view(SH, nbp, 32, 4, 8).permute(0, 1, 3, 2, 4).contiguous().to(torch.bfloat16)
+    return pad.view(SH, nbp, 32, 4, 8).permute(0, 1, 3, 2, 4).contiguous().to(HALF())
 
 
 def unfrag_qk(fr, L):
@@ -91,7 +98,7 @@ def frag_v(x, nbp):
     pad = torch.zeros((SH, nbp * 32, 32), dtype=x.dtype)
     pad[:, :L] = x
     t = pad.view(SH, nbp, 2, 2, 2, 4, 32)           # [s][jh][g][jl][d]
-    return t.permute(0, 1, 2, 4, 6, 3, 5).contiguous().view(SH, nbp, 2, 2, 32, 8).to(torch.bfloat16)
+    return t.permute(0, 1, 2, 4, 6, 3, 5).contiguous().view(SH, nbp, 2, 2, 32, 8).to(HALF())
 
 
 def unfrag_v(fr, L):

@@ -8,7 +8,7 @@ import math
 import pytest
 import torch
 
-from gpu_util import dev, frag_qk, frag_v, report, run_attn_frag, unfrag_qk, unfrag_v
+from gpu_util import HALF, dev, frag_qk, frag_v, report, run_attn_frag, unfrag_qk, unfrag_v
 
 pytestmark = pytest.mark.gpu
 
@@ -36,7 +36,7 @@ def _run(q, k, v, gates, n_seq, L, heads, **omap):
     gh = torch.zeros((SH, nbp * 32), dtype=torch.float32)
     gh[:, :L] = gates.float()
     rows = n_seq * L
-    out = torch.zeros((rows, heads * 32), dtype=torch.bfloat16, device=dev())
+    out = torch.zeros((rows, heads * 32), dtype=HALF(), device=dev())
     # poison the padding blocks of K/V beyond ceil(L/32): they must never be consumed
     kf, vf = frag_qk(k.float(), nbp), frag_v(v.float(), nbp)
     nblk = (L + 31) // 32
@@ -51,11 +51,11 @@ def _run(q, k, v, gates, n_seq, L, heads, **omap):
                                            (1, 1499, 1), (2, 129, 1), (9, 96, 1)])
 def test_attention_frag(n_seq, L, heads):
     SH = n_seq * heads
-    q = _mk((SH, L, 32), 30, 0.6).float().to(torch.bfloat16).double()
-    k = _mk((SH, L, 32), 31).float().to(torch.bfloat16).double()
-    v = _mk((SH, L, 32), 32).float().to(torch.bfloat16).double()
+    q = _mk((SH, L, 32), 30, 0.6).float().to(HALF()).double()
+    k = _mk((SH, L, 32), 31).float().to(HALF()).double()
+    v = _mk((SH, L, 32), 32).float().to(HALF()).double()
     k[0, 7 % L] *= 6.0  # one outlier key
-    k = k.float().to(torch.bfloat16).double()
+    k = k.float().to(HALF()).double()
     gates = torch.sigmoid(_mk((SH, L), 33))
     out = _run(q, k, v, gates, n_seq, L, heads)
     ref = _attn_ref(q, k, v, gates)  # [SH, L, 32]
@@ -68,7 +68,7 @@ def test_attention_frag(n_seq, L, heads):
 def test_attention_frag_time_direction_rowmap():
     B, T, F, heads = 2, 150, 4, 1
     SH = B * F
-    q, k, v = (_mk((SH, T, 32), 40 + i).float().to(torch.bfloat16).double() for i in range(3))
+    q, k, v = (_mk((SH, T, 32), 40 + i).float().to(HALF()).double() for i in range(3))
     gates = torch.sigmoid(_mk((SH, T), 44))
     out = _run(q, k, v, gates, SH, T, heads, o_div=F, o_outer=T * F, o_inner=1, o_tok=F)
     ref = _attn_ref(q, k, v, gates).view(B, F, T, 32).permute(0, 2, 1, 3).reshape(B * T * F, 32)
@@ -90,7 +90,7 @@ def test_attention_frag_overflow_fallback(L):
     q[1, 5, 0] = 25.0
     k[1, L - 40] = 0.0
     k[1, L - 40, 0] = 24.0
-    q, k, v = (t.float().to(torch.bfloat16).double() for t in (q, k, v))
+    q, k, v = (t.float().to(HALF()).double() for t in (q, k, v))
     gates = torch.ones((SH, L), dtype=torch.float64)
     out = _run(q, k, v, gates, SH, L, 1)
     ref = _attn_ref(q, k, v, gates).reshape(SH * L, 32)
@@ -135,7 +135,7 @@ def test_qkv_front(C, T):
     pp = PackedPair(sd, "a.", "f.", C, dev())
     nbp = L.lib().bt_attn_frag_blocks(T)
     SH = B * F * H
-    qf = torch.full((SH, nbp, 1024), float("nan"), dtype=torch.bfloat16, device=dev())
+    qf = torch.full((SH, nbp, 1024), float("nan"), dtype=HALF(), device=dev())
     kf, vf = qf.clone(), qf.clone()
     gh = torch.zeros((SH, nbp * 32), dtype=torch.float32, device=dev())
     xd = x0.float().to(dev())
@@ -188,7 +188,7 @@ def test_fused_out_ff(prec, C):
     sd = _pair_sd(C, 250 + C)
     M = 1000 + C
     x0 = _mk((M, C), 260 + C, 1.5)
-    dt = torch.float32 if prec == 0 else torch.bfloat16
+    dt = torch.float32 if prec == 0 else HALF()
     ao = _mk((M, C), 270 + C).float().to(dt)
     pp = PackedPair(sd, "a.", "f.", C, dev())
     x = x0.float().to(dev()).clone()
@@ -265,3 +265,40 @@ def test_fused_halves_at_scale_match_unfused(C):
         worst = max(worst, float((xa - xb).abs().max() / xa.abs().max()))
     report("fused2_scale", C=C, rel=worst)
     assert worst < 2e-3
+
+
+@pytest.mark.parametrize("C,M", [(512, 777), (512, 4096 + 33), (256, 1000)])
+def test_layer_tail(C, M):
+    """Fused tail of a main layer (csrc/tail.hip): x += to_out(ao); x += FF(x), the half shadow and the per-64-column
+    partial sums of squares of the new x, against fp64 (exact operands: the tolerance covers half operand rounding)."""
+    from beat_this_amd import _lib as L
+    from beat_this_amd.pack import PackedPair
+
+    sd = _pair_sd(C, 450 + C)
+    x0 = _mk((M, C), 460 + C, 1.5)
+    ao = _mk((M, C), 470 + C).float().to(HALF())
+    pp = PackedPair(sd, "a.", "f.", C, dev())
+    assert pp.weights.w_tail_frag
+    x = x0.float().to(dev()).clone()
+    aod = ao.to(dev())
+    xb = torch.full((M, C), float("nan"), dtype=HALF(), device=dev())
+    ssq = torch.full((C // 64, M), float("nan"), dtype=torch.float32, device=dev())
+    L.check(L.lib().bt_layer_tail(L.stream_ptr(dev()), Ct.byref(pp.weights), 4 * C, aod.data_ptr(), x.data_ptr(), M,
+                                  xb.data_ptr(), ssq.data_ptr()))
+    torch.cuda.synchronize()
+    x1 = x0.float().double() + ao.double() @ sd["a.to_out.0.weight"].T
+    ref = _ff_ref(sd, x1)
+    err = _rel(x, ref)
+    xc = x.double().cpu()
+    err_b = float((xb.double().cpu() - xc).abs().max() / xc.abs().max())
+    ref_ssq = (xc * xc).view(M, C // 64, 64).sum(-1).T
+    err_s = float((ssq.double().cpu() - ref_ssq).abs().max() / ref_ssq.abs().max())
+    # a second launch on the same inputs must reproduce the result bit for bit (no atomics, fixed accumulation order)
+    x2 = x0.float().to(dev()).clone()
+    L.check(L.lib().bt_layer_tail(L.stream_ptr(dev()), Ct.byref(pp.weights), 4 * C, aod.data_ptr(), x2.data_ptr(), M, 0, 0))
+    torch.cuda.synchronize()
+    report("layer_tail", C=C, M=M, rel=err, rel_shadow=err_b, rel_ssq=err_s)
+    assert torch.equal(x, x2)
+    assert err < (3e-3 if HALF() == torch.float16 else 1.5e-2)
+    assert err_b < 2e-3 if HALF() == torch.float16 else err_b < 1e-2
+    assert err_s < 1e-5

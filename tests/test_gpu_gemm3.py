@@ -7,7 +7,7 @@ import math
 import pytest
 import torch
 
-from gpu_util import dev, pad_rows, report, unfrag_qk, unfrag_v
+from gpu_util import HALF, dev, pad_rows, report, unfrag_qk, unfrag_v
 
 pytestmark = pytest.mark.gpu
 
@@ -41,9 +41,9 @@ def _call(**kw):
 def test_gemm3_ff1(M, K, N):
     x = _mk((M, K), 1, 2.0).float()
     W, b = _mk((N, K), 2, 1 / math.sqrt(K)), _mk((N,), 3)
-    xb = x.to(torch.bfloat16)
-    Wd = W.float().to(torch.bfloat16)
-    out = torch.zeros((M, N), dtype=torch.bfloat16, device=dev())
+    xb = x.to(HALF())
+    Wd = W.float().to(HALF())
+    out = torch.zeros((M, N), dtype=HALF(), device=dev())
     ssq = _ssq_parts(x)
     _call(A=xb.to(dev()), lda=K, M=M, K=K, W=Wd.to(dev()), N=N, epi=0, bias=b.float().to(dev()), ssq_in=ssq.to(dev()),
           ssq_parts=K // 64, out=out, ldo=N)
@@ -58,12 +58,12 @@ def test_gemm3_ff1(M, K, N):
 @pytest.mark.parametrize("M,K,N,bias", [(1500, 2048, 512, True), (777, 512, 512, False), (130, 128, 128, True),
                                         (24000, 2048, 512, True), (32768, 1024, 512, False)])
 def test_gemm3_resid(M, K, N, bias):
-    A = _mk((M, K), 4).float().to(torch.bfloat16)
-    W = _mk((N, K), 5, 0.5 / math.sqrt(K)).float().to(torch.bfloat16)
+    A = _mk((M, K), 4).float().to(HALF())
+    W = _mk((N, K), 5, 0.5 / math.sqrt(K)).float().to(HALF())
     b = _mk((N,), 6)
     x0 = _mk((M, N), 7).float()
     x = x0.to(dev()).clone()
-    xb = torch.zeros((M, N), dtype=torch.bfloat16, device=dev())
+    xb = torch.zeros((M, N), dtype=HALF(), device=dev())
     ssq = torch.full((N // 64, M), -1.0, dtype=torch.float32, device=dev())
     _call(A=A.to(dev()), lda=K, M=M, K=K, W=W.to(dev()), N=N, epi=1, bias=b.float().to(dev()) if bias else 0, x=x, ldx=N,
           xb=xb, ssq_out=ssq)
@@ -88,15 +88,15 @@ def test_gemm3_qkv(n_seq, L, heads):
     Wqkv = _mk((3 * D, D), 11, 1.6 / math.sqrt(D))
     Wqkv[:D] *= LOG2E / math.sqrt(32.0)
     Wg, bg = _mk((heads, D), 12, 0.3), _mk((heads,), 13, 0.3)
-    W = pad_rows(torch.cat([Wqkv, Wg]).float()).to(torch.bfloat16)
+    W = pad_rows(torch.cat([Wqkv, Wg]).float()).to(HALF())
     freqs = 10000.0 ** (-torch.arange(0, 32, 2).float() / 32)
     rope = torch.from_numpy(rope_table(freqs)).to(dev())
     nbp = Lb.lib().bt_attn_frag_blocks(L)
     SH = n_seq * heads
-    qf = torch.full((SH, nbp, 1024), float("nan"), dtype=torch.bfloat16, device=dev())
+    qf = torch.full((SH, nbp, 1024), float("nan"), dtype=HALF(), device=dev())
     kf, vf = qf.clone(), qf.clone()
     gh = torch.zeros((SH, nbp * 32), dtype=torch.float32, device=dev())
-    xb = x.to(torch.bfloat16)
+    xb = x.to(HALF())
     _call(A=xb.to(dev()), lda=D, M=M, K=D, W=W.to(dev()), N=3 * D + heads, epi=2, ssq_in=_ssq_parts(x).to(dev()),
           ssq_parts=D // 64, n_seq=n_seq, L=L, nbp=nbp, heads=heads, rope=rope, qf=qf, kf=kf, vf=vf, gates=gh,
           b_gates=bg.float().to(dev()))
@@ -169,7 +169,7 @@ def test_gemm3_f8_resid(M, K, N, bias):
     b = _mk((N,), 33)
     x0 = _mk((M, N), 34).float()
     x = x0.to(dev()).clone()
-    xb = torch.zeros((M, N), dtype=torch.bfloat16, device=dev())
+    xb = torch.zeros((M, N), dtype=HALF(), device=dev())
     ssq = torch.full((N // 64, M), -1.0, dtype=torch.float32, device=dev())
     _call(A=A8.view(torch.uint8).to(dev()), lda=K, M=M, K=K, W=pad_rows(W8.view(torch.uint8), 256).to(dev()), N=N, epi=1,
           bias=(b / s).float().to(dev()) if bias else 0, x=x, ldx=N, xb=xb, ssq_out=ssq, f8=1,
@@ -184,8 +184,8 @@ def test_gemm3_f8_resid(M, K, N, bias):
 @pytest.mark.parametrize("M,K,N", [(1500, 512, 512), (130, 128, 128)])
 def test_gemm3_resid_e4m3_shadow(M, K, N):
     """bf16 residual GEMM that also emits the e4m3 shadow of the new x, scaled by the RMSNorm factor of the OLD row."""
-    A = _mk((M, K), 41).float().to(torch.bfloat16)
-    W = _mk((N, K), 42, 0.5 / math.sqrt(K)).float().to(torch.bfloat16)
+    A = _mk((M, K), 41).float().to(HALF())
+    W = _mk((N, K), 42, 0.5 / math.sqrt(K)).float().to(HALF())
     x0 = _mk((M, N), 43, 3.0).float()
     x = x0.to(dev()).clone()
     x8 = torch.zeros((M, N), dtype=torch.uint8, device=dev())
@@ -206,11 +206,11 @@ def test_gemm3_resid_e4m3_shadow(M, K, N):
 def test_gemm3_store_without_residual():
     """epi 1 with no_resid (frontend.linear): x is written, never read (NaN-filled on entry)."""
     M, K, N = 3000, 1024, 512
-    A = _mk((M, K), 51).float().to(torch.bfloat16)
-    W = _mk((N, K), 52, 1 / math.sqrt(K)).float().to(torch.bfloat16)
+    A = _mk((M, K), 51).float().to(HALF())
+    W = _mk((N, K), 52, 1 / math.sqrt(K)).float().to(HALF())
     b = _mk((N,), 53)
     x = torch.full((M, N), float("nan"), dtype=torch.float32, device=dev())
-    xb = torch.zeros((M, N), dtype=torch.bfloat16, device=dev())
+    xb = torch.zeros((M, N), dtype=HALF(), device=dev())
     ssq = torch.zeros((N // 64, M), dtype=torch.float32, device=dev())
     _call(A=A.to(dev()), lda=K, M=M, K=K, W=W.to(dev()), N=N, epi=1, bias=b.float().to(dev()), x=x, ldx=N, xb=xb,
           ssq_out=ssq, no_resid=1)
@@ -246,11 +246,11 @@ def test_gemm3_frontend_conv(B, T, Fp, C2, N, bf16_out):
     """epi 1 as the (2,3) / stride (2,1) frontend convolution on the bf16 (b, t, f, c) activation: three time taps gathered
     by the LDS-DMA loader (zero rows outside 0 <= t < T), bias, tanh-form GELU; fp32 or bf16 output."""
     M, K = B * T * Fp, 3 * C2
-    x = _mk((M, C2), 71).float().to(torch.bfloat16)               # row m = (b, t, f'), C2 = 2 C channels of the frequency pair
-    W = _mk((N, K), 72, 1 / math.sqrt(K)).float().to(torch.bfloat16)
+    x = _mk((M, C2), 71).float().to(HALF())               # row m = (b, t, f'), C2 = 2 C channels of the frequency pair
+    W = _mk((N, K), 72, 1 / math.sqrt(K)).float().to(HALF())
     b = _mk((N,), 73, 0.5)
     out = torch.full((M, N), float("nan"), dtype=torch.float32, device=dev())
-    outb = torch.zeros((M, N), dtype=torch.bfloat16, device=dev())
+    outb = torch.zeros((M, N), dtype=HALF(), device=dev())
     _call(A=x.to(dev()), lda=C2, M=M, K=K, W=pad_rows(W).to(dev()), N=N, epi=1, bias=b.float().to(dev()),
           x=0 if bf16_out else out, ldx=N, xb=outb if bf16_out else 0, no_resid=1, gelu=1, conv_C2=C2, conv_T=T, conv_F=Fp)
     xd = x.double().view(B, T, Fp, C2)

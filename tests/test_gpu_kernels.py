@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from gpu_util import dev, pad_rows, report, run_attn, run_gemm, tdtype
+from gpu_util import HALF, dev, pad_rows, report, run_attn, run_gemm, tdtype
 
 pytestmark = pytest.mark.gpu
 
@@ -289,9 +289,9 @@ def test_gemm2_bf16_A_with_rms(M, K, N):
     from beat_this_amd import _lib as L
 
     A, W, b = _mk((M, K), 90, 3.0), _mk((N, K), 91, 1 / math.sqrt(K)), _mk((N,), 92)
-    Ab = A.float().to(torch.bfloat16)
-    Wd = pad_rows(W.float()).to(torch.bfloat16).to(dev())
-    out = torch.zeros((M, N), dtype=torch.bfloat16, device=dev())
+    Ab = A.float().to(HALF())
+    Wd = pad_rows(W.float()).to(HALF()).to(dev())
+    out = torch.zeros((M, N), dtype=HALF(), device=dev())
     run_gemm(BF16, Ab.to(dev()), Wd, N, L.GEMM_EPI_STORE, L.GEMM_F_RMS | L.GEMM_F_BIAS | L.GEMM_F_GELU,
              bias=b.float().to(dev()), out=out)
     Ad = Ab.double()
@@ -309,8 +309,8 @@ def test_gemm2_resid_writes_shadow():
 
     M, K, N = 900, 512, 128
     A, W, b, x0 = _mk((M, K), 93), _mk((N, K), 94, 0.05), _mk((N,), 95), _mk((M, N), 96)
-    Ab = A.float().to(torch.bfloat16)
-    Wd = pad_rows(W.float()).to(torch.bfloat16).to(dev())
+    Ab = A.float().to(HALF())
+    Wd = pad_rows(W.float()).to(HALF()).to(dev())
     x = x0.float().to(dev()).clone()
     run_gemm(BF16, Ab.to(dev()), Wd, N, L.GEMM_EPI_RESID, L.GEMM_F_BIAS, bias=b.float().to(dev()), x=x)
     ref = x0.float().double() + Ab.double() @ Wd[:N].double().cpu().T + b

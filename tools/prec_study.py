@@ -18,6 +18,7 @@ from oracle import beat_this_oracle as O
 
 SITES = ["conv", "lin", "f_qkv", "f_qk", "f_pv", "f_out", "f_ff1", "f_ff2", "m_qkv", "m_qk", "m_pv", "m_out", "m_ff1", "m_ff2"]
 MODE = {s: None for s in SITES}
+GELU = {"approx": "none"}
 
 
 def rnd(x, how):
@@ -64,7 +65,7 @@ def attention(x, sd, pfx, heads, tag):
 
 def feedforward(x, sd, pfx, tag):
     h = O.rmsnorm(x, sd[pfx + "net.0.gamma"])
-    h = F.gelu(mm(h, sd[pfx + "net.1.weight"].T, tag + "ff1") + sd[pfx + "net.1.bias"])
+    h = F.gelu(mm(h, sd[pfx + "net.1.weight"].T, tag + "ff1") + sd[pfx + "net.1.bias"], approximate=GELU["approx"])
     return mm(h, sd[pfx + "net.4.weight"].T, tag + "ff2") + sd[pfx + "net.4.bias"]
 
 
@@ -87,7 +88,7 @@ def forward(sd, x):
         x = partial_ft(x, sd, p + "partial.")
         h = MODE["conv"]
         x = F.conv2d(rnd(x, h), rnd(sd[p + "conv2d.weight"], h), stride=(2, 1), padding=(0, 1))
-        x = F.gelu(O.batchnorm(x, sd, p + "norm.", 1))
+        x = F.gelu(O.batchnorm(x, sd, p + "norm.", 1), approximate=GELU["approx"])
     b, c, f, t = x.shape
     x = x.permute(0, 3, 1, 2).reshape(b, t, c * f)
     x = mm(x, sd["frontend.linear.weight"].T, "lin") + sd["frontend.linear.bias"]
@@ -130,6 +131,16 @@ def main():
             for s in SITES:
                 MODE[s] = how
             report(f"all {how}")
+        for s in SITES:
+            MODE[s] = None
+        GELU["approx"] = "tanh"
+        report("fp32, tanh GELU (FF + conv)")
+        for s in SITES:
+            MODE[s] = "f16"
+        report("all f16, tanh GELU")
+        GELU["approx"] = "none"
+        if "--quick" in sys.argv:
+            return
         # attribution: one site at a time in bf16 and f16
         for how in ("bf16", "f16"):
             for s in SITES:
