@@ -80,6 +80,14 @@ def flops_per_chunk(D: int, T: int = CHUNK_FRAMES, ff_mult: int = 4):
     return cat
 
 
+_T0 = time.perf_counter()
+
+
+def log(msg):
+    """progress on stderr (the JSON line on stdout stays alone): a stuck phase is visible in the captured log"""
+    print(f"[bench +{time.perf_counter() - _T0:6.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -104,7 +112,11 @@ def main():
     ap.add_argument("--chunks", type=int, default=16, help="--workload forward: chunks per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the forward_only / fp32_path / frontend legs")
+    ap.add_argument("--watchdog", type=int, default=900, help="seconds after which a stuck run dumps its stacks and exits")
     args = ap.parse_args()
+    import faulthandler
+
+    faulthandler.dump_traceback_later(args.watchdog, exit=True)  # a hang becomes a traceback on stderr, not a silent timeout
 
     if args.gpus > 1 and "RANK" not in os.environ:
         # self-launch: one process per GPU under torch.distributed.run (RCCL rendezvous on 127.0.0.1)
@@ -132,6 +144,7 @@ def main():
     from beat_this_amd.inference import Audio2Beats
     from beat_this_amd.model import BeatThis
 
+    log(f"rank {rank}/{world} on {dev}, library half type {_lib.half_dtype_name()}")
     hp = W.resolve_hparams(args.model)
     # "lively" seeded weights (O(1) logits, sharp softmaxes, beats to pick): same FLOPs as any other weights of this
     # architecture, but the post-processor has real work and the parity figures mean something
@@ -205,20 +218,24 @@ def main():
 
     # Untimed settling before the W warm-up steps: a fresh process on a fresh box needs a few hundred ms of GPU work
     # before clocks, page tables and RCCL channels are in their steady state; part of the set-up, not of the W / K steps.
+    log("workload resident, settling")
     for _ in range(n_settle):
         step()
     drain()
     fence()
+    log("warm-up")
     for _ in range(args.warmup):
         step()
     drain()
     fence()
+    log("timed region")
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     last = drain()
     fence()
     elapsed = time.perf_counter() - t0
+    log(f"timed region done: {1e3 * elapsed / args.steps:.3f} ms / step")
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -250,6 +267,7 @@ def main():
             return bd
 
         # ---- roofline leg: per-kernel HIP-event timing of the same workload ------------------------------------------
+        log("roofline leg")
         if args.workload == "tracks":
             breakdown = profile_forward(lambda: a2b.many(tracks, TRACK_SR), 2, chunks_per_step)
         else:
@@ -288,6 +306,7 @@ def main():
                 b.synchronize()
                 return a.elapsed_time(b) / reps, r
 
+            log("frontend / forward-only legs")
             n_samp = sum(int(t.shape[0]) for t in tracks)
             t_front, (spect, foff) = timed(lambda: a2b.signal2spect_many(tracks, TRACK_SR))
             tr22 = [torch.from_numpy(W.synthetic_audio(TRACK_SECONDS, seed=i)).to(dev) for i in range(n_tr)]
@@ -328,6 +347,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline and args.workload == "tracks":
             from oracle import beat_this_oracle as O
 
+            log("cpu baseline: thread probe")
             sig = tracks[0].cpu().numpy()
             with torch.inference_mode():
                 # torch's default (one thread per logical core) oversubscribes big hosts badly: probe on one chunk
@@ -344,29 +364,36 @@ def main():
                     if best is None or tp < best[1]:
                         best = (nt, tp)
                 torch.set_num_threads(best[0])
+                # bounded sample: the whole 300 s track if its 11 chunks fit ~40 s of CPU time, else a shorter excerpt
+                sample_s = TRACK_SECONDS if 11 * best[1] < 40.0 else max(30.0, 29.76 * int(40.0 / best[1]))
+                sig = sig[: int(sample_s * TRACK_SR)]
+                log(f"cpu baseline: {best[0]} threads, {best[1] * 1e3:.0f} ms per chunk; Audio2Beats of {sample_s:.0f} s of track 0")
                 t1 = time.perf_counter()
                 ob, od = O.audio2frames(sd, sig, TRACK_SR)
                 obeats, odown = O.postp_minimal(ob, od)
                 tc = time.perf_counter() - t1
-            cpu = {"value": round(TRACK_SECONDS / tc, 2), "unit": "audio-seconds/s", "cores": best[0],
+            cpu = {"value": round(sample_s / tc, 2), "unit": "audio-seconds/s", "cores": best[0],
                    "host_logical_cores": os.cpu_count(), "kind": "port",
-                   "sample": f"1 x Audio2Beats of one {TRACK_SECONDS:.0f} s {TRACK_SR} Hz track (resample, log-mel, 11 chunks batch-1 "
-                             f"like the reference, SDPA attention, fp32, post-processing), oracle/beat_this_oracle.py, {tc:.1f} s; "
+                   "sample": f"1 x Audio2Beats of {sample_s:.0f} s of one {TRACK_SR} Hz track (resample, log-mel, {len(ob) // 1488 + 1} chunks "
+                             f"batch-1 like the reference, SDPA attention, fp32, post-processing), oracle/beat_this_oracle.py, {tc:.1f} s; "
                              f"thread count = fastest of 8/16/32/64 on one chunk ({best[1] * 1e3:.0f} ms per chunk)"}
+            ptrack = [torch.from_numpy(sig).to(dev)]
 
             def flips(a, b):
                 return len(set(np.round(np.asarray(a) * 100).astype(np.int64)) ^ set(np.round(np.asarray(b) * 100).astype(np.int64)))
 
             def parity_of(a2b_):
-                res = a2b_.many_async(tracks[:1], TRACK_SR)
+                res = a2b_.many_async(ptrack, TRACK_SR)
                 beats, downbeats = res.result()[0]
                 gb, gd, _ = res.logits
                 return {"max_abs_logit": round(max(float((gb.cpu() - ob).abs().max()), float((gd.cpu() - od).abs().max())), 6),
                         "flips_beat": flips(beats, obeats), "flips_downbeat": flips(downbeats, odown),
                         "n_beats": len(obeats), "n_downbeats": len(odown), "logit_spread": round(float(ob.std()), 3),
-                        "against": "CPU oracle (fp32) on the same 300 s waveform, 15001 frames"}
+                        "against": f"CPU oracle (fp32) on the same {sample_s:.0f} s waveform, {len(ob)} frames"}
+            log(f"cpu baseline done in {tc:.1f} s; parity")
             parity = parity_of(a2b)
             if half and not args.no_extras:
+                log("fp32 path leg")
                 # the exact-fp32 path on the SAME workload: the path under north_star's 1e-3 / identical-beats gate
                 a2b.float16 = False
                 for _ in range(2):

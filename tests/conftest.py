@@ -12,6 +12,10 @@ REFERENCE = "/root/reference"
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the CPU oracle on a many-core GPU host: torch's default of one thread per logical core is 10x slower than 16
+    import torch
+
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
 
 
 def pytest_collection_modifyitems(config, items):

@@ -107,6 +107,7 @@ def test_cli_end_to_end_matches_reference_cli_golden(tmp_path, compiled):
     assert out.read_text() == text
     # directory mode: outputs next to --output keeping relative paths, --skip-existing honoured (cli.py:163-191)
     out2 = tmp_path / "out2"
+    out2.mkdir()  # (--touch-first touches the output before anything creates its directory: the reference does the same)
     cli.run(inputs=[str(wav.parent)], model=str(ck), output=str(out2), suffix=".beats", append=False, skip_existing=True,
             touch_first=True, dbn=False, gpu=0, float16=False, activations=False)
     assert (out2 / "clicks.beats").read_text() == text
