@@ -187,7 +187,9 @@ class PackedModel:
             pw.w_qkv_frag = qf.data_ptr()
         pw.b_gates = self._f32(sd[pa + "to_gates.bias"])
         pw.w_out[0], pw.w_out[1] = self._mat(sd[pa + "to_out.0.weight"])
-        if dim <= 128:
+        # (the register-chained kernels of fused.hip / fused2.hip are built for a hidden width of 4 dim: a main layer with
+        # another ff_mult and dim <= 128 runs on the plain GEMM path)
+        if dim <= 128 and sd[pf + "net.1.weight"].shape[0] == 4 * dim:
             pw.w_outp[0], pw.w_outp[1] = self._mat(perm32(sd[pa + "to_out.0.weight"]))
             w1 = (sd[pf + "net.1.weight"] * sd[pf + "net.0.gamma"][None, :]).to(torch.float32)
             w2p = perm32(sd[pf + "net.4.weight"].to(torch.float32))
@@ -226,7 +228,7 @@ class PackedModel:
         pw.w_ff2[0], pw.w_ff2[1] = self._mat(sd[pf + "net.4.weight"])
         pw.b_ff2 = self._f32(sd[pf + "net.4.bias"])
         hidden = sd[pf + "net.1.weight"].shape[0]
-        if dim in (256, 512) and hidden % 64 == 0 and 128 <= hidden <= 4096:  # fused layer tail (csrc/tail.hip)
+        if dim == 512 and hidden % 64 == 0 and 128 <= hidden <= 4096:  # fused layer tail (csrc/tail.hip)
             w1 = (sd[pf + "net.1.weight"] * gf[None, :]).to(torch.float32)
             t = tail_fragment_major(sd[pa + "to_out.0.weight"].to(torch.float32), perm32(w1),
                                     perm32(sd[pf + "net.4.weight"].to(torch.float32)))

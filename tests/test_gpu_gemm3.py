@@ -258,7 +258,7 @@ def test_gemm3_frontend_conv(B, T, Fp, C2, N, bf16_out):
     xp[:, 1:-1] = xd
     Wd = W.double()
     acc = sum(xp[:, dt:dt + T].reshape(M, C2) @ Wd[:, dt * C2:(dt + 1) * C2].T for dt in range(3))
-    ref = _gelu_tanh(acc + b)
+    ref = torch.nn.functional.gelu(acc + b)  # exact GELU: the kernel's fitted sigmoid form is within 2.6e-5 of it (common.h)
     err = _rel(outb if bf16_out else out, ref)
     report("gemm3_frontend_conv", B=B, T=T, Fp=Fp, C2=C2, N=N, rel=err)
-    assert err < (5e-3 if bf16_out else 2e-5)
+    assert err < (5e-3 if bf16_out else 4e-5)

@@ -321,17 +321,21 @@ def test_gemm2_resid_writes_shadow():
 
 @pytest.mark.parametrize("sr_in", [44100, 48000, 16000, 32000, 11025])
 def test_resample_gpu_matches_polyphase_oracle(sr_in):
-    """bt_resample against scipy.signal.resample_poly in float64 -- the algorithm the oracle's soxr
-    stand-in uses (oracle/shims/soxr); ragged length, both directions, prime-ish ratios."""
-    from scipy.signal import resample_poly
-    from math import gcd
+    """bt_resample against the oracle's soxr stand-in (oracle/shims/soxr: the same published HQ specification
+    restated with scipy.signal.firwin / resample_poly in float64); ragged length, both directions, prime-ish ratios."""
+    import importlib.util
+    import os
+    from conftest import ROOT
     from beat_this_amd.inference import resample_gpu
+
+    spec = importlib.util.spec_from_file_location("_soxr_shim", os.path.join(ROOT, "oracle", "shims", "soxr", "__init__.py"))
+    shim = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(shim)
 
     n = sr_in * 3 + 777
     x = (_mk((n,), 120 + sr_in, 0.3)).float()
     y = resample_gpu(x.to(dev()), sr_in, 22050).cpu().double()
-    g = gcd(sr_in, 22050)
-    ref = torch.from_numpy(resample_poly(x.double().numpy(), 22050 // g, sr_in // g))
+    ref = torch.from_numpy(shim.resample(x.double().numpy(), sr_in, 22050))
     assert y.shape == ref.shape
     err = float((y - ref).abs().max() / ref.abs().max())
     report("resample_gpu", sr_in=sr_in, rel=err)

@@ -254,9 +254,8 @@ def test_cpu_inputs_fail_loudly():
 
 
 def test_audio2beats_44k1_input_resampled_on_gpu():
-    """44.1 kHz input: mono mix (host) -> GPU polyphase resampler -> GPU log-mel -> model, against the oracle fed
-    with the float64 scipy.signal.resample_poly waveform (the oracle's soxr stand-in): same beats, logits < 1e-3."""
-    from scipy.signal import resample_poly
+    """44.1 kHz input: mono mix (host) -> GPU polyphase resampler -> GPU log-mel -> model, against the oracle's own
+    signal2spect (float64 resampling by its soxr stand-in, oracle/shims/soxr): same beats, logits < 1e-3."""
     from beat_this_amd import weights as W
     from beat_this_amd.inference import Audio2Beats
     from oracle import beat_this_oracle as O
@@ -272,9 +271,8 @@ def test_audio2beats_44k1_input_resampled_on_gpu():
     stereo = np.stack([mono, 0.5 * mono], 1).astype(np.float64)          # (N, 2): exercises the mono mix too
     beats, downbeats = a2b(stereo, 44100)
     bl, dl = a2b.spect2frames(a2b.signal2spect(stereo, 44100))
-    sig22 = resample_poly(stereo.mean(1), 1, 2).astype(np.float32)
     with torch.inference_mode():
-        ob, od = O.spect2frames(sd, O.logmel(torch.from_numpy(sig22)))
+        ob, od = O.audio2frames(sd, stereo, 44100)
     err = float((bl.cpu() - ob).abs().max())
     obeats, odown = O.postp_minimal(ob, od)
     report("a2b_44k1", err=err, beats=len(beats), downbeats=len(downbeats))
