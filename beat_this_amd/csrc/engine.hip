@@ -553,13 +553,15 @@ int bt_postprocess_host(const int32_t* beat_idx, int nb, const int32_t* down_idx
   int md = dedup_host(down_idx, nd, downbeats);
   for (int i = 0; i < md; ++i) downbeats[i] = downbeats[i] / fps;
   if (mb > 0) {
-    for (int i = 0; i < md; ++i) {  // np.argmin(|beat - d|): first minimum wins
-      double best = std::fabs(beats[0] - downbeats[i]);
-      int bi = 0;
-      for (int j = 1; j < mb; ++j) {
-        double dd = std::fabs(beats[j] - downbeats[i]);
-        if (dd < best) { best = dd; bi = j; }
-      }
+    // np.argmin(|beats - d|), first minimum wins (postprocessor.py:131-133).  beats ascend strictly (means of disjoint
+    // runs), |b - d| is V-shaped over them and floating-point rounding is monotone, so the minimum sits at the first beat
+    // >= d or at its predecessor -- the predecessor on an exact tie (= the first minimum).  O(log n) per downbeat instead of
+    // the reference's O(n): 2000 x 2000 candidates per 5-minute track were 2.5 ms of host time with noisy logits.
+    for (int i = 0; i < md; ++i) {
+      const double d = downbeats[i];
+      const int j = (int)(std::lower_bound(beats, beats + mb, d) - beats);
+      int bi = j < mb ? j : mb - 1;
+      if (j > 0 && (j >= mb || std::fabs(beats[j - 1] - d) <= std::fabs(beats[j] - d))) bi = j - 1;
       downbeats[i] = beats[bi];
     }
   }

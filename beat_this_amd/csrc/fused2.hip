@@ -74,9 +74,14 @@ struct WRing {
     const int ahead = min(NST - 2, total - 1 - s);  // younger steps that may stay in flight
     long long q0 = 0, q1 = 0;
     if (timing) q0 = clock64();
-    if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * CH) : "memory");
-    else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CH) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // lgkmcnt(0): every LDS read this wave issued has RETURNED before the barrier.  The stage refilled right after the
+    // barrier is the one step s - 1 was read from, and hipcc sinks the MFMAs of a step's last tiles (with their still
+    // outstanding ds_reads) below this wait: a fast wave's LDS-DMA then raced a slow wave's queued read (WAR; a few
+    // garbage 32-token blocks per launch of 6000 workgroups, only under load -- found in round 2 by running the same batch
+    // twice, tools/kernel_determinism.py).  A raw s_barrier orders nothing by itself.
+    if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * CH) : "memory");
+    else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(CH) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     if (timing) q1 = clock64();
     __builtin_amdgcn_s_barrier();
     if (timing) { const long long q2 = clock64(); t_wait += q1 - q0; t_bar += q2 - q1; }

@@ -259,8 +259,10 @@ void gemm3_kernel(const Gemm3P p, int n_tiles, int total_tiles, int per_xcd) {
     long long tq0 = 0, tq1 = 0;
     if constexpr ((ABL & 8) != 0) tq0 = clock64();
     // tile kt has landed in every wave; NST - 2 younger tiles may stay in flight across the barrier
-    if (NST > 2 && kt + 1 < nk && !(ABL & 1)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * LPS) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // lgkmcnt(0): the fragment reads of tile kt - 1 have returned in THIS wave before the barrier -- the stage they came
+    // from is refilled right after it (WAR: see WRing::acquire in fused2.hip)
+    if (NST > 2 && kt + 1 < nk && !(ABL & 1)) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((NST - 2) * LPS) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     if constexpr ((ABL & 8) != 0) tq1 = clock64();
     __builtin_amdgcn_s_barrier();
     if constexpr ((ABL & 8) != 0) { const long long tq2 = clock64(); t_wait += tq1 - tq0; t_bar += tq2 - tq1; }

@@ -93,9 +93,10 @@ struct TRing {
   // make step s readable by every wave (all older LDS-DMA done in every wave), then refill the stage freed by step s-1
   DEVI const char* acquire(int s) {
     const int ahead = min(NST - 2, total - 1 - s);  // younger steps that may stay in flight
-    if (NST == 4 && ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * CH) : "memory");
-    else if (NST == 4 && ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CH) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // (lgkmcnt(0): this wave's fragment reads of step s - 1 have returned before the barrier: its stage is refilled next)
+    if (NST == 4 && ahead >= 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * CH) : "memory");
+    else if (NST == 4 && ahead == 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(CH) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     issue(s + NST - 1);
     return lds + (s % NST) * STEP_B;
@@ -305,9 +306,7 @@ int launch_t(const LayerTailP& p, hipStream_t s) {
 }  // namespace
 
 bool layer_tail_supported(int C, int hidden) {
-  // (the C = 256 instantiation exists but fails its unit test -- NaNs, tests/test_gpu_frag.py::test_layer_tail -- and is
-  // not dispatched until that is understood; transformer_dim = 256 models run their tails on gemm3.hip)
-  return C == 512 && hidden % 64 == 0 && hidden >= 128 && hidden <= 4096;
+  return (C == 256 || C == 512) && hidden % 64 == 0 && hidden >= 128 && hidden <= 4096;
 }
 
 int launch_layer_tail(const LayerTailP& p, hipStream_t s) {
