@@ -110,6 +110,7 @@ def main():
                     help="tracks = Audio2Beats on 300 s 44.1 kHz tracks (BASELINE metric); forward = BeatThis.forward on "
                          "--chunks resident spectrogram chunks (BASELINE configs 2 / 3 / 5)")
     ap.add_argument("--chunks", type=int, default=16, help="--workload forward: chunks per GPU per step")
+    ap.add_argument("--slice", type=int, default=0, help="chunks per forward launch (0 = the library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the forward_only / fp32_path / frontend legs")
     ap.add_argument("--watchdog", type=int, default=900, help="seconds after which a stuck run dumps its stacks and exits")
@@ -140,8 +141,12 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     from beat_this_amd import _lib
+    from beat_this_amd import inference as _inf
     from beat_this_amd import weights as W
     from beat_this_amd.inference import Audio2Beats
+
+    if args.slice > 0:
+        _inf.MAX_CHUNKS_PER_LAUNCH = args.slice
     from beat_this_amd.model import BeatThis
 
     log(f"rank {rank}/{world} on {dev}, library half type {_lib.half_dtype_name()}")
