@@ -306,7 +306,9 @@ int launch_t(const LayerTailP& p, hipStream_t s) {
 }  // namespace
 
 bool layer_tail_supported(int C, int hidden) {
-  return (C == 256 || C == 512) && hidden % 64 == 0 && hidden >= 128 && hidden <= 4096;
+  // (the C = 256 instantiation exists but its unit test shows NaNs -- not a race: reproducible -- and it is not dispatched
+  // until that is understood; transformer_dim = 256 models run their tails on gemm3.hip)
+  return C == 512 && hidden % 64 == 0 && hidden >= 128 && hidden <= 4096;
 }
 
 int launch_layer_tail(const LayerTailP& p, hipStream_t s) {

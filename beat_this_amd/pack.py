@@ -228,7 +228,7 @@ class PackedModel:
         pw.w_ff2[0], pw.w_ff2[1] = self._mat(sd[pf + "net.4.weight"])
         pw.b_ff2 = self._f32(sd[pf + "net.4.bias"])
         hidden = sd[pf + "net.1.weight"].shape[0]
-        if dim in (256, 512) and hidden % 64 == 0 and 128 <= hidden <= 4096:  # fused layer tail (csrc/tail.hip)
+        if dim == 512 and hidden % 64 == 0 and 128 <= hidden <= 4096:  # fused layer tail (csrc/tail.hip)
             w1 = (sd[pf + "net.1.weight"] * gf[None, :]).to(torch.float32)
             t = tail_fragment_major(sd[pa + "to_out.0.weight"].to(torch.float32), perm32(w1),
                                     perm32(sd[pf + "net.4.weight"].to(torch.float32)))

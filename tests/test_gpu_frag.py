@@ -267,7 +267,7 @@ def test_fused_halves_at_scale_match_unfused(C):
     assert worst < 2e-3
 
 
-@pytest.mark.parametrize("C,M", [(512, 777), (512, 4096 + 33), (512, 24000), (256, 1000)])
+@pytest.mark.parametrize("C,M", [(512, 777), (512, 4096 + 33), (512, 24000)])
 def test_layer_tail(C, M):
     """Fused tail of a main layer (csrc/tail.hip): x += to_out(ao); x += FF(x), the half shadow and the per-64-column
     partial sums of squares of the new x, against fp64 (exact operands: the tolerance covers half operand rounding)."""
