@@ -123,7 +123,7 @@ EXPORTS = {
     "bt_peaks_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "bt_peaks_host": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.POINTER(C.c_int32)]),
     "bt_gemm": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(GemmArgs)]),
-    "bt_attention": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(AttnArgs), C.c_int]),
+    "bt_attention": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(AttnArgs)]),
     "bt_gemm3": (C.c_int, [C.c_void_p, C.POINTER(Gemm3Args)]),
     "bt_attn_frag_blocks": (C.c_int, [C.c_int]),
     "bt_attention_frag": (C.c_int, [C.c_void_p, C.POINTER(AttnFragArgs)]),
@@ -134,7 +134,6 @@ EXPORTS = {
     "bt_layer_tail": (C.c_int, [C.c_void_p, C.POINTER(PairWeights), C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
                                 C.c_void_p]),
     "bt_ff_fused": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(PairWeights), C.c_void_p, C.c_int64]),
-    "bt_attn_freq_fused": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(PairWeights), C.c_void_p, C.c_void_p, C.c_int64]),
 }
 
 

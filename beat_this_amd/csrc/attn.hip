@@ -12,9 +12,7 @@
 // second MFMA (O^T = V^T . P^T) -- no cross-lane traffic for P at all.  For half the V tile
 // is transposed on its way into LDS so the A operand (V^T) is read with two ds_read_b64;
 // for fp32 (k = 2 MFMA) V is read row-major.
-//
-// attn_small: the frequency-direction partial attention (8/16/32 tokens, heads*tokens = 32):
-// one thread per (time step, head, query); K/V of 8 time steps live in LDS; fp32 VALU math.
+// (The frequency-direction attention of the frontend lives in fused2.hip: attnff_fused_kernel.)
 #include <type_traits>
 
 #include "common.h"
@@ -206,121 +204,6 @@ __global__ __launch_bounds__(256) void attn_flash_kernel(const AttnP p) {
 }
 
 // ---------------------------------------------------------------------------------------
-template <typename T> DEVI f32x4 ldg4f(const T* p);
-template <> DEVI f32x4 ldg4f<float>(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
-template <> DEVI f32x4 ldg4f<hf>(const hf* p) {
-  hfx4 v = *reinterpret_cast<const hfx4*>(p);
-  return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
-}
-
-constexpr int SM_ROWS = 8;     // time steps per workgroup
-constexpr int SM_HPITCH = 36;  // floats per head slice in LDS (32 + 4 pad -> distinct 16 B slots)
-
-template <typename T, int F>
-__global__ __launch_bounds__(256) void attn_small_kernel(const AttnP p) {
-  constexpr int H = 32 / F;              // heads
-  constexpr int TOKP = H * SM_HPITCH;    // floats per token
-  __shared__ __attribute__((aligned(16))) float Ks[SM_ROWS * F * TOKP];
-  __shared__ __attribute__((aligned(16))) float Vs[SM_ROWS * F * TOKP];
-  const int tid = threadIdx.x;
-  const long n_steps = p.n_seq;          // sequences = (b, t) pairs
-  const long step0 = (long)blockIdx.x * SM_ROWS;
-  const T* qkv = reinterpret_cast<const T*>(p.qkv);
-  const int inner = 32 * H;
-
-  // cooperative K/V load: SM_ROWS * F tokens, inner/4 float4 each
-  constexpr int C4 = (32 * H) / 4;
-  for (int idx = tid; idx < SM_ROWS * F * C4; idx += 256) {
-    int tok = idx / C4, c4 = idx - tok * C4;
-    long grow = step0 * F + tok;
-    int col = c4 * 4, hh = col >> 5, d = col & 31;
-    f32x4 kv = f32x4{0.f, 0.f, 0.f, 0.f}, vv = kv;
-    if (grow < n_steps * F) {
-      const T* base = qkv + grow * p.ld;
-      kv = ldg4f<T>(base + inner + col);
-      vv = ldg4f<T>(base + 2 * inner + col);
-    }
-    *reinterpret_cast<f32x4*>(&Ks[tok * TOKP + hh * SM_HPITCH + d]) = kv;
-    *reinterpret_cast<f32x4*>(&Vs[tok * TOKP + hh * SM_HPITCH + d]) = vv;
-  }
-  const int r = tid >> 5, idx = tid & 31;
-  const int head = idx / F, f = idx - head * F;
-  const long step = step0 + r;
-  const bool ok = step < n_steps;
-  const long qrow = (ok ? step : 0) * F + f;
-  float q[32];
-  {
-    const T* qp = qkv + qrow * p.ld + head * 32;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      f32x4 v = ldg4f<T>(qp + 4 * i);
-      q[4 * i] = v[0]; q[4 * i + 1] = v[1]; q[4 * i + 2] = v[2]; q[4 * i + 3] = v[3];
-    }
-  }
-  __syncthreads();
-  const float* kb = &Ks[(r * F) * TOKP + head * SM_HPITCH];
-  const float* vb = &Vs[(r * F) * TOKP + head * SM_HPITCH];
-  float s[F];
-  float mx = -1e30f;
-#pragma unroll
-  for (int j = 0; j < F; ++j) {
-    float a = 0.f;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      f32x4 kk = *reinterpret_cast<const f32x4*>(kb + j * TOKP + 4 * i);
-      a = fmaf(q[4 * i], kk[0], a); a = fmaf(q[4 * i + 1], kk[1], a);
-      a = fmaf(q[4 * i + 2], kk[2], a); a = fmaf(q[4 * i + 3], kk[3], a);
-    }
-    s[j] = a;
-    mx = fmaxf(mx, a);
-  }
-  float l = 0.f;
-#pragma unroll
-  for (int j = 0; j < F; ++j) {
-    s[j] = __builtin_amdgcn_exp2f(s[j] - mx);
-    l += s[j];
-  }
-  float o[32];
-#pragma unroll
-  for (int i = 0; i < 32; ++i) o[i] = 0.f;
-#pragma unroll
-  for (int j = 0; j < F; ++j) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      f32x4 vv = *reinterpret_cast<const f32x4*>(vb + j * TOKP + 4 * i);
-      o[4 * i] = fmaf(s[j], vv[0], o[4 * i]); o[4 * i + 1] = fmaf(s[j], vv[1], o[4 * i + 1]);
-      o[4 * i + 2] = fmaf(s[j], vv[2], o[4 * i + 2]); o[4 * i + 3] = fmaf(s[j], vv[3], o[4 * i + 3]);
-    }
-  }
-  if (ok) {
-    const float scale = p.gates[qrow * H + head] / l;
-    T* op = reinterpret_cast<T*>(p.out) + qrow * inner + head * 32;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      if constexpr (std::is_same<T, float>::value) {
-        *reinterpret_cast<f32x4*>(op + 4 * i) =
-            f32x4{o[4 * i] * scale, o[4 * i + 1] * scale, o[4 * i + 2] * scale, o[4 * i + 3] * scale};
-      } else {
-        hfx4 ov = {(hf)(o[4 * i] * scale), (hf)(o[4 * i + 1] * scale), (hf)(o[4 * i + 2] * scale),
-                     (hf)(o[4 * i + 3] * scale)};
-        *reinterpret_cast<hfx4*>(op + 4 * i) = ov;
-      }
-    }
-  }
-}
-
-template <typename T>
-int launch_small_t(const AttnP& p, hipStream_t s) {
-  dim3 grid((unsigned)((p.n_seq + SM_ROWS - 1) / SM_ROWS)), block(256);
-  switch (p.L) {
-    case 32: hipLaunchKernelGGL((attn_small_kernel<T, 32>), grid, block, 0, s, p); break;
-    case 16: hipLaunchKernelGGL((attn_small_kernel<T, 16>), grid, block, 0, s, p); break;
-    case 8: hipLaunchKernelGGL((attn_small_kernel<T, 8>), grid, block, 0, s, p); break;
-    default: return -2;
-  }
-  return (int)hipGetLastError();
-}
-
 }  // namespace
 
 int launch_attn_flash(const AttnP& p, int prec, hipStream_t s) {
@@ -332,9 +215,4 @@ int launch_attn_flash(const AttnP& p, int prec, hipStream_t s) {
   else
     hipLaunchKernelGGL((attn_flash_kernel<hf>), grid, block, 0, s, p);
   return (int)hipGetLastError();
-}
-
-int launch_attn_small(const AttnP& p, int prec, hipStream_t s) {
-  if (p.heads * p.L != 32 || p.inner != p.heads * 32) return -2;
-  return prec == BT_PREC_F32 ? launch_small_t<float>(p, s) : launch_small_t<hf>(p, s);
 }

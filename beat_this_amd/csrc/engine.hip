@@ -109,7 +109,7 @@ Workspace carve(char* base, int B, int T, int D, int ff_mult, int prec) {
   do { int _rc; { prof::Scope _ps(pf, cat, st); _rc = (expr); } CHECK_RC(what) } while (0)
 
 // mode 0: main transformer (sequences = chunks, tokens = frames)
-// mode 1: frequency direction (sequences = (b,t), tokens = f)      -- attn_small
+// mode 1: frequency direction (sequences = (b,t), tokens = f)      -- attnff_fused_kernel only
 // mode 2: time direction      (sequences = (b,f), tokens = t)      -- rows permuted around attn_flash
 // Main transformer layer in BT_PREC_HALF on the gemm3 / attn2 kernels.  ws.ssq[0] holds the partial row sums of
 // squares of x on entry and on exit (written by the producer of x: frontend.linear or the previous FF2), ws.ssq[1]
@@ -163,7 +163,7 @@ int run_layer_half(prof::State* pf, const bt_pair_weights& pw, const float* rope
 // half shadow of the residual stream written by the fused out-projection + FF kernel (time-direction half; A operand of
 // the following frontend conv on gemm3)
 inline bool pair_fused2_ok(const bt_pair_weights& pw, int prec) {
-  return pw.dim <= 128 && pw.w_outp[prec] && pw.w_ff_frag[prec] && pw.w_outff_frag[prec] && pw.w_attnff_frag[prec];
+  return pw.dim <= 128 && pw.w_ff_frag[prec] && pw.w_outff_frag[prec] && pw.w_attnff_frag[prec];
 }
 
 int run_pair(prof::State* pf, const bt_pair_weights& pw, const float* rope, float* x, void* xshadow, const Workspace& ws,
@@ -174,7 +174,7 @@ int run_pair(prof::State* pf, const bt_pair_weights& pw, const float* rope, floa
   GemmP g;
   // main layers in half mode read the half shadow of x (half the operand bytes, no conversion in the k-loop)
   const bool shadow = xshadow != nullptr && prec == BT_PREC_HALF;
-  const bool fused_ok = C <= 128 && pw.w_outp[prec] && pw.w_ff_frag[prec];
+  const bool fused_ok = C <= 128 && pw.w_ff_frag[prec];
   const bool fused2_ok = fused_ok && pw.w_outff_frag[prec] && pw.w_attnff_frag[prec];
   auto outff = [&]() -> int {  // x += to_out(ws.ao); x += FF(x) in one launch
     FusedOutFFP f;
@@ -190,12 +190,9 @@ int run_pair(prof::State* pf, const bt_pair_weights& pw, const float* rope, floa
     LAUNCH_CAT(CAT_ATTN_FREQ_FUSED, s, launch_attnff_fused(f, prec, s), "fused frequency attention + feed-forward");
     return BT_OK;
   }
-  if (mode == 1 && fused_ok) {  // whole frequency-direction attention block in one register-resident kernel
-    FusedAttnP fa;
-    fa.x = x; fa.M = M; fa.C = C; fa.w_qkvg = pw.w_qkvg[prec]; fa.b_gates = pw.b_gates; fa.w_outp = pw.w_outp[prec];
-    fa.rope = rope;
-    LAUNCH_CAT(CAT_ATTN_FREQ_FUSED, s, launch_attn_freq_fused(fa, prec, s), "fused frequency attention");
-  } else if (mode == 2 && fused_ok && prec == BT_PREC_HALF && pw.w_qkv_frag) {
+  if (mode == 1)  // (pack.py always supplies the fused-half weight streams for the frontend's pairs)
+    return bt_set_error(BT_ERR_ARG, "frequency-direction half needs bt_pair_weights.w_attnff_frag");
+  if (mode == 2 && fused_ok && prec == BT_PREC_HALF && pw.w_qkv_frag) {
     // half time direction: fragment-major QKV straight from the projection, flash attention on it
     QkvFrontP qp;
     memset(&qp, 0, sizeof qp);
@@ -227,10 +224,7 @@ int run_pair(prof::State* pf, const bt_pair_weights& pw, const float* rope, floa
   AttnP a;
   memset(&a, 0, sizeof a);
   a.qkv = ws.qkv; a.ld = 3 * C; a.gates = ws.gates; a.out = ws.ao; a.heads = H; a.inner = C;
-  if (mode == 1) {
-    a.n_seq = B * T; a.L = F; a.o_div = 1; a.o_outer = F; a.o_inner = 0; a.o_tok = 1;
-    LAUNCH_CAT(CAT_ATTN_SMALL, s, launch_attn_small(a, prec, s), "frequency attention");
-  } else if (mode == 2) {
+  if (mode == 2) {
     a.n_seq = B * F; a.L = T; a.o_div = F; a.o_outer = (long)T * F; a.o_inner = 1; a.o_tok = F;
     LAUNCH_CAT(CAT_ATTN_FLASH, s, launch_attn_flash(a, prec, s), "time attention");
   } else {
@@ -607,16 +601,6 @@ int bt_ff_fused(void* stream, int prec, const bt_pair_weights* w, float* d_x, in
   return BT_OK;
 }
 
-int bt_attn_freq_fused(void* stream, int prec, const bt_pair_weights* w, const float* d_rope, float* d_x, int64_t M) {
-  if (!w || !d_x || !d_rope || M <= 0 || w->dim > 128 || !w->w_outp[prec])
-    return bt_set_error(BT_ERR_ARG, "bad argument to bt_attn_freq_fused");
-  FusedAttnP fa;
-  fa.x = d_x; fa.M = M; fa.C = w->dim; fa.w_qkvg = w->w_qkvg[prec]; fa.b_gates = w->b_gates; fa.w_outp = w->w_outp[prec];
-  fa.rope = d_rope;
-  LAUNCH(launch_attn_freq_fused(fa, prec, (hipStream_t)stream), "fused frequency attention");
-  return BT_OK;
-}
-
 int bt_gemm(void* stream, int prec, const bt_gemm_args* a) {
   if (!a) return bt_set_error(BT_ERR_ARG, "null argument");
   GemmP g;
@@ -630,17 +614,14 @@ int bt_gemm(void* stream, int prec, const bt_gemm_args* a) {
   return BT_OK;
 }
 
-int bt_attention(void* stream, int prec, const bt_attn_args* a, int small_kernel) {
+int bt_attention(void* stream, int prec, const bt_attn_args* a) {
   if (!a) return bt_set_error(BT_ERR_ARG, "null argument");
   AttnP p;
   memset(&p, 0, sizeof p);
   p.qkv = a->qkv; p.ld = a->ld; p.gates = a->gates; p.out = a->out; p.n_seq = a->n_seq; p.L = a->L;
   p.heads = a->heads; p.inner = a->inner; p.o_div = a->o_div; p.o_outer = a->o_outer; p.o_inner = a->o_inner;
   p.o_tok = a->o_tok;
-  if (small_kernel)
-    LAUNCH(launch_attn_small(p, prec, (hipStream_t)stream), "attention (small)");
-  else
-    LAUNCH(launch_attn_flash(p, prec, (hipStream_t)stream), "attention (flash)");
+  LAUNCH(launch_attn_flash(p, prec, (hipStream_t)stream), "attention (flash)");
   return BT_OK;
 }
 

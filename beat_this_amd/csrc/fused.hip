@@ -9,8 +9,8 @@
 // (RMSNorm factor, RoPE angle, gate, softmax statistics) is lane-local.  One wave = 32 tokens.
 //
 //   ff_fused_kernel        x += W2 . gelu(W1 . rmsnorm(x) + b1) + b2          (roformer.py:38-61)
-//   attn_freq_fused_kernel x += Wout . gate * softmax(rope(q) rope(k)^T) v    (roformer.py:83-132,
-//                          frequency direction of PartialFTTransformer, beat_tracker.py:293-295)
+// Reached by bt_forward for main layers with transformer_dim <= 128 (small0) outside the gemm3 path (fp32).  The frontend
+// halves run on the second generation of this idea, fused2.hip (whole halves per launch, LDS-DMA weight ring).
 //
 // Weights stream from L2/L1 straight into A-operand registers (<= 256 KB per block, shared by all
 // waves of the launch); the residual stream x is read once (64 B per lane per k-tile) and
@@ -112,130 +112,6 @@ __global__ __launch_bounds__(256) void ff_fused_kernel(const FusedFFP p) {
 }
 
 // ---------------------------------------------------------------------------------------------
-template <typename T, int C>
-__global__ __launch_bounds__(256) void attn_freq_fused_kernel(const FusedAttnP p) {
-  constexpr int KT = C / 32;
-  constexpr int H = C / 32;       // heads
-  constexpr int F = 1024 / C;     // tokens per (b,t) row: 32, 16, 8
-  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int g = lane >> 5, lr = lane & 31;
-  const long tok = ((long)blockIdx.x * 4 + wave) * 32 + lr;
-  const bool ok = tok < p.M;
-  float* xrow = p.x + (ok ? tok : 0) * C;
-  const T* W = reinterpret_cast<const T*>(p.w_qkvg);
-  const T* Wo = reinterpret_cast<const T*>(p.w_outp);
-
-  float ss = 0.f;
-  Frag<T> xf[KT];
-#pragma unroll
-  for (int kt = 0; kt < KT; ++kt) xf[kt] = ldx_frag<T>(xrow + kt * 32 + 16 * g, ok, ss);
-  ss += __shfl_xor(ss, 32);
-  const float scale = sqrtf((float)C) / fmaxf(sqrtf(ss), 1e-12f);
-  // RMSNorm factors of the 16 tokens whose V rows this lane holds (register r <-> token crow(r,g))
-  float sk[16];
-#pragma unroll
-  for (int r = 0; r < 16; ++r) sk[r] = __shfl(scale, crow(r, g));
-
-  // gates of all heads: one padded tile, rows 3C + (0..H) are the gate rows
-  float gate[H];
-  {
-    f32x16 ag;
-    zero16(ag);
-    const T* wg = W + (long)(3 * C + lr) * C + 16 * g;
-#pragma unroll
-    for (int kt = 0; kt < KT; ++kt) mma32(ag, ldg_frag<T>(wg + kt * 32), xf[kt]);
-#pragma unroll
-    for (int hd = 0; hd < H; ++hd) {  // gate hd sits in register hd of the g = 0 half (crow(hd,0) = hd, hd < 4)
-      float v = __shfl(ag[hd], lr);
-      gate[hd] = sigmoidf(fmaf(v, scale, p.b_gates[hd]));
-    }
-  }
-  // RoPE factors for this lane's token: position = token index inside its (b,t) row
-  const int pos = (int)(tok & (F - 1));
-  f32x2 cs[8];
-#pragma unroll
-  for (int a = 0; a < 4; ++a)
-#pragma unroll
-    for (int b = 0; b < 2; ++b)  // features d = 8a + 4g + 2b (+1): pair index d/2 = 4a + 2g + b
-      cs[2 * a + b] = *reinterpret_cast<const f32x2*>(p.rope + ((long)pos * 16 + 4 * a + 2 * g + b) * 2);
-
-  f32x16 acco[KT];
-#pragma unroll
-  for (int mt = 0; mt < KT; ++mt) zero16(acco[mt]);
-
-#pragma unroll 1
-  for (int hd = 0; hd < H; ++hd) {
-    // ---- q^T, k^T (lane = token) and v (lane = feature) for this head ---------------------------
-    f32x16 aq, ak, av;
-    zero16(aq); zero16(ak); zero16(av);
-    const T* wq = W + (long)(hd * 32 + lr) * C + 16 * g;
-    const T* wk = wq + (long)C * C;
-    const T* wv = wk + (long)C * C;
-#pragma unroll
-    for (int kt = 0; kt < KT; ++kt) {
-      mma32(aq, ldg_frag<T>(wq + kt * 32), xf[kt]);
-      mma32(ak, ldg_frag<T>(wk + kt * 32), xf[kt]);
-      mma32(av, xf[kt], ldg_frag<T>(wv + kt * 32));   // roles swapped: [token][feature]
-    }
-    float q[16], k[16], v[16];
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-      for (int b = 0; b < 2; ++b) {
-        const f32x2 t = cs[2 * a + b];
-        const int r = 4 * a + 2 * b;
-        const float q0 = aq[r] * scale, q1 = aq[r + 1] * scale, k0 = ak[r] * scale, k1 = ak[r + 1] * scale;
-        q[r] = q0 * t.x - q1 * t.y; q[r + 1] = q1 * t.x + q0 * t.y;
-        k[r] = k0 * t.x - k1 * t.y; k[r + 1] = k1 * t.x + k0 * t.y;
-      }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) v[r] = av[r] * sk[r];
-    // ---- S^T[key][query] = K . Q^T over d (k-slots = registers of both) -----------------------------
-    f32x16 sc;
-    zero16(sc);
-    mma32(sc, pack_frag<T>(k), pack_frag<T>(q));
-    float mx = -1e30f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      if (F < 32 && ((crow(r, g) ^ lr) & ~(F - 1))) sc[r] = -1e30f;  // key and query in different rows
-      mx = fmaxf(mx, sc[r]);
-    }
-    mx = fmaxf(mx, __shfl_xor(mx, 32));
-    float pr[16], l = 0.f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      pr[r] = __builtin_amdgcn_exp2f(sc[r] - mx);
-      l += pr[r];
-    }
-    l += __shfl_xor(l, 32);
-    // ---- O^T[d][query] = V^T . P^T over keys ------------------------------------------------------------
-    f32x16 ao;
-    zero16(ao);
-    mma32(ao, pack_frag<T>(v), pack_frag<T>(pr));
-    const float fin = gate[hd] / l;
-    float o[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) o[r] = ao[r] * fin;
-    const Frag<T> of = pack_frag<T>(o);
-    // ---- out^T += Wout[:, head slice (PERM32 order)] . O^T ------------------------------------------------
-    const T* wo = Wo + (long)lr * C + hd * 32 + 16 * g;
-#pragma unroll
-    for (int mt = 0; mt < KT; ++mt) mma32(acco[mt], ldg_frag<T>(wo + (long)mt * 32 * C), of);
-  }
-  if (ok) {
-#pragma unroll
-    for (int mt = 0; mt < KT; ++mt)
-#pragma unroll
-      for (int a = 0; a < 4; ++a) {
-        f32x4* xp = reinterpret_cast<f32x4*>(xrow + mt * 32 + 8 * a + 4 * g);
-        f32x4 vv = *xp;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) vv[j] += acco[mt][4 * a + j];
-        *xp = vv;
-      }
-  }
-}
-
 template <typename T>
 int launch_ff_t(const FusedFFP& p, hipStream_t s) {
   dim3 grid((unsigned)((p.M + 127) / 128)), block(256);
@@ -247,25 +123,9 @@ int launch_ff_t(const FusedFFP& p, hipStream_t s) {
   }
   return (int)hipGetLastError();
 }
-template <typename T>
-int launch_af_t(const FusedAttnP& p, hipStream_t s) {
-  dim3 grid((unsigned)((p.M + 127) / 128)), block(256);
-  switch (p.C) {
-    case 32: hipLaunchKernelGGL((attn_freq_fused_kernel<T, 32>), grid, block, 0, s, p); break;
-    case 64: hipLaunchKernelGGL((attn_freq_fused_kernel<T, 64>), grid, block, 0, s, p); break;
-    case 128: hipLaunchKernelGGL((attn_freq_fused_kernel<T, 128>), grid, block, 0, s, p); break;
-    default: return -2;
-  }
-  return (int)hipGetLastError();
-}
-
 }  // namespace
 
 int launch_ff_fused(const FusedFFP& p, int prec, hipStream_t s) {
   if (p.M <= 0) return -2;
   return prec == BT_PREC_F32 ? launch_ff_t<float>(p, s) : launch_ff_t<hf>(p, s);
-}
-int launch_attn_freq_fused(const FusedAttnP& p, int prec, hipStream_t s) {
-  if (p.M <= 0) return -2;
-  return prec == BT_PREC_F32 ? launch_af_t<float>(p, s) : launch_af_t<hf>(p, s);
 }

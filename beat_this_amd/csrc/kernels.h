@@ -117,7 +117,6 @@ struct QkvFrontP {
   int nbp;
 };
 int launch_qkv_front(const QkvFrontP& p, hipStream_t s);
-int launch_attn_small(const AttnP& p, int prec, hipStream_t s);  // L in {8,16,32}, heads*L == 32
 
 // ---- register-chained fused frontend blocks (fused.hip), C in {32, 64, 128} ----------------------
 struct FusedFFP {
@@ -127,13 +126,6 @@ struct FusedFFP {
   void* xb;                          // optional half shadow of the updated x (same layout), may be null
 };
 int launch_ff_fused(const FusedFFP& p, int prec, hipStream_t s);
-struct FusedAttnP {
-  float* x; long M; int C;
-  const void* w_qkvg; const float* b_gates;  // as for the QKV GEMM
-  const void* w_outp;                        // [C (padded), C] columns in PERM32 order
-  const float* rope;
-};
-int launch_attn_freq_fused(const FusedAttnP& p, int prec, hipStream_t s);
 
 // ---- fused halves of a PartialFTTransformer (fused2.hip): x read once, written once -----------------------------
 struct FusedOutFFP {  // x += Wout . ao ; x += FF(x)      (time direction, after the flash attention)

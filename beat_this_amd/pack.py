@@ -190,7 +190,6 @@ class PackedModel:
         # (the register-chained kernels of fused.hip / fused2.hip are built for a hidden width of 4 dim: a main layer with
         # another ff_mult and dim <= 128 runs on the plain GEMM path)
         if dim <= 128 and sd[pf + "net.1.weight"].shape[0] == 4 * dim:
-            pw.w_outp[0], pw.w_outp[1] = self._mat(perm32(sd[pa + "to_out.0.weight"]))
             w1 = (sd[pf + "net.1.weight"] * sd[pf + "net.0.gamma"][None, :]).to(torch.float32)
             w2p = perm32(sd[pf + "net.4.weight"].to(torch.float32))
             f32 = ff_fragment_major(w1, w2p, 4).to(self.device)

@@ -53,7 +53,7 @@ typedef struct {
   /* PERM32 copies (columns reordered inside every block of 32: new[16 g + r] = old[(r & 3) +
    * 8 (r >> 2) + 4 g], g in {0,1}, r in [0,16)) consumed by the register-chained fused kernels of
    * csrc/fused.hip; only used for dim <= 128 (frontend), may be NULL otherwise. */
-  const void* w_outp[2];   /* to_out.0.weight, PERM32 columns, [dim padded][dim] */
+  const void* w_outp[2];   /* (unused since round 2: was to_out.0.weight with PERM32 columns for the retired attn_freq_fused_kernel) */
   /* FF weights for ff_fused_kernel, fragment-major: for each hidden block hb (32 hidden units):
    * dim/32 tiles of W1 (rows hb*32.., k-tile kt) then dim/32 tiles of PERM32'd W2 (rows mt*32..,
    * cols hb*32..); a tile is [half h][lane 0..63][8] (bf16) or [quarter][lane][4] (fp32) with
@@ -204,7 +204,7 @@ int bt_postprocess_host(const int32_t* beat_idx, int n_beat_idx, const int32_t* 
  * milliseconds and launch counts per category (index = BT_CAT_*). */
 #define BT_CAT_STEM 0
 #define BT_CAT_QKV_GEMM 1
-#define BT_CAT_ATTN_FREQ 2   /* attn_small_kernel */
+#define BT_CAT_ATTN_FREQ 2   /* (unused since round 2: the frequency-direction attention runs inside BT_CAT_ATTN_FREQ_FUSED) */
 #define BT_CAT_ATTN_FLASH 3  /* attn_flash_kernel: time-direction + main attention */
 #define BT_CAT_OUT_GEMM 4
 #define BT_CAT_FF1_GEMM 5
@@ -213,7 +213,7 @@ int bt_postprocess_host(const int32_t* beat_idx, int n_beat_idx, const int32_t* 
 #define BT_CAT_LINEAR_GEMM 8
 #define BT_CAT_HEAD 9
 #define BT_CAT_FF_FUSED 10        /* ff_fused_kernel (frontend FF blocks) */
-#define BT_CAT_ATTN_FREQ_FUSED 11 /* attn_freq_fused_kernel (QKV + attention + out-proj) */
+#define BT_CAT_ATTN_FREQ_FUSED 11 /* attnff_fused_kernel: frequency-direction half (QKV + attention + out-proj + FF) */
 #define BT_CAT_LAYER_TAIL 12      /* layer_tail_kernel (main layers: out-projection + FF1 + FF2 in one launch) */
 #define BT_PROFILE_CATEGORIES 13
 void bt_profile_begin(bt_engine* e);
@@ -232,7 +232,7 @@ typedef struct {
   const void* qkv; int64_t ld; const float* gates; void* out;
   int32_t n_seq, L, heads, inner, o_div; int64_t o_outer, o_inner, o_tok;
 } bt_attn_args;
-int bt_attention(void* stream, int prec, const bt_attn_args* a, int small_kernel);
+int bt_attention(void* stream, int prec, const bt_attn_args* a);
 
 /* bf16 attention on FRAGMENT-MAJOR operands (csrc/attn2.hip): per (sequence, head) `nbp` blocks of
  * 32 tokens, 2 KB each.  Q/K block: [quarter a][token][8 dims 8a..8a+7]; V block: [s][lane = 32 g + d]
@@ -270,9 +270,8 @@ int bt_attention_frag(void* stream, const bt_attn_frag_args* a);
 /* Time-direction QKV projection of a frontend block: d_x [B,T,F,C] fp32 -> fragment-major q, k, v, gates */
 int bt_qkv_front(void* stream, const bt_pair_weights* w, const float* d_rope, const float* d_x, int B, int T, int F,
                  void* d_q, void* d_k, void* d_v, float* d_gates, int nbp);
-/* x[M,C] += FF(x) / x += frequency-direction attention(x) with one bt_pair_weights, dim = C <= 128 */
+/* x[M,C] += FF(x) with one bt_pair_weights, dim = C <= 128 */
 int bt_ff_fused(void* stream, int prec, const bt_pair_weights* w, float* d_x, int64_t M);
-int bt_attn_freq_fused(void* stream, int prec, const bt_pair_weights* w, const float* d_rope, float* d_x, int64_t M);
 /* fused halves (csrc/fused2.hip): x += to_out(ao) then x += FF(x);  x += AttnF(x) then x += FF(x) */
 int bt_outff_fused(void* stream, int prec, const bt_pair_weights* w, const void* d_ao, float* d_x, int64_t M);
 int bt_attnff_fused(void* stream, int prec, const bt_pair_weights* w, const float* d_rope, float* d_x, int64_t M);

@@ -58,7 +58,7 @@ def run_gemm(prec, A, W, N, epi, flags, bias=None, out=None, ldo=0, x=None, conv
         torch.cuda.synchronize()
 
 
-def run_attn(prec, qkv, gates, out, n_seq, L, heads, o_div=1, o_outer=None, o_inner=0, o_tok=1, small=False):
+def run_attn(prec, qkv, gates, out, n_seq, L, heads, o_div=1, o_outer=None, o_inner=0, o_tok=1):
     from beat_this_amd import _lib
 
     a = _lib.AttnArgs()
@@ -66,7 +66,7 @@ def run_attn(prec, qkv, gates, out, n_seq, L, heads, o_div=1, o_outer=None, o_in
     a.n_seq, a.L, a.heads, a.inner, a.o_div = n_seq, L, heads, heads * 32, o_div
     a.o_outer = L if o_outer is None else o_outer
     a.o_inner, a.o_tok = o_inner, o_tok
-    _lib.check(_lib.lib().bt_attention(_lib.stream_ptr(dev()), prec, C.byref(a), int(small)))
+    _lib.check(_lib.lib().bt_attention(_lib.stream_ptr(dev()), prec, C.byref(a)))
     torch.cuda.synchronize()
 
 

@@ -188,26 +188,6 @@ def test_attention_flash_time_direction_rowmap(prec):
     assert err < (2e-5 if prec == F32 else 2e-2)
 
 
-@pytest.mark.parametrize("prec", [F32, BF16])
-@pytest.mark.parametrize("L,heads", [(32, 1), (16, 2), (8, 4)])
-def test_attention_small(prec, L, heads):
-    n_seq = 21  # not a multiple of 8: exercises the ragged tail
-    C = heads * 32
-    qkv = _mk((n_seq * L, 3 * C), 40)
-    gates = torch.sigmoid(_mk((n_seq * L, heads), 41))
-    qd = qkv.float().to(tdtype(prec)).to(dev())
-    out = torch.zeros((n_seq * L, C), dtype=tdtype(prec), device=dev())
-    run_attn(prec, qd, gates.float().to(dev()), out, n_seq, L, heads, small=True)
-    qq = qd.double().cpu()
-    def split(i):
-        return qq[:, i * C:(i + 1) * C].reshape(n_seq, L, heads, 32).permute(0, 2, 1, 3)
-    ref = _attn_ref(split(0), split(1), split(2), gates.reshape(n_seq, L, heads).permute(0, 2, 1))
-    ref = ref.permute(0, 2, 1, 3).reshape(n_seq * L, C)
-    err = _rel(out, ref)
-    report("attn_small", prec=prec, L=L, heads=heads, rel=err)
-    assert err < (2e-5 if prec == F32 else 1e-2)
-
-
 def _pair_sd(C, seed):
     H = C // 32
     g = torch.Generator().manual_seed(seed)
@@ -244,43 +224,6 @@ def test_fused_ff(prec, C):
     err = _rel(x, ref)
     report("ff_fused", prec=prec, C=C, rel=err)
     assert err < (2e-5 if prec == F32 else 1.5e-2)
-
-
-@pytest.mark.parametrize("prec", [F32, BF16])
-@pytest.mark.parametrize("C", [32, 64, 128])
-def test_fused_freq_attention(prec, C):
-    """x += to_out(gate * softmax(rope(q) rope(k)^T / sqrt(32)) v) over the F = 1024/C tokens of each (b,t) row."""
-    import ctypes as Ct
-    from beat_this_amd import _lib as L
-    from beat_this_amd.pack import PackedPair
-    from beat_this_amd.tables import rope_table
-
-    H, F = C // 32, 1024 // C
-    sd = _pair_sd(C, 70 + C)
-    rows = 37  # (b,t) rows; 37*F tokens is not a multiple of 128
-    M = rows * F
-    x0 = _mk((M, C), 80 + C, 1.5)
-    freqs = 10000.0 ** (-torch.arange(0, 32, 2).float() / 32)
-    rope = torch.from_numpy(rope_table(freqs)).to(dev())
-    pp = PackedPair(sd, "a.", "f.", C, dev())
-    x = x0.float().to(dev()).clone()
-    L.check(L.lib().bt_attn_freq_fused(L.stream_ptr(dev()), prec, Ct.byref(pp.weights), rope.data_ptr(), x.data_ptr(), M))
-    torch.cuda.synchronize()
-    xn = x0 / x0.norm(dim=-1, keepdim=True).clamp_min(1e-12) * math.sqrt(C) * sd["a.norm.gamma"]
-    qkv = (xn @ sd["a.to_qkv.weight"].T).reshape(rows, F, 3, H, 32).permute(2, 0, 3, 1, 4)  # qkv b h n d
-    ang = torch.arange(F, dtype=torch.float64)[:, None] * freqs.double()[None, :]
-    cos, sin = ang.cos().repeat_interleave(2, -1), ang.sin().repeat_interleave(2, -1)
-    def rot(t):
-        te, to = t[..., 0::2], t[..., 1::2]
-        return t * cos + torch.stack((-to, te), -1).flatten(-2) * sin
-    q, k, v = rot(qkv[0]), rot(qkv[1]), qkv[2]
-    att = torch.softmax(q @ k.transpose(-1, -2) / math.sqrt(32.0), -1) @ v
-    gates = torch.sigmoid(xn @ sd["a.to_gates.weight"].T + sd["a.to_gates.bias"]).reshape(rows, F, H).permute(0, 2, 1)
-    out = (att * gates[..., None]).permute(0, 2, 1, 3).reshape(M, C) @ sd["a.to_out.0.weight"].T
-    ref = x0 + out
-    err = float((x.double().cpu() - ref).abs().max() / out.abs().max())
-    report("attn_freq_fused", prec=prec, C=C, rel=err)
-    assert err < (3e-5 if prec == F32 else 2e-2)
 
 
 @pytest.mark.parametrize("M,K,N", [(1500, 128, 512), (700, 512, 2048), (1500, 128, 128)])
