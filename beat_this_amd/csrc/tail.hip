@@ -65,9 +65,10 @@ DEVI void mma32_agpr(f32x16& acc, const Frag<hf>& a, const Frag<hf>& b) {
 DEVI void mfma_results_ready() { asm volatile("s_nop 15\n\ts_nop 15" ::: "memory"); }
 DEVI void agpr_fence(f32x16& acc) { asm volatile("" : "+a"(acc)); }
 
-// DS reads are pinned where they are written (everything else may move across): the scheduler otherwise hoists all 32
-// fragment reads of a step in front of its MFMAs -- 128 VGPRs of landing space that do not exist here.
-#define TAIL_PIN_DS() __builtin_amdgcn_sched_barrier(0x1 | 0x2 | 0x4 | 0x8 | 0x10 | 0x400)
+// DS reads and LDS-DMA issues are pinned where they are written (ALU / MFMA may move across): the scheduler otherwise
+// hoists all 32 fragment reads of a step in front of its MFMAs -- 128 VGPRs of landing space that do not exist here --
+// and bunches the LDS-DMA issues (see issue_piece).
+#define TAIL_PIN_DS() __builtin_amdgcn_sched_barrier(0x1 | 0x2 | 0x4 | 0x8 | 0x400)
 
 template <int C>
 struct TRing {
@@ -86,11 +87,34 @@ struct TRing {
     for (int i = 0; i < CH; ++i)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)(dst + i * 4096), 16, tid * 16, s * STEP_B + i * 4096, 0, 0);
   }
+  // Piece i (4 KB of the workgroup, 1 KB of this wave) of step s.  A step's CH = KT pieces are issued ONE PER TILE
+  // ITERATION of the step that is being multiplied, not all at once behind the barrier: an LDS-DMA instruction costs the
+  // issuing wave 60-180 cycles of issue time (MI355X_MICROARCH.md), and with one wave per SIMD sixteen of them in a
+  // row were ~2 k cycles of idle matrix pipe per 2 k-cycle step (rocprofv3: MFMA busy 27 % of the kernel, 28 GB/s per
+  // CU of ring fill).  Spread out, they issue in the shadow of the MFMAs.
+  // OPEN ISSUE (round 2): BT_TAIL_ISSUE = 0 -- the spread-out issue described above -- produces garbage (wrong weights in
+  // every wave, reproducible, tools/tail_debug.py) although its instruction stream reads correct (M0, offsets, waits);
+  // the two burst forms (1: all pieces at the first tile iteration, 2: all pieces right behind the barrier) are correct
+  // and bit-identical.  Until that is understood the kernel ships with form 2 and pays the ~2 k idle cycles per step.
+#ifndef BT_TAIL_ISSUE
+#define BT_TAIL_ISSUE 2
+#endif
+  DEVI void issue_piece(int s, int i) {
+#if BT_TAIL_ISSUE == 2
+    return;
+#elif BT_TAIL_ISSUE == 1
+    if (i == 0) issue(s);
+    return;
+#endif
+    if (s >= total) return;
+    char* dst = lds + (s % NST) * STEP_B + wave * 1024;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)(dst + i * 4096), 16, tid * 16, s * STEP_B + i * 4096, 0, 0);
+  }
   DEVI void prologue() {
 #pragma unroll
     for (int s = 0; s < NST - 1; ++s) issue(s);
   }
-  // make step s readable by every wave (all older LDS-DMA done in every wave), then refill the stage freed by step s-1
+  // make step s readable by every wave (all older LDS-DMA done in every wave); the stage of step s - 1 is free from here on
   DEVI const char* acquire(int s) {
     const int ahead = min(NST - 2, total - 1 - s);  // younger steps that may stay in flight
     // (lgkmcnt(0): this wave's fragment reads of step s - 1 have returned before the barrier: its stage is refilled next)
@@ -98,8 +122,10 @@ struct TRing {
     else if (NST == 4 && ahead == 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(CH) : "memory");
     else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+#if BT_TAIL_ISSUE == 2
     issue(s + NST - 1);
-    return lds + (s % NST) * STEP_B;
+#endif
+    return lds + (s % NST) * STEP_B;   // (the caller issues step s + NST - 1 piece by piece while it multiplies step s)
   }
 };
 
@@ -109,9 +135,11 @@ struct TRing {
 //   hcur   = gelu(ce * scale + b1)   activation of hidden block i, one element per tile pair, in the MFMAs' shadow
 // The two MFMA streams alternate, so the dependent chain on `ne` never issues back to back; fragments are read one tile
 // pair ahead.
-template <int KT, bool HAS_A, bool HAS_G, bool HAS_B>
-DEVI void ff_step(const char* wb, int lane, const Frag<hf> (&xf)[KT], f32x16 (&acc2)[KT], const f32x16& ce, f32x16& ne,
+template <int KT, bool HAS_A, bool HAS_G, bool HAS_B, typename RING>
+DEVI void ff_step(RING& ws, int step, int lane, const Frag<hf> (&xf)[KT], f32x16 (&acc2)[KT], const f32x16& ce, f32x16& ne,
                   const Frag<hf>& hprev, Frag<hf>& hcur, const float* b1lane, float scale) {
+  static_assert(RING::CH == KT, "one LDS-DMA piece per tile iteration");
+  const char* wb = ws.acquire(step);
   Frag<hf> fa, fb, na, nb;
   if (HAS_A) fa = lds_frag<hf>(wb, lane);
   if (HAS_B) fb = lds_frag<hf>(wb + KT * TILE_B, lane);
@@ -122,6 +150,7 @@ DEVI void ff_step(const char* wb, int lane, const Frag<hf> (&xf)[KT], f32x16 (&a
       if (HAS_A) na = lds_frag<hf>(wb + (t + 1) * TILE_B, lane);
       if (HAS_B) nb = lds_frag<hf>(wb + (KT + t + 1) * TILE_B, lane);
     }
+    ws.issue_piece(step + RING::NST - 1, t);
     TAIL_PIN_DS();
     if (HAS_A) {
       if (t == 0) mma32_vgpr_first(ne, fa, xf[0]);
@@ -206,6 +235,7 @@ __global__ __launch_bounds__(256, 1) void layer_tail_kernel(const LayerTailP p) 
         n0 = lds_frag<hf>(wb + (kt + 1) * TILE_B, lane);
         n1 = lds_frag<hf>(wb + (KT + kt + 1) * TILE_B, lane);
       }
+      ws.issue_piece(st + NST - 1, kt);
       TAIL_PIN_DS();
       // straight into the residual row's accumulator tiles (AGPRs): x += Wout . ao costs no VALU and no extra registers
       asm volatile(TAIL_MFMA " %0, %1, %2, %0" : "+a"(acc2[2 * st]) : "v"(f0.v[0]), "v"(af[kt].v[0]));
@@ -238,16 +268,16 @@ __global__ __launch_bounds__(256, 1) void layer_tail_kernel(const LayerTailP p) 
   f32x16 c0, c1;
   Frag<hf> h0, h1;
   const int s0 = KT / 2;  // first FF step of the stream
-  ff_step<KT, true, false, false>(ws.acquire(s0), lane, xf, acc2, c0, c0, h0, h0, b1lane, scale);             // S(-1): c0 = A(0)
-  ff_step<KT, true, true, false>(ws.acquire(s0 + 1), lane, xf, acc2, c0, c1, h0, h0, b1lane, scale);          // S(0): c1 = A(1), h0 = act(0)
+  ff_step<KT, true, false, false>(ws, s0, lane, xf, acc2, c0, c0, h0, h0, b1lane, scale);             // S(-1): c0 = A(0)
+  ff_step<KT, true, true, false>(ws, s0 + 1, lane, xf, acc2, c0, c1, h0, h0, b1lane, scale);          // S(0): c1 = A(1), h0 = act(0)
 #pragma unroll 1
   for (int i = 1; i + 2 < HB; i += 2) {  // S(i): ce = c1, ne = c0, hprev = h0, hcur = h1;  S(i + 1): roles swapped
-    ff_step<KT, true, true, true>(ws.acquire(s0 + 1 + i), lane, xf, acc2, c1, c0, h0, h1, b1lane + 32 * i, scale);
-    ff_step<KT, true, true, true>(ws.acquire(s0 + 2 + i), lane, xf, acc2, c0, c1, h1, h0, b1lane + 32 * (i + 1), scale);
+    ff_step<KT, true, true, true>(ws, s0 + 1 + i, lane, xf, acc2, c1, c0, h0, h1, b1lane + 32 * i, scale);
+    ff_step<KT, true, true, true>(ws, s0 + 2 + i, lane, xf, acc2, c0, c1, h1, h0, b1lane + 32 * (i + 1), scale);
   }
   // HB is even: S(HB - 1) has no A half, S(HB) neither A nor activation
-  ff_step<KT, false, true, true>(ws.acquire(s0 + HB), lane, xf, acc2, c1, c1, h0, h1, b1lane + 32 * (HB - 1), scale);
-  ff_step<KT, false, false, true>(ws.acquire(s0 + HB + 1), lane, xf, acc2, c0, c0, h1, h1, b1lane, scale);
+  ff_step<KT, false, true, true>(ws, s0 + HB, lane, xf, acc2, c1, c1, h0, h1, b1lane + 32 * (HB - 1), scale);
+  ff_step<KT, false, false, true>(ws, s0 + HB + 1, lane, xf, acc2, c0, c0, h1, h1, b1lane, scale);
   mfma_results_ready();
 #pragma unroll
   for (int mt = 0; mt < KT; ++mt) agpr_fence(acc2[mt]);
