@@ -160,10 +160,22 @@ DEVI void ff_step(RING& ws, int step, int lane, const Frag<hf> (&xf)[KT], f32x16
     if (t == 0) ws.issue(step + RING::NST - 1);
 #endif
     TAIL_PIN_DS();
+#ifndef BT_TAIL_ALTERNATE
+    // the two MFMAs (k-halves) of a product back to back
     if (HAS_A) {
       if (t == 0) mma32_vgpr_first(ne, fa, xf[0]);
       else mma32_vgpr(ne, fa, xf[t]);
     }
+#else
+    // EXPERIMENT (-DBT_TAIL_ALTERNATE): the k-halves of the A product and of the B product alternate, so that no MFMA takes
+    // the accumulator its predecessor is still writing.  A/B: 1.07 vs 1.047 ms per forward -- not faster: dependent
+    // back-to-back accumulation is not what this kernel waits for (its weight stream is).
+    if (HAS_A) {
+      if (t == 0) asm volatile(TAIL_MFMA " %0, %1, %2, 0" : "=&v"(ne) : "v"(fa.v[0]), "v"(xf[0].v[0]));
+      else asm volatile(TAIL_MFMA " %0, %1, %2, %0" : "+v"(ne) : "v"(fa.v[0]), "v"(xf[t].v[0]));
+    }
+    if (HAS_B) asm volatile(TAIL_MFMA " %0, %1, %2, %0" : "+a"(acc2[t]) : "v"(fb.v[0]), "v"(hprev.v[0]));
+#endif
     if (HAS_G && (t * 8) % KT == 0) {
 #pragma unroll
       for (int q = 0; q < (KT >= 8 ? 1 : 8 / KT); ++q) {  // elements r, r + 1 -> one packed dword of the next B operand
@@ -172,7 +184,12 @@ DEVI void ff_step(RING& ws, int step, int lane, const Frag<hf> (&xf)[KT], f32x16
         hw[r >> 1] = pk2(gelu_tanh(fmaf(ce[r], scale, b[0])), gelu_tanh(fmaf(ce[r + 1], scale, b[1])));
       }
     }
+#ifndef BT_TAIL_ALTERNATE
     if (HAS_B) mma32_agpr(acc2[t], fb, hprev);
+#else
+    if (HAS_A) asm volatile(TAIL_MFMA " %0, %1, %2, %0" : "+v"(ne) : "v"(fa.v[1]), "v"(xf[t].v[1]));
+    if (HAS_B) asm volatile(TAIL_MFMA " %0, %1, %2, %0" : "+a"(acc2[t]) : "v"(fb.v[1]), "v"(hprev.v[1]));
+#endif
 #if BT_TAIL_ISSUE == 5
     ws.issue_piece(step + RING::NST - 1, t);
 #endif

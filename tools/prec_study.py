@@ -139,6 +139,10 @@ def main():
             MODE[s] = "f16"
         report("all f16, tanh GELU")
         GELU["approx"] = "none"
+        for s in SITES:
+            MODE[s] = "f16"
+        MODE["f_pv"] = MODE["m_pv"] = "bf16"
+        report("all f16, P.V bf16")
         if "--quick" in sys.argv:
             return
         # attribution: one site at a time in bf16 and f16
