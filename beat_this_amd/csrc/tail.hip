@@ -93,9 +93,9 @@ struct TRing {
   // iteration between full sched_barrier(0)s 1.028 ms; 5 = one piece per iteration after its MFMAs 1.036 ms; 1 = burst at
   // the first iteration.  0 / 3 / 4 (one piece per iteration in front of the masked sched_barrier, free to move) produce
   // GARBAGE -- hipcc's placement of the DMA around the masked barrier, not the hardware: the pinned forms 5 and 6 are
-  // correct (tools/tail_debug.py).  The 2 % tell that the DMA issue cost is not what holds this kernel back: its weight
-  // stream is.  74 steps x 64 KB per workgroup, every CU pulling the same lines at the same time, arrive at 28 GB/s per
-  // CU (7.3 TB/s of L2 -> LDS over the chip): 2.3 us per step against 0.85 us of MFMA work.
+  // correct (tools/tail_debug.py).  The placement hardly matters because an LDS-DMA instruction blocks the issuing wave
+  // until the load path takes it (75 GB/s per CU at best: 64 us for the layer's 4.7 MB) and with one wave per SIMD no
+  // other wave issues MFMAs meanwhile: stream (64 us) and MFMAs (63 us) serialise to ~150 us (tools/ubench/tail_stream.hip).
 #ifndef BT_TAIL_ISSUE
 #define BT_TAIL_ISSUE 2
 #endif
