@@ -31,6 +31,16 @@ from .utils import replace_state_dict_key, save_beat_tsv
 
 CHECKPOINT_URL = "https://cloud.cp.jku.at/public.php/dav/files/7ik4RrBKTS273gp"
 MAX_CHUNKS_PER_LAUNCH = 96  # workspace is ~70 MB (fp32) / ~45 MB (half) per chunk; larger batches are split into equal slices
+CONCURRENT_STREAMS = 2      # forward slices of a big batch run on this many streams (1 = everything on the caller's stream)
+CONCURRENT_SLICE_CHUNKS = 32  # ... from this many chunks on
+_SIDE_STREAMS: dict = {}
+
+
+def _side_streams(dev, n):
+    key = (torch.device(dev).index, n)
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = [torch.cuda.Stream(dev) for _ in range(n)]
+    return _SIDE_STREAMS[key]
 
 
 def load_checkpoint(checkpoint_path, device="cpu") -> dict:
@@ -392,16 +402,34 @@ def batch_predict_aggregate(spect: torch.Tensor, frame_off, chunk_size: int, bor
     cb = torch.empty((B, chunk_size), dtype=torch.float32, device=dev)
     cd = torch.empty((B, chunk_size), dtype=torch.float32, device=dev)
     lib, st = _lib.lib(), _lib.stream_ptr(dev)
+    # Equal slices of at most MAX_CHUNKS_PER_LAUNCH chunks; from CONCURRENT_SLICE_CHUNKS chunks on, at least two of them
+    # on two streams: a launch rarely fills its last round of workgroups (the layer tail of 33 chunks is 387 workgroups
+    # on 256 CUs), and the other slice's kernels take the idle CUs.  Each stream has its own chunk buffer and workspace.
     n_slices = -(-B // MAX_CHUNKS_PER_LAUNCH)
-    step = -(-B // n_slices)                 # equal slices (66 chunks -> 33 + 33, not 64 + 2)
-    chunks = torch.empty((step, chunk_size, 128), dtype=torch.float32, device=dev)
+    if B >= CONCURRENT_SLICE_CHUNKS and CONCURRENT_STREAMS > 1:
+        n_slices = max(n_slices, CONCURRENT_STREAMS)
+    step = -(-B // n_slices)                 # (66 chunks -> 33 + 33, not 64 + 2)
     with torch.cuda.device(dev):
-        for i in range(0, B, step):
+        main = torch.cuda.current_stream(dev)
+        side = _side_streams(dev, min(n_slices, CONCURRENT_STREAMS)) if n_slices > 1 and CONCURRENT_STREAMS > 1 else [main]
+        if side[0] is not main:
+            ready = torch.cuda.Event()
+            ready.record(main)
+        for j, i in enumerate(range(0, B, step)):
             nb = min(step, B - i)
-            _lib.check(lib.bt_split_chunks_batch(st, spect.data_ptr(), d_rows[4 * i:].data_ptr(), nb, chunk_size,
-                                                 chunks.data_ptr()))
-            r = model(chunks[:nb])
-            cb[i: i + nb], cd[i: i + nb] = r["beat"], r["downbeat"]
+            st_ = side[j % len(side)]
+            with torch.cuda.stream(st_):
+                if st_ is not main:
+                    st_.wait_event(ready)
+                chunks = torch.empty((nb, chunk_size, 128), dtype=torch.float32, device=dev)
+                _lib.check(lib.bt_split_chunks_batch(_lib.stream_ptr(dev), spect.data_ptr(), d_rows[4 * i:].data_ptr(), nb,
+                                                     chunk_size, chunks.data_ptr()))
+                r = model(chunks)
+                cb[i: i + nb], cd[i: i + nb] = r["beat"], r["downbeat"]
+        for st_ in side:
+            if st_ is not main:
+                main.wait_stream(st_)
+        st = _lib.stream_ptr(dev)
         max_frames = max(hi - lo for lo, hi, _, _ in pieces)
         _lib.check(lib.bt_aggregate_batch(st, cb.data_ptr(), cd.data_ptr(), d_rows.data_ptr(), d_pieces.data_ptr(),
                                           len(pieces), max_frames, chunk_size, border_size, beat.data_ptr(),

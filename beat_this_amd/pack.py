@@ -268,7 +268,7 @@ class Engine:
         h = C.c_void_p()
         _lib.check(_lib.lib().bt_engine_create(C.byref(packed.desc), C.byref(h)))
         self._h = h
-        self._ws = None
+        self._ws = {}   # one workspace per stream: the C ABI's workspace belongs to ONE stream at a time
 
     def __del__(self):
         try:
@@ -288,12 +288,14 @@ class Engine:
         need = _lib.lib().bt_workspace_bytes(self._h, B, T, prec)
         if need == 0:
             raise ValueError("empty batch")
-        if self._ws is None or self._ws.numel() < need:
-            self._ws = None
-            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        key = _lib.stream_ptr(self.device)
+        ws = self._ws.get(key)
+        if ws is None or ws.numel() < need:
+            self._ws.pop(key, None)
+            ws = self._ws[key] = torch.empty(need, dtype=torch.uint8, device=self.device)
         beat = torch.empty((B, T), dtype=torch.float32, device=self.device)
         down = torch.empty((B, T), dtype=torch.float32, device=self.device)
         with torch.cuda.device(self.device):
             _lib.check(_lib.lib().bt_forward(self._h, _lib.stream_ptr(self.device), prec, x.data_ptr(), B, T,
-                                             self._ws.data_ptr(), self._ws.numel(), beat.data_ptr(), down.data_ptr()))
+                                             ws.data_ptr(), ws.numel(), beat.data_ptr(), down.data_ptr()))
         return beat, down

@@ -111,6 +111,7 @@ def main():
                          "--chunks resident spectrogram chunks (BASELINE configs 2 / 3 / 5)")
     ap.add_argument("--chunks", type=int, default=16, help="--workload forward: chunks per GPU per step")
     ap.add_argument("--slice", type=int, default=0, help="chunks per forward launch (0 = the library default)")
+    ap.add_argument("--streams", type=int, default=0, help="streams the forward slices of a step run on (0 = the library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the forward_only / fp32_path / frontend legs")
     ap.add_argument("--watchdog", type=int, default=900, help="seconds after which a stuck run dumps its stacks and exits")
@@ -147,6 +148,8 @@ def main():
 
     if args.slice > 0:
         _inf.MAX_CHUNKS_PER_LAUNCH = args.slice
+    if args.streams > 0:
+        _inf.CONCURRENT_STREAMS = args.streams
     from beat_this_amd.model import BeatThis
 
     log(f"rank {rank}/{world} on {dev}, library half type {_lib.half_dtype_name()}")
@@ -256,9 +259,14 @@ def main():
         eng = a2b.model.engine()
 
         def profile_forward(run, n_prof, chunks):
+            # (per-launch durations are taken with the forward slices on ONE stream: concurrent slices share the chip and
+            # would stretch each other's event intervals)
+            saved, _inf.CONCURRENT_STREAMS = _inf.CONCURRENT_STREAMS, 1
+            run()
             lib.bt_profile_begin(eng._h)
             for _ in range(n_prof):
                 run()
+            _inf.CONCURRENT_STREAMS = saved
             ncat = len(_lib.PROFILE_CATEGORIES)
             ms = (C.c_double * ncat)()
             cnt = (C.c_int32 * ncat)()
