@@ -11,6 +11,7 @@ cd /tmp
 HEAD="python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-extras --watchdog 150"
 FWD="python $R/bench.py --workload forward --chunks 16 --steps 10 --warmup 2 --no-cpu-baseline --no-extras --watchdog 150"
 timeout 200 rocprofv3 --kernel-trace --stats -d $O/trace_head -o t --output-format csv -- $HEAD > $O/trace_head.log 2>&1; echo "trace_head $?"
+timeout 200 rocprofv3 --kernel-trace --stats -d $O/trace_head1s -o t --output-format csv -- $HEAD --streams 1 > $O/trace_head1s.log 2>&1; echo "trace_head1s $?"
 timeout 200 rocprofv3 --kernel-trace --stats -d $O/trace_fwd -o t --output-format csv -- $FWD > $O/trace_fwd.log 2>&1; echo "trace_fwd $?"
 timeout 200 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVES GRBM_GUI_ACTIVE -d $O/pmc_sq -o p --output-format csv -- $FWD > $O/pmc_sq.log 2>&1; echo "pmc_sq $?"
 timeout 200 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -d $O/pmc_sq2 -o p --output-format csv -- $FWD > $O/pmc_sq2.log 2>&1; echo "pmc_sq2 $?"

@@ -50,6 +50,8 @@ def write(name, lines):
 
 
 for tag, cmd in (("head", "python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-extras"),
+                 ("head1s", "python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-extras --streams 1   (the launch configuration "
+                            "of bench.py's roofline leg: whole 66-chunk launches on one stream)"),
                  ("fwd", "python bench.py --workload forward --chunks 16 --steps 10 --warmup 2 --no-cpu-baseline --no-extras")):
     tr = read_trace("trace_" + tag)
     if not tr:
