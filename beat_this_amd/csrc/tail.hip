@@ -70,6 +70,23 @@ DEVI void agpr_fence(f32x16& acc) { asm volatile("" : "+a"(acc)); }
 // and bunches the LDS-DMA issues (see issue_piece).
 #define TAIL_PIN_DS() __builtin_amdgcn_sched_barrier(0x1 | 0x2 | 0x4 | 0x8 | 0x400)
 
+// Development ablations (-DBT_TAIL_ABL=bits, results are garbage; tools/tail_time.py): 1 no LDS-DMA, 2 no fragment reads,
+// 4 no activation.  M = 24000 (188 workgroups) / 32768 (256): whole kernel 161 / 186 us; without the LDS-DMA 119 / 120;
+// without the fragment reads 157 / 161; without the activation 147 / 160; MFMAs + prologue + epilogue only 108 / 109.
+#ifndef BT_TAIL_ABL
+#define BT_TAIL_ABL 0
+#endif
+DEVI Frag<hf> tail_frag(const char* p, int lane) {
+#if BT_TAIL_ABL & 2
+  Frag<hf> f;
+  f.v[0] = f.v[1] = __builtin_bit_cast(hfx8, u32x4{(unsigned)lane, 1u, 2u, 3u});
+  asm volatile("" : "+v"(f.v[0]), "+v"(f.v[1]));
+  return f;
+#else
+  return lds_frag<hf>(p, lane);
+#endif
+}
+
 template <int C>
 struct TRing {
   static constexpr int KT = C / 32;
@@ -81,6 +98,9 @@ struct TRing {
   char* lds;
   int tid, wave, total;
   DEVI void issue(int s) {
+#if BT_TAIL_ABL & 1
+    return;
+#endif
     if (s >= total) return;
     char* dst = lds + (s % NST) * STEP_B + wave * 1024;
 #pragma unroll
@@ -106,6 +126,9 @@ struct TRing {
     if (i == 0) issue(s);
     return;
 #endif
+#if BT_TAIL_ABL & 1
+    return;
+#endif
     if (s >= total) return;
     char* dst = lds + (s % NST) * STEP_B + wave * 1024;
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)(dst + i * 4096), 16, tid * 16, s * STEP_B + i * 4096, 0, 0);
@@ -123,7 +146,16 @@ struct TRing {
     else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 #if BT_TAIL_ISSUE == 2
+    // hipcc reloads spilled registers (scratch_load -> VGPR) wherever it likes and waits for them with COUNTED vmcnt
+    // values that assume LDS-DMA and VGPR returns retire in one order -- they do not (fused2.hip): a reload placed between
+    // this barrier and the burst and used behind it (the build of round 2 had one, an LDS address) would be "waited for"
+    // with vmcnt(16) while any one of the 16 younger LDS-DMA instructions may retire first.  Nothing of the ring is in
+    // flight here (2-stage ring: vmcnt(0) above), so draining whatever the compiler has put here costs a reload's latency
+    // at most, and nothing can move across: the burst sits between full scheduling barriers.
+    __builtin_amdgcn_sched_barrier(0);
+    if (NST == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     issue(s + NST - 1);
+    __builtin_amdgcn_sched_barrier(0);
 #endif
     return lds + (s % NST) * STEP_B;   // (the caller issues step s + NST - 1 piece by piece while it multiplies step s)
   }
@@ -141,14 +173,14 @@ DEVI void ff_step(RING& ws, int step, int lane, const Frag<hf> (&xf)[KT], f32x16
   static_assert(RING::CH == KT, "one LDS-DMA piece per tile iteration");
   const char* wb = ws.acquire(step);
   Frag<hf> fa, fb, na, nb;
-  if (HAS_A) fa = lds_frag<hf>(wb, lane);
-  if (HAS_B) fb = lds_frag<hf>(wb + KT * TILE_B, lane);
+  if (HAS_A) fa = tail_frag(wb, lane);
+  if (HAS_B) fb = tail_frag(wb + KT * TILE_B, lane);
   unsigned hw[8];
 #pragma unroll
   for (int t = 0; t < KT; ++t) {
     if (t + 1 < KT) {
-      if (HAS_A) na = lds_frag<hf>(wb + (t + 1) * TILE_B, lane);
-      if (HAS_B) nb = lds_frag<hf>(wb + (KT + t + 1) * TILE_B, lane);
+      if (HAS_A) na = tail_frag(wb + (t + 1) * TILE_B, lane);
+      if (HAS_B) nb = tail_frag(wb + (KT + t + 1) * TILE_B, lane);
     }
 #if BT_TAIL_ISSUE == 0 || BT_TAIL_ISSUE == 3
     ws.issue_piece(step + RING::NST - 1, t);
@@ -176,7 +208,7 @@ DEVI void ff_step(RING& ws, int step, int lane, const Frag<hf> (&xf)[KT], f32x16
     }
     if (HAS_B) asm volatile(TAIL_MFMA " %0, %1, %2, %0" : "+a"(acc2[t]) : "v"(fb.v[0]), "v"(hprev.v[0]));
 #endif
-    if (HAS_G && (t * 8) % KT == 0) {
+    if (HAS_G && !(BT_TAIL_ABL & 4) && (t * 8) % KT == 0) {
 #pragma unroll
       for (int q = 0; q < (KT >= 8 ? 1 : 8 / KT); ++q) {  // elements r, r + 1 -> one packed dword of the next B operand
         const int r = 2 * (t * 8 / KT + q);
@@ -195,6 +227,9 @@ DEVI void ff_step(RING& ws, int step, int lane, const Frag<hf> (&xf)[KT], f32x16
 #endif
     if (t + 1 < KT) { fa = na; fb = nb; }
   }
+#if BT_TAIL_ABL & 4
+  for (int i = 0; i < 8; ++i) hw[i] = 0x3c003c00u;
+#endif
   if (HAS_G) {
     hcur.v[0] = __builtin_bit_cast(hfx8, u32x4{hw[0], hw[1], hw[2], hw[3]});
     hcur.v[1] = __builtin_bit_cast(hfx8, u32x4{hw[4], hw[5], hw[6], hw[7]});
@@ -256,12 +291,12 @@ __global__ __launch_bounds__(256, 1) void layer_tail_kernel(const LayerTailP p) 
 #pragma unroll
   for (int st = 0; st < KT / 2; ++st) {
     const char* wb = ws.acquire(st);
-    Frag<hf> f0 = lds_frag<hf>(wb, lane), f1 = lds_frag<hf>(wb + KT * TILE_B, lane), n0, n1;
+    Frag<hf> f0 = tail_frag(wb, lane), f1 = tail_frag(wb + KT * TILE_B, lane), n0, n1;
 #pragma unroll
     for (int kt = 0; kt < KT; ++kt) {
       if (kt + 1 < KT) {
-        n0 = lds_frag<hf>(wb + (kt + 1) * TILE_B, lane);
-        n1 = lds_frag<hf>(wb + (KT + kt + 1) * TILE_B, lane);
+        n0 = tail_frag(wb + (kt + 1) * TILE_B, lane);
+        n1 = tail_frag(wb + (KT + kt + 1) * TILE_B, lane);
       }
 #if BT_TAIL_ISSUE == 0 || BT_TAIL_ISSUE == 4
       ws.issue_piece(st + NST - 1, kt);

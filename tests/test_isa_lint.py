@@ -1,0 +1,34 @@
+"""The generated code of every kernel source is free of the reload-behind-LDS-DMA pattern (tools/isa_lint.py): a
+VGPR-returning load whose first use is guarded only by counted vmcnt waits although LDS-DMA instructions were issued in
+between.  CPU only (hipcc -S cross-compiles gfx950)."""
+import os
+import shutil
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+
+@pytest.mark.skipif(not (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")), reason="needs hipcc")
+def test_no_counted_wait_guards_a_load_across_lds_dma(capsys):
+    import isa_lint
+    assert isa_lint.main([]) == 0, capsys.readouterr().out
+
+
+def test_lint_sees_the_pattern(tmp_path):
+    """The detector itself: a hand-written listing with the hazard (the round-2 build of tail.hip had exactly this)."""
+    import isa_lint
+    listing = "\n".join(["_Zk:", "\ts_waitcnt vmcnt(0) lgkmcnt(0)", "\ts_barrier", "\tscratch_load_dword v48, off, off offset:16",
+                         *["\tbuffer_load_dwordx4 v1, s[12:15], s4 offen lds"] * 16, "\ts_waitcnt vmcnt(16)", "\tv_add_u32_e32 v47, s1, v48",
+                         "\ts_endpgm"])
+    safe = listing.replace("s_waitcnt vmcnt(16)", "s_waitcnt vmcnt(0)")
+    orig = isa_lint.asm_of
+    try:
+        isa_lint.asm_of = lambda src: listing
+        assert len(isa_lint.lint("x.hip")) == 1
+        isa_lint.asm_of = lambda src: safe
+        assert isa_lint.lint("x.hip") == []
+    finally:
+        isa_lint.asm_of = orig

@@ -1,0 +1,89 @@
+#!/usr/bin/env python
+"""ISA lint for the LDS-DMA rings (CPU only: hipcc -S).
+
+hipcc waits for a VGPR-returning VMEM load (global / buffer / scratch reload) with a COUNTED `s_waitcnt vmcnt(N)`, N = the
+VMEM instructions it issued after the load, which is right only if everything retires in issue order.  LDS-DMA
+(`buffer_load ... lds`) and VGPR-returning loads do not retire in one order, so a load whose first use
+is guarded only by counted waits, with LDS-DMA instructions issued in between, can be read before it has landed.  The
+kernels avoid the pattern by construction (explicit vmcnt(0) before a ring starts and before every burst); this script
+proves it on the generated code: for every VGPR-returning load it follows the straight-line code to the first read of
+its destination and reports the load if LDS-DMA was issued on the way and no wait on the way was vmcnt(0).
+
+    python tools/isa_lint.py [source.hip ...]        exit status 1 if anything is reported
+"""
+import concurrent.futures
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from beat_this_amd import _lib  # noqa: E402
+
+LOAD = re.compile(r"^\s*(scratch_load|global_load|buffer_load|flat_load)\w*\s+(v\[(\d+):(\d+)\]|v(\d+))")
+WAIT = re.compile(r"vmcnt\((\d+)\)")
+
+
+def asm_of(src):
+    out = tempfile.NamedTemporaryFile(suffix=".s", delete=False).name
+    flags = _lib.FLAGS_BY_SOURCE.get(os.path.basename(src), _lib.HIPCC_FLAGS)
+    cmd = [os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), "--offload-arch=gfx950", "-O3", "-std=c++17", *flags, "-S", "--cuda-device-only",
+           f"-I{os.path.join(ROOT, 'include')}", f"-I{os.path.dirname(src)}", src, "-o", out]
+    subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    text = open(out).read()
+    os.unlink(out)
+    return text
+
+
+def lint(src):
+    findings = []
+    kernel = "?"
+    lines = asm_of(src).split("\n")
+    for i, line in enumerate(lines):
+        m = re.match(r"^(_Z\w+):", line)
+        if m:
+            kernel = m.group(1)
+        m = LOAD.match(line)
+        if not m or " lds" in line:
+            continue
+        lo, hi = (int(m.group(3)), int(m.group(4))) if m.group(3) else (int(m.group(5)), int(m.group(5)))
+        regs = re.compile(r"\bv(?:%s)\b|\bv\[(\d+):(\d+)\]" % "|".join(str(r) for r in range(lo, hi + 1)))
+        dma, drained = 0, False
+        for j in range(i + 1, min(i + 4000, len(lines))):
+            x = lines[j]
+            if "s_endpgm" in x:
+                break
+            w = WAIT.search(x)
+            if w and int(w.group(1)) == 0:
+                drained = True
+                break
+            if "buffer_load" in x and " lds" in x:
+                dma += 1
+                continue
+            used = False
+            for u in regs.finditer(x.split(";")[0]):
+                if u.group(1) is None or (int(u.group(1)) <= hi and int(u.group(2)) >= lo):
+                    used = True
+            if used and not LOAD.match(x):
+                break
+        if dma and not drained:
+            findings.append(f"{os.path.basename(src)}: {kernel}: line {i + 1}: `{line.strip().split(';')[0].strip()}` is first used "
+                            f"behind {dma} LDS-DMA instruction(s) without a vmcnt(0) in between")
+    return findings
+
+
+def main(argv):
+    srcs = argv or [os.path.join(_lib.PKG_DIR, "csrc", s) for s in _lib.SOURCES]
+    with concurrent.futures.ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
+        res = list(ex.map(lint, srcs))
+    bad = [f for r in res for f in r]
+    for f in bad:
+        print(f)
+    print(f"isa_lint: {len(srcs)} sources, {len(bad)} finding(s)")
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main(sys.argv[1:]))
