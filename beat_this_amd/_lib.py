@@ -248,5 +248,15 @@ def stream_ptr(device) -> int:
     return torch.cuda.current_stream(device).cuda_stream
 
 
+def upload(a, device) -> torch.Tensor:
+    """A small host table (numpy) -> device WITHOUT blocking the host: an ordinary ``.to(device)`` of pageable memory
+    synchronises the stream, i.e. waits for everything enqueued before it (a whole forward, when the table is the peak
+    picker's).  The copy goes through a pinned staging block on the current stream; torch's caching host allocator keeps
+    the block until the copy has run."""
+    import numpy as np
+
+    return torch.from_numpy(np.ascontiguousarray(a)).pin_memory().to(device, non_blocking=True)
+
+
 def ptr(t) -> int:
     return 0 if t is None else t.data_ptr()

@@ -43,6 +43,13 @@ def _side_streams(dev, n):
     return _SIDE_STREAMS[key]
 
 
+def _copy_stream(dev):
+    key = (torch.device(dev).index, "copy")
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = torch.cuda.Stream(dev)
+    return _SIDE_STREAMS[key]
+
+
 def load_checkpoint(checkpoint_path, device="cpu") -> dict:
     """Local file, short name or URL -> checkpoint dict (inference.py:16-53)."""
     try:
@@ -235,7 +242,7 @@ class Audio2Frames(Spect2Frames):
         return self.spect(signal)
 
     def signal2spect_many(self, signals, sr):
-        """Extension: a list of waveforms (numpy (N,) / (N, C) or torch tensors, all at sample rate ``sr``) ->
+        """Extension: a list of waveforms (numpy (N,) / (N, C) or torch tensors on the host or the device, all at sample rate ``sr``) ->
         (spect, frame_off): ONE (sum of frames, 128) spectrogram tensor with the tracks back to back and the int64 numpy
         array of their first rows (length n + 1).  Mono mix as in ``signal2spect``; resampling and the log-mel run as one
         launch each for all tracks (bt_resample_batch / bt_logmel_batch)."""
@@ -243,21 +250,31 @@ class Audio2Frames(Spect2Frames):
         from math import gcd
 
         dev = self.device
-        waves = []
         for sig in signals:
-            if isinstance(sig, torch.Tensor):
-                w = sig.to(dev, torch.float32)
-                if w.dim() == 2:
-                    w = w.mean(1)
-                elif w.dim() != 1:
-                    raise ValueError(f"Expected 1D or 2D signal, got shape {tuple(sig.shape)}")
-            else:
-                if sig.ndim == 2:
-                    sig = sig.mean(1)
-                elif sig.ndim != 1:
-                    raise ValueError(f"Expected 1D or 2D signal, got shape {sig.shape}")
-                w = torch.tensor(sig, dtype=torch.float32, device=dev)
-            waves.append(w.contiguous())
+            if sig.ndim not in (1, 2):
+                raise ValueError(f"Expected 1D or 2D signal, got shape {tuple(sig.shape)}")
+        # Host buffers: PINNED tensors go up on a copy stream of their own (the caller's stream waits for one event), so the
+        # upload of batch i + 1 overlaps the kernels of batch i when batches are submitted ahead (many_async); anything else
+        # is copied the ordinary, synchronous way.
+        cur = torch.cuda.current_stream(dev)
+        pinned = [isinstance(sig, torch.Tensor) and sig.device.type == "cpu" and sig.is_pinned() for sig in signals]
+        waves = [None] * len(signals)
+        if any(pinned):
+            copy = _copy_stream(dev)
+            with torch.cuda.stream(copy):
+                for k, sig in enumerate(signals):
+                    if pinned[k]:
+                        waves[k] = sig.to(dev, non_blocking=True)
+                        waves[k].record_stream(cur)
+            ev = torch.cuda.Event()
+            ev.record(copy)
+            cur.wait_event(ev)
+        for k, sig in enumerate(signals):
+            w = waves[k]
+            if w is None:
+                w = sig.to(dev) if isinstance(sig, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(sig)).to(dev)
+            w = w.to(torch.float32)
+            waves[k] = (w.mean(1) if w.dim() == 2 else w).contiguous()
         n = len(waves)
         if n == 0:
             return torch.empty((0, 128), dtype=torch.float32, device=dev), np.zeros(1, dtype=np.int64)
@@ -282,7 +299,7 @@ class Audio2Frames(Spect2Frames):
             else:
                 table[1, :, 0] = [w.data_ptr() for w in waves]
             table[1, :, 1], table[1, :, 2], table[1, :, 3] = n22, frame_off[:-1], n_fr
-            d_table = torch.from_numpy(table).to(dev)
+            d_table = _lib.upload(table, dev)
             if up != down:
                 h, half = _resample_filter(up, down, dev)
                 _lib.check(lib.bt_resample_batch(st, d_table[0].data_ptr(), n, int(n22.max()), up, down, h.data_ptr(), half,
@@ -396,8 +413,7 @@ def batch_predict_aggregate(spect: torch.Tensor, frame_off, chunk_size: int, bor
     if total + chunk_size >= 2 ** 31:
         raise ValueError("batch too long for 32-bit frame indices: split the track list")
     B = len(rows)
-    tab = torch.from_numpy(np.concatenate([np.asarray(rows, dtype=np.int32).reshape(-1),
-                                           np.asarray(pieces, dtype=np.int32).reshape(-1)])).to(dev)
+    tab = _lib.upload(np.concatenate([np.asarray(rows, dtype=np.int32).reshape(-1), np.asarray(pieces, dtype=np.int32).reshape(-1)]), dev)
     d_rows, d_pieces = tab[: 4 * B], tab[4 * B:]
     cb = torch.empty((B, chunk_size), dtype=torch.float32, device=dev)
     cd = torch.empty((B, chunk_size), dtype=torch.float32, device=dev)

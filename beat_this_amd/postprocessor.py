@@ -140,7 +140,7 @@ class Postprocessor:
         size = 2 * total + 2 * n
         buf = torch.empty((size,), dtype=torch.int32, device=dev)   # [indices | counts]
         with torch.cuda.device(dev):
-            d_spans = torch.from_numpy(spans).to(dev)
+            d_spans = _lib.upload(spans, dev)
             _lib.check(_lib.lib().bt_peaks_batch(_lib.stream_ptr(dev), logits.data_ptr(), d_spans.data_ptr(), 2 * n,
                                                  buf.data_ptr(), buf[2 * total:].data_ptr()))
             host = self._pinned(size)

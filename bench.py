@@ -22,6 +22,7 @@ Extra objects on the JSON line:
                 ALGORITHMIC bytes (3.41 MB per chunk for the log-mel).
   forward_only  BASELINE config 2 (16 chunks through BeatThis.forward, spectrograms resident), for continuity with round 1.
   fp32_path     the same headline workload on the exact-fp32 MFMA path (the one under the 1e-3 gate), fewer steps.
+  host_inclusive  the headline job with the waveforms starting in pinned HOST memory (PCIe-inclusive rate; never `value`).
   cpu_baseline  the CPU oracle's Audio2Beats (torch fp32, SDPA attention like the reference) on ONE 300 s track on this
                 host, thread count probed and stated (rank 0, N = 1 only).
 """
@@ -306,7 +307,7 @@ def main():
                     "whole_forward_tflops": round(FLOP_PER_CHUNK * chunks_per_step /
                                                   (sum(v["ms_per_step"] for v in breakdown.values()) * 1e-3) / 1e12, 2)}
 
-        frontend = forward_only = fp32_path = None
+        frontend = forward_only = fp32_path = host_inclusive = None
         if args.workload == "tracks" and not args.no_extras:
             # ---- HBM-bound stages: events around each stage on torch's current stream (the launch stream) -------------
             def timed(fn, reps=5):
@@ -354,6 +355,33 @@ def main():
             forward_only = {"workload": "BASELINE config 2: 16 chunks x 1500 frames, BeatThis.forward, spectrograms resident",
                             "ms_per_step": round(tf * 1e3, 3), "audio_seconds_per_s": round(16 * FRESH_SECONDS_PER_CHUNK / tf, 1),
                             "whole_forward_tflops": round(FLOP_PER_CHUNK * 16 / tf / 1e12, 1)}
+
+            # ---- the same job from HOST buffers (PCIe-inclusive; never `value`): waveforms in pinned host memory, uploaded
+            # on a copy stream by Audio2Beats.many_async while the previous step computes -----------------------------------
+            log("host-inclusive leg")
+            htracks = [t.cpu().pin_memory() for t in tracks]
+            hpend = []
+
+            def hstep():
+                hpend.append(a2b.many_async(htracks, TRACK_SR))
+                if len(hpend) > 1:
+                    hpend.pop(0).result()
+            for _ in range(3):
+                hstep()
+            while hpend:
+                hpend.pop(0).result()
+            torch.cuda.synchronize(dev)
+            th = time.perf_counter()
+            for _ in range(10):
+                hstep()
+            while hpend:
+                hpend.pop(0).result()
+            torch.cuda.synchronize(dev)
+            th = (time.perf_counter() - th) / 10
+            host_inclusive = {"ms_per_step": round(th * 1e3, 3), "audio_seconds_per_s": round(n_tr * TRACK_SECONDS / th, 1),
+                              "upload_MB_per_step": round(4 * n_samp / 1e6, 1),
+                              "note": "waveforms start in pinned host memory; H2D on a copy stream overlaps the previous step"}
+            del htracks
 
         # ---- CPU baseline + in-run parity: the oracle's Audio2Beats on track 0, bounded sample ------------------------
         cpu = parity = None
@@ -433,7 +461,7 @@ def main():
                        "parallelism": f"track-sharded x{world}, framewise logits all-gathered" if args.workload == "tracks"
                        else f"chunk-sharded x{world}, logits all-gathered"},
             "parity": parity, "roofline": roofline, "cpu_baseline": cpu, "frontend": frontend, "forward_only": forward_only,
-            "fp32_path": fp32_path, "breakdown": breakdown,
+            "fp32_path": fp32_path, "host_inclusive": host_inclusive, "breakdown": breakdown,
         }
         if last is not None and args.workload == "tracks":
             out["config"]["beats_in_last_track"] = int(len(last[-1][0]))

@@ -379,6 +379,14 @@ def test_audio2beats_many_matches_single_track_calls_and_oracle():
     report("a2b_many_44k1", err_vs_oracle=e44)
     assert e44 < LOGIT_TOL_F32
     assert a2b.many([], 22050) == []
+    # host buffers: pinned tensors (uploaded on the copy stream, two batches in flight), plain CPU tensors and numpy in
+    # one batch give what the device-resident waveforms give
+    host = [torch.from_numpy(sigs[2]).pin_memory(), torch.from_numpy(sigs[3]), sigs[0], torch.from_numpy(sigs[1]).pin_memory()]
+    order = (2, 3, 0, 1)
+    first, second = a2b.many_async(host, 22050), a2b.many_async(host, 22050)
+    for res in (first.result(), second.result()):
+        for k, i in enumerate(order):
+            assert np.array_equal(res[k][0], many[i][0]) and np.array_equal(res[k][1], many[i][1]), (k, i)
 
 
 def test_empty_and_oversize_inputs():
