@@ -49,7 +49,8 @@ class ModelDesc(C.Structure):
                 ("conv_w", (C.c_void_p * 2) * 3), ("conv_b", C.c_void_p * 3),
                 ("lin_w", C.c_void_p * 2), ("lin_b", C.c_void_p),
                 ("layers", PairWeights * MAX_LAYERS),
-                ("head_w", C.c_void_p), ("head_b", C.c_float * 2), ("rope", C.c_void_p), ("ff_mult", C.c_int32)]
+                ("head_w", C.c_void_p), ("head_b", C.c_float * 2), ("rope", C.c_void_p), ("ff_mult", C.c_int32),
+                ("norm_out_g", C.c_void_p), ("head_w_raw", C.c_void_p)]
 
 
 class LogmelTables(C.Structure):
@@ -103,6 +104,8 @@ EXPORTS = {
     "bt_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "bt_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t,
                              C.c_void_p, C.c_void_p]),
+    "bt_forward_stages": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
+                                    C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
     "bt_split_chunks": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "bt_aggregate": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int64,
                                C.c_void_p, C.c_void_p]),

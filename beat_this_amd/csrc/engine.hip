@@ -298,7 +298,14 @@ size_t bt_workspace_bytes(const bt_engine* e, int B, int T, int prec) {
 
 int bt_forward(bt_engine* e, void* stream, int prec, const float* d_spect, int B, int T, void* d_ws, size_t ws_bytes,
                float* d_beat, float* d_downbeat) {
-  if (!e || !d_spect || !d_ws || !d_beat || !d_downbeat) return bt_set_error(BT_ERR_ARG, "null argument");
+  return bt_forward_stages(e, stream, prec, 0, 2, d_spect, B, T, d_ws, ws_bytes, nullptr, d_beat, d_downbeat);
+}
+
+int bt_forward_stages(bt_engine* e, void* stream, int prec, int first, int last, const float* d_spect, int B, int T, void* d_ws,
+                      size_t ws_bytes, float* d_out, float* d_beat, float* d_downbeat) {
+  if (!e || !d_spect || !d_ws) return bt_set_error(BT_ERR_ARG, "null argument");
+  if (first < 0 || last > 2 || first > last) return bt_set_error(BT_ERR_ARG, "stages: need 0 <= first <= last <= 2");
+  if (last == 2 ? (!d_beat || !d_downbeat) : !d_out) return bt_set_error(BT_ERR_ARG, "null output");
   if (B <= 0 || T <= 0 || T > 1536) return bt_set_error(BT_ERR_ARG, "need B >= 1 and 1 <= T <= 1536");
   if (prec != BT_PREC_F32 && prec != BT_PREC_HALF && prec != BT_PREC_FP8) return bt_set_error(BT_ERR_ARG, "unknown precision");
   const bt_model_desc& d = e->d;
@@ -332,6 +339,21 @@ int bt_forward(bt_engine* e, void* stream, int prec, const float* d_spect, int B
     lin3 = gemm3_supported(g);
   }
 
+  const size_t xm_bytes = (size_t)B * T * D * 4;
+  if (first == 2) {  // task_heads on a normalised [B,T,D] input
+    if (!d.head_w_raw) return bt_set_error(BT_ERR_ARG, "stage entry at task_heads needs head_w_raw");
+    HeadP hp;
+    hp.x = d_spect; hp.w = d.head_w_raw; hp.b0 = d.head_b[0]; hp.b1 = d.head_b[1];
+    hp.beat = d_beat; hp.downbeat = d_downbeat; hp.M = B * T; hp.D = D; hp.sum_head = d.sum_head; hp.prenorm = 1;
+    LAUNCH_CAT(CAT_HEAD, s, launch_head(hp, s), "head");
+    return BT_OK;
+  }
+  if (first == 1) {  // transformer_blocks on a [B,T,D] input: the residual stream and what its producer would have left
+    if (hipMemcpyAsync(ws.xm, d_spect, xm_bytes, hipMemcpyDeviceToDevice, s) != hipSuccess)
+      return bt_set_error(BT_ERR_HIP, "copy of the stage input");
+    if (use_shadow) LAUNCH_CAT(CAT_LINEAR, s, launch_shadow_ssq(ws.xm, ws.xmb, fast_layers ? ws.ssq[0] : nullptr, (long)B * T, D, s), "stage entry");
+  }
+  if (first == 0) {
   StemP sp;
   sp.spect = d_spect; sp.x = ws.xa; sp.bn1_scale = d.bn1_scale; sp.bn1_shift = d.bn1_shift;
   sp.w = d.stem_w; sp.bias = d.stem_b; sp.B = B; sp.T = T;
@@ -390,15 +412,26 @@ int bt_forward(bt_engine* e, void* stream, int prec, const float* d_spect, int B
     g.ssq_out = fast_layers ? ws.ssq[0] : nullptr;
     LAUNCH_CAT(CAT_LINEAR, s, launch_gemm(g, prec, s), "frontend linear gemm");
   }
+  }  // first == 0
+  if (last == 0) {
+    if (hipMemcpyAsync(d_out, ws.xm, xm_bytes, hipMemcpyDeviceToDevice, s) != hipSuccess)
+      return bt_set_error(BT_ERR_HIP, "copy of the stage output");
+    return BT_OK;
+  }
   for (int l = 0; l < d.n_layers; ++l) {
     int rc = fast_layers ? run_layer_half(pf, d.layers[l], d.rope, ws, B, T, d.ff_mult, fp8, s)
                          : run_pair(pf, d.layers[l], d.rope, ws.xm, use_shadow ? ws.xmb : nullptr, ws, B, T, 1, 0, prec, s, nullptr,
                                     d.ff_mult);
     if (rc) return rc;
   }
+  if (last == 1) {
+    if (!d.norm_out_g) return bt_set_error(BT_ERR_ARG, "stage exit after transformer_blocks needs norm_out_g");
+    LAUNCH_CAT(CAT_HEAD, s, launch_norm_out(ws.xm, d.norm_out_g, d_out, (long)B * T, D, s), "final norm");
+    return BT_OK;
+  }
   HeadP hp;
   hp.x = ws.xm; hp.w = d.head_w; hp.b0 = d.head_b[0]; hp.b1 = d.head_b[1];
-  hp.beat = d_beat; hp.downbeat = d_downbeat; hp.M = B * T; hp.D = D; hp.sum_head = d.sum_head;
+  hp.beat = d_beat; hp.downbeat = d_downbeat; hp.M = B * T; hp.D = D; hp.sum_head = d.sum_head; hp.prenorm = 0;
   LAUNCH_CAT(CAT_HEAD, s, launch_head(hp, s), "head");
   return BT_OK;
 }

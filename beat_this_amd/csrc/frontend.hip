@@ -85,10 +85,41 @@ __global__ __launch_bounds__(256) void head_kernel(const HeadP p) {
     d1 += __shfl_xor(d1, o);
   }
   if (lane == 0) {
-    const float sc = sqrtf((float)p.D) / fmaxf(sqrtf(ss), 1e-12f);
+    const float sc = p.prenorm ? 1.f : sqrtf((float)p.D) / fmaxf(sqrtf(ss), 1e-12f);
     const float y0 = d0 * sc + p.b0, y1 = d1 * sc + p.b1;
     p.beat[row] = p.sum_head ? y0 + y1 : y0;
     p.downbeat[row] = y1;
+  }
+}
+
+// one wave per token row: y = x * sqrt(D) / max(|x|, 1e-12) * gamma (F.normalize semantics, roformer.py:20-30)
+__global__ __launch_bounds__(256) void norm_out_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                       float* __restrict__ y, long M, int D) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const float* xr = x + row * D;
+  float ss = 0.f;
+  for (int k = lane; k < D; k += 64) ss = fmaf(xr[k], xr[k], ss);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+  const float sc = sqrtf((float)D) / fmaxf(sqrtf(ss), 1e-12f);
+  for (int k = lane; k < D; k += 64) y[row * D + k] = xr[k] * sc * gamma[k];
+}
+
+// one wave per token row, lane = column of a 64-column group: the half shadow of x and the group's sum of squares
+__global__ __launch_bounds__(256) void shadow_ssq_kernel(const float* __restrict__ x, hf* __restrict__ xb,
+                                                         float* __restrict__ ssq, long M, int D) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  for (int g = 0; g < D / 64; ++g) {
+    const float v = x[row * D + g * 64 + lane];
+    xb[row * D + g * 64 + lane] = (hf)v;
+    float sq = v * v;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+    if (ssq && lane == 0) ssq[(long)g * M + row] = sq;
   }
 }
 
@@ -341,6 +372,15 @@ int launch_stem(const StemP& p, hipStream_t s) {
 }
 int launch_head(const HeadP& p, hipStream_t s) {
   hipLaunchKernelGGL(head_kernel, dim3((unsigned)((p.M + 3) / 4)), dim3(256), 0, s, p);
+  return (int)hipGetLastError();
+}
+int launch_norm_out(const float* x, const float* gamma, float* y, long M, int D, hipStream_t s) {
+  hipLaunchKernelGGL(norm_out_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, x, gamma, y, M, D);
+  return (int)hipGetLastError();
+}
+int launch_shadow_ssq(const float* x, void* xb, float* ssq, long M, int D, hipStream_t s) {
+  if (D % 64 != 0) return -2;
+  hipLaunchKernelGGL(shadow_ssq_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, x, reinterpret_cast<hf*>(xb), ssq, M, D);
   return (int)hipGetLastError();
 }
 int launch_split(const float* spect, long n_frames, const int* starts, const int* table, int B, int T, float* chunks,

@@ -170,12 +170,17 @@ int launch_stem(const StemP& p, hipStream_t s);
 
 struct HeadP {
   const float* x;      // [M, D]
-  const float* w;      // [2, D] with final-norm gamma folded
+  const float* w;      // [2, D] with final-norm gamma folded (prenorm: the plain task_heads weight)
   float b0, b1;
   float* beat; float* downbeat;  // [M]
   int M, D, sum_head;
+  int prenorm;         // x is already normalised (BeatThis.task_heads called on its own)
 };
 int launch_head(const HeadP& p, hipStream_t s);
+// transformer_blocks' final RMSNorm as a pass of its own: y = x * sqrt(D) / |x| * gamma   (roformer.py:181, stage exit)
+int launch_norm_out(const float* x, const float* gamma, float* y, long M, int D, hipStream_t s);
+// half shadow and per-64-column sums of squares [D/64][M] of a residual stream handed in from outside (stage entry)
+int launch_shadow_ssq(const float* x, void* xb, float* ssq, long M, int D, hipStream_t s);
 
 // One track of a batched front-end launch: input samples, their count, and where the track's output starts in the
 // concatenated output buffer (samples for the resampler, frames for the log-mel kernel) / how many outputs it has.

@@ -9,6 +9,8 @@ the exact-fp32 MFMA path.  There is no CPU implementation here.
 """
 from __future__ import annotations
 
+import weakref
+
 import torch
 from torch import nn
 
@@ -21,6 +23,28 @@ _BUFFER_LEAVES = ("running_mean", "running_var", "num_batches_tracked")
 
 class _Node(nn.Module):
     """Plain container; exists only so parameters carry the reference's dotted names."""
+
+
+class _Stage(_Node):
+    """``BeatThis.frontend`` / ``.transformer_blocks`` / ``.task_heads`` (beat_tracker.py:54-106): parameter containers
+    with the reference's names that can also be CALLED like the reference's sub-modules -- the stage runs in the owning
+    model's engine (bt_forward_stages), so forward hooks and partial forwards written against the reference keep working:
+    frontend (B,T,128) -> (B,T,D); transformer_blocks (B,T,D) -> (B,T,D) incl. its final RMSNorm; task_heads (B,T,D) ->
+    {"beat", "downbeat"}."""
+
+    def __init__(self, root: "BeatThis", stage: int):
+        super().__init__()
+        object.__setattr__(self, "_root", weakref.ref(root))   # (not a registered sub-module: no cycle)
+        self._stage = stage
+
+    def __getstate__(self):  # (copy.deepcopy / pickle: the owner re-binds itself, BeatThis.__setstate__)
+        state = self.__dict__.copy()
+        state.pop("_root", None)
+        return state
+
+    def forward(self, x: torch.Tensor):
+        out = self._root()._run(x, self._stage, self._stage)
+        return {"beat": out[0], "downbeat": out[1]} if self._stage == 2 else out
 
 
 def _attach(root: nn.Module, key: str, value: torch.Tensor) -> None:
@@ -46,6 +70,8 @@ class BeatThis(nn.Module):
             head_dim=head_dim, stem_dim=stem_dim, sum_head=sum_head, partial_transformers=partial_transformers))
         # reference init statistics (beat_tracker.py:170-186); inference-only, so plain tensors
         init = random_state_dict(self.hparams, seed=0, style="init0")
+        for i, name in enumerate(("frontend", "transformer_blocks", "task_heads")):
+            self.add_module(name, _Stage(self, i))
         for key in state_dict_shapes(self.hparams):
             _attach(self, key, init[key])
         self._engine = None
@@ -53,6 +79,16 @@ class BeatThis(nn.Module):
         # activations (BT_PREC_FP8); everything else stays on the bf16 path.  Off by default.
         self.fp8_weights = False
         self.eval()
+
+    def __getstate__(self):
+        state = self.__dict__.copy()
+        state["_engine"] = None   # (a handle of the HIP library: rebuilt on first use)
+        return state
+
+    def __setstate__(self, state):
+        super().__setstate__(state)
+        for name in ("frontend", "transformer_blocks", "task_heads"):
+            object.__setattr__(self._modules[name], "_root", weakref.ref(self))
 
     # -- state dict plumbing (beat_tracker.py:194-203: strip torch.compile's "_orig_mod.") ----
     def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False):
@@ -91,7 +127,22 @@ class BeatThis(nn.Module):
         if x.shape[0] == 0 or x.shape[1] == 0:
             empty = torch.empty((x.shape[0], x.shape[1]), dtype=torch.float32, device=x.device)
             return {"beat": empty, "downbeat": empty.clone()}
+        stages = (self.frontend, self.transformer_blocks, self.task_heads)
+        if any(st._forward_hooks or st._forward_pre_hooks for st in stages):
+            # somebody hooked a sub-module: run the stages through the modules so the hooks fire (beat_tracker.py:188-192)
+            return self.task_heads(self.transformer_blocks(self.frontend(x)))
+        beat, down = self._run(x, 0, 2)
+        return {"beat": beat, "downbeat": down}
+
+    def _run(self, x: torch.Tensor, first: int, last: int):
+        """Stages first..last in the engine; precision follows autocast like the whole forward."""
+        if x.dim() != 3 or x.shape[1] > 1536:
+            raise ValueError(f"expected a (batch, time <= 1536, features) input, got {tuple(x.shape)}")
+        _lib.require_gpu(x, "stage input")
+        if x.shape[0] == 0 or x.shape[1] == 0:
+            D = self.hparams["transformer_dim"]
+            empty = torch.empty((x.shape[0], x.shape[1]), dtype=torch.float32, device=x.device)
+            return (empty, empty.clone()) if last == 2 else torch.empty((x.shape[0], x.shape[1], D), dtype=torch.float32, device=x.device)
         half = torch.is_autocast_enabled("cuda") if hasattr(torch, "is_autocast_enabled") else False
         prec = _lib.PREC_F32 if not half else (_lib.PREC_FP8 if self.fp8_weights else _lib.PREC_HALF)
-        beat, down = self.engine().forward(x, prec)
-        return {"beat": beat, "downbeat": down}
+        return self.engine().forward_stages(x, prec, first, last)

@@ -147,6 +147,7 @@ class PackedModel:
             self._pair(d.layers[l], sd, p + "0.", p + "1.", D, fp8=True)
         g = sd["transformer_blocks.norm.gamma"]
         d.head_w = self._f32(sd["task_heads.beat_downbeat_lin.weight"] * g[None, :])
+        d.norm_out_g, d.head_w_raw = self._f32(g), self._f32(sd["task_heads.beat_downbeat_lin.weight"])  # (stage calls)
         hb = sd["task_heads.beat_downbeat_lin.bias"]
         d.head_b[0], d.head_b[1] = float(hb[0]), float(hb[1])
         freqs = next(v for k, v in sd.items() if k.endswith("rotary_embed.freqs"))
@@ -280,10 +281,16 @@ class Engine:
 
     def forward(self, spect: torch.Tensor, prec: int):
         """spect: (B, T, 128) fp32 on the engine's device -> (beat, downbeat) fp32 (B, T)."""
-        _lib.require_gpu(spect, "input spectrogram")
+        return self.forward_stages(spect, prec, 0, 2)
+
+    def forward_stages(self, spect: torch.Tensor, prec: int, first: int, last: int):
+        """Stages first..last of BeatThis.forward (0 frontend, 1 transformer_blocks, 2 task_heads; bt_forward_stages):
+        (B, T, 128) or (B, T, D) fp32 in -> (B, T, D) fp32, or (beat, downbeat) when the head is included."""
+        _lib.require_gpu(spect, "stage input")
         B, T, M = spect.shape
-        if M != 128:
-            raise ValueError(f"expected 128 mel bins, got {M}")
+        D = self.packed.desc.transformer_dim
+        if M != (128 if first == 0 else D):
+            raise ValueError(f"expected {128 if first == 0 else D} input features, got {M}")
         x = spect.to(torch.float32).contiguous()
         need = _lib.lib().bt_workspace_bytes(self._h, B, T, prec)
         if need == 0:
@@ -293,9 +300,13 @@ class Engine:
         if ws is None or ws.numel() < need:
             self._ws.pop(key, None)
             ws = self._ws[key] = torch.empty(need, dtype=torch.uint8, device=self.device)
-        beat = torch.empty((B, T), dtype=torch.float32, device=self.device)
-        down = torch.empty((B, T), dtype=torch.float32, device=self.device)
+        beat = down = out = None
+        if last == 2:
+            beat = torch.empty((B, T), dtype=torch.float32, device=self.device)
+            down = torch.empty((B, T), dtype=torch.float32, device=self.device)
+        else:
+            out = torch.empty((B, T, D), dtype=torch.float32, device=self.device)
         with torch.cuda.device(self.device):
-            _lib.check(_lib.lib().bt_forward(self._h, _lib.stream_ptr(self.device), prec, x.data_ptr(), B, T,
-                                             ws.data_ptr(), ws.numel(), beat.data_ptr(), down.data_ptr()))
-        return beat, down
+            _lib.check(_lib.lib().bt_forward_stages(self._h, _lib.stream_ptr(self.device), prec, first, last, x.data_ptr(), B, T,
+                                                    ws.data_ptr(), ws.numel(), _lib.ptr(out), _lib.ptr(beat), _lib.ptr(down)))
+        return (beat, down) if last == 2 else out

@@ -111,6 +111,9 @@ typedef struct {
   const float* rope;   /* [1536][16][2] cos/sin of pos * freqs (rotary-embedding-torch) */
   int32_t ff_mult;     /* hidden width of the main layers' FeedForward = ff_mult * transformer_dim (the frontend's partial
                         * transformers always use 4, beat_tracker.py:279,288) */
+  /* for bt_forward_stages only: the final RMSNorm's gamma [D] and the task_heads weight [2][D] without it */
+  const float* norm_out_g;
+  const float* head_w_raw;
 } bt_model_desc;
 
 typedef struct {
@@ -141,6 +144,14 @@ size_t bt_workspace_bytes(const bt_engine* e, int B, int T, int prec);
  * d_beat, d_downbeat [B,T] fp32 logits (SumHead applied). T <= 1500. */
 int bt_forward(bt_engine* e, void* stream, int prec, const float* d_spect, int B, int T, void* d_ws,
                size_t ws_bytes, float* d_beat, float* d_downbeat);
+
+/* The three stages of BeatThis.forward on their own (beat_tracker.py:188-192: x = frontend(x); x = transformer_blocks(x);
+ * x = task_heads(x)), for callers that call or hook the sub-modules: stages first..last run (0 = frontend: [B,T,128] ->
+ * [B,T,D]; 1 = transformer_blocks incl. its final RMSNorm: [B,T,D] -> [B,T,D]; 2 = task_heads: [B,T,D] -> logits).
+ * d_in is the input of stage `first`; d_out [B,T,D] receives the output of stage `last` when last < 2, otherwise
+ * d_beat / d_downbeat do.  Same kernels and workspace as bt_forward (== stages 0..2). */
+int bt_forward_stages(bt_engine* e, void* stream, int prec, int first, int last, const float* d_in, int B, int T, void* d_ws,
+                      size_t ws_bytes, float* d_out, float* d_beat, float* d_downbeat);
 
 /* split_piece + zeropad (inference.py:90-135): d_chunks[b,t,:] = d_spect[d_starts[b]+t,:] or 0 */
 int bt_split_chunks(void* stream, const float* d_spect, int64_t n_frames, const int32_t* d_starts, int B, int T,

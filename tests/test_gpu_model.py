@@ -389,6 +389,54 @@ def test_audio2beats_many_matches_single_track_calls_and_oracle():
             assert np.array_equal(res[k][0], many[i][0]) and np.array_equal(res[k][1], many[i][1]), (k, i)
 
 
+@pytest.mark.parametrize("name", ["small0", "final0"])
+def test_submodules_are_callable_like_the_reference(name):
+    """BeatThis.frontend / .transformer_blocks / .task_heads called on their own (beat_tracker.py:188-192), each against
+    the oracle's stage on the oracle's input, their composition against the one-call forward, hooks, half precision."""
+    from beat_this_amd import weights as W
+    from oracle import beat_this_oracle as O
+
+    hp = W.resolve_hparams(name)
+    sd = W.random_state_dict(hp, seed=5, style="lively")
+    m = _model(name, 5, "lively")
+    D = hp["transformer_dim"]
+    x = torch.from_numpy(np.stack([W.synthetic_spect(333, seed=70 + i) for i in range(2)]))
+    with torch.inference_mode():
+        o_front = O.frontend(x, sd)
+        o_tr = O.transformer(o_front, sd, hp["n_layers"], D // 32)
+        bd = o_tr @ sd["task_heads.beat_downbeat_lin.weight"].T + sd["task_heads.beat_downbeat_lin.bias"]
+        o_beat, o_down = bd[..., 0] + bd[..., 1], bd[..., 1]
+        g_front = m.frontend(x.to(dev()))
+        g_tr = m.transformer_blocks(o_front.to(dev()))
+        g_head = m.task_heads(o_tr.to(dev()))
+        whole = m(x.to(dev()))
+        chain = m.task_heads(m.transformer_blocks(m.frontend(x.to(dev()))))
+    assert g_front.shape == (2, 333, D) and g_tr.shape == (2, 333, D) and set(g_head) == {"beat", "downbeat"}
+    e_front = float((g_front.cpu() - o_front).abs().max()) / float(o_front.abs().max())
+    e_tr = float((g_tr.cpu() - o_tr).abs().max()) / float(o_tr.abs().max())
+    e_head = max(float((g_head["beat"].cpu() - o_beat).abs().max()), float((g_head["downbeat"].cpu() - o_down).abs().max()))
+    e_chain = max(float((chain[k] - whole[k]).abs().max()) for k in ("beat", "downbeat"))
+    report("stages", model=name, frontend_rel=e_front, transformer_rel=e_tr, head_abs=e_head, chain_vs_forward=e_chain)
+    assert e_front < 2e-5 and e_tr < 2e-5 and e_head < 1e-4 and e_chain < 1e-4
+    # hooks on a sub-module fire in the whole forward too (it then runs stage by stage) and see the stage's output
+    seen = []
+    h = m.transformer_blocks.register_forward_hook(lambda mod, inp, out: seen.append((tuple(inp[0].shape), tuple(out.shape))))
+    with torch.inference_mode():
+        hooked = m(x.to(dev()))
+    h.remove()
+    assert seen == [((2, 333, D), (2, 333, D))]
+    assert max(float((hooked[k] - whole[k]).abs().max()) for k in ("beat", "downbeat")) < 1e-4
+    # half precision: the stage entry rebuilds what the fused producer leaves (half shadow, partial sums of squares)
+    with torch.inference_mode(), torch.autocast("cuda", enabled=True):
+        whole_h = m(x.to(dev()))
+        chain_h = m.task_heads(m.transformer_blocks(m.frontend(x.to(dev()))))
+    e_half = max(float((chain_h[k] - whole_h[k]).abs().max()) for k in ("beat", "downbeat"))
+    report("stages_half", model=name, chain_vs_forward=e_half)
+    # (the partial sums of squares are added in another order than the fused producer's: a last-bit difference that the
+    # fp16 roundings of six layers turn into ~2e-3 on these noise-like weights -- the half path's own error is 6e-3)
+    assert e_half < 6e-3
+
+
 def test_empty_and_oversize_inputs():
     from beat_this_amd.inference import Spect2Frames
 
