@@ -30,5 +30,14 @@ def test_lint_sees_the_pattern(tmp_path):
         assert len(isa_lint.lint("x.hip")) == 1
         isa_lint.asm_of = lambda src: safe
         assert isa_lint.lint("x.hip") == []
+        # second rule: the result of an inline-assembly MFMA read too early / late enough / by the compiler's own MFMA
+        early = "\n".join(["_Zk:", "\t;;#ASMSTART", "\tv_mfma_f32_32x32x16_f16 v[2:17], v[20:23], v[24:27], v[2:17]", "\t;;#ASMEND",
+                           "\tv_mul_f32_e32 v40, v3, v3", "\ts_endpgm"])
+        isa_lint.asm_of = lambda src: early
+        assert len(isa_lint.lint("x.hip")) == 1
+        isa_lint.asm_of = lambda src: early.replace("\tv_mul_f32", "\ts_nop 7\n\ts_nop 3\n\tv_mul_f32")
+        assert isa_lint.lint("x.hip") == []
+        isa_lint.asm_of = lambda src: early.replace("\t;;#ASMSTART\n", "").replace("\t;;#ASMEND\n", "")
+        assert isa_lint.lint("x.hip") == []
     finally:
         isa_lint.asm_of = orig

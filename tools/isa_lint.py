@@ -9,6 +9,11 @@ kernels avoid the pattern by construction (explicit vmcnt(0) before a ring start
 proves it on the generated code: for every VGPR-returning load it follows the straight-line code to the first read of
 its destination and reports the load if LDS-DMA was issued on the way and no wait on the way was vmcnt(0).
 
+Second rule (tail.hip issues its MFMAs from inline assembly, which hipcc's hazard recogniser does not see): between such
+an MFMA and the first instruction that reads its result without being an MFMA accumulating into the same registers there must
+be >= 12 wait states (what hipcc itself leaves behind the 8-pass 32x32x16 MFMAs these kernels use), counted
+conservatively: s_nop N = N + 1, any other MFMA = 16 (4x4x4: 8), anything else = 1.
+
     python tools/isa_lint.py [source.hip ...]        exit status 1 if anything is reported
 """
 import concurrent.futures
@@ -37,10 +42,52 @@ def asm_of(src):
     return text
 
 
+MFMA = re.compile(r"^\s*v_mfma_\w+\s+([av])\[(\d+):(\d+)\]")
+REG = re.compile(r"\b([av])(\d+)\b|\b([av])\[(\d+):(\d+)\]")
+MFMA_WAIT_STATES = 12
+
+
+def lint_mfma(lines, src):
+    findings = []
+    kernel = "?"
+    in_asm = False
+    for i, line in enumerate(lines):
+        m = re.match(r"^(_Z\w+):", line)
+        if m:
+            kernel = m.group(1)
+        if "#ASMSTART" in line:
+            in_asm = True
+        elif "#ASMEND" in line:
+            in_asm = False
+        m = MFMA.match(line)
+        if not m or not in_asm:   # (MFMAs the compiler emitted itself are covered by its hazard recogniser)
+            continue
+        bank, lo, hi = m.group(1), int(m.group(2)), int(m.group(3))
+        states = 0
+        for j in range(i + 1, min(i + 200, len(lines))):
+            x = lines[j].split(";")[0]
+            if not x.strip() or x.lstrip().startswith(".") or x.rstrip().endswith(":"):
+                continue
+            if "s_endpgm" in x or states >= MFMA_WAIT_STATES:
+                break
+            ops = x.split(None, 1)
+            touches = any((g[0] == bank and lo <= int(g[1]) <= hi) if g[0] else (g[2] == bank and int(g[3]) <= hi and int(g[4]) >= lo)
+                          for g in REG.findall(ops[1] if len(ops) > 1 else ""))
+            m2 = MFMA.match(x)
+            if touches and not (m2 and m2.group(1) == bank and int(m2.group(2)) == lo):
+                findings.append(f"{os.path.basename(src)}: {kernel}: line {j + 1}: `{x.strip()}` uses the result of the MFMA at line "
+                                f"{i + 1} after {states} wait state(s)")
+                break
+            n = re.match(r"\s*s_nop\s+(\d+)", x)
+            states += int(n.group(1)) + 1 if n else ((8 if "_4x4x4" in x else 16) if m2 else 1)
+    return findings
+
+
 def lint(src):
     findings = []
     kernel = "?"
     lines = asm_of(src).split("\n")
+    findings += lint_mfma(lines, src)
     for i, line in enumerate(lines):
         m = re.match(r"^(_Z\w+):", line)
         if m:
