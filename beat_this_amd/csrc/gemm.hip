@@ -90,10 +90,15 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
   constexpr int WM = (BN == 128) ? 2 : 4, WN = 4 / WM;
   constexpr int TM = 128 / WM / 32, TN = BN / WN / 32;
   constexpr int PITCH = Tile<T>::PITCH;
-  __shared__ __attribute__((aligned(16))) char smem[(128 + BN) * PITCH + 128 * 4];
+  __shared__ __attribute__((aligned(16))) char smem[(128 + BN) * PITCH + 128 * 4 + (EPI == GEMM_EPI_QKV ? 128 * 12 : 0)];
   char* As = smem;
   char* Bs = smem + 128 * PITCH;
   float* rs = reinterpret_cast<float*>(smem + (128 + BN) * PITCH);
+  // QKV epilogue: output row and rotary position of the tile's 128 rows, worked out ONCE per row (thread = row) -- they
+  // take 64-bit divisions by run-time values, which the epilogue used to repeat for each of a lane's 32 (row, tile) pairs
+  // (2 to 6 divisions each: more instructions than the whole k-loop)
+  long* orow_t = reinterpret_cast<long*>(smem + (128 + BN) * PITCH + 128 * 4);
+  int* pos_t = reinterpret_cast<int*>(smem + (128 + BN) * PITCH + 128 * 12);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // (wave index in an SGPR: uniform index math stays scalar)
   const int g = lane >> 5, lr = lane & 31;
@@ -177,8 +182,13 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
   if (rms) {
     float tot = ss + __shfl_xor(ss, 1);
     if (half == 0) rs[srow] = sqrtf((float)p.K) / fmaxf(sqrtf(tot), 1e-12f);
-    __syncthreads();
   }
+  if (EPI == GEMM_EPI_QKV && tid < 128) {
+    const long gm = m0 + tid;
+    pos_t[tid] = (int)((gm / p.pdiv) % p.pmod);
+    orow_t[tid] = (p.flags & GEMM_F_ROWMAP) ? btf_to_bft(gm < p.M ? gm : 0, p.map_T, p.map_F) : gm;
+  }
+  if (rms || EPI == GEMM_EPI_QKV) __syncthreads();
 
   // ---- epilogue --------------------------------------------------------------------
 #pragma unroll
@@ -190,8 +200,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
       const bool row_ok = gm < p.M;
       const float sc = rms ? rs[row_l] : 1.0f;
       if (EPI == GEMM_EPI_QKV) {
-        const int pos = (int)((gm / p.pdiv) % p.pmod);
-        const long orow = (p.flags & GEMM_F_ROWMAP) ? btf_to_bft(row_ok ? gm : 0, p.map_T, p.map_F) : gm;
+        const int pos = pos_t[row_l];
+        const long orow = orow_t[row_l];
         const f32x2 cs = *reinterpret_cast<const f32x2*>(p.rope + ((long)pos * 16 + (lr >> 1)) * 2);
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
