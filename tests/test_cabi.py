@@ -42,6 +42,9 @@ def test_argument_errors_map_to_exceptions():
     with pytest.raises(ValueError):
         L.check(rc)
     assert L.lib().bt_workspace_bytes(None, 1, 1, 0) == 0
+    # the staged entry point rejects its arguments before touching a GPU as well
+    assert L.lib().bt_forward_stages(None, None, 0, 0, 2, None, 1, 1, None, 0, None, None, None) == L.BT_ERR_ARG
+    assert b"null" in L.lib().bt_last_error()
 
 
 def test_struct_layout_matches_header():
