@@ -39,5 +39,12 @@ def test_lint_sees_the_pattern(tmp_path):
         assert isa_lint.lint("x.hip") == []
         isa_lint.asm_of = lambda src: early.replace("\t;;#ASMSTART\n", "").replace("\t;;#ASMEND\n", "")
         assert isa_lint.lint("x.hip") == []
+        # third rule: an LDS read still outstanding at a ring barrier (round 1's race) / drained first
+        racy = "\n".join(["_Zk:", "\tbuffer_load_dwordx4 v1, s[12:15], s4 offen lds", "\ts_waitcnt vmcnt(0) lgkmcnt(0)", "\ts_barrier",
+                          "\tds_read_b128 v[4:7], v2", "\ts_waitcnt vmcnt(0)", "\ts_barrier", "\ts_endpgm"])
+        isa_lint.asm_of = lambda src: racy
+        assert len(isa_lint.lint("x.hip")) == 1
+        isa_lint.asm_of = lambda src: racy.replace("\ts_waitcnt vmcnt(0)\n\ts_barrier", "\ts_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier")
+        assert isa_lint.lint("x.hip") == []
     finally:
         isa_lint.asm_of = orig

@@ -14,6 +14,10 @@ an MFMA and the first instruction that reads its result without being an MFMA ac
 be >= 12 wait states (what hipcc itself leaves behind the 8-pass 32x32x16 MFMAs these kernels use), counted
 conservatively: s_nop N = N + 1, any other MFMA = 16 (4x4x4: 8), anything else = 1.
 
+Third rule (the race of DESIGN.md section 3): in a kernel that issues LDS-DMA, no LDS read sits between an s_barrier and
+the nearest wait in front of it that drains the wave's LDS counter (lgkmcnt(0)) -- otherwise a
+fast wave's refill of a ring stage can overtake a slow wave's outstanding fragment reads of that stage.
+
     python tools/isa_lint.py [source.hip ...]        exit status 1 if anything is reported
 """
 import concurrent.futures
@@ -83,11 +87,37 @@ def lint_mfma(lines, src):
     return findings
 
 
+def lint_barriers(lines, src):
+    findings = []
+    bounds = [i for i, l in enumerate(lines) if re.match(r"^_Z\w+:", l)] + [len(lines)]
+    for a, b in zip(bounds, bounds[1:]):
+        body = lines[a:b]
+        if not any("buffer_load" in x and " lds" in x for x in body):
+            continue
+        kernel = body[0].split(":")[0]
+        for i, x in enumerate(body):
+            if not re.match(r"\s*s_barrier\b", x):
+                continue
+            ok = True
+            for j in range(i - 1, 0, -1):   # back to the nearest drain of the LDS counter; an LDS read on the way is outstanding
+                y = body[j].split(";")[0]
+                if "s_waitcnt" in y and "lgkmcnt(0)" in y:
+                    break
+                if re.match(r"\s*ds_(read|bpermute|permute|swizzle)", y):
+                    ok = False
+                    break
+            if not ok:
+                findings.append(f"{os.path.basename(src)}: {kernel}: line {a + i + 1}: s_barrier without a preceding lgkmcnt(0) "
+                                f"(LDS reads may be outstanding when another wave refills the stage)")
+    return findings
+
+
 def lint(src):
     findings = []
     kernel = "?"
     lines = asm_of(src).split("\n")
     findings += lint_mfma(lines, src)
+    findings += lint_barriers(lines, src)
     for i, line in enumerate(lines):
         m = re.match(r"^(_Z\w+):", line)
         if m:
