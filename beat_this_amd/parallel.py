@@ -84,7 +84,7 @@ def forward_chunks_sharded(model, spects, chunk_size=1500, border=6, group=None,
             cb, cd = run(model, chunks)
             local[: hi - lo, 0] = cb.float()
             local[: hi - lo, 1] = cd.float()
-        if world > 1:
+        if distributed:   # (also in a world of one: the collective path is the same code on 1 and N ranks)
             full = torch.empty((world * per, 2, chunk_size), dtype=torch.float32, device=dev)
             dist.all_gather_into_tensor(full, local, group=group)
         else:
@@ -132,7 +132,7 @@ def audio2frames_sharded(signals, sr, frames_fn, group=None, device=None):
         beat = down = torch.zeros(0, device=dev)
     local = torch.zeros((2, width), dtype=torch.float32, device=dev)
     local[0, : beat.shape[0]], local[1, : down.shape[0]] = beat.float(), down.float()
-    if world > 1:
+    if distributed:
         full = torch.empty((world * 2, width), dtype=torch.float32, device=dev)  # (concatenation along dim 0)
         dist.all_gather_into_tensor(full, local, group=group)
         full = full.view(world, 2, width)

@@ -127,6 +127,12 @@ def main():
                "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__), *sys.argv[1:]]
         raise SystemExit(subprocess.run(cmd).returncode)
 
+    # stdout carries ONE JSON line and nothing else: libraries that write to file descriptor 1 behind Python's back (RCCL
+    # prints a version banner there when the process group comes up) are sent to stderr for the duration of the run
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -138,8 +144,14 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # (BT_BENCH_FORCE_DIST=1: run the RCCL code path -- process group, logits all-gather, barrier, all-reduce of the time --
+    # with a world of ONE, the only way to exercise it on a single-GPU box; never set by the driver)
+    use_dist = world > 1 or os.environ.get("BT_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(_free_port()))
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)
 
     from beat_this_amd import _lib
@@ -167,7 +179,7 @@ def main():
     half_name = _lib.half_dtype_name()
 
     def fence():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -179,12 +191,12 @@ def main():
         from beat_this_amd.parallel import track_frames
 
         frames_per_track = track_frames(tracks[0].shape[0], TRACK_SR)
-        gathered = torch.empty((world * 2, n_tr * frames_per_track), dtype=torch.float32, device=dev) if world > 1 else None
+        gathered = torch.empty((world * 2, n_tr * frames_per_track), dtype=torch.float32, device=dev) if use_dist else None
         pending = []
 
         def step():
             h = a2b.many_async(tracks, TRACK_SR)
-            if world > 1:
+            if use_dist:
                 beat, down, _ = h.logits
                 dist.all_gather_into_tensor(gathered, torch.stack((beat, down)))
             pending.append(h)
@@ -207,12 +219,12 @@ def main():
     else:
         B = args.chunks
         x = torch.from_numpy(np.stack([W.synthetic_spect(CHUNK_FRAMES, seed=1000 * rank + i) for i in range(B)])).to(dev)
-        gathered = torch.empty((world * B, 2, CHUNK_FRAMES), dtype=torch.float32, device=dev) if world > 1 else None
+        gathered = torch.empty((world * B, 2, CHUNK_FRAMES), dtype=torch.float32, device=dev) if use_dist else None
 
         def step():
             with torch.inference_mode(), torch.autocast("cuda", enabled=half):
                 r = a2b.model(x)
-            if world > 1:
+            if use_dist:
                 dist.all_gather_into_tensor(gathered, torch.stack((r["beat"], r["downbeat"]), 1))
             return r
 
@@ -245,7 +257,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     log(f"timed region done: {1e3 * elapsed / args.steps:.3f} ms / step")
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -465,8 +477,9 @@ def main():
         }
         if last is not None and args.workload == "tracks":
             out["config"]["beats_in_last_track"] = int(len(last[-1][0]))
-        print(json.dumps(out))
-    if world > 1:
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 
