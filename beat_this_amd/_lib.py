@@ -22,7 +22,7 @@ SOURCES = ["gemm.hip", "gemm2.hip", "gemm3.hip", "attn.hip", "attn2.hip", "fused
 HEADERS = ["common.h", "chain.h", "kernels.h", os.path.join("..", "..", "include", "beat_this_amd.h")]
 
 BT_OK, BT_ERR_ARG, BT_ERR_HIP, BT_ERR_WORKSPACE = 0, -1, -2, -3
-PREC_F32, PREC_HALF, PREC_FP8 = 0, 1, 2
+PREC_F32, PREC_HALF, PREC_FP8, PREC_F32X3 = 0, 1, 2, 3
 MAX_LAYERS = 32
 PROFILE_CATEGORIES = ["stem", "qkv_gemm", "attn_freq", "attn_flash", "out_gemm", "ff1_gemm", "ff2_gemm", "conv_gemm",
                       "linear_gemm", "head", "ff_fused", "attn_freq_fused", "layer_tail"]

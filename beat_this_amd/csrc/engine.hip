@@ -62,6 +62,7 @@ struct Workspace {
 Workspace carve(char* base, int B, int T, int D, int ff_mult, int prec) {
   const bool fp8 = prec == BT_PREC_FP8;
   if (fp8) prec = BT_PREC_HALF;
+  if (prec == BT_PREC_F32X3) prec = BT_PREC_F32;   // (fp32 activations everywhere)
   const size_t es = prec == BT_PREC_F32 ? 4 : 2;
   const size_t bt = (size_t)B * T;
   const size_t dmax = std::max<size_t>(1024, D);
@@ -167,8 +168,11 @@ inline bool pair_fused2_ok(const bt_pair_weights& pw, int prec) {
 }
 
 int run_pair(prof::State* pf, const bt_pair_weights& pw, const float* rope, float* x, void* xshadow, const Workspace& ws,
-             int B, int T, int F, int mode, int prec, hipStream_t s, void* out_shadow = nullptr, int ff_mult = 4) {
+             int B, int T, int F, int mode, int prec, hipStream_t s, void* out_shadow = nullptr, int ff_mult = 4,
+             bool x3 = false) {
   const int C = pw.dim, H = pw.heads, HID = ff_mult * C;
+  // BT_PREC_F32X3: prec is BT_PREC_F32 for everything but the plain GEMMs, which take the [hi | lo] half weights
+  const int gp = x3 ? BT_PREC_F32X3 : prec, wp = x3 ? BT_PREC_HALF : prec;
   const long M = (long)B * T * F;
   if (M > 0x7fffffffL) return bt_set_error(BT_ERR_ARG, "batch too large for one forward call");
   GemmP g;
@@ -206,37 +210,37 @@ int run_pair(prof::State* pf, const bt_pair_weights& pw, const float* rope, floa
     LAUNCH_CAT(CAT_ATTN_FLASH, s, launch_attn_frag(a, s), "time attention");
     if (fused2_ok) return outff();
     memset(&g, 0, sizeof g);
-    g.A = ws.ao; g.lda = C; g.W = pw.w_out[prec]; g.M = (int)M; g.N = C; g.K = C;
+    g.A = ws.ao; g.lda = C; g.W = pw.w_out[wp]; g.M = (int)M; g.N = C; g.K = C;
     g.epi = GEMM_EPI_RESID; g.flags = 0; g.x = x; g.ldx = C; g.xb = nullptr;
-    LAUNCH_CAT(CAT_OUT, s, launch_gemm(g, prec, s), "out-proj gemm");
+    LAUNCH_CAT(CAT_OUT, s, launch_gemm(g, gp, s), "out-proj gemm");
   } else {
   // ---- q|k|v|gates = RMSNorm(x) . W^T, RoPE, sigmoid ------------------------------------
   memset(&g, 0, sizeof g);
-  g.A = shadow ? xshadow : (const void*)x; g.lda = C; g.W = pw.w_qkvg[prec]; g.M = (int)M; g.N = 3 * C + H; g.K = C;
+  g.A = shadow ? xshadow : (const void*)x; g.lda = C; g.W = pw.w_qkvg[wp]; g.M = (int)M; g.N = 3 * C + H; g.K = C;
   g.epi = GEMM_EPI_QKV; g.flags = GEMM_F_RMS | (shadow ? 0 : GEMM_F_A_F32) | (mode == 2 ? GEMM_F_ROWMAP : 0);
   g.bias = pw.b_gates; g.out = ws.qkv; g.ldo = 3 * C; g.gates = ws.gates; g.inner = C; g.heads = H;
   g.rope = rope; g.map_T = T; g.map_F = F;
   if (mode == 0) { g.pdiv = 1; g.pmod = T; }
   else if (mode == 1) { g.pdiv = 1; g.pmod = F; }
   else { g.pdiv = F; g.pmod = T; }
-  LAUNCH_CAT(CAT_QKV, s, launch_gemm(g, prec, s), "qkv gemm");
+  LAUNCH_CAT(CAT_QKV, s, launch_gemm(g, gp, s), "qkv gemm");
   // ---- attention ------------------------------------------------------------------------
   AttnP a;
   memset(&a, 0, sizeof a);
   a.qkv = ws.qkv; a.ld = 3 * C; a.gates = ws.gates; a.out = ws.ao; a.heads = H; a.inner = C;
   if (mode == 2) {
     a.n_seq = B * F; a.L = T; a.o_div = F; a.o_outer = (long)T * F; a.o_inner = 1; a.o_tok = F;
-    LAUNCH_CAT(CAT_ATTN_FLASH, s, launch_attn_flash(a, prec, s), "time attention");
+    LAUNCH_CAT(CAT_ATTN_FLASH, s, launch_attn_flash(a, gp, s), "time attention");
   } else {
     a.n_seq = B; a.L = T; a.o_div = 1; a.o_outer = T; a.o_inner = 0; a.o_tok = 1;
-    LAUNCH_CAT(CAT_ATTN_FLASH, s, launch_attn_flash(a, prec, s), "attention");
+    LAUNCH_CAT(CAT_ATTN_FLASH, s, launch_attn_flash(a, gp, s), "attention");
   }
   if (mode == 2 && fused2_ok) return outff();
   // ---- x += ao . Wout^T -------------------------------------------------------------------
   memset(&g, 0, sizeof g);
-  g.A = ws.ao; g.lda = C; g.W = pw.w_out[prec]; g.M = (int)M; g.N = C; g.K = C;
+  g.A = ws.ao; g.lda = C; g.W = pw.w_out[wp]; g.M = (int)M; g.N = C; g.K = C;
   g.epi = GEMM_EPI_RESID; g.flags = 0; g.x = x; g.ldx = C; g.xb = shadow ? xshadow : nullptr;
-  LAUNCH_CAT(CAT_OUT, s, launch_gemm(g, prec, s), "out-proj gemm");
+  LAUNCH_CAT(CAT_OUT, s, launch_gemm(g, gp, s), "out-proj gemm");
   }
   if (fused_ok) {
     FusedFFP ff;
@@ -247,15 +251,15 @@ int run_pair(prof::State* pf, const bt_pair_weights& pw, const float* rope, floa
   }
   // ---- h = gelu(RMSNorm(x) . W1^T + b1) ------------------------------------------------------
   memset(&g, 0, sizeof g);
-  g.A = shadow ? xshadow : (const void*)x; g.lda = C; g.W = pw.w_ff1[prec]; g.M = (int)M; g.N = HID; g.K = C;
+  g.A = shadow ? xshadow : (const void*)x; g.lda = C; g.W = pw.w_ff1[wp]; g.M = (int)M; g.N = HID; g.K = C;
   g.epi = GEMM_EPI_STORE; g.flags = GEMM_F_RMS | (shadow ? 0 : GEMM_F_A_F32) | GEMM_F_BIAS | GEMM_F_GELU;
   g.bias = pw.b_ff1; g.out = ws.hid; g.ldo = HID;
-  LAUNCH_CAT(CAT_FF1, s, launch_gemm(g, prec, s), "ff1 gemm");
+  LAUNCH_CAT(CAT_FF1, s, launch_gemm(g, gp, s), "ff1 gemm");
   // ---- x += h . W2^T + b2 ---------------------------------------------------------------------
   memset(&g, 0, sizeof g);
-  g.A = ws.hid; g.lda = HID; g.W = pw.w_ff2[prec]; g.M = (int)M; g.N = C; g.K = HID;
+  g.A = ws.hid; g.lda = HID; g.W = pw.w_ff2[wp]; g.M = (int)M; g.N = C; g.K = HID;
   g.epi = GEMM_EPI_RESID; g.flags = GEMM_F_BIAS; g.bias = pw.b_ff2; g.x = x; g.ldx = C; g.xb = shadow ? xshadow : nullptr;
-  LAUNCH_CAT(CAT_FF2, s, launch_gemm(g, prec, s), "ff2 gemm");
+  LAUNCH_CAT(CAT_FF2, s, launch_gemm(g, gp, s), "ff2 gemm");
   return BT_OK;
 }
 
@@ -307,13 +311,20 @@ int bt_forward_stages(bt_engine* e, void* stream, int prec, int first, int last,
   if (first < 0 || last > 2 || first > last) return bt_set_error(BT_ERR_ARG, "stages: need 0 <= first <= last <= 2");
   if (last == 2 ? (!d_beat || !d_downbeat) : !d_out) return bt_set_error(BT_ERR_ARG, "null output");
   if (B <= 0 || T <= 0 || T > 1536) return bt_set_error(BT_ERR_ARG, "need B >= 1 and 1 <= T <= 1536");
-  if (prec != BT_PREC_F32 && prec != BT_PREC_HALF && prec != BT_PREC_FP8) return bt_set_error(BT_ERR_ARG, "unknown precision");
+  if (prec != BT_PREC_F32 && prec != BT_PREC_HALF && prec != BT_PREC_FP8 && prec != BT_PREC_F32X3)
+    return bt_set_error(BT_ERR_ARG, "unknown precision");
   const bt_model_desc& d = e->d;
   prof::State* pf = &e->prof;
   const int D = d.transformer_dim;
   Workspace ws = carve((char*)d_ws, B, T, D, d.ff_mult, prec);
   if (ws.total > ws_bytes) return bt_set_error(BT_ERR_WORKSPACE, "workspace too small");
   hipStream_t s = (hipStream_t)stream;
+  const bool x3 = prec == BT_PREC_F32X3;
+  if (x3) {
+    if (BT_HALF_IS_BF16) return bt_set_error(BT_ERR_ARG, "BT_PREC_F32X3 needs an IEEE fp16 build");
+    prec = BT_PREC_F32;
+  }
+  const int gp = x3 ? BT_PREC_F32X3 : prec, wp = x3 ? BT_PREC_HALF : prec;   // plain GEMMs: launch / weight precision
   const bool fp8 = prec == BT_PREC_FP8;
   if (fp8) {  // everything but the e4m3 GEMMs of the main layers is the half path
     prec = BT_PREC_HALF;
@@ -375,9 +386,9 @@ int bt_forward_stages(bt_engine* e, void* stream, int prec, int first, int last,
     const bool conv3 = fast_layers && d.partial_transformers && pair_fused2_ok(d.front[blk][1], prec) && cg.N >= 128 &&
                        gemm3_supported(cg);
     if (d.partial_transformers) {
-      int rc = run_pair(pf, d.front[blk][0], d.rope, x, nullptr, ws, B, T, F, 1, prec, s);
+      int rc = run_pair(pf, d.front[blk][0], d.rope, x, nullptr, ws, B, T, F, 1, prec, s, nullptr, 4, x3);
       if (rc) return rc;
-      rc = run_pair(pf, d.front[blk][1], d.rope, x, nullptr, ws, B, T, F, 2, prec, s, conv3 ? ws.hid : nullptr);
+      rc = run_pair(pf, d.front[blk][1], d.rope, x, nullptr, ws, B, T, F, 2, prec, s, conv3 ? ws.hid : nullptr, 4, x3);
       if (rc) return rc;
     }
     if (conv3) {
@@ -387,14 +398,14 @@ int bt_forward_stages(bt_engine* e, void* stream, int prec, int first, int last,
     }
     GemmP g;
     memset(&g, 0, sizeof g);
-    g.A = x; g.W = d.conv_w[blk][prec]; g.M = B * T * (F / 2); g.N = 2 * C; g.K = 6 * C;
+    g.A = x; g.W = d.conv_w[blk][wp]; g.M = B * T * (F / 2); g.N = 2 * C; g.K = 6 * C;
     g.epi = GEMM_EPI_STORE; g.flags = GEMM_F_CONV | GEMM_F_A_F32 | GEMM_F_BIAS | GEMM_F_GELU | GEMM_F_OUT_F32;
     // the last block's output is read by frontend.linear only: half when that runs on gemm3 (same rounding point as
     // the fp32 -> half conversion of its A operand, half the bytes both ways)
     if (blk == 2 && lin3) g.flags &= ~GEMM_F_OUT_F32;
     g.bias = d.conv_b[blk]; g.out = xn; g.ldo = 2 * C;
     g.conv_C2 = 2 * C; g.conv_T = T; g.conv_F = F / 2;
-    LAUNCH_CAT(CAT_CONV, s, launch_gemm(g, prec, s), "frontend conv gemm");
+    LAUNCH_CAT(CAT_CONV, s, launch_gemm(g, gp, s), "frontend conv gemm");
     std::swap(x, xn);
   }
   if (lin3) {
@@ -406,11 +417,11 @@ int bt_forward_stages(bt_engine* e, void* stream, int prec, int first, int last,
   } else {
     GemmP g;
     memset(&g, 0, sizeof g);
-    g.A = x; g.lda = 1024; g.W = d.lin_w[prec]; g.M = B * T; g.N = D; g.K = 1024;
+    g.A = x; g.lda = 1024; g.W = d.lin_w[wp]; g.M = B * T; g.N = D; g.K = 1024;
     g.epi = GEMM_EPI_STORE; g.flags = GEMM_F_A_F32 | GEMM_F_BIAS | GEMM_F_OUT_F32;
     g.bias = d.lin_b; g.out = ws.xm; g.ldo = D; g.xb = use_shadow ? ws.xmb : nullptr;
     g.ssq_out = fast_layers ? ws.ssq[0] : nullptr;
-    LAUNCH_CAT(CAT_LINEAR, s, launch_gemm(g, prec, s), "frontend linear gemm");
+    LAUNCH_CAT(CAT_LINEAR, s, launch_gemm(g, gp, s), "frontend linear gemm");
   }
   }  // first == 0
   if (last == 0) {
@@ -421,7 +432,7 @@ int bt_forward_stages(bt_engine* e, void* stream, int prec, int first, int last,
   for (int l = 0; l < d.n_layers; ++l) {
     int rc = fast_layers ? run_layer_half(pf, d.layers[l], d.rope, ws, B, T, d.ff_mult, fp8, s)
                          : run_pair(pf, d.layers[l], d.rope, ws.xm, use_shadow ? ws.xmb : nullptr, ws, B, T, 1, 0, prec, s, nullptr,
-                                    d.ff_mult);
+                                    d.ff_mult, x3);
     if (rc) return rc;
   }
   if (last == 1) {

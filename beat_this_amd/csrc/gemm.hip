@@ -84,21 +84,45 @@ DEVI void sts16(char* dst, const Stg<float>& s, hf) {
   }
 }
 
-template <typename T, bool A_F32, int BN, int EPI>
+// fp32 -> hi + lo halves (BT_PREC_F32X3): hi = half(a), lo = half(a - hi); 16 staged elements to the two LDS tiles
+DEVI void sts16_split(char* hi, char* lo, const Stg<float>& s) {
+  hfx8* dh = reinterpret_cast<hfx8*>(hi);
+  hfx8* dl = reinterpret_cast<hfx8*>(lo);
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    hfx8 oh, ol;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float v = s.v[2 * h + (j >> 2)][j & 3];
+      const hf vh = (hf)v;
+      oh[j] = vh;
+      ol[j] = (hf)(v - (float)vh);
+    }
+    dh[h] = oh;
+    dl[h] = ol;
+  }
+}
+
+// SPLIT (BT_PREC_F32X3; T = half, A fp32): a second pair of LDS tiles holds the lo parts of A (split while it is staged) and
+// of W (packed behind the hi part: p.W + rows_padded * K); three half MFMAs per product, small terms first.
+template <typename T, bool A_F32, int BN, int EPI, bool SPLIT = false>
 __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
   using EA = typename std::conditional<A_F32, float, T>::type;
+  using TO = typename std::conditional<SPLIT, float, T>::type;   // element type of q|k|v / plain outputs
   constexpr int WM = (BN == 128) ? 2 : 4, WN = 4 / WM;
   constexpr int TM = 128 / WM / 32, TN = BN / WN / 32;
   constexpr int PITCH = Tile<T>::PITCH;
-  __shared__ __attribute__((aligned(16))) char smem[(128 + BN) * PITCH + 128 * 4 + (EPI == GEMM_EPI_QKV ? 128 * 12 : 0)];
+  constexpr int TILES = (128 + BN) * PITCH;          // one A tile + one W tile
+  constexpr int LO = SPLIT ? TILES : 0;              // offset of the lo tiles
+  __shared__ __attribute__((aligned(16))) char smem[TILES + LO + 128 * 4 + (EPI == GEMM_EPI_QKV ? 128 * 12 : 0)];
   char* As = smem;
   char* Bs = smem + 128 * PITCH;
-  float* rs = reinterpret_cast<float*>(smem + (128 + BN) * PITCH);
+  float* rs = reinterpret_cast<float*>(smem + TILES + LO);
   // QKV epilogue: output row and rotary position of the tile's 128 rows, worked out ONCE per row (thread = row) -- they
   // take 64-bit divisions by run-time values, which the epilogue used to repeat for each of a lane's 32 (row, tile) pairs
   // (2 to 6 divisions each: more instructions than the whole k-loop)
-  long* orow_t = reinterpret_cast<long*>(smem + (128 + BN) * PITCH + 128 * 4);
-  int* pos_t = reinterpret_cast<int*>(smem + (128 + BN) * PITCH + 128 * 12);
+  long* orow_t = reinterpret_cast<long*>(smem + TILES + LO + 128 * 4);
+  int* pos_t = reinterpret_cast<int*>(smem + TILES + LO + 128 * 12);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // (wave index in an SGPR: uniform index math stays scalar)
   const int g = lane >> 5, lr = lane & 31;
@@ -140,6 +164,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
   const bool b_thread = srow < BN;
   const T* Wp = reinterpret_cast<const T*>(p.W) + (long)(n0 + (b_thread ? srow : 0)) * p.K + half * 16;
   auto loadB = [&](int kt) -> Stg<T> { return ldg16<T>(Wp + (long)kt * 32, b_thread); };
+  const long w_lo = (long)((p.N + 127) / 128 * 128) * p.K;  // (SPLIT) the lo part follows the hi part of the padded matrix
+  auto loadB2 = [&](int kt) -> Stg<T> { return ldg16<T>(Wp + w_lo + (long)kt * 32, b_thread && SPLIT); };
 
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -151,7 +177,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
 
   float ss = 0.f;
   Stg<EA> ra = loadA(0);
-  Stg<T> rb = loadB(0);
+  Stg<T> rb = loadB(0), rb2;
+  if (SPLIT) rb2 = loadB2(0);
   char* a_dst = As + srow * PITCH + half * 16 * (int)sizeof(T);
   char* b_dst = Bs + srow * PITCH + half * 16 * (int)sizeof(T);
   const char* a_src = As + (wm * TM * 32 + lr) * PITCH;
@@ -160,18 +187,38 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
   for (int kt = 0; kt < nk; ++kt) {
     __syncthreads();
     ss += sumsq(ra);
-    sts16(a_dst, ra, T());
-    if (b_thread) sts16(b_dst, rb, T());
+    if constexpr (SPLIT) {
+      sts16_split(a_dst, a_dst + LO, ra);
+      if (b_thread) { sts16(b_dst, rb, T()); sts16(b_dst + LO, rb2, T()); }
+    } else {
+      sts16(a_dst, ra, T());
+      if (b_thread) sts16(b_dst, rb, T());
+    }
     __syncthreads();
     if (kt + 1 < nk) {
       ra = loadA(kt + 1);
       rb = loadB(kt + 1);
+      if (SPLIT) rb2 = loadB2(kt + 1);
     }
     Frag<T> fa[TM], fb[TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i) fa[i] = ld_frag<T>(a_src + i * 32 * PITCH, g);
 #pragma unroll
     for (int j = 0; j < TN; ++j) fb[j] = ld_frag<T>(b_src + j * 32 * PITCH, g);
+    if constexpr (SPLIT) {
+      Frag<T> fa2[TM], fb2[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) fa2[i] = ld_frag<T>(a_src + LO + i * 32 * PITCH, g);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) fb2[j] = ld_frag<T>(b_src + LO + j * 32 * PITCH, g);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          mma32(acc[i][j], fa2[i], fb[j]);
+          mma32(acc[i][j], fa[i], fb2[j]);
+        }
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -214,7 +261,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
             v = (lr & 1) ? fmaf(other, cs.y, v * cs.x) : fmaf(-other, cs.y, v * cs.x);
           }
           if (cat < 3) {
-            if (row_ok) reinterpret_cast<T*>(p.out)[orow * p.ldo + col] = from_f32<T>(v);
+            if (row_ok) reinterpret_cast<TO*>(p.out)[orow * p.ldo + col] = from_f32<TO>(v);
           } else {
             const int hc = col - 3 * p.inner;
             if (row_ok && hc < p.heads) p.gates[orow * p.heads + hc] = sigmoidf(v + p.bias[hc]);
@@ -232,7 +279,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
             *xp = *xp + v;
           } else {
             if (p.flags & GEMM_F_GELU) v = gelu_erf(v);
-            if (std::is_same<T, float>::value || (p.flags & GEMM_F_OUT_F32))
+            if (std::is_same<TO, float>::value || (p.flags & GEMM_F_OUT_F32))
               reinterpret_cast<float*>(p.out)[gm * p.ldo + col] = v;
             else
               reinterpret_cast<T*>(p.out)[gm * p.ldo + col] = from_f32<T>(v);
@@ -243,29 +290,29 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
   }
 }
 
-template <typename T, bool A_F32, int EPI>
+template <typename T, bool A_F32, int EPI, bool SPLIT = false>
 int launch_bn(const GemmP& p, hipStream_t s) {
   dim3 block(256);
   long mt = ((long)p.M + 127) / 128;
   if (p.N > 64) {
     dim3 grid((p.N + 127) / 128, (unsigned)mt);
-    hipLaunchKernelGGL((gemm_kernel<T, A_F32, 128, EPI>), grid, block, 0, s, p);
+    hipLaunchKernelGGL((gemm_kernel<T, A_F32, 128, EPI, SPLIT>), grid, block, 0, s, p);
   } else if (p.N > 32) {
     dim3 grid(1, (unsigned)mt);
-    hipLaunchKernelGGL((gemm_kernel<T, A_F32, 64, EPI>), grid, block, 0, s, p);
+    hipLaunchKernelGGL((gemm_kernel<T, A_F32, 64, EPI, SPLIT>), grid, block, 0, s, p);
   } else {
     dim3 grid(1, (unsigned)mt);
-    hipLaunchKernelGGL((gemm_kernel<T, A_F32, 32, EPI>), grid, block, 0, s, p);
+    hipLaunchKernelGGL((gemm_kernel<T, A_F32, 32, EPI, SPLIT>), grid, block, 0, s, p);
   }
   return (int)hipGetLastError();
 }
 
-template <typename T, bool A_F32>
+template <typename T, bool A_F32, bool SPLIT = false>
 int launch_epi(const GemmP& p, hipStream_t s) {
   switch (p.epi) {
-    case GEMM_EPI_STORE: return launch_bn<T, A_F32, GEMM_EPI_STORE>(p, s);
-    case GEMM_EPI_RESID: return launch_bn<T, A_F32, GEMM_EPI_RESID>(p, s);
-    case GEMM_EPI_QKV: return launch_bn<T, A_F32, GEMM_EPI_QKV>(p, s);
+    case GEMM_EPI_STORE: return launch_bn<T, A_F32, GEMM_EPI_STORE, SPLIT>(p, s);
+    case GEMM_EPI_RESID: return launch_bn<T, A_F32, GEMM_EPI_RESID, SPLIT>(p, s);
+    case GEMM_EPI_QKV: return launch_bn<T, A_F32, GEMM_EPI_QKV, SPLIT>(p, s);
   }
   return -1;
 }
@@ -281,6 +328,10 @@ int launch_gemm(const GemmP& p, int prec, hipStream_t s) {
   if ((p.flags & GEMM_F_CONV) && (p.conv_C2 % 32 != 0 || p.K != 3 * p.conv_C2)) return -2;
   if (p.epi == GEMM_EPI_QKV && (p.inner % 32 != 0)) return -2;
   if (prec == BT_PREC_F32) return launch_epi<float, true>(p, s);
+  if (prec == BT_PREC_F32X3) {  // fp32 activations and outputs, hi + lo half operands (p.W = [hi | lo])
+    if (BT_HALF_IS_BF16) return -2;
+    return launch_epi<hf, true, true>(p, s);
+  }
   if (p.flags & GEMM_F_A_F32) return launch_epi<hf, true>(p, s);
   return launch_epi<hf, false>(p, s);
 }

@@ -7,6 +7,9 @@
 #define BT_PREC_F32 0
 #define BT_PREC_HALF 1
 #endif
+#ifndef BT_PREC_F32X3
+#define BT_PREC_F32X3 3   // (include/beat_this_amd.h)
+#endif
 
 // ---- GEMM: C[M,N] = epilogue( A[M,K] . W[N,K]^T ) ------------------------------------
 enum {

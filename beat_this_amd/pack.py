@@ -167,9 +167,13 @@ class PackedModel:
         return t.data_ptr()
 
     def _mat(self, w: torch.Tensor):
+        """[N padded to 128][K] fp32 and half copies of a GEMM weight; the half copy is followed by its lo part
+        (w - half(w), again in half): BT_PREC_F32X3 multiplies hi + lo, the half path reads the hi part only."""
         w = _pad_rows(w.to(torch.float32))
         a = w.to(self.device)
-        b = w.to(_lib.half_torch_dtype()).to(self.device)
+        ht = _lib.half_torch_dtype()
+        hi = w.to(ht)
+        b = torch.cat([hi, (w - hi.to(torch.float32)).to(ht)]).to(self.device)
         self._keep += [a, b]
         return a.data_ptr(), b.data_ptr()
 

@@ -103,7 +103,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--model", default="final0")
-    ap.add_argument("--prec", default="half", choices=["half", "f32", "fp8"],
+    ap.add_argument("--prec", default="half", choices=["half", "f32", "f32x3", "fp8"],
                     help="half = half-precision MFMA operands (float16=True of the Python API); fp8 = EXPERIMENTAL: half path "
                          "with the main layers' feed-forward GEMMs on e4m3 (BASELINE config 5)")
     ap.add_argument("--tracks", type=int, default=TRACKS_PER_GPU, help="5-minute tracks per GPU per step")
@@ -172,10 +172,11 @@ def main():
     sd = W.random_state_dict(hp, seed=1, style="lively")
     model = BeatThis(**{k: hp[k] for k in ("spect_dim", "transformer_dim", "ff_mult", "n_layers", "head_dim", "stem_dim")})
     model.load_state_dict(sd)
-    a2b = Audio2Beats(checkpoint_path=None, device=dev, float16=args.prec != "f32", dbn=False)
+    a2b = Audio2Beats(checkpoint_path=None, device=dev, float16=args.prec not in ("f32", "f32x3"), dbn=False)
     a2b.model = model.to(dev)
     a2b.model.fp8_weights = args.prec == "fp8"
-    half = args.prec != "f32"
+    a2b.model.fp32_split_gemms = args.prec == "f32x3"
+    half = args.prec not in ("f32", "f32x3")
     half_name = _lib.half_dtype_name()
 
     def fence():
@@ -301,7 +302,7 @@ def main():
         dom = max(breakdown, key=lambda k: breakdown[k]["ms_per_step"])
         d = breakdown[dom]
         peak = PEAK_TFLOPS["fp8" if args.prec == "fp8" and dom in ("ff1_gemm", "ff2_gemm") else
-                           ("f32" if args.prec == "f32" else "half")]
+                           ("f32" if args.prec in ("f32", "f32x3") else "half")]
         traffic, traffic_src = None, None
         try:  # HBM bytes per launch of the dominant category: PMC counters of separate rocprofv3 passes, committed
             tj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
@@ -466,7 +467,8 @@ def main():
             "metric": "audio-seconds processed/sec", "value": round(value, 1), "unit": "audio-seconds/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": {"half": half_name, "f32": "f32", "fp8": f"{half_name}+fp8(e4m3 feed-forward GEMMs, experimental)"}[args.prec],
+            "dtype": {"half": half_name, "f32": "f32", "f32x3": "f32 (GEMMs: 3 x f16 MFMA on hi+lo operands)",
+                      "fp8": f"{half_name}+fp8(e4m3 feed-forward GEMMs, experimental)"}[args.prec],
             "data": "synthetic",
             "config": {"workload": workload, "tracks_per_gpu": args.tracks if args.workload == "tracks" else None,
                        "chunks_per_gpu": chunks_per_step, "global_chunks": world * chunks_per_step,

@@ -31,6 +31,13 @@ extern "C" {
                         * operands (2x the bf16 MFMA rate), fp32 accumulate + fp32 residual stream; attention, frontend
                         * and head as in BT_PREC_HALF */
 
+#define BT_PREC_F32X3 3 /* BT_PREC_F32 with the GEMMs (QKV, out-projection, feed-forward, convolutions, frontend.linear) on
+                        * three half MFMAs per product instead of fp32 MFMAs: every fp32 operand is split on the fly into
+                        * hi + lo halves (a = hi + lo to 2^-22), a.b ~ hi.hi + hi.lo + lo.hi, fp32 accumulate -- 16/3 times
+                        * the fp32 matrix rate at fp32-class accuracy.  Needs the half weight arrays to be followed by their
+                        * lo parts (beat_this_amd/pack.py: [hi | lo], each [N padded to 128][K]); IEEE fp16 builds only.
+                        * Attention and the register-chained frontend halves stay on fp32 MFMAs. */
+
 #define BT_MAX_LAYERS 32
 
 typedef struct bt_engine bt_engine;

@@ -437,6 +437,37 @@ def test_submodules_are_callable_like_the_reference(name):
     assert e_half < 6e-3
 
 
+@pytest.mark.parametrize("name", ["small0", "final0"])
+def test_fp32_split_gemms_stay_within_the_fp32_gate(name):
+    """BT_PREC_F32X3 (the fp32 path with its plain GEMMs on three half MFMAs per product, operands split into hi + lo):
+    logits against the oracle and against the exact fp32 path, beats identical."""
+    from beat_this_amd import weights as W
+    from beat_this_amd.postprocessor import Postprocessor
+    from oracle import beat_this_oracle as O
+
+    hp = W.resolve_hparams(name)
+    sd = W.random_state_dict(hp, seed=6, style="lively")
+    m = _model(name, 6, "lively")
+    x = torch.from_numpy(np.stack([W.synthetic_spect(1500, seed=75 + i) for i in range(2)]))
+    with torch.inference_mode():
+        ob, od = O.model_forward(sd, x)
+        exact = m(x.to(dev()))
+        m.fp32_split_gemms = True
+        split = m(x.to(dev()))
+        m.fp32_split_gemms = False
+    e_oracle = max(float((split["beat"].cpu() - ob).abs().max()), float((split["downbeat"].cpu() - od).abs().max()))
+    e_exact = max(float((split[k] - exact[k]).abs().max()) for k in ("beat", "downbeat"))
+    post = Postprocessor()
+    flips = 0
+    for i in range(2):
+        b0, d0 = post(exact["beat"][i], exact["downbeat"][i])
+        b1, d1 = post(split["beat"][i], split["downbeat"][i])
+        flips += len(set(np.round(b0 * 100).astype(int)) ^ set(np.round(b1 * 100).astype(int)))
+        flips += len(set(np.round(d0 * 100).astype(int)) ^ set(np.round(d1 * 100).astype(int)))
+    report("f32x3", model=name, err_vs_oracle=e_oracle, err_vs_exact_fp32=e_exact, flips_vs_exact=flips)
+    assert e_oracle < LOGIT_TOL_F32 and flips == 0
+
+
 def test_empty_and_oversize_inputs():
     from beat_this_amd.inference import Spect2Frames
 
