@@ -324,7 +324,6 @@ int bt_forward_stages(bt_engine* e, void* stream, int prec, int first, int last,
     if (BT_HALF_IS_BF16) return bt_set_error(BT_ERR_ARG, "BT_PREC_F32X3 needs an IEEE fp16 build");
     prec = BT_PREC_F32;
   }
-  const int gp = x3 ? BT_PREC_F32X3 : prec, wp = x3 ? BT_PREC_HALF : prec;   // plain GEMMs: launch / weight precision
   const bool fp8 = prec == BT_PREC_FP8;
   if (fp8) {  // everything but the e4m3 GEMMs of the main layers is the half path
     prec = BT_PREC_HALF;
@@ -335,6 +334,7 @@ int bt_forward_stages(bt_engine* e, void* stream, int prec, int first, int last,
           !d.layers[l].b_ff2_f8)
         return bt_set_error(BT_ERR_ARG, "BT_PREC_FP8 needs the e4m3 feed-forward weights of every layer");
   }
+  const int gp = x3 ? BT_PREC_F32X3 : prec, wp = x3 ? BT_PREC_HALF : prec;   // plain GEMMs: launch / weight precision
 
   // the half shadow of the main residual stream is maintained by the gemm2 / gemm3 epilogues only
   const bool use_shadow = prec == BT_PREC_HALF && D >= 128 && D % 64 == 0;

@@ -189,10 +189,12 @@ class Spect2Frames:
     def __init__(self, checkpoint_path="final0", device="cuda", float16=False):
         super().__init__()
         self.device = _gpu_device(device)
-        self.float16 = bool(float16)
+        self.float16 = bool(float16) and float16 != "f32x3"
         self.model = load_model(checkpoint_path, self.device)
         if float16 == "fp8":  # extension: float16="fp8" -> autocast + e4m3 feed-forward GEMMs (BT_PREC_FP8)
             self.model.fp8_weights = True
+        if float16 == "f32x3":  # extension: fp32 activations, GEMMs and attention on three fp16 MFMAs per product (BT_PREC_F32X3)
+            self.model.fp32_split_gemms = True
 
     def spect2frames(self, spect):
         with torch.inference_mode():

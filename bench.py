@@ -22,6 +22,8 @@ Extra objects on the JSON line:
                 ALGORITHMIC bytes (3.41 MB per chunk for the log-mel).
   forward_only  BASELINE config 2 (16 chunks through BeatThis.forward, spectrograms resident), for continuity with round 1.
   fp32_path     the same headline workload on the exact-fp32 MFMA path (the one under the 1e-3 gate), fewer steps.
+  f32x3_path    the fp32 path with its GEMMs and attention on three fp16 MFMAs per product (hi + lo operand split): the
+                same 1e-3 / identical-beats gate at about twice the fp32-MFMA rate.
   host_inclusive  the headline job with the waveforms starting in pinned HOST memory (PCIe-inclusive rate; never `value`).
   cpu_baseline  the CPU oracle's Audio2Beats (torch fp32, SDPA attention like the reference) on ONE 300 s track on this
                 host, thread count probed and stated (rank 0, N = 1 only).
@@ -320,7 +322,7 @@ def main():
                     "whole_forward_tflops": round(FLOP_PER_CHUNK * chunks_per_step /
                                                   (sum(v["ms_per_step"] for v in breakdown.values()) * 1e-3) / 1e12, 2)}
 
-        frontend = forward_only = fp32_path = host_inclusive = None
+        frontend = forward_only = fp32_path = f32x3_path = host_inclusive = None
         if args.workload == "tracks" and not args.no_extras:
             # ---- HBM-bound stages: events around each stage on torch's current stream (the launch stream) -------------
             def timed(fn, reps=5):
@@ -461,6 +463,23 @@ def main():
                 t32 = (time.perf_counter() - t32) / 3
                 fp32_path = {"ms_per_step": round(t32 * 1e3, 2), "audio_seconds_per_s": round(units_per_step / t32, 1),
                              "dtype": "f32 (v_mfma_f32_32x32x2_f32)", "parity": parity_of(a2b)}
+                if not _lib.lib().bt_half_is_bf16():
+                    # ... and with its GEMMs and attention on three fp16 MFMAs per product (BT_PREC_F32X3): same gate
+                    log("f32x3 path leg")
+                    a2b.model.fp32_split_gemms = True
+                    for _ in range(2):
+                        a2b.many(tracks, TRACK_SR)
+                    torch.cuda.synchronize(dev)
+                    t3 = time.perf_counter()
+                    for _ in range(3):
+                        step()
+                    drain()
+                    torch.cuda.synchronize(dev)
+                    t3 = (time.perf_counter() - t3) / 3
+                    f32x3_path = {"ms_per_step": round(t3 * 1e3, 2), "audio_seconds_per_s": round(units_per_step / t3, 1),
+                                  "dtype": "f32 activations; GEMMs and attention: 3 x v_mfma_f32_32x32x16_f16 on hi + lo operands",
+                                  "parity": parity_of(a2b)}
+                    a2b.model.fp32_split_gemms = False
                 a2b.float16 = True
 
         out = {
@@ -475,7 +494,7 @@ def main():
                        "parallelism": f"track-sharded x{world}, framewise logits all-gathered" if args.workload == "tracks"
                        else f"chunk-sharded x{world}, logits all-gathered"},
             "parity": parity, "roofline": roofline, "cpu_baseline": cpu, "frontend": frontend, "forward_only": forward_only,
-            "fp32_path": fp32_path, "host_inclusive": host_inclusive, "breakdown": breakdown,
+            "fp32_path": fp32_path, "f32x3_path": f32x3_path, "host_inclusive": host_inclusive, "breakdown": breakdown,
         }
         if last is not None and args.workload == "tracks":
             out["config"]["beats_in_last_track"] = int(len(last[-1][0]))
