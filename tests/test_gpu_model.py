@@ -466,6 +466,14 @@ def test_fp32_split_gemms_stay_within_the_fp32_gate(name):
         flips += len(set(np.round(d0 * 100).astype(int)) ^ set(np.round(d1 * 100).astype(int)))
     report("f32x3", model=name, err_vs_oracle=e_oracle, err_vs_exact_fp32=e_exact, flips_vs_exact=flips)
     assert e_oracle < LOGIT_TOL_F32 and flips == 0
+    # the user-facing switch: float16="f32x3" selects it without autocast
+    from beat_this_amd.inference import Spect2Frames
+
+    s2f = Spect2Frames(checkpoint_path={"hyper_parameters": dict(hp), "state_dict": {"model." + k: v for k, v in sd.items()}},
+                       device=dev(), float16="f32x3")
+    assert s2f.float16 is False and s2f.model.fp32_split_gemms
+    b2, d2 = s2f.spect2frames(x[0].to(dev()))
+    assert float((b2 - split["beat"][0]).abs().max()) < 1e-4 and float((d2 - split["downbeat"][0]).abs().max()) < 1e-4
 
 
 def test_empty_and_oversize_inputs():
