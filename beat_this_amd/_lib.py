@@ -38,7 +38,8 @@ class PairWeights(C.Structure):
                 ("w_ff_frag", C.c_void_p * 2), ("w_qkv_frag", C.c_void_p),
                 ("w_outff_frag", C.c_void_p * 2), ("w_attnff_frag", C.c_void_p * 2),
                 ("w_ff1_f8", C.c_void_p), ("s_ff1", C.c_void_p), ("w_ff2_f8", C.c_void_p), ("s_ff2", C.c_void_p),
-                ("b_ff2_f8", C.c_void_p), ("w_tail_frag", C.c_void_p)]
+                ("b_ff2_f8", C.c_void_p), ("w_tail_frag", C.c_void_p),
+                ("w_outff_frag_x3", C.c_void_p), ("w_attnff_frag_x3", C.c_void_p)]
 
 
 class ModelDesc(C.Structure):

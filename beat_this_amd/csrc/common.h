@@ -41,6 +41,17 @@ typedef __attribute__((ext_vector_type(2))) float f32x2;
 template <typename T> struct Frag;
 template <> struct Frag<float> { f32x4 v[4]; };
 template <> struct Frag<hf> { hfx8 v[2]; };
+// BT_PREC_F32X3 in the register-chained kernels: an fp32 operand as a (hi, lo) pair of halves, hi = half(s a),
+// lo = half(s a - hi).  sizeof = 4 like float: pointers into fp32 activations and 4 KB weight tiles ([hi 2 KB | lo 2 KB])
+// index the same way as the float instantiation.  The power-of-two pre-scale s keeps lo a NORMAL fp16 number for every
+// operand above 2^-3 / s (unscaled, the lo half of anything below 0.125 is a subnormal with a few bits, and the
+// frontend's weights and activations mostly are: 1.2e-4 instead of 2e-5 at the logits): activations (everything split in
+// registers) are scaled by OpScale::ACT, packed weights by OpScale::WGT, and every product is scaled back where its
+// accumulator is consumed (OpScale::PW for weight . activation, PA for activation . activation; 1 for float / half).
+struct hl { hf hi, lo; };
+template <> struct Frag<hl> { hfx8 v[4]; };  // v[0], v[1] the hi fragment (as Frag<hf>), v[2], v[3] the lo fragment
+template <typename T> struct OpScale { static constexpr float ACT = 1.f, PW = 1.f, PA = 1.f; };
+template <> struct OpScale<hl> { static constexpr float ACT = 32.f, PW = 1.f / (32.f * 64.f), PA = 1.f / (32.f * 32.f); };  // WGT = 64 (pack.py)
 
 // LDS row pitch (bytes) of a 32-deep k-tile: +16 B pad makes the 16 B column slots of any
 // 16 rows distinct (pitch/16 is odd), i.e. ds_read_b128 fragment reads are conflict free.
@@ -69,6 +80,15 @@ DEVI void mma32(f32x16& acc, const Frag<float>& a, const Frag<float>& b) {
     for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.v[i][j], b.v[i][j], acc, 0, 0, 0);
 }
 DEVI void mma32(f32x16& acc, const Frag<hf>& a, const Frag<hf>& b) {
+  acc = MFMA32_H(a.v[0], b.v[0], acc);
+  acc = MFMA32_H(a.v[1], b.v[1], acc);
+}
+// (a_hi + a_lo) . (b_hi + b_lo) without the lo . lo term: three half products, small ones first
+DEVI void mma32(f32x16& acc, const Frag<hl>& a, const Frag<hl>& b) {
+  acc = MFMA32_H(a.v[2], b.v[0], acc);
+  acc = MFMA32_H(a.v[3], b.v[1], acc);
+  acc = MFMA32_H(a.v[0], b.v[2], acc);
+  acc = MFMA32_H(a.v[1], b.v[3], acc);
   acc = MFMA32_H(a.v[0], b.v[0], acc);
   acc = MFMA32_H(a.v[1], b.v[1], acc);
 }
@@ -103,6 +123,7 @@ DEVI float gelu_tanh(float x) {
 template <typename T> DEVI float gelu_t(float x);
 template <> DEVI float gelu_t<float>(float x) { return gelu_erf(x); }
 template <> DEVI float gelu_t<hf>(float x) { return gelu_tanh(x); }
+template <> DEVI float gelu_t<hl>(float x) { return gelu_erf(x); }
 DEVI float sigmoidf(float x) { return 1.0f / (1.0f + __expf(-x)); }
 
 template <typename T> DEVI T from_f32(float x);

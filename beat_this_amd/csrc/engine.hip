@@ -180,18 +180,21 @@ int run_pair(prof::State* pf, const bt_pair_weights& pw, const float* rope, floa
   const bool shadow = xshadow != nullptr && prec == BT_PREC_HALF;
   const bool fused_ok = C <= 128 && pw.w_ff_frag[prec];
   const bool fused2_ok = fused_ok && pw.w_outff_frag[prec] && pw.w_attnff_frag[prec];
+  // BT_PREC_F32X3: the register-chained halves on (hi, lo) operands too when their split streams were packed
+  const bool f2x3 = x3 && pw.w_outff_frag_x3 && pw.w_attnff_frag_x3;
   auto outff = [&]() -> int {  // x += to_out(ws.ao); x += FF(x) in one launch
     FusedOutFFP f;
-    f.x = x; f.M = M; f.C = C; f.ao = ws.ao; f.wfrag = pw.w_outff_frag[prec]; f.b1 = pw.b_ff1; f.b2 = pw.b_ff2;
-    f.xb = out_shadow; f.abl = 0;
-    LAUNCH_CAT(CAT_FF_FUSED, s, launch_outff_fused(f, prec, s), "fused out-projection + feed-forward");
+    f.x = x; f.M = M; f.C = C; f.ao = ws.ao; f.wfrag = f2x3 ? pw.w_outff_frag_x3 : pw.w_outff_frag[prec];
+    f.b1 = pw.b_ff1; f.b2 = pw.b_ff2; f.xb = out_shadow; f.abl = 0;
+    LAUNCH_CAT(CAT_FF_FUSED, s, launch_outff_fused(f, f2x3 ? BT_PREC_F32X3 : prec, s), "fused out-projection + feed-forward");
     return BT_OK;
   };
   if (mode == 1 && fused2_ok) {  // whole frequency-direction half (attention + FF) in one register-resident kernel
     FusedAttnFFP f;
-    f.x = x; f.M = M; f.C = C; f.b_gates = pw.b_gates; f.rope = rope; f.wfrag = pw.w_attnff_frag[prec];
-    f.b1 = pw.b_ff1; f.b2 = pw.b_ff2;
-    LAUNCH_CAT(CAT_ATTN_FREQ_FUSED, s, launch_attnff_fused(f, prec, s), "fused frequency attention + feed-forward");
+    f.x = x; f.M = M; f.C = C; f.b_gates = pw.b_gates; f.rope = rope;
+    f.wfrag = f2x3 ? pw.w_attnff_frag_x3 : pw.w_attnff_frag[prec]; f.b1 = pw.b_ff1; f.b2 = pw.b_ff2;
+    LAUNCH_CAT(CAT_ATTN_FREQ_FUSED, s, launch_attnff_fused(f, f2x3 ? BT_PREC_F32X3 : prec, s),
+               "fused frequency attention + feed-forward");
     return BT_OK;
   }
   if (mode == 1)  // (pack.py always supplies the fused-half weight streams for the frontend's pairs)
@@ -670,20 +673,22 @@ int bt_attention(void* stream, int prec, const bt_attn_args* a) {
 }
 
 int bt_outff_fused(void* stream, int prec, const bt_pair_weights* w, const void* d_ao, float* d_x, int64_t M) {
-  if (!w || !d_ao || !d_x || M <= 0 || w->dim > 128 || !w->w_outff_frag[prec])
-    return bt_set_error(BT_ERR_ARG, "bad argument to bt_outff_fused");
+  if (prec != BT_PREC_F32 && prec != BT_PREC_HALF && prec != BT_PREC_F32X3) return bt_set_error(BT_ERR_ARG, "unknown precision");
+  const void* wf = !w ? nullptr : prec == BT_PREC_F32X3 ? w->w_outff_frag_x3 : w->w_outff_frag[prec];
+  if (!w || !d_ao || !d_x || M <= 0 || w->dim > 128 || !wf) return bt_set_error(BT_ERR_ARG, "bad argument to bt_outff_fused");
   FusedOutFFP f;
-  f.x = d_x; f.M = M; f.C = w->dim; f.ao = d_ao; f.wfrag = w->w_outff_frag[prec]; f.b1 = w->b_ff1; f.b2 = w->b_ff2;
+  f.x = d_x; f.M = M; f.C = w->dim; f.ao = d_ao; f.wfrag = wf; f.b1 = w->b_ff1; f.b2 = w->b_ff2;
   f.xb = nullptr; f.abl = 0;
   LAUNCH(launch_outff_fused(f, prec, (hipStream_t)stream), "fused out-projection + feed-forward");
   return BT_OK;
 }
 
 int bt_attnff_fused(void* stream, int prec, const bt_pair_weights* w, const float* d_rope, float* d_x, int64_t M) {
-  if (!w || !d_x || !d_rope || M <= 0 || w->dim > 128 || !w->w_attnff_frag[prec])
-    return bt_set_error(BT_ERR_ARG, "bad argument to bt_attnff_fused");
+  if (prec != BT_PREC_F32 && prec != BT_PREC_HALF && prec != BT_PREC_F32X3) return bt_set_error(BT_ERR_ARG, "unknown precision");
+  const void* wf = !w ? nullptr : prec == BT_PREC_F32X3 ? w->w_attnff_frag_x3 : w->w_attnff_frag[prec];
+  if (!w || !d_x || !d_rope || M <= 0 || w->dim > 128 || !wf) return bt_set_error(BT_ERR_ARG, "bad argument to bt_attnff_fused");
   FusedAttnFFP f;
-  f.x = d_x; f.M = M; f.C = w->dim; f.b_gates = w->b_gates; f.rope = d_rope; f.wfrag = w->w_attnff_frag[prec];
+  f.x = d_x; f.M = M; f.C = w->dim; f.b_gates = w->b_gates; f.rope = d_rope; f.wfrag = wf;
   f.b1 = w->b_ff1; f.b2 = w->b_ff2;
   LAUNCH(launch_attnff_fused(f, prec, (hipStream_t)stream), "fused frequency attention + feed-forward");
   return BT_OK;

@@ -104,7 +104,8 @@ DEVI void ff_tail(WRing<T, C>& ws, int step0, float (&xn)[C / 32][16], const flo
 #pragma unroll
     for (int r = 0; r < 16; ++r) ss = fmaf(xn[kt][r], xn[kt][r], ss);
   ss += __shfl_xor(ss, 32);
-  const float scale = sqrtf((float)C) / fmaxf(sqrtf(ss), 1e-12f);
+  constexpr float PW = OpScale<T>::PW;   // (1 unless T = hl: products of pre-scaled operands are scaled back where consumed)
+  const float scale = sqrtf((float)C) / fmaxf(sqrtf(ss), 1e-12f) * PW;
   Frag<T> xf[KT];
 #pragma unroll
   for (int kt = 0; kt < KT; ++kt) xf[kt] = pack_frag<T>(xn[kt]);
@@ -112,7 +113,7 @@ DEVI void ff_tail(WRing<T, C>& ws, int step0, float (&xn)[C / 32][16], const flo
 #pragma unroll
   for (int mt = 0; mt < KT; ++mt)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc2[mt][r] = xn[mt][r];
+    for (int r = 0; r < 16; ++r) acc2[mt][r] = xn[mt][r] * (1.f / PW);
 #pragma unroll 1
   for (int hb = 0; hb < HB; ++hb) {
     const char* wb = ws.acquire(step0 + hb);
@@ -139,7 +140,7 @@ DEVI void ff_tail(WRing<T, C>& ws, int step0, float (&xn)[C / 32][16], const flo
       const int f0 = mt * 32 + 8 * a + 4 * g;
       const f32x4 b = *reinterpret_cast<const f32x4*>(b2 + f0);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) v[a][j] = acc2[mt][4 * a + j] + b[j];
+      for (int j = 0; j < 4; ++j) v[a][j] = fmaf(acc2[mt][4 * a + j], PW, b[j]);
       if (ok) *reinterpret_cast<f32x4*>(xrow + f0) = v[a];
     }
     if (xbrow) {  // half shadow: the two halves of the wave exchange 4-feature runs so that a lane stores 16 bytes
@@ -205,7 +206,7 @@ __global__ __launch_bounds__(256) void outff_fused_kernel(const FusedOutFFP p) {
 #pragma unroll
     for (int kt = 0; kt < KT; ++kt) mma32(acc, lds_frag<T>(wb + kt * TILE_B, lane), af[kt]);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) xn[mt][r] += acc[r];
+    for (int r = 0; r < 16; ++r) xn[mt][r] = fmaf(acc[r], OpScale<T>::PW, xn[mt][r]);
   }
   hf* xbrow = p.xb ? reinterpret_cast<hf*>(p.xb) + tok * C : nullptr;
   ff_tail<T, C>(ws, KT, xn, b1s, p.b2, xrow, xbrow, ok_st, lane, g);
@@ -239,7 +240,8 @@ __global__ __launch_bounds__(256) void attnff_fused_kernel(const FusedAttnFFP p)
 #pragma unroll
   for (int kt = 0; kt < KT; ++kt) xf[kt] = ldx_frag<T>(xrow + kt * 32 + 16 * g, ok, ss);
   ss += __shfl_xor(ss, 32);
-  const float scale = sqrtf((float)C) / fmaxf(sqrtf(ss), 1e-12f);
+  constexpr float PW = OpScale<T>::PW, PA = OpScale<T>::PA;  // (1 unless T = hl, see common.h)
+  const float scale = sqrtf((float)C) / fmaxf(sqrtf(ss), 1e-12f) * PW;   // (every use multiplies a weight . activation product)
   // RMSNorm factors of the 16 tokens whose V rows this lane holds (register r <-> token crow(r,g))
   float sk[16];
 #pragma unroll
@@ -316,6 +318,7 @@ __global__ __launch_bounds__(256) void attnff_fused_kernel(const FusedAttnFFP p)
       float mx = -1e30f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
+        sc[r] *= PA;
         if (F < 32 && ((crow(r, g) ^ lr) & ~(F - 1))) sc[r] = -1e30f;  // key and query in different rows
         mx = fmaxf(mx, sc[r]);
       }
@@ -340,7 +343,7 @@ __global__ __launch_bounds__(256) void attnff_fused_kernel(const FusedAttnFFP p)
       f32x16 ao;
       zero16(ao);
       mma32(ao, pack_frag<T>(v), pack_frag<T>(pr));
-      const float fin = gate[hd] / l;
+      const float fin = gate[hd] / l * PA;
       float o[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) o[r] = ao[r] * fin;
@@ -366,7 +369,7 @@ __global__ __launch_bounds__(256) void attnff_fused_kernel(const FusedAttnFFP p)
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) xn[mt][4 * a + j] = xv[mt][a][j] + acco[mt][4 * a + j];
+      for (int j = 0; j < 4; ++j) xn[mt][4 * a + j] = fmaf(acco[mt][4 * a + j], PW, xv[mt][a][j]);
   const long long t_ff = dbg ? clock64() : 0;
   ff_tail<T, C>(ws, 1 + 2 * H, xn, b1s, p.b2, xrow, nullptr, ok, lane, g);
   if (dbg && lane == 0) {
@@ -414,9 +417,11 @@ int launch_outff_fused(const FusedOutFFP& p0, int prec, hipStream_t s) {
   static const int abl = getenv("BT_F2_ABL") ? atoi(getenv("BT_F2_ABL")) : 0;
   p.abl = abl;
 #endif
+  if (prec == BT_PREC_F32X3) return BT_HALF_IS_BF16 ? -2 : launch_outff_t<hl>(p, s);
   return prec == BT_PREC_F32 ? launch_outff_t<float>(p, s) : launch_outff_t<hf>(p, s);
 }
 int launch_attnff_fused(const FusedAttnFFP& p, int prec, hipStream_t s) {
   if (p.M <= 0) return -2;
+  if (prec == BT_PREC_F32X3) return BT_HALF_IS_BF16 ? -2 : launch_attnff_t<hl>(p, s);
   return prec == BT_PREC_F32 ? launch_attnff_t<float>(p, s) : launch_attnff_t<hf>(p, s);
 }

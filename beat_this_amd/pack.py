@@ -166,6 +166,17 @@ class PackedModel:
         self._keep.append(t)
         return t.data_ptr()
 
+    def _x3_stream(self, flat: torch.Tensor) -> int:
+        """BT_PREC_F32X3 form of a half fragment stream (fp32 values in half-fragment order, whole 32 x 32 tiles): the
+        weights times 64 (csrc/common.h: OpScale -- keeps the lo halves normal fp16 numbers), per tile the hi half tile
+        followed by the lo half tile (64 w = hi + lo to 2^-22)."""
+        flat = flat * 64.0
+        hi = flat.to(torch.float16)
+        lo = (flat - hi.to(torch.float32)).to(torch.float16)
+        t = torch.cat([hi.reshape(-1, 1024), lo.reshape(-1, 1024)], 1).reshape(-1).to(self.device)
+        self._keep.append(t)
+        return t.data_ptr()
+
     def _mat(self, w: torch.Tensor):
         """[N padded to 128][K] fp32 and half copies of a GEMM weight; the half copy is followed by its lo part
         (w - half(w), again in half): BT_PREC_F32X3 multiplies hi + lo, the half path reads the hi part only."""
@@ -208,9 +219,12 @@ class PackedModel:
                 ot = fragment_tiles(wo)                                   # [mt, kt, 64, 16]
                 ot = ot.reshape(ot.shape[0], ot.shape[1], 64, 16 // epp, epp).permute(0, 1, 3, 2, 4)
                 ot = torch.cat([ot, torch.zeros_like(ot)], 1).reshape(-1)  # every step is 2 KT tiles: pad with zeros
-                t = torch.cat([ot, ff_fragment_major(w1p, w2p, epp)]).to(dt).to(self.device)
+                flat = torch.cat([ot, ff_fragment_major(w1p, w2p, epp)])
+                t = flat.to(dt).to(self.device)
                 self._keep.append(t)
                 pw.w_outff_frag[i] = t.data_ptr()
+                if i == 1 and dt == torch.float16:
+                    pw.w_outff_frag_x3 = self._x3_stream(flat)
                 # fused frequency-direction half: [gates | pad], per head [q | k] [v | outp tiles], FF steps
                 kt = dim // 32
 
@@ -223,9 +237,12 @@ class PackedModel:
                 for hd in range(heads):
                     steps += [pieces(qt[hd]), pieces(qt[heads + hd]), pieces(qt[2 * heads + hd]), pieces(opt[:, hd])]
                 steps.append(ff_fragment_major(w1p, w2p, epp))
-                t = torch.cat(steps).to(dt).to(self.device)
+                flat = torch.cat(steps)
+                t = flat.to(dt).to(self.device)
                 self._keep.append(t)
                 pw.w_attnff_frag[i] = t.data_ptr()
+                if i == 1 and dt == torch.float16:
+                    pw.w_attnff_frag_x3 = self._x3_stream(flat)
         gf = sd[pf + "net.0.gamma"]
         pw.w_ff1[0], pw.w_ff1[1] = self._mat(sd[pf + "net.1.weight"] * gf[None, :])
         pw.b_ff1 = self._f32(sd[pf + "net.1.bias"])
@@ -262,6 +279,7 @@ class PackedPair:
     _f32 = PackedModel._f32
     _mat = PackedModel._mat
     _e4m3 = PackedModel._e4m3
+    _x3_stream = PackedModel._x3_stream
 
 
 class Engine:

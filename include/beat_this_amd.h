@@ -93,6 +93,10 @@ typedef struct {
    * (net.1.weight * FF gamma) rows 32 j .. (k columns PERM32-ordered), B(j) = the dim/32 row tiles of net.4.weight's
    * columns 32 j .. (PERM32-ordered inside the block); halves that do not exist (j < 0, j >= hidden/32) are zero tiles. */
   const void* w_tail_frag;
+  /* BT_PREC_F32X3 forms of w_outff_frag / w_attnff_frag: the half fragment stream of 64 x the weight's hi part and of
+   * its lo part, interleaved per 32 x 32 tile ([hi tile 2 KB | lo tile 2 KB]).  NULL: the fp32 kernels run instead. */
+  const void* w_outff_frag_x3;
+  const void* w_attnff_frag_x3;
 } bt_pair_weights;
 
 /* Packed BeatThis weights (beat_tracker.py:38-106).  Host-side packing is done by
