@@ -36,7 +36,8 @@ extern "C" {
                         * hi + lo halves (a = hi + lo to 2^-22), a.b ~ hi.hi + hi.lo + lo.hi, fp32 accumulate -- 16/3 times
                         * the fp32 matrix rate at fp32-class accuracy.  Needs the half weight arrays to be followed by their
                         * lo parts (beat_this_amd/pack.py: [hi | lo], each [N padded to 128][K]); IEEE fp16 builds only.
-                        * Attention and the register-chained frontend halves stay on fp32 MFMAs. */
+                        * The attention (both products) and, when bt_pair_weights.w_*_frag_x3 are set, the register-chained
+                        * frontend halves run the same way; stem, head and every reduction stay fp32. */
 
 #define BT_MAX_LAYERS 32
 
