@@ -170,6 +170,18 @@ def build(force: bool = False, verbose: bool = False, lib_path: str | None = Non
     # instruction on gfx950 against 2 x 1.8 for the scalar forms (tools/ubench/valu_rates.hip); without the pairing the
     # forward is 3.7 % faster (frequency-direction fused halves 0.43 -> 0.32 ms), A/B on one box with tools/ab.sh
     common = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
+    # Objects are only comparable when they were compiled with the same switches (-DBT_HALF_BF16 objects linked next to fp16
+    # ones give silently wrong results): the flags and defines of a build are hashed into a stamp file in obj_dir, and a
+    # stamp that differs (or is missing) forces a full rebuild.
+    import hashlib
+
+    stamp_path = os.path.join(obj_dir, "flags.stamp")
+    stamp = hashlib.sha256(repr((common[1:], HIPCC_FLAGS, sorted(FLAGS_BY_SOURCE.items()), EXTRA_DEFINES, list(defines))).encode()).hexdigest()
+    try:
+        if open(stamp_path).read().strip() != stamp:
+            force = True
+    except OSError:
+        force = True
     todo, objs = [], []
     for name in SOURCES:
         src = os.path.join(src_dir, name)
@@ -180,6 +192,8 @@ def build(force: bool = False, verbose: bool = False, lib_path: str | None = Non
     if not todo and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(o) for o in objs):
         return LIB_PATH
     os.makedirs(obj_dir, exist_ok=True)
+    if os.path.exists(stamp_path):
+        os.unlink(stamp_path)   # (a build that dies half way leaves no stamp: the next one starts over)
 
     def compile_one(job):
         flags = FLAGS_BY_SOURCE.get(os.path.basename(job[0]), HIPCC_FLAGS)
@@ -200,6 +214,8 @@ def build(force: bool = False, verbose: bool = False, lib_path: str | None = Non
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)
+    with open(stamp_path, "w") as f:
+        f.write(stamp + "\n")
     return LIB_PATH
 
 

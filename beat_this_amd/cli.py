@@ -29,7 +29,7 @@ OPTIONS = (
                                    "processes can share one file set")),
     (("--dbn",), dict(default=False, action=argparse.BooleanOptionalAction, help="madmom DBN post-processing")),
     (("--gpu",), dict(type=int, default=0, help="index of the GPU to use (default: %(default)s)")),
-    (("--float16",), dict(action="store_true", help="bf16-MFMA path (float16=True of the Python API)")),
+    (("--float16",), dict(action="store_true", help="half-precision path: fp16 MFMA operands, fp32 accumulation (float16=True of the Python API)")),
     (("--activations",), dict(action="store_true", help="also save the raw logits as .npy")),
 )
 

@@ -4,7 +4,7 @@ Same constructor signature, same ``state_dict`` keys (so reference checkpoints l
 ``load_state_dict``), same ``forward(x: (B,T,128)) -> {"beat": (B,T), "downbeat": (B,T)}``;
 the arithmetic runs in the hand-written HIP kernels of libbeat_this_amd.so.  Precision
 follows the caller exactly like the reference: under ``torch.autocast`` (what
-``Spect2Frames(float16=True)`` enters, inference.py:246) the bf16-MFMA path runs, otherwise
+``Spect2Frames(float16=True)`` enters, inference.py:246) the half-precision (fp16 MFMA operand) path runs, otherwise
 the exact-fp32 MFMA path.  There is no CPU implementation here.
 """
 from __future__ import annotations

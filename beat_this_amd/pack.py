@@ -5,6 +5,7 @@ frontend.linear weights to the (b, t, f, c) activation layout, pad N to 128 rows
 fp32 and a half-precision (fp16, or bf16 in a -DBT_HALF_BF16 build) device copy of every matrix.  One-time host work (torch CPU ops)."""
 from __future__ import annotations
 
+import collections
 import ctypes as C
 import math
 
@@ -36,7 +37,7 @@ def fragment_tiles(w: torch.Tensor) -> torch.Tensor:
 def ff_fragment_major(w1: torch.Tensor, w2p: torch.Tensor, elem_per_piece: int) -> torch.Tensor:
     """Fragment-major FF weights for ff_fused_kernel: per hidden block hb, KT tiles of W1 then KT tiles of
     PERM32'd W2; inside a tile the 16 elements of a lane are split into pieces of ``elem_per_piece``
-    (8 for bf16 = one 16-byte read, 4 for fp32) stored piece-major: [piece][lane][elem]."""
+    (8 for half = one 16-byte read, 4 for fp32) stored piece-major: [piece][lane][elem]."""
     dim = w1.shape[1]
     kt = dim // 32
     t1 = fragment_tiles(w1)                      # [HB, KT, 64, 16]
@@ -48,7 +49,7 @@ def ff_fragment_major(w1: torch.Tensor, w2p: torch.Tensor, elem_per_piece: int) 
 
 
 def qkv_fragment_major(w: torch.Tensor, dim: int) -> torch.Tensor:
-    """bf16 QKV+gate weights for qkv_front_kernel: ``w`` = [3 dim + heads (padded to >= 3 dim + 32), dim];
+    """half-precision QKV+gate weights for qkv_front_kernel: ``w`` = [3 dim + heads (padded to >= 3 dim + 32), dim];
     per head the k-tiles of its q, k, v row blocks, then the k-tiles of the gate row block; a tile is
     [half h][lane][8] (see fragment_tiles)."""
     heads = dim // 32
@@ -291,7 +292,15 @@ class Engine:
         h = C.c_void_p()
         _lib.check(_lib.lib().bt_engine_create(C.byref(packed.desc), C.byref(h)))
         self._h = h
-        self._ws = {}   # one workspace per stream: the C ABI's workspace belongs to ONE stream at a time
+        # One workspace per stream (the C ABI's workspace belongs to ONE stream at a time), keyed by the torch Stream
+        # (torch hands out its streams from a fixed pool, so equal keys are the same HIP stream, and a workspace is
+        # allocated under the stream that uses it: the caching allocator's stream-ordered reuse covers its release).  At
+        # most MAX_WORKSPACES are kept (least recently used goes first: callers that cycle through many streams do not
+        # leak one workspace each), and a workspace far larger than the current need (> 4x) is dropped instead of
+        # pinning e.g. 6.7 GB of a past 96-chunk fp32 batch for the engine's lifetime.
+        # Footprint: ~66 MB (fp32) / ~45 MB (half) per chunk and stream; inference.py runs slices of <= 96 chunks
+        # (MAX_CHUNKS_PER_LAUNCH) on the caller's stream + CONCURRENT_STREAMS side streams.
+        self._ws = collections.OrderedDict()
 
     def __del__(self):
         try:
@@ -300,6 +309,20 @@ class Engine:
                 self._h = None
         except Exception:
             pass
+
+    MAX_WORKSPACES = 4
+
+    def _workspace(self, need: int) -> torch.Tensor:
+        key = torch.cuda.current_stream(self.device)
+        ws = self._ws.pop(key, None)
+        if ws is not None and (ws.numel() < need or ws.numel() > 4 * need):
+            ws = None
+        if ws is None:
+            ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        self._ws[key] = ws            # (most recently used last)
+        while len(self._ws) > self.MAX_WORKSPACES:
+            self._ws.popitem(last=False)
+        return ws
 
     def forward(self, spect: torch.Tensor, prec: int):
         """spect: (B, T, 128) fp32 on the engine's device -> (beat, downbeat) fp32 (B, T)."""
@@ -317,11 +340,7 @@ class Engine:
         need = _lib.lib().bt_workspace_bytes(self._h, B, T, prec)
         if need == 0:
             raise ValueError("empty batch")
-        key = _lib.stream_ptr(self.device)
-        ws = self._ws.get(key)
-        if ws is None or ws.numel() < need:
-            self._ws.pop(key, None)
-            ws = self._ws[key] = torch.empty(need, dtype=torch.uint8, device=self.device)
+        ws = self._workspace(need)
         beat = down = out = None
         if last == 2:
             beat = torch.empty((B, T), dtype=torch.float32, device=self.device)

@@ -128,7 +128,14 @@ def audio2frames_sharded(signals, sr, frames_fn, group=None, device=None):
         beat, down, off = frames_fn(mine)
         dev = beat.device
     else:
-        dev = torch.device(device) if device is not None else torch.device("cpu")
+        # (an empty block -- fewer tracks than ranks -- still takes part in the collective, on the device the backend moves:
+        # a CPU tensor handed to an RCCL group errors out or hangs the other ranks)
+        if device is not None:
+            dev = torch.device(device)
+        elif distributed and dist.get_backend(group) == "nccl":
+            dev = torch.device("cuda", torch.cuda.current_device())
+        else:
+            dev = torch.device("cpu")
         beat = down = torch.zeros(0, device=dev)
     local = torch.zeros((2, width), dtype=torch.float32, device=dev)
     local[0, : beat.shape[0]], local[1, : down.shape[0]] = beat.float(), down.float()

@@ -80,7 +80,7 @@ def pad_rows(w, mult=128):
 
 # ---- fragment-major attention operands (csrc/attn2.hip) ---------------------------------------------
 def frag_qk(x, nbp):
-    """[SH, L, 32] -> bf16 [SH, nbp, 4 (quarter), 32 (token), 8]"""
+    """[SH, L, 32] -> half [SH, nbp, 4 (quarter), 32 (token), 8]"""
     SH, L, _ = x.shape
     pad = torch.zeros((SH, nbp * 32, 32), dtype=x.dtype)
     pad[:, :L] = x
@@ -93,7 +93,7 @@ def unfrag_qk(fr, L):
 
 
 def frag_v(x, nbp):
-    """[SH, L, 32] -> bf16 [SH, nbp, 2 (s), 2 (g), 32 (d), 8]; token = 16 s + 8 (j >> 2) + 4 g + (j & 3)"""
+    """[SH, L, 32] -> half [SH, nbp, 2 (s), 2 (g), 32 (d), 8]; token = 16 s + 8 (j >> 2) + 4 g + (j & 3)"""
     SH, L, _ = x.shape
     pad = torch.zeros((SH, nbp * 32, 32), dtype=x.dtype)
     pad[:, :L] = x

@@ -1,4 +1,4 @@
-"""Parity of the fragment-major bf16 attention path on the MI355X (csrc/attn2.hip, csrc/qkv_front.hip)
+"""Parity of the fragment-major half-precision attention path on the MI355X (csrc/attn2.hip, csrc/qkv_front.hip)
 against float64 torch restatements of roformer.py:83-132: attention on pre-arranged operands (all
 sequence-length edge cases, the time-direction row scatter, the overflow fallback), and the frontend's
 time-direction QKV projection producing those operands."""
@@ -28,7 +28,7 @@ def _attn_ref(q, k, v, gates):
 
 
 def _run(q, k, v, gates, n_seq, L, heads, **omap):
-    """q, k, v: [SH, L, 32] float64 (already bf16-representable); gates [SH, L]."""
+    """q, k, v: [SH, L, 32] float64 (already representable in the half type); gates [SH, L]."""
     from beat_this_amd import _lib as Lb
 
     nbp = Lb.lib().bt_attn_frag_blocks(L)

@@ -1,5 +1,5 @@
-"""Parity of the main-layer bf16 GEMM (csrc/gemm3.hip) on the MI355X against float64 torch restatements:
-FF1 (RMSNorm factor from partial sums of squares + bias + GELU), residual update (+ bf16 shadow + partial sums
+"""Parity of the main-layer half-precision GEMM (csrc/gemm3.hip) on the MI355X against float64 torch restatements:
+FF1 (RMSNorm factor from partial sums of squares + bias + GELU), residual update (+ half shadow + partial sums
 of squares for the next RMSNorm), and the QKV projection with RoPE / gates written fragment-major."""
 import ctypes as C
 import math
@@ -240,11 +240,11 @@ def test_gemm3_f8_hidden_saturates_instead_of_overflowing():
     assert torch.all(dec[:, 1::2] == 448.0) and torch.all(dec[:, 0::2].abs() < 1e-3)
 
 
-@pytest.mark.parametrize("B,T,Fp,C2,N,bf16_out", [(2, 50, 8, 128, 128, False), (1, 33, 4, 256, 256, True), (3, 7, 16, 64, 128, False),
+@pytest.mark.parametrize("B,T,Fp,C2,N,half_out", [(2, 50, 8, 128, 128, False), (1, 33, 4, 256, 256, True), (3, 7, 16, 64, 128, False),
                                                    (2, 40, 16, 64, 64, False)])
-def test_gemm3_frontend_conv(B, T, Fp, C2, N, bf16_out):
-    """epi 1 as the (2,3) / stride (2,1) frontend convolution on the bf16 (b, t, f, c) activation: three time taps gathered
-    by the LDS-DMA loader (zero rows outside 0 <= t < T), bias, tanh-form GELU; fp32 or bf16 output."""
+def test_gemm3_frontend_conv(B, T, Fp, C2, N, half_out):
+    """epi 1 as the (2,3) / stride (2,1) frontend convolution on the half (b, t, f, c) activation: three time taps gathered
+    by the LDS-DMA loader (zero rows outside 0 <= t < T), bias, tanh-form GELU; fp32 or half output."""
     M, K = B * T * Fp, 3 * C2
     x = _mk((M, C2), 71).float().to(HALF())               # row m = (b, t, f'), C2 = 2 C channels of the frequency pair
     W = _mk((N, K), 72, 1 / math.sqrt(K)).float().to(HALF())
@@ -252,13 +252,13 @@ def test_gemm3_frontend_conv(B, T, Fp, C2, N, bf16_out):
     out = torch.full((M, N), float("nan"), dtype=torch.float32, device=dev())
     outb = torch.zeros((M, N), dtype=HALF(), device=dev())
     _call(A=x.to(dev()), lda=C2, M=M, K=K, W=pad_rows(W).to(dev()), N=N, epi=1, bias=b.float().to(dev()),
-          x=0 if bf16_out else out, ldx=N, xb=outb if bf16_out else 0, no_resid=1, gelu=1, conv_C2=C2, conv_T=T, conv_F=Fp)
+          x=0 if half_out else out, ldx=N, xb=outb if half_out else 0, no_resid=1, gelu=1, conv_C2=C2, conv_T=T, conv_F=Fp)
     xd = x.double().view(B, T, Fp, C2)
     xp = torch.zeros((B, T + 2, Fp, C2), dtype=torch.float64)
     xp[:, 1:-1] = xd
     Wd = W.double()
     acc = sum(xp[:, dt:dt + T].reshape(M, C2) @ Wd[:, dt * C2:(dt + 1) * C2].T for dt in range(3))
     ref = torch.nn.functional.gelu(acc + b)  # exact GELU: the kernel's fitted sigmoid form is within 2.6e-5 of it (common.h)
-    err = _rel(outb if bf16_out else out, ref)
+    err = _rel(outb if half_out else out, ref)
     report("gemm3_frontend_conv", B=B, T=T, Fp=Fp, C2=C2, N=N, rel=err)
-    assert err < (5e-3 if bf16_out else 4e-5)
+    assert err < (5e-3 if half_out else 4e-5)

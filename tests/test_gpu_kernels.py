@@ -227,8 +227,8 @@ def test_fused_ff(prec, C):
 
 
 @pytest.mark.parametrize("M,K,N", [(1500, 128, 512), (700, 512, 2048), (1500, 128, 128)])
-def test_gemm2_bf16_A_with_rms(M, K, N):
-    """Wide bf16 GEMM reading the bf16 shadow of the residual stream: RMSNorm factor from the bf16 operands."""
+def test_gemm2_half_A_with_rms(M, K, N):
+    """Wide half-precision GEMM reading the half shadow of the residual stream: RMSNorm factor from the half operands."""
     from beat_this_amd import _lib as L
 
     A, W, b = _mk((M, K), 90, 3.0), _mk((N, K), 91, 1 / math.sqrt(K)), _mk((N,), 92)
@@ -241,12 +241,12 @@ def test_gemm2_bf16_A_with_rms(M, K, N):
     xn = Ad / Ad.norm(dim=-1, keepdim=True).clamp_min(1e-12) * math.sqrt(K)
     ref = torch.nn.functional.gelu(xn @ Wd[:N].double().cpu().T + b)
     err = _rel(out, ref)
-    report("gemm2_bf16A_rms", M=M, K=K, N=N, rel=err)
+    report("gemm2_halfA_rms", M=M, K=K, N=N, rel=err)
     assert err < 6e-3
 
 
 def test_gemm2_resid_writes_shadow():
-    """EPI_RESID in the wide kernel also emits the bf16 shadow of the updated residual stream (bt_gemm has no
+    """EPI_RESID in the wide kernel also emits the half shadow of the updated residual stream (bt_gemm has no
     shadow argument, so this checks the fp32 result only; the shadow is covered end to end by the model tests)."""
     from beat_this_amd import _lib as L
 

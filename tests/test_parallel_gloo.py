@@ -81,7 +81,7 @@ def _tracks():
     return [torch.full((m,), float(i + 1)) for i, m in enumerate((22050 * 7, 441 * 30 + 5, 22050 * 3, 5000, 22050 * 11))]
 
 
-def _track_worker(rank, world, port, q):
+def _track_worker(rank, world, port, q, n_tracks=None):
     import sys
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -89,7 +89,7 @@ def _track_worker(rank, world, port, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from beat_this_amd.parallel import audio2frames_sharded
 
-    res = audio2frames_sharded(_tracks(), 22050, _fake_frames)
+    res = audio2frames_sharded(_tracks()[:n_tracks], 22050, _fake_frames)
     q.put((rank, [(b.numpy(), d.numpy()) for b, d in res]))
     dist.barrier()
     dist.destroy_process_group()
@@ -116,6 +116,28 @@ def test_track_sharding_two_ranks_matches_single_process():
     for r in range(2):
         for (b, d), (sb, sd_) in zip(got[r], single):
             assert np.array_equal(b, sb.numpy()) and np.array_equal(d, sd_.numpy())
+
+
+@pytest.mark.timeout(120)
+def test_track_sharding_with_fewer_tracks_than_ranks():
+    """One track on two ranks: rank 1's block is empty, it still joins the collective (with zeros on the backend's device)
+    and every rank gets the track's logits."""
+    from beat_this_amd.parallel import audio2frames_sharded
+
+    single = audio2frames_sharded(_tracks()[:1], 22050, _fake_frames)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_track_worker, args=(r, 2, port, q, 1)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=100) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in range(2):
+        assert len(got[r]) == 1
+        assert np.array_equal(got[r][0][0], single[0][0].numpy()) and np.array_equal(got[r][0][1], single[0][1].numpy())
 
 
 def test_partition_covers_everything():
