@@ -22,7 +22,7 @@ SOURCES = ["gemm.hip", "gemm2.hip", "gemm3.hip", "attn.hip", "attn2.hip", "fused
 HEADERS = ["common.h", "chain.h", "kernels.h", os.path.join("..", "..", "include", "beat_this_amd.h")]
 
 BT_OK, BT_ERR_ARG, BT_ERR_HIP, BT_ERR_WORKSPACE = 0, -1, -2, -3
-PREC_F32, PREC_HALF, PREC_FP8, PREC_F32X3 = 0, 1, 2, 3
+PREC_F32, PREC_HALF, PREC_F32X3 = 0, 1, 3   # (2 was the withdrawn e4m3 experiment)
 MAX_LAYERS = 32
 PROFILE_CATEGORIES = ["stem", "qkv_gemm", "attn_freq", "attn_flash", "out_gemm", "ff1_gemm", "ff2_gemm", "conv_gemm",
                       "linear_gemm", "head", "ff_fused", "attn_freq_fused", "layer_tail"]
@@ -37,9 +37,10 @@ class PairWeights(C.Structure):
                 ("w_ff2", C.c_void_p * 2), ("b_ff2", C.c_void_p), ("w_outp", C.c_void_p * 2),
                 ("w_ff_frag", C.c_void_p * 2), ("w_qkv_frag", C.c_void_p),
                 ("w_outff_frag", C.c_void_p * 2), ("w_attnff_frag", C.c_void_p * 2),
-                ("w_ff1_f8", C.c_void_p), ("s_ff1", C.c_void_p), ("w_ff2_f8", C.c_void_p), ("s_ff2", C.c_void_p),
-                ("b_ff2_f8", C.c_void_p), ("w_tail_frag", C.c_void_p),
-                ("w_outff_frag_x3", C.c_void_p), ("w_attnff_frag_x3", C.c_void_p)]
+                ("w_tail_frag", C.c_void_p),
+                ("w_outff_frag_x3", C.c_void_p), ("w_attnff_frag_x3", C.c_void_p),
+                ("w_qkvg_x3", C.c_void_p), ("w_out_x3", C.c_void_p), ("w_ff1_x3", C.c_void_p), ("w_ff2_x3", C.c_void_p),
+                ("w_qkv_frag_x3", C.c_void_p)]
 
 
 class ModelDesc(C.Structure):
@@ -51,7 +52,8 @@ class ModelDesc(C.Structure):
                 ("lin_w", C.c_void_p * 2), ("lin_b", C.c_void_p),
                 ("layers", PairWeights * MAX_LAYERS),
                 ("head_w", C.c_void_p), ("head_b", C.c_float * 2), ("rope", C.c_void_p), ("ff_mult", C.c_int32),
-                ("norm_out_g", C.c_void_p), ("head_w_raw", C.c_void_p)]
+                ("norm_out_g", C.c_void_p), ("head_w_raw", C.c_void_p),
+                ("conv_w_x3", C.c_void_p * 3), ("lin_w_x3", C.c_void_p)]
 
 
 class LogmelTables(C.Structure):
@@ -78,7 +80,7 @@ class AttnFragArgs(C.Structure):
     _fields_ = [("q", C.c_void_p), ("k", C.c_void_p), ("v", C.c_void_p), ("gates", C.c_void_p), ("out", C.c_void_p),
                 ("n_seq", C.c_int32), ("L", C.c_int32), ("heads", C.c_int32), ("inner", C.c_int32),
                 ("nbp", C.c_int32), ("o_div", C.c_int32), ("o_outer", C.c_int64), ("o_inner", C.c_int64),
-                ("o_tok", C.c_int64)]
+                ("o_tok", C.c_int64), ("x3", C.c_int32), ("out_f32", C.c_int32), ("status", C.c_void_p)]
 
 
 class Gemm3Args(C.Structure):
@@ -88,9 +90,8 @@ class Gemm3Args(C.Structure):
                 ("ldx", C.c_int64), ("xb", C.c_void_p), ("ssq_out", C.c_void_p), ("n_seq", C.c_int32),
                 ("L", C.c_int32), ("nbp", C.c_int32), ("heads", C.c_int32), ("rope", C.c_void_p), ("qf", C.c_void_p),
                 ("kf", C.c_void_p), ("vf", C.c_void_p), ("gates", C.c_void_p), ("b_gates", C.c_void_p),
-                ("f8", C.c_int32), ("wscale", C.c_void_p), ("ascale", C.c_void_p), ("x8", C.c_void_p),
-                ("ascale_out", C.c_void_p), ("no_resid", C.c_int32), ("gelu", C.c_int32), ("conv_C2", C.c_int32),
-                ("conv_T", C.c_int32), ("conv_F", C.c_int32)]
+                ("no_resid", C.c_int32), ("gelu", C.c_int32), ("conv_C2", C.c_int32),
+                ("conv_T", C.c_int32), ("conv_F", C.c_int32), ("x3", C.c_int32), ("status", C.c_void_p)]
 
 
 G3_FF1, G3_RESID, G3_QKV = 0, 1, 2
@@ -131,9 +132,9 @@ EXPORTS = {
     "bt_gemm3": (C.c_int, [C.c_void_p, C.POINTER(Gemm3Args)]),
     "bt_attn_frag_blocks": (C.c_int, [C.c_int]),
     "bt_attention_frag": (C.c_int, [C.c_void_p, C.POINTER(AttnFragArgs)]),
-    "bt_qkv_front": (C.c_int, [C.c_void_p, C.POINTER(PairWeights), C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+    "bt_qkv_front": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(PairWeights), C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
-    "bt_outff_fused": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(PairWeights), C.c_void_p, C.c_void_p, C.c_int64]),
+    "bt_outff_fused": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(PairWeights), C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "bt_attnff_fused": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(PairWeights), C.c_void_p, C.c_void_p, C.c_int64]),
     "bt_layer_tail": (C.c_int, [C.c_void_p, C.POINTER(PairWeights), C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
                                 C.c_void_p]),

@@ -491,6 +491,314 @@ __global__ __launch_bounds__(256, (QB == 1 ? 4 : 2)) void attn_frag_kernel(const
   }
 }
 
+
+// =====================================================================================================================
+// BT_PREC_F32X3: the same kernel design on hi + lo operands (fp32-class results, the path that carries the 1e-3 gate).
+// A 32-token block of Q, K or V is [hi block 2 KB | lo block 2 KB] (written by the X3 QKV producers: gemm3.hip,
+// qkv_front.hip): q = hi + lo to 2^-22.  Both products run on three MFMAs per fragment pair (lo . hi + hi . lo + hi . hi,
+// fp32 accumulation); the probabilities are split in registers after the exponential (P = hi + lo), their row sums are
+// plain fp32 adds of the unsplit values (the matrix pipe is the busy side here, the VALU has the slack), and the output
+// leaves as fp32 (frontend: consumed by outff_fused_kernel<hl>) or as hl32 planes (main layers: A operand of the
+// out-projection on gemm3.hip).  K / V tiles: 128 keys = 16 KB each, double buffered = 64 KB -> 2 workgroups per CU.
+constexpr int BLKX_BYTES = 2 * BLK_BYTES;
+constexpr int TILEX_BYTES = KB * BLKX_BYTES;
+constexpr int SMEMX_BYTES = 2 * 2 * TILEX_BYTES + 16;
+
+struct QStateX {
+  hfx8 q0, q1, q0l, q1l;  // Q^T operand (hi, lo): dims [16g, 16g+8) and [16g+8, 16g+16) of this lane's query
+  f32x16 negm;            // -m - P_SHIFT splat: accumulator input of the first score MFMA (fast pass)
+  f32x16 acc;             // O^T accumulator
+  float l;                // row sum of this lane's 16 keys per block (the two halves are added at the end)
+  float m;                // running max (SAFE pass) / reference max (fast pass)
+};
+struct KFragX { hfx8 k0, k1, k0l, k1l; };
+struct VFragX { hfx8 v0, v1, v0l, v1l; };
+DEVI KFragX ld_kx(const char* kb, int g, int lr) {
+  KFragX f;
+  f.k0 = *reinterpret_cast<const hfx8*>(kb + ((2 * g) * 32 + lr) * 16);
+  f.k1 = *reinterpret_cast<const hfx8*>(kb + ((2 * g + 1) * 32 + lr) * 16);
+  f.k0l = *reinterpret_cast<const hfx8*>(kb + BLK_BYTES + ((2 * g) * 32 + lr) * 16);
+  f.k1l = *reinterpret_cast<const hfx8*>(kb + BLK_BYTES + ((2 * g + 1) * 32 + lr) * 16);
+  return f;
+}
+DEVI VFragX ld_vx(const char* vb, int lane) {
+  VFragX f;
+  f.v0 = *reinterpret_cast<const hfx8*>(vb + lane * 16);
+  f.v1 = *reinterpret_cast<const hfx8*>(vb + 1024 + lane * 16);
+  f.v0l = *reinterpret_cast<const hfx8*>(vb + BLK_BYTES + lane * 16);
+  f.v1l = *reinterpret_cast<const hfx8*>(vb + BLK_BYTES + 1024 + lane * 16);
+  return f;
+}
+// 8 fp32 probabilities -> packed hi halves and packed lo halves (p = hi + lo)
+DEVI void split8(const f32x16& p, int s, u32x4& whi, u32x4& wlo) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float a = p[8 * s + 2 * j], b = p[8 * s + 2 * j + 1];
+    const hf ha = (hf)a, hb = (hf)b;
+    const hfx2 th = {ha, hb};
+    const hfx2 tl = {(hf)(a - (float)ha), (hf)(b - (float)hb)};
+    whi[j] = __builtin_bit_cast(unsigned int, th);
+    wlo[j] = __builtin_bit_cast(unsigned int, tl);
+  }
+}
+// scores of one key block: init + K . Q^T on three MFMA pairs, small terms last onto the running value
+template <int QB>
+DEVI void score_x(const KFragX& kf, const QStateX (&st)[QB], f32x16 (&sc)[QB], bool safe) {
+#pragma unroll
+  for (int j = 0; j < QB; ++j) {
+    if (safe) zero16(sc[j]); else sc[j] = st[j].negm;
+    sc[j] = MFMA32_H(kf.k0, st[j].q0, sc[j]);
+  }
+#pragma unroll
+  for (int j = 0; j < QB; ++j) sc[j] = MFMA32_H(kf.k1, st[j].q1, sc[j]);
+#pragma unroll
+  for (int j = 0; j < QB; ++j) sc[j] = MFMA32_H(kf.k0l, st[j].q0, sc[j]);
+#pragma unroll
+  for (int j = 0; j < QB; ++j) sc[j] = MFMA32_H(kf.k1l, st[j].q1, sc[j]);
+#pragma unroll
+  for (int j = 0; j < QB; ++j) sc[j] = MFMA32_H(kf.k0, st[j].q0l, sc[j]);
+#pragma unroll
+  for (int j = 0; j < QB; ++j) sc[j] = MFMA32_H(kf.k1, st[j].q1l, sc[j]);
+}
+// probabilities (already exponentiated, masked) of one key block: row sums, split, O^T += V^T . P^T
+template <int QB>
+DEVI void pv_x(f32x16 (&sc)[QB], const VFragX& vf, QStateX (&st)[QB]) {
+#pragma unroll
+  for (int j = 0; j < QB; ++j) {
+    const float a = (sc[j][0] + sc[j][1]) + (sc[j][2] + sc[j][3]), b = (sc[j][4] + sc[j][5]) + (sc[j][6] + sc[j][7]);
+    const float c = (sc[j][8] + sc[j][9]) + (sc[j][10] + sc[j][11]), d = (sc[j][12] + sc[j][13]) + (sc[j][14] + sc[j][15]);
+    st[j].l += (a + b) + (c + d);
+    u32x4 h0, l0, h1, l1;
+    split8(sc[j], 0, h0, l0);
+    split8(sc[j], 1, h1, l1);
+    st[j].acc = MFMA32_H(vf.v0l, __builtin_bit_cast(hfx8, h0), st[j].acc);
+    st[j].acc = MFMA32_H(vf.v1l, __builtin_bit_cast(hfx8, h1), st[j].acc);
+    st[j].acc = MFMA32_H(vf.v0, __builtin_bit_cast(hfx8, l0), st[j].acc);
+    st[j].acc = MFMA32_H(vf.v1, __builtin_bit_cast(hfx8, l1), st[j].acc);
+    st[j].acc = MFMA32_H(vf.v0, __builtin_bit_cast(hfx8, h0), st[j].acc);
+    st[j].acc = MFMA32_H(vf.v1, __builtin_bit_cast(hfx8, h1), st[j].acc);
+  }
+}
+template <bool SAFE, bool MASK, int QB>
+DEVI void finish_x(f32x16 (&sc)[QB], const VFragX& vf, int g, QStateX (&st)[QB], int key0, int L) {
+#pragma unroll
+  for (int j = 0; j < QB; ++j) {
+    if constexpr (SAFE) {
+      if constexpr (MASK) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (key0 + crow(r, g) >= L) sc[j][r] = -1e30f;
+      }
+      float bm = sc[j][0];
+#pragma unroll
+      for (int r = 1; r < 16; ++r) bm = fmaxf(bm, sc[j][r]);
+      bm = fmaxf(bm, __shfl_xor(bm, 32));
+      const float m_new = fmaxf(st[j].m, bm);
+      const float alpha = __builtin_amdgcn_exp2f(st[j].m - m_new);
+      st[j].m = m_new;
+      st[j].l *= alpha;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) st[j].acc[r] *= alpha;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sc[j][r] = __builtin_amdgcn_exp2f(sc[j][r] - m_new);
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sc[j][r] = __builtin_amdgcn_exp2f(sc[j][r]);
+      if constexpr (MASK) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (key0 + crow(r, g) >= L) sc[j][r] = 0.f;
+      }
+    }
+  }
+  pv_x<QB>(sc, vf, st);
+}
+
+DEVI void stage_tile_x(rsrc_t rk, rsrc_t rv, int tile, char* smem, int buf, int tid, int wave) {
+  char* kd = smem + buf * 2 * TILEX_BYTES + wave * 1024;
+  char* vd = kd + TILEX_BYTES;
+  const int so = tile * TILEX_BYTES;
+  static_assert(TILEX_BYTES == 16384, "stage_tile_x copies four 4 KB pieces per operand");
+#pragma unroll
+  for (int i = 0; i < 4; ++i) __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, (lptr_t)(kd + i * 4096), 16, tid * 16, so + i * 4096, 0, 0);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (lptr_t)(vd + i * 4096), 16, tid * 16, so + i * 4096, 0, 0);
+}
+
+// One pass over all keys.  Fast pass (SAFE = false): reference maximum from key block 0, scores of block c + 1 issued
+// before the exponentials of block c; SAFE: classic online softmax, unpipelined.  One barrier per 128-key tile.
+template <bool SAFE, int QB>
+DEVI void attn_pass_x(rsrc_t rk, rsrc_t rv, char* smem, int tid, int wave, int lane, int g, int lr, QStateX (&st)[QB], int L,
+                      int nblk) {
+  const int ntiles = (nblk + KB - 1) / KB;
+  const bool partial = (L & 31) != 0;
+  stage_tile_x(rk, rv, 0, smem, 0, tid, wave);
+  __syncthreads();
+  if (ntiles > 1) stage_tile_x(rk, rv, 1, smem, 1, tid, wave);
+#pragma unroll
+  for (int j = 0; j < QB; ++j) {
+    zero16(st[j].acc);
+    zero16(st[j].negm);
+    st[j].l = 0.f;
+    st[j].m = -1e30f;
+  }
+  if constexpr (!SAFE) {  // reference max of each query: its scores against key block 0
+    const KFragX k00 = ld_kx(smem, g, lr);
+    f32x16 sc[QB];
+    score_x<QB>(k00, st, sc, true);
+#pragma unroll
+    for (int j = 0; j < QB; ++j) {
+      float bm = -1e30f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) bm = fmaxf(bm, (crow(r, g) < L) ? sc[j][r] : -1e30f);
+      bm = fmaxf(bm, __shfl_xor(bm, 32));
+      st[j].m = bm;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) st[j].negm[r] = -bm - P_SHIFT;
+    }
+  }
+  f32x16 sc[QB];
+  KFragX kf = ld_kx(smem, g, lr);
+  score_x<QB>(kf, st, sc, SAFE);
+  for (int t = 0; t < ntiles; ++t) {
+    const char* kb = smem + (t & 1) * 2 * TILEX_BYTES;
+    const char* vb = kb + TILEX_BYTES;
+    const int nb = min(KB, nblk - t * KB);
+    for (int c = 0; c < nb; ++c) {
+      const int blk = t * KB + c;
+      const VFragX vf = ld_vx(vb + c * BLKX_BYTES, lane);
+      const bool last_of_tile = c + 1 == nb;
+      const bool more = blk + 1 < nblk;  // (uniform)
+      f32x16 sn[QB];
+      if (last_of_tile) {
+        // every wave has issued and received its last fragment reads of tile t (vf above, kf earlier): after the barrier the
+        // buffer of tile t is free for tile t + 2, and tile t + 1 has landed in every wave (vmcnt(0) in __syncthreads)
+        __syncthreads();
+        if (t + 2 < ntiles) stage_tile_x(rk, rv, t + 2, smem, t & 1, tid, wave);
+        if (more) kf = ld_kx(smem + ((t + 1) & 1) * 2 * TILEX_BYTES, g, lr);
+      } else {
+        kf = ld_kx(kb + (c + 1) * BLKX_BYTES, g, lr);
+      }
+      if (more) score_x<QB>(kf, st, sn, SAFE);
+      if (partial && blk == nblk - 1) finish_x<SAFE, true, QB>(sc, vf, g, st, blk * 32, L);
+      else finish_x<SAFE, false, QB>(sc, vf, g, st, blk * 32, L);
+      if (more) {
+#pragma unroll
+        for (int j = 0; j < QB; ++j) sc[j] = sn[j];
+      }
+    }
+  }
+  __syncthreads();
+}
+
+// OUT: 0 = hl32 planes [rows, 2 inner] (main layers), 1 = fp32 [rows, inner] (frontend)
+template <int QB, int OUT>
+__global__ __launch_bounds__(256, 2) void attn_frag_x3_kernel(const AttnFragP p, int nqt, int sh_total) {
+  __shared__ __attribute__((aligned(16))) char smem[SMEMX_BYTES];
+  const int bid = blockIdx.x;
+  const int idx = bid >> 3;
+  const int sh = (idx / nqt) * 8 + (bid & 7);
+  const int qt = idx % nqt;
+  if (sh >= sh_total) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 5, lr = lane & 31;
+  const int L = p.L;
+  const int nblk = (L + 31) >> 5;
+  const long seq_off = (long)sh * p.nbp * BLKX_BYTES;
+  const char* kseq = reinterpret_cast<const char*>(p.k) + seq_off;
+  const char* vseq = reinterpret_cast<const char*>(p.v) + seq_off;
+  int* flag = reinterpret_cast<int*>(smem + 4 * TILEX_BYTES);
+  if (tid == 0) *flag = 0;
+
+  QStateX st[QB];
+  const int qb0 = (qt * 4 + wave) * QB;  // this wave's first query block
+#pragma unroll
+  for (int j = 0; j < QB; ++j) {
+    const int qbc = min(qb0 + j, nblk - 1);
+    const char* qblk = reinterpret_cast<const char*>(p.q) + seq_off + (long)qbc * BLKX_BYTES;
+    st[j].q0 = *reinterpret_cast<const hfx8*>(qblk + ((2 * g) * 32 + lr) * 16);
+    st[j].q1 = *reinterpret_cast<const hfx8*>(qblk + ((2 * g + 1) * 32 + lr) * 16);
+    st[j].q0l = *reinterpret_cast<const hfx8*>(qblk + BLK_BYTES + ((2 * g) * 32 + lr) * 16);
+    st[j].q1l = *reinterpret_cast<const hfx8*>(qblk + BLK_BYTES + ((2 * g + 1) * 32 + lr) * 16);
+  }
+  // (the Q loads return to VGPRs: they must have landed before the first LDS-DMA is in flight -- counted vmcnt waits are
+  // wrong across the two kinds of loads)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+  const unsigned seq_bytes = (unsigned)p.nbp * BLKX_BYTES;
+  const rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(kseq), 0, seq_bytes, 0x00020000);
+  const rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(vseq), 0, seq_bytes, 0x00020000);
+  attn_pass_x<false, QB>(rk, rv, smem, tid, wave, lane, g, lr, st, L, nblk);
+  float l_tot[QB];
+  bool bad = false;
+#pragma unroll
+  for (int j = 0; j < QB; ++j) {
+    l_tot[j] = st[j].l + __shfl_xor(st[j].l, 32);
+    const bool valid = qb0 + j < nblk && (qb0 + j) * 32 + lr < L;
+    // the row sum is taken from the UNSPLIT fp32 probabilities, so an fp16 overflow of a hi part (p > 65504) does not turn
+    // it into inf: but such a p makes the sum exceed 65504 as well -> this query needs the running-max pass (a sum that
+    // large without any single overflow only costs the re-run)
+    bad = bad || (valid && !(l_tot[j] < 65504.f));
+  }
+  if (__any(bad) && lane == 0) *flag = 1;
+  __syncthreads();
+  if (*flag) {  // workgroup-uniform
+    __syncthreads();
+    attn_pass_x<true, QB>(rk, rv, smem, tid, wave, lane, g, lr, st, L, nblk);
+#pragma unroll
+    for (int j = 0; j < QB; ++j) l_tot[j] = st[j].l + __shfl_xor(st[j].l, 32);
+  }
+
+  const int seq = sh / p.heads, head = sh - seq * p.heads;
+  float amax = 0.f;
+#pragma unroll
+  for (int j = 0; j < QB; ++j) {
+    const int qi = (qb0 + j) * 32 + lr;
+    const bool okq = qb0 + j < nblk && qi < L;
+    const float gatev = okq ? p.gates[(long)sh * p.nbp * 32 + qi] : 0.f;
+    const long orow = okq ? (long)(seq / p.o_div) * p.o_outer + (long)(seq % p.o_div) * p.o_inner + (long)qi * p.o_tok : 0;
+    const float scale = okq ? gatev / l_tot[j] : 0.f;
+    if constexpr (OUT == 1) {
+      float* op = reinterpret_cast<float*>(p.out) + orow * p.inner + head * 32 + 4 * g;
+      if (okq) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+          *reinterpret_cast<f32x4*>(op + 8 * a) = f32x4{st[j].acc[4 * a] * scale, st[j].acc[4 * a + 1] * scale,
+                                                         st[j].acc[4 * a + 2] * scale, st[j].acc[4 * a + 3] * scale};
+      }
+    } else {
+      // hl32 row: the head's 32 features are one [hi 32 | lo 32] group at half offset 64 head.  A lane holds 4-feature
+      // runs 8 a + 4 g; the two halves of the wave exchange runs so that every lane stores 16-byte pieces (features
+      // 16 k + 8 g .. + 7), for the hi and for the lo part.  (The exchange is executed by all lanes.)
+      hf* op = reinterpret_cast<hf*>(p.out) + orow * 2 * p.inner + head * 64 + 8 * g;
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        unsigned xh[2], xl[2], yh[2], yl[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const float a0 = st[j].acc[8 * k + 2 * i] * scale, a1 = st[j].acc[8 * k + 2 * i + 1] * scale;
+          const float b0 = st[j].acc[8 * k + 4 + 2 * i] * scale, b1 = st[j].acc[8 * k + 4 + 2 * i + 1] * scale;
+          const hf ha0 = (hf)a0, ha1 = (hf)a1, hb0 = (hf)b0, hb1 = (hf)b1;
+          xh[i] = __builtin_bit_cast(unsigned, hfx2{ha0, ha1});
+          xl[i] = __builtin_bit_cast(unsigned, hfx2{(hf)(a0 - (float)ha0), (hf)(a1 - (float)ha1)});
+          yh[i] = __builtin_bit_cast(unsigned, hfx2{hb0, hb1});
+          yl[i] = __builtin_bit_cast(unsigned, hfx2{(hf)(b0 - (float)hb0), (hf)(b1 - (float)hb1)});
+          amax = fmaxf(amax, fmaxf(fmaxf(fabsf(a0), fabsf(a1)), fmaxf(fabsf(b0), fabsf(b1))));
+        }
+        auto h0 = __builtin_amdgcn_permlane32_swap(xh[0], yh[0], false, false);
+        auto h1 = __builtin_amdgcn_permlane32_swap(xh[1], yh[1], false, false);
+        auto l0 = __builtin_amdgcn_permlane32_swap(xl[0], yl[0], false, false);
+        auto l1 = __builtin_amdgcn_permlane32_swap(xl[1], yl[1], false, false);
+        if (okq) {
+          *reinterpret_cast<u32x4*>(op + 16 * k) = u32x4{h0[0], h1[0], h0[1], h1[1]};
+          *reinterpret_cast<u32x4*>(op + 32 + 16 * k) = u32x4{l0[0], l1[0], l0[1], l1[1]};
+        }
+      }
+    }
+  }
+  if (OUT == 0 && p.status && __any(!(amax <= 65504.f)) && lane == 0) atomicOr(p.status, 1);
+}
+
 }  // namespace
 
 int attn_frag_blocks(int L) { return ((L + 31) / 32 + KB - 1) / KB * KB; }
@@ -504,9 +812,23 @@ static void launch_v(const AttnFragP& p, hipStream_t s) {
   hipLaunchKernelGGL((attn_frag_kernel<ABL, QB>), dim3((unsigned)grid), dim3(256), 0, s, p, nqt, (int)sh);
 }
 
+template <int QB, int OUT>
+static void launch_x3(const AttnFragP& p, hipStream_t s) {
+  const int nblk = (p.L + 31) / 32;
+  const int nqt = (nblk + 4 * QB - 1) / (4 * QB);
+  const long sh = (long)p.n_seq * p.heads;
+  const long grid = (sh + 7) / 8 * 8 * nqt;
+  hipLaunchKernelGGL((attn_frag_x3_kernel<QB, OUT>), dim3((unsigned)grid), dim3(256), 0, s, p, nqt, (int)sh);
+}
+
 int launch_attn_frag(const AttnFragP& p, hipStream_t s) {
   if (p.L <= 0 || p.n_seq <= 0 || p.heads <= 0 || p.inner != p.heads * 32 || p.nbp < attn_frag_blocks(p.L)) return -2;
   if ((long)p.n_seq * p.heads * ((p.L + 127) / 128) > 0x3fffffffL) return -3;
+  if (p.x3) {
+    if (BT_HALF_IS_BF16 || (long)p.nbp * 4096 >= 0x7fffffffL) return -2;
+    if (p.out_f32) launch_x3<1, 1>(p, s); else launch_x3<1, 0>(p, s);
+    return (int)hipGetLastError();
+  }
   // (Two query blocks per wave -- QB = 2, half the fragment reads per MFMA at half the occupancy -- measured equal.)
 #ifdef BT_DEV
   // development builds only: BT_ATTN_ABL=128 dumps per-wave phase timings over the gates buffer (tools/attn_probe.py)

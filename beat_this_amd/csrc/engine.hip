@@ -55,43 +55,39 @@ struct Workspace {
   void* qkv; void* ao; void* hid;
   void* qf; void* kf; void* vf; float* gates_h; int nbp;  // fragment-major attention operands (half path)
   float* ssq[2];  // [D / 64][B T] partial row sums of squares of the main residual stream (ping-pong)
-  void* x8; float* ascale;  // BT_PREC_FP8: e4m3 shadow of the residual stream [B T][D] and its row factors [B T]
+  int* status;    // BT_PREC_F32X3 range flag: the FIRST word of the workspace (include/beat_this_amd.h)
   size_t total;
 };
 
 Workspace carve(char* base, int B, int T, int D, int ff_mult, int prec) {
-  const bool fp8 = prec == BT_PREC_FP8;
-  if (fp8) prec = BT_PREC_HALF;
-  if (prec == BT_PREC_F32X3) prec = BT_PREC_F32;   // (fp32 activations everywhere)
+  const bool x3 = prec == BT_PREC_F32X3;
+  if (x3) prec = BT_PREC_F32;   // (fp32 activations; hl32 planes = 4 bytes per element as well)
   const size_t es = prec == BT_PREC_F32 ? 4 : 2;
   const size_t bt = (size_t)B * T;
   const size_t dmax = std::max<size_t>(1024, D);
   size_t off = 0;
   auto take = [&](size_t bytes) { size_t o = off; off += align_up(bytes, 256); return base ? base + o : (char*)nullptr; };
   Workspace w;
+  w.status = (int*)take(256);
   w.xa = (float*)take(bt * 1024 * 4);
   w.xb = (float*)take(bt * 1024 * 4);
   w.xm = (float*)take(bt * D * 4);
-  w.xmb = take(bt * D * 2);  // half shadow of the main residual stream (A operand of the wide GEMMs)
+  w.xmb = take(bt * D * (x3 ? 4 : 2));  // half (x3: hl32) shadow of the main residual stream (A operand of the wide GEMMs)
   w.gates = (float*)take(bt * std::max(32, D / 32) * 4);
   w.qkv = take(bt * 3 * dmax * es);
   w.ao = take(bt * dmax * es);
   w.hid = take(bt * std::max<size_t>(4 * 1024, (size_t)ff_mult * D) * es);  // FF hidden activation / conv shadow
   w.nbp = attn_frag_blocks(T);
   w.qf = w.kf = w.vf = nullptr; w.gates_h = nullptr;
-  if (prec == BT_PREC_HALF) {  // (sequences x heads) = 32 B in the frontend, (D / 32) B in the main layers
+  if (prec == BT_PREC_HALF || x3) {  // (sequences x heads) = 32 B in the frontend, (D / 32) B in the main layers
     const size_t sh = (size_t)B * std::max(32, D / 32);
-    w.qf = take(sh * w.nbp * 2048); w.kf = take(sh * w.nbp * 2048); w.vf = take(sh * w.nbp * 2048);
+    const size_t blk = x3 ? 4096 : 2048;  // bytes per 32-token block (x3: [hi block | lo block])
+    w.qf = take(sh * w.nbp * blk); w.kf = take(sh * w.nbp * blk); w.vf = take(sh * w.nbp * blk);
     w.gates_h = (float*)take(sh * w.nbp * 32 * 4);
     w.ssq[0] = (float*)take(bt * (D / 64 + 1) * 4);
     w.ssq[1] = (float*)take(bt * (D / 64 + 1) * 4);
   } else {
     w.ssq[0] = w.ssq[1] = nullptr;
-  }
-  w.x8 = nullptr; w.ascale = nullptr;
-  if (fp8) {
-    w.x8 = take(bt * D);
-    w.ascale = (float*)take(bt * 4);
   }
   w.total = off;
   return w;
@@ -115,10 +111,8 @@ Workspace carve(char* base, int B, int T, int D, int ff_mult, int prec) {
 // Main transformer layer in BT_PREC_HALF on the gemm3 / attn2 kernels.  ws.ssq[0] holds the partial row sums of
 // squares of x on entry and on exit (written by the producer of x: frontend.linear or the previous FF2), ws.ssq[1]
 // those of x after the attention half.
-// fp8: the GEMMs whose e4m3 weights are present run on e4m3 operands (FF1 reads the e4m3 shadow of x written by the
-// out-projection's epilogue and writes an e4m3 hidden activation; FF2 reads that).
 int run_layer_half(prof::State* pf, const bt_pair_weights& pw, const float* rope, const Workspace& ws, int B, int T,
-                   int ff_mult, bool fp8, hipStream_t s) {
+                   int ff_mult, hipStream_t s) {
   const int D = pw.dim, H = pw.heads, HID = ff_mult * D;
   const int M = B * T;
   const int parts = D / 64;
@@ -134,7 +128,7 @@ int run_layer_half(prof::State* pf, const bt_pair_weights& pw, const float* rope
   a.q = ws.qf; a.k = ws.kf; a.v = ws.vf; a.gates = ws.gates_h; a.out = ws.ao; a.n_seq = B; a.L = T; a.heads = H;
   a.inner = D; a.nbp = ws.nbp; a.o_div = 1; a.o_outer = T; a.o_inner = 0; a.o_tok = 1;
   LAUNCH_CAT(CAT_ATTN_FLASH, s, launch_attn_frag(a, s), "attention");
-  if (!fp8 && pw.w_tail_frag && layer_tail_supported(D, HID)) {
+  if (pw.w_tail_frag && layer_tail_supported(D, HID)) {
     // out-projection + FF1 + FF2 in ONE launch: x, its half shadow and the statistics of the new x written once
     LayerTailP t;
     t.x = ws.xm; t.M = M; t.C = D; t.hidden = HID; t.ao = ws.ao; t.wfrag = pw.w_tail_frag; t.b1 = pw.b_ff1; t.b2 = pw.b_ff2;
@@ -145,19 +139,51 @@ int run_layer_half(prof::State* pf, const bt_pair_weights& pw, const float* rope
   memset(&g, 0, sizeof g);
   g.A = ws.ao; g.lda = D; g.M = M; g.K = D; g.W = pw.w_out[BT_PREC_HALF]; g.N = D; g.epi = G3_RESID;
   g.x = ws.xm; g.ldx = D; g.xb = ws.xmb; g.ssq_out = ws.ssq[1];
-  const bool ff8 = fp8 && pw.w_ff1_f8 && pw.w_ff2_f8;
-  if (ff8) { g.ssq_in = ws.ssq[0]; g.ssq_parts = parts; g.x8 = ws.x8; g.ascale_out = ws.ascale; }
   LAUNCH_CAT(CAT_OUT, s, launch_gemm3(g, s), "out-proj gemm");
   memset(&g, 0, sizeof g);
   g.A = ws.xmb; g.lda = D; g.M = M; g.K = D; g.W = pw.w_ff1[BT_PREC_HALF]; g.N = HID; g.epi = G3_FF1;
   g.bias = pw.b_ff1; g.ssq_in = ws.ssq[1]; g.ssq_parts = parts; g.out = ws.hid; g.ldo = HID;
-  if (ff8) { g.A = ws.x8; g.W = pw.w_ff1_f8; g.f8 = 1; g.wscale = pw.s_ff1; g.ascale = ws.ascale; }
   LAUNCH_CAT(CAT_FF1, s, launch_gemm3(g, s), "ff1 gemm");
   memset(&g, 0, sizeof g);
   g.A = ws.hid; g.lda = HID; g.M = M; g.K = HID; g.W = pw.w_ff2[BT_PREC_HALF]; g.N = D; g.epi = G3_RESID;
   g.bias = pw.b_ff2; g.x = ws.xm; g.ldx = D; g.xb = ws.xmb; g.ssq_out = ws.ssq[0];
-  if (ff8) { g.W = pw.w_ff2_f8; g.f8 = 1; g.wscale = pw.s_ff2; g.bias = pw.b_ff2_f8; }
   LAUNCH_CAT(CAT_FF2, s, launch_gemm3(g, s), "ff2 gemm");
+  return BT_OK;
+}
+
+// Main transformer layer in BT_PREC_F32X3 on the same kernels with hi + lo operands (gemm3.hip X3, attn2.hip
+// attn_frag_x3_kernel): the fp32 residual stream ws.xm is shadowed by hl32 planes (ws.xmb), the attention output and
+// the hidden activation travel as hl32 planes, q / k / v as 4 KB [hi | lo] fragment blocks; statistics as in the half layer.
+int run_layer_x3(prof::State* pf, const bt_pair_weights& pw, const float* rope, const Workspace& ws, int B, int T,
+                 int ff_mult, hipStream_t s) {
+  const int D = pw.dim, H = pw.heads, HID = ff_mult * D;
+  const int M = B * T;
+  const int parts = D / 64;
+  Gemm3P g;
+  memset(&g, 0, sizeof g);
+  g.A = ws.xmb; g.lda = D; g.M = M; g.K = D; g.W = pw.w_qkvg_x3; g.N = 3 * D + H; g.epi = G3_QKV;
+  g.ssq_in = ws.ssq[0]; g.ssq_parts = parts; g.x3 = 1; g.status = ws.status;
+  g.n_seq = B; g.L = T; g.nblk = (T + 31) / 32; g.nbp = ws.nbp; g.heads = H; g.inner = D; g.rope = rope;
+  g.qf = ws.qf; g.kf = ws.kf; g.vf = ws.vf; g.gates = ws.gates_h; g.b_gates = pw.b_gates;
+  LAUNCH_CAT(CAT_QKV, s, launch_gemm3(g, s), "qkv gemm (hi + lo)");
+  AttnFragP a;
+  memset(&a, 0, sizeof a);
+  a.q = ws.qf; a.k = ws.kf; a.v = ws.vf; a.gates = ws.gates_h; a.out = ws.ao; a.n_seq = B; a.L = T; a.heads = H;
+  a.inner = D; a.nbp = ws.nbp; a.o_div = 1; a.o_outer = T; a.o_inner = 0; a.o_tok = 1;
+  a.x3 = 1; a.out_f32 = 0; a.status = ws.status;
+  LAUNCH_CAT(CAT_ATTN_FLASH, s, launch_attn_frag(a, s), "attention (hi + lo)");
+  memset(&g, 0, sizeof g);
+  g.A = ws.ao; g.lda = D; g.M = M; g.K = D; g.W = pw.w_out_x3; g.N = D; g.epi = G3_RESID; g.x3 = 1; g.status = ws.status;
+  g.x = ws.xm; g.ldx = D; g.xb = ws.xmb; g.ssq_out = ws.ssq[1];
+  LAUNCH_CAT(CAT_OUT, s, launch_gemm3(g, s), "out-proj gemm (hi + lo)");
+  memset(&g, 0, sizeof g);
+  g.A = ws.xmb; g.lda = D; g.M = M; g.K = D; g.W = pw.w_ff1_x3; g.N = HID; g.epi = G3_FF1; g.x3 = 1; g.status = ws.status;
+  g.bias = pw.b_ff1; g.ssq_in = ws.ssq[1]; g.ssq_parts = parts; g.out = ws.hid; g.ldo = HID;
+  LAUNCH_CAT(CAT_FF1, s, launch_gemm3(g, s), "ff1 gemm (hi + lo)");
+  memset(&g, 0, sizeof g);
+  g.A = ws.hid; g.lda = HID; g.M = M; g.K = HID; g.W = pw.w_ff2_x3; g.N = D; g.epi = G3_RESID; g.x3 = 1; g.status = ws.status;
+  g.bias = pw.b_ff2; g.x = ws.xm; g.ldx = D; g.xb = ws.xmb; g.ssq_out = ws.ssq[0];
+  LAUNCH_CAT(CAT_FF2, s, launch_gemm3(g, s), "ff2 gemm (hi + lo)");
   return BT_OK;
 }
 
@@ -199,17 +225,23 @@ int run_pair(prof::State* pf, const bt_pair_weights& pw, const float* rope, floa
   }
   if (mode == 1)  // (pack.py always supplies the fused-half weight streams for the frontend's pairs)
     return bt_set_error(BT_ERR_ARG, "frequency-direction half needs bt_pair_weights.w_attnff_frag");
-  if (mode == 2 && fused_ok && prec == BT_PREC_HALF && pw.w_qkv_frag) {
-    // half time direction: fragment-major QKV straight from the projection, flash attention on it
+  // BT_PREC_F32X3 time direction on the fragment-major kernels: hi + lo QKV blocks straight from the projection, the
+  // attention's fp32 output feeds the (hi, lo) out-projection + FF kernel
+  const bool t2x3 = mode == 2 && f2x3 && fused2_ok && pw.w_qkv_frag_x3 && ws.qf;
+  if (mode == 2 && fused_ok && ((prec == BT_PREC_HALF && pw.w_qkv_frag) || t2x3)) {
+    // time direction: fragment-major QKV straight from the projection, flash attention on it
     QkvFrontP qp;
     memset(&qp, 0, sizeof qp);
-    qp.x = x; qp.B = B; qp.T = T; qp.F = F; qp.C = C; qp.wfrag = pw.w_qkv_frag; qp.b_gates = pw.b_gates; qp.rope = rope;
+    qp.x = x; qp.B = B; qp.T = T; qp.F = F; qp.C = C; qp.wfrag = t2x3 ? pw.w_qkv_frag_x3 : pw.w_qkv_frag;
+    qp.b_gates = pw.b_gates; qp.rope = rope;
     qp.q = ws.qf; qp.k = ws.kf; qp.v = ws.vf; qp.gates = ws.gates_h; qp.nbp = ws.nbp;
+    qp.x3 = t2x3; qp.status = ws.status;
     LAUNCH_CAT(CAT_QKV, s, launch_qkv_front(qp, s), "frontend qkv projection");
     AttnFragP a;
     memset(&a, 0, sizeof a);
     a.q = ws.qf; a.k = ws.kf; a.v = ws.vf; a.gates = ws.gates_h; a.out = ws.ao; a.n_seq = B * F; a.L = T; a.heads = H;
     a.inner = C; a.nbp = ws.nbp; a.o_div = F; a.o_outer = (long)T * F; a.o_inner = 1; a.o_tok = F;
+    a.x3 = t2x3; a.out_f32 = 1; a.status = ws.status;
     LAUNCH_CAT(CAT_ATTN_FLASH, s, launch_attn_frag(a, s), "time attention");
     if (fused2_ok) return outff();
     memset(&g, 0, sizeof g);
@@ -314,7 +346,7 @@ int bt_forward_stages(bt_engine* e, void* stream, int prec, int first, int last,
   if (first < 0 || last > 2 || first > last) return bt_set_error(BT_ERR_ARG, "stages: need 0 <= first <= last <= 2");
   if (last == 2 ? (!d_beat || !d_downbeat) : !d_out) return bt_set_error(BT_ERR_ARG, "null output");
   if (B <= 0 || T <= 0 || T > 1536) return bt_set_error(BT_ERR_ARG, "need B >= 1 and 1 <= T <= 1536");
-  if (prec != BT_PREC_F32 && prec != BT_PREC_HALF && prec != BT_PREC_FP8 && prec != BT_PREC_F32X3)
+  if (prec != BT_PREC_F32 && prec != BT_PREC_HALF && prec != BT_PREC_F32X3)
     return bt_set_error(BT_ERR_ARG, "unknown precision");
   const bt_model_desc& d = e->d;
   prof::State* pf = &e->prof;
@@ -326,16 +358,8 @@ int bt_forward_stages(bt_engine* e, void* stream, int prec, int first, int last,
   if (x3) {
     if (BT_HALF_IS_BF16) return bt_set_error(BT_ERR_ARG, "BT_PREC_F32X3 needs an IEEE fp16 build");
     prec = BT_PREC_F32;
-  }
-  const bool fp8 = prec == BT_PREC_FP8;
-  if (fp8) {  // everything but the e4m3 GEMMs of the main layers is the half path
-    prec = BT_PREC_HALF;
-    if (D % 128 != 0 || (long)B * T * d.ff_mult * D * 2 >= 0x7fffffffL)
-      return bt_set_error(BT_ERR_ARG, "BT_PREC_FP8 needs transformer_dim % 128 == 0 (gemm3 main layers)");
-    for (int l = 0; l < d.n_layers; ++l)
-      if (!d.layers[l].w_ff1_f8 || !d.layers[l].w_ff2_f8 || !d.layers[l].s_ff1 || !d.layers[l].s_ff2 ||
-          !d.layers[l].b_ff2_f8)
-        return bt_set_error(BT_ERR_ARG, "BT_PREC_FP8 needs the e4m3 feed-forward weights of every layer");
+    // range flag of this forward (first word of the workspace): cleared here, ORed by every kernel that splits operands
+    if (hipMemsetAsync(ws.status, 0, 4, s) != hipSuccess) return bt_set_error(BT_ERR_HIP, "clearing the range flag");
   }
   const int gp = x3 ? BT_PREC_F32X3 : prec, wp = x3 ? BT_PREC_HALF : prec;   // plain GEMMs: launch / weight precision
 
@@ -343,13 +367,17 @@ int bt_forward_stages(bt_engine* e, void* stream, int prec, int first, int last,
   const bool use_shadow = prec == BT_PREC_HALF && D >= 128 && D % 64 == 0;
   // main layers on gemm3 + fragment-major attention (needs q | k | v column blocks that are whole 128-tiles)
   const bool fast_layers = use_shadow && D % 128 == 0 && (long)B * T * d.ff_mult * D * 2 < 0x7fffffffL;
+  // BT_PREC_F32X3 on the same kernels (hl32 operands): needs the hl32 weights of every layer
+  bool fast_x3 = x3 && D >= 128 && D % 128 == 0 && (long)B * T * d.ff_mult * D * 4 < 0x7fffffffL;
+  for (int l = 0; fast_x3 && l < d.n_layers; ++l)
+    fast_x3 = d.layers[l].w_qkvg_x3 && d.layers[l].w_out_x3 && d.layers[l].w_ff1_x3 && d.layers[l].w_ff2_x3;
 
   // frontend.linear on gemm3 (half A written by the last conv block) when its shape fits
   bool lin3 = false;
-  if (fast_layers) {
+  if (fast_layers || (fast_x3 && d.lin_w_x3)) {
     Gemm3P g;
     memset(&g, 0, sizeof g);
-    g.lda = 1024; g.M = B * T; g.K = 1024; g.N = D; g.epi = G3_RESID; g.ldx = D; g.x = ws.xm;
+    g.lda = 1024; g.M = B * T; g.K = 1024; g.N = D; g.epi = G3_RESID; g.ldx = D; g.x = ws.xm; g.x3 = fast_x3;
     lin3 = gemm3_supported(g);
   }
 
@@ -359,6 +387,7 @@ int bt_forward_stages(bt_engine* e, void* stream, int prec, int first, int last,
     HeadP hp;
     hp.x = d_spect; hp.w = d.head_w_raw; hp.b0 = d.head_b[0]; hp.b1 = d.head_b[1];
     hp.beat = d_beat; hp.downbeat = d_downbeat; hp.M = B * T; hp.D = D; hp.sum_head = d.sum_head; hp.prenorm = 1;
+    hp.status = nullptr;
     LAUNCH_CAT(CAT_HEAD, s, launch_head(hp, s), "head");
     return BT_OK;
   }
@@ -366,6 +395,7 @@ int bt_forward_stages(bt_engine* e, void* stream, int prec, int first, int last,
     if (hipMemcpyAsync(ws.xm, d_spect, xm_bytes, hipMemcpyDeviceToDevice, s) != hipSuccess)
       return bt_set_error(BT_ERR_HIP, "copy of the stage input");
     if (use_shadow) LAUNCH_CAT(CAT_LINEAR, s, launch_shadow_ssq(ws.xm, ws.xmb, fast_layers ? ws.ssq[0] : nullptr, (long)B * T, D, s), "stage entry");
+    if (fast_x3) LAUNCH_CAT(CAT_LINEAR, s, launch_shadow_ssq(ws.xm, ws.xmb, ws.ssq[0], (long)B * T, D, s, 1), "stage entry");
   }
   if (first == 0) {
   StemP sp;
@@ -380,14 +410,21 @@ int bt_forward_stages(bt_engine* e, void* stream, int prec, int first, int last,
     // conv of this block on gemm3 (LDS-DMA ring on the half shadow of x that the time-direction half leaves in ws.hid)
     Gemm3P cg;
     memset(&cg, 0, sizeof cg);
-    cg.A = ws.hid; cg.lda = 2 * C; cg.M = B * T * (F / 2); cg.K = 6 * C; cg.W = d.conv_w[blk][BT_PREC_HALF]; cg.N = 2 * C;
+    cg.A = ws.hid; cg.lda = 2 * C; cg.M = B * T * (F / 2); cg.K = 6 * C; cg.N = 2 * C;
+    cg.W = fast_x3 ? d.conv_w_x3[blk] : d.conv_w[blk][BT_PREC_HALF];
     cg.epi = G3_RESID; cg.no_resid = 1; cg.gelu = 1; cg.bias = d.conv_b[blk]; cg.ldx = 2 * C;
-    cg.conv_C2 = 2 * C; cg.conv_T = T; cg.conv_F = F / 2;
+    cg.conv_C2 = 2 * C; cg.conv_T = T; cg.conv_F = F / 2; cg.x3 = fast_x3; cg.status = ws.status;
     const bool to_bf16 = blk == 2 && lin3;  // the last block's output is read by frontend.linear (gemm3) only
     cg.x = to_bf16 ? nullptr : xn; cg.xb = to_bf16 ? (void*)xn : nullptr;
     // (the first conv, N = 64, works as well but only pays 4 us for the 12 us its shadow write costs: it stays on gemm.hip)
-    const bool conv3 = fast_layers && d.partial_transformers && pair_fused2_ok(d.front[blk][1], prec) && cg.N >= 128 &&
+    // x3: the shadow is the hl32 form written by the (hi, lo) out-projection + FF kernel of the time-direction half
+    const bt_pair_weights& tw = d.front[blk][1];
+    const bool conv3 = d.partial_transformers && cg.N >= 128 && cg.W &&
+                       (fast_x3 ? (pair_fused2_ok(tw, prec) && tw.w_outff_frag_x3 && tw.w_attnff_frag_x3)
+                                : (fast_layers && pair_fused2_ok(tw, prec))) &&
                        gemm3_supported(cg);
+    // (x3: frontend.linear on gemm3 reads hl32 planes, which only the gemm3 form of the last convolution writes)
+    if (blk == 2 && fast_x3 && !conv3) lin3 = false;
     if (d.partial_transformers) {
       int rc = run_pair(pf, d.front[blk][0], d.rope, x, nullptr, ws, B, T, F, 1, prec, s, nullptr, 4, x3);
       if (rc) return rc;
@@ -414,8 +451,9 @@ int bt_forward_stages(bt_engine* e, void* stream, int prec, int first, int last,
   if (lin3) {
     Gemm3P g;
     memset(&g, 0, sizeof g);
-    g.A = x; g.lda = 1024; g.M = B * T; g.K = 1024; g.W = d.lin_w[BT_PREC_HALF]; g.N = D; g.epi = G3_RESID;
+    g.A = x; g.lda = 1024; g.M = B * T; g.K = 1024; g.W = fast_x3 ? d.lin_w_x3 : d.lin_w[BT_PREC_HALF]; g.N = D; g.epi = G3_RESID;
     g.no_resid = 1; g.bias = d.lin_b; g.x = ws.xm; g.ldx = D; g.xb = ws.xmb; g.ssq_out = ws.ssq[0];
+    g.x3 = fast_x3; g.status = ws.status;
     LAUNCH_CAT(CAT_LINEAR, s, launch_gemm3(g, s), "frontend linear gemm");
   } else {
     GemmP g;
@@ -425,6 +463,7 @@ int bt_forward_stages(bt_engine* e, void* stream, int prec, int first, int last,
     g.bias = d.lin_b; g.out = ws.xm; g.ldo = D; g.xb = use_shadow ? ws.xmb : nullptr;
     g.ssq_out = fast_layers ? ws.ssq[0] : nullptr;
     LAUNCH_CAT(CAT_LINEAR, s, launch_gemm(g, gp, s), "frontend linear gemm");
+    if (fast_x3) LAUNCH_CAT(CAT_LINEAR, s, launch_shadow_ssq(ws.xm, ws.xmb, ws.ssq[0], (long)B * T, D, s, 1), "hl32 shadow of the residual stream");
   }
   }  // first == 0
   if (last == 0) {
@@ -433,7 +472,8 @@ int bt_forward_stages(bt_engine* e, void* stream, int prec, int first, int last,
     return BT_OK;
   }
   for (int l = 0; l < d.n_layers; ++l) {
-    int rc = fast_layers ? run_layer_half(pf, d.layers[l], d.rope, ws, B, T, d.ff_mult, fp8, s)
+    int rc = fast_x3 ? run_layer_x3(pf, d.layers[l], d.rope, ws, B, T, d.ff_mult, s)
+             : fast_layers ? run_layer_half(pf, d.layers[l], d.rope, ws, B, T, d.ff_mult, s)
                          : run_pair(pf, d.layers[l], d.rope, ws.xm, use_shadow ? ws.xmb : nullptr, ws, B, T, 1, 0, prec, s, nullptr,
                                     d.ff_mult, x3);
     if (rc) return rc;
@@ -446,6 +486,7 @@ int bt_forward_stages(bt_engine* e, void* stream, int prec, int first, int last,
   HeadP hp;
   hp.x = ws.xm; hp.w = d.head_w; hp.b0 = d.head_b[0]; hp.b1 = d.head_b[1];
   hp.beat = d_beat; hp.downbeat = d_downbeat; hp.M = B * T; hp.D = D; hp.sum_head = d.sum_head; hp.prenorm = 0;
+  hp.status = x3 ? ws.status : nullptr;
   LAUNCH_CAT(CAT_HEAD, s, launch_head(hp, s), "head");
   return BT_OK;
 }
@@ -672,13 +713,13 @@ int bt_attention(void* stream, int prec, const bt_attn_args* a) {
   return BT_OK;
 }
 
-int bt_outff_fused(void* stream, int prec, const bt_pair_weights* w, const void* d_ao, float* d_x, int64_t M) {
+int bt_outff_fused(void* stream, int prec, const bt_pair_weights* w, const void* d_ao, float* d_x, int64_t M, void* d_xb) {
   if (prec != BT_PREC_F32 && prec != BT_PREC_HALF && prec != BT_PREC_F32X3) return bt_set_error(BT_ERR_ARG, "unknown precision");
   const void* wf = !w ? nullptr : prec == BT_PREC_F32X3 ? w->w_outff_frag_x3 : w->w_outff_frag[prec];
   if (!w || !d_ao || !d_x || M <= 0 || w->dim > 128 || !wf) return bt_set_error(BT_ERR_ARG, "bad argument to bt_outff_fused");
   FusedOutFFP f;
   f.x = d_x; f.M = M; f.C = w->dim; f.ao = d_ao; f.wfrag = wf; f.b1 = w->b_ff1; f.b2 = w->b_ff2;
-  f.xb = nullptr; f.abl = 0;
+  f.xb = prec == BT_PREC_F32 ? nullptr : d_xb; f.abl = 0;
   LAUNCH(launch_outff_fused(f, prec, (hipStream_t)stream), "fused out-projection + feed-forward");
   return BT_OK;
 }
@@ -714,7 +755,7 @@ int bt_gemm3(void* stream, const bt_gemm3_args* a) {
   g.xb = a->xb; g.ssq_out = a->ssq_out; g.n_seq = a->n_seq; g.L = a->L; g.nblk = (a->L + 31) / 32; g.nbp = a->nbp;
   g.heads = a->heads; g.inner = a->heads * 32; g.rope = a->rope; g.qf = a->qf; g.kf = a->kf; g.vf = a->vf;
   g.gates = a->gates; g.b_gates = a->b_gates;
-  g.f8 = a->f8; g.wscale = a->wscale; g.ascale = a->ascale; g.x8 = a->x8; g.ascale_out = a->ascale_out;
+  g.x3 = a->x3; g.status = a->status;
   g.no_resid = a->no_resid; g.gelu = a->gelu; g.conv_C2 = a->conv_C2; g.conv_T = a->conv_T; g.conv_F = a->conv_F;
   if (!gemm3_supported(g)) return bt_set_error(BT_ERR_ARG, "shape not supported by bt_gemm3");
   LAUNCH(launch_gemm3(g, (hipStream_t)stream), "gemm3");
@@ -730,18 +771,22 @@ int bt_attention_frag(void* stream, const bt_attn_frag_args* a) {
   p.q = a->q; p.k = a->k; p.v = a->v; p.gates = a->gates; p.out = a->out; p.n_seq = a->n_seq; p.L = a->L;
   p.heads = a->heads; p.inner = a->inner; p.nbp = a->nbp; p.o_div = a->o_div; p.o_outer = a->o_outer;
   p.o_inner = a->o_inner; p.o_tok = a->o_tok;
+  p.x3 = a->x3; p.out_f32 = a->out_f32; p.status = a->status;
   LAUNCH(launch_attn_frag(p, (hipStream_t)stream), "attention (fragment-major)");
   return BT_OK;
 }
 
-int bt_qkv_front(void* stream, const bt_pair_weights* w, const float* d_rope, const float* d_x, int B, int T, int F,
+int bt_qkv_front(void* stream, int prec, const bt_pair_weights* w, const float* d_rope, const float* d_x, int B, int T, int F,
                  void* d_q, void* d_k, void* d_v, float* d_gates, int nbp) {
-  if (!w || !w->w_qkv_frag || !d_rope || !d_x || !d_q || !d_k || !d_v || !d_gates || w->dim > 128)
+  if (prec != BT_PREC_HALF && prec != BT_PREC_F32X3) return bt_set_error(BT_ERR_ARG, "bt_qkv_front: BT_PREC_HALF or BT_PREC_F32X3");
+  const bool x3 = prec == BT_PREC_F32X3;
+  const void* wf = !w ? nullptr : x3 ? w->w_qkv_frag_x3 : w->w_qkv_frag;
+  if (!w || !wf || !d_rope || !d_x || !d_q || !d_k || !d_v || !d_gates || w->dim > 128)
     return bt_set_error(BT_ERR_ARG, "bad argument to bt_qkv_front");
   QkvFrontP p;
   memset(&p, 0, sizeof p);
-  p.x = d_x; p.B = B; p.T = T; p.F = F; p.C = w->dim; p.wfrag = w->w_qkv_frag; p.b_gates = w->b_gates; p.rope = d_rope;
-  p.q = d_q; p.k = d_k; p.v = d_v; p.gates = d_gates; p.nbp = nbp;
+  p.x = d_x; p.B = B; p.T = T; p.F = F; p.C = w->dim; p.wfrag = wf; p.b_gates = w->b_gates; p.rope = d_rope;
+  p.q = d_q; p.k = d_k; p.v = d_v; p.gates = d_gates; p.nbp = nbp; p.x3 = x3;
   LAUNCH(launch_qkv_front(p, (hipStream_t)stream), "frontend qkv projection");
   return BT_OK;
 }

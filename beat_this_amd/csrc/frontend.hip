@@ -89,6 +89,9 @@ __global__ __launch_bounds__(256) void head_kernel(const HeadP p) {
     const float y0 = d0 * sc + p.b0, y1 = d1 * sc + p.b1;
     p.beat[row] = p.sum_head ? y0 + y1 : y0;
     p.downbeat[row] = y1;
+    // BT_PREC_F32X3 range guard, last line of defence: an operand that left the fp16 range upstream reaches the logits of
+    // its chunk as inf / NaN (every token of a sequence meets every other in the attention)
+    if (p.status && !(fabsf(y0) <= 3.0e38f && fabsf(y1) <= 3.0e38f)) atomicOr(p.status, 2);
   }
 }
 
@@ -108,14 +111,22 @@ __global__ __launch_bounds__(256) void norm_out_kernel(const float* __restrict__
 }
 
 // one wave per token row, lane = column of a 64-column group: the half shadow of x and the group's sum of squares
+// (hl32 != 0: the BT_PREC_F32X3 form of the shadow, per 32 columns [32 hi halves | 32 lo halves], gemm3.hip)
 __global__ __launch_bounds__(256) void shadow_ssq_kernel(const float* __restrict__ x, hf* __restrict__ xb,
-                                                         float* __restrict__ ssq, long M, int D) {
+                                                         float* __restrict__ ssq, long M, int D, int hl32) {
   const int lane = threadIdx.x & 63;
   const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
   for (int g = 0; g < D / 64; ++g) {
     const float v = x[row * D + g * 64 + lane];
-    xb[row * D + g * 64 + lane] = (hf)v;
+    if (hl32) {
+      const hf h = (hf)v;
+      hf* d = xb + (row * D + g * 64) * 2 + (lane >> 5) * 64 + (lane & 31);
+      d[0] = h;
+      d[32] = (hf)(v - (float)h);
+    } else {
+      xb[row * D + g * 64 + lane] = (hf)v;
+    }
     float sq = v * v;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
@@ -378,9 +389,9 @@ int launch_norm_out(const float* x, const float* gamma, float* y, long M, int D,
   hipLaunchKernelGGL(norm_out_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, x, gamma, y, M, D);
   return (int)hipGetLastError();
 }
-int launch_shadow_ssq(const float* x, void* xb, float* ssq, long M, int D, hipStream_t s) {
+int launch_shadow_ssq(const float* x, void* xb, float* ssq, long M, int D, hipStream_t s, int hl32) {
   if (D % 64 != 0) return -2;
-  hipLaunchKernelGGL(shadow_ssq_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, x, reinterpret_cast<hf*>(xb), ssq, M, D);
+  hipLaunchKernelGGL(shadow_ssq_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, x, reinterpret_cast<hf*>(xb), ssq, M, D, hl32);
   return (int)hipGetLastError();
 }
 int launch_split(const float* spect, long n_frames, const int* starts, const int* table, int B, int T, float* chunks,

@@ -145,14 +145,40 @@ DEVI void ff_tail(WRing<T, C>& ws, int step0, float (&xn)[C / 32][16], const flo
     }
     if (xbrow) {  // half shadow: the two halves of the wave exchange 4-feature runs so that a lane stores 16 bytes
                   // (features 16 k + 8 g .. + 7); 8-byte row-strided stores cost 44 us per forward here.  Executed by all lanes.
+      typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+      if constexpr (std::is_same<T, hl>::value) {
+        // BT_PREC_F32X3: the shadow is the hl32 form of the row (gemm3.hip: per 32 features [32 hi halves | 32 lo halves]),
+        // UNSCALED (the GEMM that reads it applies no operand scale)
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          unsigned xh[2], xl[2], yh[2], yl[2];
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            const float a0 = v[2 * k][2 * i], a1 = v[2 * k][2 * i + 1], b0 = v[2 * k + 1][2 * i], b1 = v[2 * k + 1][2 * i + 1];
+            const hf ha0 = (hf)a0, ha1 = (hf)a1, hb0 = (hf)b0, hb1 = (hf)b1;
+            xh[i] = __builtin_bit_cast(unsigned, hfx2{ha0, ha1});
+            xl[i] = __builtin_bit_cast(unsigned, hfx2{(hf)(a0 - (float)ha0), (hf)(a1 - (float)ha1)});
+            yh[i] = __builtin_bit_cast(unsigned, hfx2{hb0, hb1});
+            yl[i] = __builtin_bit_cast(unsigned, hfx2{(hf)(b0 - (float)hb0), (hf)(b1 - (float)hb1)});
+          }
+          auto h0 = __builtin_amdgcn_permlane32_swap(xh[0], yh[0], false, false);
+          auto h1 = __builtin_amdgcn_permlane32_swap(xh[1], yh[1], false, false);
+          auto l0 = __builtin_amdgcn_permlane32_swap(xl[0], yl[0], false, false);
+          auto l1 = __builtin_amdgcn_permlane32_swap(xl[1], yl[1], false, false);
+          if (ok) {
+            *reinterpret_cast<u32x4*>(xbrow + mt * 64 + 16 * k + 8 * g) = u32x4{h0[0], h1[0], h0[1], h1[1]};
+            *reinterpret_cast<u32x4*>(xbrow + mt * 64 + 32 + 16 * k + 8 * g) = u32x4{l0[0], l1[0], l0[1], l1[1]};
+          }
+        }
+      } else {
 #pragma unroll
       for (int k = 0; k < 2; ++k) {
         const unsigned x0 = pk2_hf(v[2 * k][0], v[2 * k][1]), x1 = pk2_hf(v[2 * k][2], v[2 * k][3]);
         const unsigned y0 = pk2_hf(v[2 * k + 1][0], v[2 * k + 1][1]), y1 = pk2_hf(v[2 * k + 1][2], v[2 * k + 1][3]);
         auto r0 = __builtin_amdgcn_permlane32_swap(x0, y0, false, false);
         auto r1 = __builtin_amdgcn_permlane32_swap(x1, y1, false, false);
-        typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
         if (ok) *reinterpret_cast<u32x4*>(xbrow + mt * 32 + 16 * k + 8 * g) = u32x4{r0[0], r1[0], r0[1], r1[1]};
+      }
       }
     }
   }
@@ -208,7 +234,7 @@ __global__ __launch_bounds__(256) void outff_fused_kernel(const FusedOutFFP p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) xn[mt][r] = fmaf(acc[r], OpScale<T>::PW, xn[mt][r]);
   }
-  hf* xbrow = p.xb ? reinterpret_cast<hf*>(p.xb) + tok * C : nullptr;
+  hf* xbrow = p.xb ? reinterpret_cast<hf*>(p.xb) + tok * C * (std::is_same<T, hl>::value ? 2 : 1) : nullptr;
   ff_tail<T, C>(ws, KT, xn, b1s, p.b2, xrow, xbrow, ok_st, lane, g);
 }
 

@@ -1,6 +1,14 @@
-// half / e4m3 GEMM of the BT_PREC_HALF / BT_PREC_FP8 forward:  C[M,N] = epilogue(A[M,K] . W[N,K]^T), A = half (e4m3)
-// activations (shadow of the residual stream / attention output / FF hidden), W = half (e4m3) weights.  Main-layer QKV,
+// half GEMM of the BT_PREC_HALF forward and hi + lo GEMM of the BT_PREC_F32X3 forward:  C[M,N] = epilogue(A[M,K] . W[N,K]^T),
+// A = half activations (shadow of the residual stream / attention output / FF hidden), W = half weights.  Main-layer QKV,
 // out-projection, FF1, FF2; frontend.linear; the second and third frontend convolution (implicit-GEMM gather).
+//
+// X3 (BT_PREC_F32X3, the path that carries the 1e-3 / identical-beats gate): both operands are fp32 values stored as
+// INTERLEAVED hi / lo half planes ("hl32": per 32 consecutive k the 32 hi halves, then the 32 lo halves; a = hi + lo to
+// 2^-22), so a k-step of 32 is ONE 128-byte row per operand row -- the LDS-DMA ring, the swizzle and the fragment reads
+// of the 64-deep half configuration carry it unchanged -- and the product is three MFMAs per fragment pair (lo . hi +
+// hi . lo + hi . hi, fp32 accumulation): 3x the matrix work for 2x the operand bytes of the half GEMM, on the same
+// engine.  The epilogues keep fp32 results exact (erf GELU, fp32 residual stream) and write activations for the next
+// GEMM / the attention as hl32 planes again.
 //
 // Engine (differences from gemm2.hip):
 //   * 128 x 128 x 32 tiles, 4 waves as 2 x 2 (64 x 64 each = 2 x 2 MFMA 32x32 tiles);
@@ -29,26 +37,23 @@
 // 128 KB -> 1 workgroup per CU: half the L2 -> LDS operand traffic per flop (the 128^2 FF GEMMs were bound by
 // LDS-DMA fill rate, not MFMA: 84 us with the MFMAs removed vs 95 us with them), and 128-byte LDS rows, i.e. every
 // fetched cache line is used whole.  FF1 / RESID only (the V columns of QKV need a square wave tile).
-struct G3CfgS { static constexpr int BM = 128, BN = 128, BK = 32, WGM = 2, WGN = 2, NST = 3, OCC = 3, ES = 2; };
-struct G3CfgB { static constexpr int BM = 256, BN = 256, BK = 64, WGM = 2, WGN = 4, NST = 2, OCC = 1, ES = 2; };
-// e4m3 operands (BT_PREC_FP8, ES = 1 byte per element): the same LDS images (64- / 128-byte rows) hold twice the k
-// range; one v_mfma_scale_f32_32x32x64_f8f6f4 with unit block scales per 64-byte row group (lane = row, 32
-// consecutive k bytes at 32 (lane >> 5); layout and rate -- 4.15 PFLOP/s vs 2.3 for half -- checked by
-// tools/ubench/mfma_f8_probe.hip), so the k-loop is half as long for the same LDS-DMA bytes per step.
+struct G3CfgS { static constexpr int BM = 128, BN = 128, BK = 32, WGM = 2, WGN = 2, NST = 3, OCC = 3; };
+struct G3CfgB { static constexpr int BM = 256, BN = 256, BK = 64, WGM = 2, WGN = 4, NST = 2, OCC = 1; };
 // T = B with 192 token rows (waves of 96 x 64): picked when it covers M in fewer CU-rounds x rows -- final0's FF2 at
 // M = 24000 is 125 x 2 = 250 tiles = one round on 98 % of the CUs instead of 188 tiles on 73 % (72 -> 65 us).
 // (A 128^2 2-stage variant at 4 workgroups per CU, 1024 slots so that QKV's 2444 tiles take 3 rounds, was no faster.)
-struct G3CfgT { static constexpr int BM = 192, BN = 256, BK = 64, WGM = 2, WGN = 4, NST = 2, OCC = 1, ES = 2; };
-struct G3CfgT8 { static constexpr int BM = 192, BN = 256, BK = 128, WGM = 2, WGN = 4, NST = 2, OCC = 1, ES = 1; };
-struct G3CfgS8 { static constexpr int BM = 128, BN = 128, BK = 64, WGM = 2, WGN = 2, NST = 3, OCC = 3, ES = 1; };
-struct G3CfgB8 { static constexpr int BM = 256, BN = 256, BK = 128, WGM = 2, WGN = 4, NST = 2, OCC = 1, ES = 1; };
+struct G3CfgT { static constexpr int BM = 192, BN = 256, BK = 64, WGM = 2, WGN = 4, NST = 2, OCC = 1; };
+// X3: BK counts HALF elements of an hl32 row, i.e. a k-step of 32 (hi | lo = 64 halves = 128 B per row).  SX: 32 KB per
+// stage, 2 stages -> 2 workgroups per CU (a third stage would leave one workgroup per CU alone with its epilogue);
+// BX / TX: the 256- / 192-row tiles of the long-K residual GEMM, 64 KB per stage.
+struct G3CfgSX { static constexpr int BM = 128, BN = 128, BK = 64, WGM = 2, WGN = 2, NST = 2, OCC = 2; };
+struct G3CfgBX { static constexpr int BM = 256, BN = 256, BK = 64, WGM = 2, WGN = 4, NST = 2, OCC = 1; };
+struct G3CfgTX { static constexpr int BM = 192, BN = 256, BK = 64, WGM = 2, WGN = 4, NST = 2, OCC = 1; };
 
 namespace {
 
 typedef G3CfgS CfgS;
 typedef G3CfgB CfgB;
-typedef G3CfgS8 CfgS8;
-typedef G3CfgB8 CfgB8;
 
 constexpr unsigned OOB = 0x80000000u;         // voffset of a lane that must read zeros (beyond num_records)
 
@@ -56,18 +61,6 @@ typedef __amdgpu_buffer_rsrc_t rsrc_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
-typedef __attribute__((ext_vector_type(8))) int i32x8;
-
-// 4 floats -> 4 e4m3 bytes (OCP e4m3fn, round to nearest even), saturating at +-448
-DEVI unsigned pk4_f8(float a, float b, float c, float d) {
-  a = __builtin_amdgcn_fmed3f(a, -448.f, 448.f);
-  b = __builtin_amdgcn_fmed3f(b, -448.f, 448.f);
-  c = __builtin_amdgcn_fmed3f(c, -448.f, 448.f);
-  d = __builtin_amdgcn_fmed3f(d, -448.f, 448.f);
-  int w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
-  w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
-  return (unsigned)w;
-}
 
 DEVI unsigned pk2(float a, float b) {
   const hfx2 t = {(hf)a, (hf)b};
@@ -87,23 +80,58 @@ DEVI void pack_row_hf(const float (&v)[16], u32x4 (&piece)[2]) {
   }
 }
 
+// (a, b) -> packed hi halves and packed lo halves of the hi + lo split: hi = half(v), lo = half(v - hi); amax tracks the
+// largest magnitude that went through a split (range guard of BT_PREC_F32X3: a hi part beyond the fp16 range is inf)
+DEVI void split2(float a, float b, unsigned& whi, unsigned& wlo, float& amax) {
+  const hf ha = (hf)a, hb = (hf)b;
+  const hfx2 th = {ha, hb};
+  const hfx2 tl = {(hf)(a - (float)ha), (hf)(b - (float)hb)};
+  whi = __builtin_bit_cast(unsigned, th);
+  wlo = __builtin_bit_cast(unsigned, tl);
+  amax = fmaxf(amax, fmaxf(fabsf(a), fabsf(b)));
+}
+// pack_row_hf for both parts of the split
+DEVI void pack_row_hl(const float (&v)[16], u32x4 (&hi)[2], u32x4 (&lo)[2], float& amax) {
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    unsigned xh[2], xl[2], yh[2], yl[2];
+    split2(v[8 * k], v[8 * k + 1], xh[0], xl[0], amax);
+    split2(v[8 * k + 2], v[8 * k + 3], xh[1], xl[1], amax);
+    split2(v[8 * k + 4], v[8 * k + 5], yh[0], yl[0], amax);
+    split2(v[8 * k + 6], v[8 * k + 7], yh[1], yl[1], amax);
+    auto h0 = __builtin_amdgcn_permlane32_swap(xh[0], yh[0], false, false);
+    auto h1 = __builtin_amdgcn_permlane32_swap(xh[1], yh[1], false, false);
+    auto l0 = __builtin_amdgcn_permlane32_swap(xl[0], yl[0], false, false);
+    auto l1 = __builtin_amdgcn_permlane32_swap(xl[1], yl[1], false, false);
+    hi[k] = u32x4{h0[0], h1[0], h0[1], h1[1]};
+    lo[k] = u32x4{l0[0], l1[0], l0[1], l1[1]};
+  }
+}
+// range guard: one flag word per forward (Gemm3P.status), set when a value beyond the fp16 range went through a split
+DEVI void flag_range(int* status, float amax) {
+  if (status && __any(!(amax <= 65504.f)) && (threadIdx.x & 63) == 0) atomicOr(status, 1);
+}
+
 // ABL (development, BT_G3_ABL = 8): per-wave timing dump (k-loop, waits, epilogue) read by tools/gemm3_probe.py;
 // bits 0 - 2 (no LDS-DMA after the prologue / no GELU / no MFMAs) are ablations that can be instantiated by hand
-template <int EPI, typename CFG, int ABL = 0>
+template <int EPI, typename CFG, bool X3 = false, int ABL = 0>
 __global__ __launch_bounds__(64 * CFG::WGM * CFG::WGN, (CFG::OCC * CFG::WGM * CFG::WGN + 3) / 4)
 void gemm3_kernel(const Gemm3P p, int n_tiles, int total_tiles, int per_xcd) {
   constexpr int BM = CFG::BM, BN = CFG::BN, BK = CFG::BK, NST = CFG::NST;
   constexpr int NW = CFG::WGM * CFG::WGN, NT = 64 * NW;
   constexpr int TB = BM / CFG::WGM / 32;       // 32-token blocks per wave
   constexpr int FB = BN / CFG::WGN / 32;       // 32-feature blocks per wave
-  constexpr int ES = CFG::ES;                  // bytes per operand element: 2 = half, 1 = e4m3
-  constexpr int ROWB = BK * ES;                // bytes per LDS row
+  constexpr int ROWB = BK * 2;                 // bytes per LDS row (BK half elements)
+  constexpr int KR = X3 ? BK / 2 : BK;         // k values per k-step (X3: a row is 32 hi + 32 lo halves)
+  constexpr int EB = X3 ? 4 : 2;               // operand bytes per k value
   constexpr int CPR = ROWB / 16;               // 16-byte chunks per row (4 or 8)
   constexpr int RPI = 64 / CPR;                // rows covered by one wave-instruction (1 KB)
   constexpr int A_BYTES = BM * ROWB, W_BYTES = BN * ROWB, ST_BYTES = A_BYTES + W_BYTES;
   constexpr int APC = A_BYTES / (NT * 16), WPC = W_BYTES / (NT * 16);  // LDS-DMA pieces per thread and k-step
   static_assert(EPI != G3_QKV || TB == FB, "the V columns swap the operand roles: square wave tile needed");
   static_assert(BN / CFG::WGN == 64, "ssq partials are per 64 columns = one wave");
+  static_assert(!X3 || ROWB == 128, "hl32: one k-step of 32 = 64 hi + 64 lo bytes per row");
+  static_assert(NST * ST_BYTES >= NW * 8192, "the epilogues stage 8 KB per wave in the ring's LDS");
   __shared__ __attribute__((aligned(16))) char smem[NST * ST_BYTES];
   // XCD-aware tile order: the n-tiles sharing one 128-row A panel run on the same XCD (block b -> XCD b % 8)
   const int bid = blockIdx.x;
@@ -114,7 +142,7 @@ void gemm3_kernel(const Gemm3P p, int n_tiles, int total_tiles, int per_xcd) {
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // (wave index in an SGPR: uniform index math stays scalar)
   const int g = lane >> 5, lr = lane & 31;
   const int wm = wave / CFG::WGN, wn = wave % CFG::WGN;
-  const int nk = p.K / BK;
+  const int nk = p.K / KR;
   auto swz = [](int r) { return ROWB == 64 ? (r >> 2) & 3 : (r >> 1) & 7; };  // chunk XOR of LDS row r
   const int Lv = p.nblk * 32;  // QKV: rows are addressed per sequence, padded to whole 32-token blocks
 
@@ -124,7 +152,7 @@ void gemm3_kernel(const Gemm3P p, int n_tiles, int total_tiles, int per_xcd) {
   const bool normal = EPI == G3_QKV && kind == 2;
 
   // ---- staging: per-lane source offsets (bytes) of the two 4 KB pieces of each operand ---------------------
-  const unsigned a_bytes = (unsigned)((long)p.M * p.lda * ES), w_bytes = (unsigned)((long)n_tiles * BN * p.K * ES);
+  const unsigned a_bytes = (unsigned)((long)p.M * p.lda * EB), w_bytes = (unsigned)((long)n_tiles * BN * p.K * EB);
   static_assert(APC >= 1 && WPC >= 1, "tile too small for the workgroup");
   // (fixed-size arrays: an array whose size depends on a template parameter, used as an argument of the LDS-DMA
   // builtin, is what makes the HOST pass drop the kernel stub)
@@ -142,7 +170,7 @@ void gemm3_kernel(const Gemm3P p, int n_tiles, int total_tiles, int per_xcd) {
       ok = seq < p.n_seq && t < p.L;
       row = (long)seq * p.L + t;
     }
-    voffA[i] = ok ? (unsigned)(row * p.lda * ES + c * 16) : OOB;
+    voffA[i] = ok ? (unsigned)(row * p.lda * EB + c * 16) : OOB;
     if constexpr (EPI == G3_RESID) {  // conv: which of the three time taps exist for this row
       const int t = p.conv_C2 > 0 ? (int)((row / p.conv_F) % p.conv_T) : 1;
       tapmask[i] = ok ? ((t >= 1 ? 1 : 0) | 2 | (t + 1 < p.conv_T ? 4 : 0)) : 0;
@@ -152,14 +180,14 @@ void gemm3_kernel(const Gemm3P p, int n_tiles, int total_tiles, int per_xcd) {
   for (int i = 0; i < WPC; ++i) {
     const int r = (i * NW + wave) * RPI + lane / CPR;
     const int c = (lane % CPR) ^ swz(r);
-    voffW[i] = (unsigned)((long)(n0 + r) * p.K * ES + c * 16);
+    voffW[i] = (unsigned)((long)(n0 + r) * p.K * EB + c * 16);
   }
   // LDS-DMA of one k-step: APC pieces of the A tile, WPC of the W tile (1 KB per wave-instruction; the pieces of a
   // thread are NW KB apart).  The instruction's immediate offset would also move the LDS address, so it stays 0 and
   // the k offset goes into the scalar offset.
   // conv: the descriptor starts one time step (conv_F rows) BEFORE A so that the tap offset dt * conv_F rows is >= 0
   const bool conv = EPI == G3_RESID && p.conv_C2 > 0;
-  const unsigned tap_bytes = conv ? (unsigned)(p.conv_F * p.conv_C2 * ES) : 0u;
+  const unsigned tap_bytes = conv ? (unsigned)(p.conv_F * p.conv_C2 * EB) : 0u;
   const int c2_shift = conv ? __builtin_ctz((unsigned)p.conv_C2) : 0;
   const rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(p.A)) - tap_bytes, 0,
                                                       a_bytes + 2 * tap_bytes, 0x00020000);
@@ -169,8 +197,8 @@ void gemm3_kernel(const Gemm3P p, int n_tiles, int total_tiles, int per_xcd) {
     char* st_ = smem + (stage) * ST_BYTES + wave * 1024;                                                              \
     const int so_ = (kt) * ROWB;                                                                                      \
     if (conv) {                                                                                                       \
-      const int tap_ = ((kt) * BK) >> c2_shift;                                                                       \
-      const int soa_ = tap_ * (int)tap_bytes + (((kt) * BK) & (p.conv_C2 - 1)) * ES;                                  \
+      const int tap_ = ((kt) * KR) >> c2_shift;                                                                       \
+      const int soa_ = tap_ * (int)tap_bytes + (((kt) * KR) & (p.conv_C2 - 1)) * EB;                                  \
       _Pragma("unroll") for (int i_ = 0; i_ < APC; ++i_)                                                              \
           __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lptr_t)(st_ + i_ * NW * 1024), 16,                            \
                                                    ((tapmask[i_] >> tap_) & 1) ? voffA[i_] : OOB, soa_, 0, 0);        \
@@ -188,11 +216,10 @@ void gemm3_kernel(const Gemm3P p, int n_tiles, int total_tiles, int per_xcd) {
   const int pofs = (normal ? wm * (TB * 32) * ROWB : A_BYTES + wn * (FB * 32) * ROWB) + lr * ROWB;
   const int qofs = (normal ? A_BYTES + wn * (FB * 32) * ROWB : wm * (TB * 32) * ROWB) + lr * ROWB;
   const int sw = swz(lr);
-  constexpr int MS = ES == 2 ? ROWB / 32 : ROWB / 64;  // MFMA steps per k-step: 32 B (half k16) / 64 B (e4m3 k64) of a row
-  int kc[ROWB / 32];
+  constexpr int MS = ROWB / 32;  // 32-byte (k16) pieces of a row: half = MS MFMA steps; X3 = MS / 2 steps of hi (m) and lo (m + MS / 2)
+  int kc[MS];
 #pragma unroll
-  for (int m = 0; m < ROWB / 32; ++m)  // half step m: chunk 2 m + g;  e4m3 step m: chunks 4 m + 2 g, + 1 (kc[2m], kc[2m+1])
-    kc[m] = ((ES == 2 ? 2 * m + g : 4 * (m >> 1) + 2 * g + (m & 1)) ^ sw) * 16;
+  for (int m = 0; m < MS; ++m) kc[m] = ((2 * m + g) ^ sw) * 16;  // piece m: chunk 2 m + g
 
   f32x16 acc[NP][NQ];
 #pragma unroll
@@ -223,22 +250,19 @@ void gemm3_kernel(const Gemm3P p, int n_tiles, int total_tiles, int per_xcd) {
   // RMSNorm factors: the partial sums of squares are requested BEFORE the LDS-DMA prologue and consumed right after
   // it behind an explicit vmcnt(0) (ordinary loads and LDS-DMA do not return in order, so no counted wait may separate
   // them): their latency overlaps the first tiles' instead of sitting in the epilogue (~2 k cycles of a 31 k wave life).
-  // (RESID with ssq_in: the statistics are those of the OLD x rows, used as the quantisation scale of the e4m3 shadow)
-  float rs[TB], part[TB][8], asc[TB];
-  const float dimf = EPI == G3_RESID ? (float)p.N : (float)p.K;
+  float rs[TB], part[TB][8];
 #pragma unroll
   for (int j = 0; j < TB; ++j) {
     rs[j] = 1.f;
-    asc[j] = (EPI != G3_RESID && p.ascale && trow[j] >= 0) ? p.ascale[trow[j]] : 1.f;
 #pragma unroll
     for (int q = 0; q < 8; ++q)
-      part[j][q] = (p.ssq_in && trow[j] >= 0 && q < p.ssq_parts) ? p.ssq_in[(long)q * p.M + trow[j]] : 0.f;
+      part[j][q] = (EPI != G3_RESID && p.ssq_in && trow[j] >= 0 && q < p.ssq_parts) ? p.ssq_in[(long)q * p.M + trow[j]] : 0.f;
   }
   constexpr int LPS = APC + WPC;  // LDS-DMA instructions per thread and k-step
 #pragma unroll
   for (int s0 = 0; s0 < NST - 1; ++s0)
     if (s0 < nk) G3_ISSUE(s0, s0);
-  if (p.ssq_in) {
+  if (EPI != G3_RESID && p.ssq_in) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -247,9 +271,7 @@ void gemm3_kernel(const Gemm3P p, int n_tiles, int total_tiles, int per_xcd) {
 #pragma unroll
       for (int q = 0; q < 8; ++q) sum += part[j][q];
       for (int q = 8; q < p.ssq_parts; ++q) sum += trow[j] >= 0 ? p.ssq_in[(long)q * p.M + trow[j]] : 0.f;  // D > 512
-      rs[j] = trow[j] >= 0 ? sqrtf(dimf) / fmaxf(sqrtf(sum), 1e-12f) : 0.f;
-      if constexpr (EPI == G3_RESID) rs[j] = fminf(rs[j], 1048576.f);  // quantisation scale of the e4m3 shadow row
-      else rs[j] = rs[j] / asc[j];  // A holds x * asc (e4m3 shadow): undo the producer's scale
+      rs[j] = trow[j] >= 0 ? sqrtf((float)p.K) / fmaxf(sqrtf(sum), 1e-12f) : 0.f;
     }
   }
   int stage = 0, stage2 = NST - 1;
@@ -268,7 +290,7 @@ void gemm3_kernel(const Gemm3P p, int n_tiles, int total_tiles, int per_xcd) {
     if constexpr ((ABL & 8) != 0) { const long long tq2 = clock64(); t_wait += tq1 - tq0; t_bar += tq2 - tq1; }
     if (kt + NST - 1 < nk && !(ABL & 1)) G3_ISSUE(kt + NST - 1, stage2);
     const char* st = smem + stage * ST_BYTES;
-    if constexpr (ES == 2) {
+    if constexpr (!X3) {
 #pragma unroll
       for (int m = 0; m < ((ABL & 4) ? 0 : MS); ++m) {
         hfx8 fp[NP], fq[NQ];
@@ -283,26 +305,31 @@ void gemm3_kernel(const Gemm3P p, int n_tiles, int total_tiles, int per_xcd) {
       }
     } else {
 #pragma unroll
-      for (int m = 0; m < ((ABL & 4) ? 0 : MS); ++m) {
-        i32x8 fp[NP], fq[NQ];
+      for (int m = 0; m < ((ABL & 4) ? 0 : MS / 2); ++m) {  // k16 piece m: hi at chunk pair m, lo at chunk pair m + MS / 2
+        hfx8 ph[NP], pl[NP], qh[NQ], ql[NQ];
 #pragma unroll
         for (int a = 0; a < NP; ++a) {
-          const u32x4 lo = *reinterpret_cast<const u32x4*>(st + pofs + a * 32 * ROWB + kc[2 * m]);
-          const u32x4 hi = *reinterpret_cast<const u32x4*>(st + pofs + a * 32 * ROWB + kc[2 * m + 1]);
-          fp[a] = i32x8{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
+          ph[a] = *reinterpret_cast<const hfx8*>(st + pofs + a * 32 * ROWB + kc[m]);
+          pl[a] = *reinterpret_cast<const hfx8*>(st + pofs + a * 32 * ROWB + kc[m + MS / 2]);
         }
 #pragma unroll
         for (int b = 0; b < NQ; ++b) {
-          const u32x4 lo = *reinterpret_cast<const u32x4*>(st + qofs + b * 32 * ROWB + kc[2 * m]);
-          const u32x4 hi = *reinterpret_cast<const u32x4*>(st + qofs + b * 32 * ROWB + kc[2 * m + 1]);
-          fq[b] = i32x8{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
+          qh[b] = *reinterpret_cast<const hfx8*>(st + qofs + b * 32 * ROWB + kc[m]);
+          ql[b] = *reinterpret_cast<const hfx8*>(st + qofs + b * 32 * ROWB + kc[m + MS / 2]);
         }
+        // three passes over the wave's tiles (small terms first): consecutive MFMAs never share an accumulator
 #pragma unroll
         for (int a = 0; a < NP; ++a)
 #pragma unroll
-          for (int b = 0; b < NQ; ++b)  // e4m3 x e4m3, E8M0 block scales 127 = 1.0
-            acc[a][b] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fp[a], fq[b], acc[a][b], 0, 0, 0, 0x7f7f7f7f, 0,
-                                                                         0x7f7f7f7f);
+          for (int b = 0; b < NQ; ++b) acc[a][b] = MFMA32_H(pl[a], qh[b], acc[a][b]);
+#pragma unroll
+        for (int a = 0; a < NP; ++a)
+#pragma unroll
+          for (int b = 0; b < NQ; ++b) acc[a][b] = MFMA32_H(ph[a], ql[b], acc[a][b]);
+#pragma unroll
+        for (int a = 0; a < NP; ++a)
+#pragma unroll
+          for (int b = 0; b < NQ; ++b) acc[a][b] = MFMA32_H(ph[a], qh[b], acc[a][b]);
       }
     }
     stage = stage == NST - 1 ? 0 : stage + 1;
@@ -320,36 +347,38 @@ void gemm3_kernel(const Gemm3P p, int n_tiles, int total_tiles, int per_xcd) {
   // stride per instruction, every line written in 4 pieces) ran at ~1.2 TB/s: FF1 took 81 us with its MFMAs removed.
   __syncthreads();
   char* wst = smem + wave * 8192;
-  if constexpr (EPI == G3_FF1 && ES == 1) {
-    // e4m3 operands: acc * (row factor) * (weight row scale) + bias -> GELU -> e4m3 hidden (unit scale, saturating).
-    // A token row of this wave is 64 features = 64 B: four 16-byte chunks c = 2 a + g, staged at chunk c ^ ((row >> 1) & 3).
-    unsigned char* out8 = reinterpret_cast<unsigned char*>(p.out);
-    const int nb0 = n0 + wn * 64;
+  float amax = 0.f;  // (X3) largest magnitude that went through a hi + lo split
+  if constexpr (EPI == G3_FF1 && X3) {
+    // hl32 hidden activation: a token row of this wave is 64 features = [hi 0..31 | lo 0..31 | hi 32..63 | lo 32..63] =
+    // 256 B; 16-byte chunk c = 8 a + 4 (lo) + 2 k + g is staged at chunk c ^ (row & 15) like the RESID rows below
+    char* out8 = reinterpret_cast<char*>(p.out);
+    const int nb0 = n0 + wn * 64;  // first feature of this wave
+    const int r4 = lane >> 4, cp = lane & 15;
 #pragma unroll
     for (int b = 0; b < TB; ++b) {
 #pragma unroll
       for (int a = 0; a < FB; ++a) {
-        unsigned d[4];
+        f32x4 bq[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const f32x4 bq = *reinterpret_cast<const f32x4*>(p.bias + nb0 + a * 32 + 8 * q + 4 * g);
-          const f32x4 sq = *reinterpret_cast<const f32x4*>(p.wscale + nb0 + a * 32 + 8 * q + 4 * g);
-          float v[4];
+        for (int q = 0; q < 4; ++q) bq[q] = *reinterpret_cast<const f32x4*>(p.bias + nb0 + a * 32 + 8 * q + 4 * g);
+        float v[16];
 #pragma unroll
-          for (int i = 0; i < 4; ++i) v[i] = gelu_tanh(fmaf(acc[a][b][4 * q + i] * rs[b], sq[i], bq[i]));
-          d[q] = pk4_f8(v[0], v[1], v[2], v[3]);
+        for (int r = 0; r < 16; ++r) v[r] = gelu_erf(fmaf(acc[a][b][r], rs[b], bq[r >> 2][r & 3]));
+        u32x4 hi[2], lo[2];
+        pack_row_hl(v, hi, lo, amax);
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          *reinterpret_cast<u32x4*>(wst + lr * 256 + (((8 * a + 2 * k + g) ^ (lr & 15)) << 4)) = hi[k];
+          *reinterpret_cast<u32x4*>(wst + lr * 256 + (((8 * a + 4 + 2 * k + g) ^ (lr & 15)) << 4)) = lo[k];
         }
-        auto r0 = __builtin_amdgcn_permlane32_swap(d[0], d[2], false, false);
-        auto r1 = __builtin_amdgcn_permlane32_swap(d[1], d[3], false, false);
-        *reinterpret_cast<u32x4*>(wst + lr * 64 + (((2 * a + g) ^ ((lr >> 1) & 3)) << 4)) = u32x4{r0[0], r0[1], r1[0], r1[1]};
       }
-      static_assert(FB == 2, "row = 64 features");
+      static_assert(FB == 2, "row = 64 features = 256 B of hl32");
 #pragma unroll
-      for (int ps = 0; ps < 2; ++ps) {  // 16 rows x 64 B per wave-instruction
-        const int r = ps * 16 + (lane >> 2), cp = lane & 3;
-        const u32x4 w = *reinterpret_cast<const u32x4*>(wst + r * 64 + (cp << 4));
+      for (int ps = 0; ps < 8; ++ps) {  // 4 rows x 256 B per wave-instruction
+        const int r = ps * 4 + r4;
+        const u32x4 w = *reinterpret_cast<const u32x4*>(wst + r * 256 + (cp << 4));
         const long row = (long)row0 + 32 * b + r;
-        if (row < p.M) *reinterpret_cast<u32x4*>(out8 + row * p.ldo + nb0 + ((cp ^ ((r >> 1) & 3)) << 4)) = w;
+        if (row < p.M) *reinterpret_cast<u32x4*>(out8 + (row * p.ldo + nb0) * 4 + ((cp ^ (r & 15)) << 4)) = w;
       }
     }
   } else if constexpr (EPI == G3_FF1) {
@@ -389,9 +418,6 @@ void gemm3_kernel(const Gemm3P p, int n_tiles, int total_tiles, int per_xcd) {
     if (nb0 < p.N) {  // (N = 64: the first frontend conv -- the upper column half of the tile is weight padding)
     // The x loads of a token block are all requested before the first is used: one at a time (load x, add, store,
     // next pass) they cost a memory round trip EACH -- 16 of them were 31 k of a 122 k-cycle wave life in FF2.
-    // (e4m3 operands: ONE dequantisation factor for the whole weight matrix, applied with the residual add below;
-    // p.bias then holds bias / factor)
-    const float wsc = ES == 1 ? p.wscale[0] : 1.f;
     if (p.bias) {  // bias in the MFMA layout (lane = token, 4-feature runs): 8 small loads, no extra live registers
 #pragma unroll
       for (int a = 0; a < FB; ++a)
@@ -415,13 +441,13 @@ void gemm3_kernel(const Gemm3P p, int n_tiles, int total_tiles, int per_xcd) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) colq[q] = (unsigned)((cp ^ (4 * q + r4)) << 2);  // (row & 15) = 4 (ps & 3) + r4
     const int rows_left = p.M - row0 - r4;  // row (32 b + 4 ps + r4) exists iff 32 b + 4 ps < rows_left
-    if (p.gelu) {  // frontend convs: BatchNorm is folded into W / bias, GELU in the tanh form of the half path
+    if (p.gelu) {  // frontend convs: BatchNorm is folded into W / bias; GELU in the tanh form of the half path, exact for X3
 #pragma unroll
       for (int a = 0; a < FB; ++a)
 #pragma unroll
         for (int b = 0; b < TB; ++b)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) acc[a][b][r] = gelu_tanh(acc[a][b][r]);
+          for (int r = 0; r < 16; ++r) acc[a][b][r] = X3 ? gelu_erf(acc[a][b][r]) : gelu_tanh(acc[a][b][r]);
     }
 #pragma unroll
     for (int b = 0; b < TB; ++b) {
@@ -446,17 +472,23 @@ void gemm3_kernel(const Gemm3P p, int n_tiles, int total_tiles, int per_xcd) {
         const bool ok = 32 * b + 4 * ps < rows_left;
         f32x4 v = *reinterpret_cast<const f32x4*>(wst + r * 256 + (cp << 4));
 #pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] = ES == 1 ? fmaf(v[i], wsc, xv[ps][i]) : v[i] + xv[ps][i];
+        for (int i = 0; i < 4; ++i) v[i] += xv[ps][i];
         if (ok) {
           if (p.x) *reinterpret_cast<f32x4*>(p.x + off) = v;
-          if (xb) *reinterpret_cast<u32x2*>(xb + off) = u32x2{pk2(v[0], v[1]), pk2(v[2], v[3])};
-        }
-        if (p.x8) {  // e4m3 shadow x * c, c = RMSNorm factor of the OLD row (within a few % of the new one; the consumer
-                     // divides it out again, so only the e4m3 range matters); c of row r lives in lane r of rs[b]
-          const float c = __shfl(rs[b], r);
-          if (ok) {
-            *reinterpret_cast<unsigned*>(reinterpret_cast<unsigned char*>(p.x8) + off) = pk4_f8(v[0] * c, v[1] * c, v[2] * c, v[3] * c);
-            if (n0 == 0 && wn == 0 && cp == 0) p.ascale_out[row0 + 32 * b + r] = c;
+          if constexpr (X3) {
+            // hl32 shadow [M, 2 ldx]: features f .. f + 3 (f = nb0 + 4 (cp ^ (row & 15)), inside one 32-block): the hi run
+            // at half offset 2 (off - f) + 64 (f / 32) + f % 32 = 2 off - (f & 31), the lo run 32 halves further
+            if (xb) {
+              const unsigned f = (unsigned)nb0 + colq[ps & 3];
+              unsigned wh[2], wl[2];
+              split2(v[0], v[1], wh[0], wl[0], amax);
+              split2(v[2], v[3], wh[1], wl[1], amax);
+              hf* d = xb + (2u * off - (f & 31u));
+              *reinterpret_cast<u32x2*>(d) = u32x2{wh[0], wh[1]};
+              *reinterpret_cast<u32x2*>(d + 32) = u32x2{wl[0], wl[1]};
+            }
+          } else {
+            if (xb) *reinterpret_cast<u32x2*>(xb + off) = u32x2{pk2(v[0], v[1]), pk2(v[2], v[3])};
           }
         }
         float ssq = ok ? fmaf(v[0], v[0], fmaf(v[1], v[1], fmaf(v[2], v[2], v[3] * v[3]))) : 0.f;
@@ -467,6 +499,8 @@ void gemm3_kernel(const Gemm3P p, int n_tiles, int total_tiles, int per_xcd) {
     }
     }
   } else {  // G3_QKV
+    // fragment-major attention operands; X3: a 32-token block is [hi block 2 KB | lo block 2 KB] (attn2.hip)
+    constexpr int BLK_E = X3 ? 2048 : 1024;  // half elements per block
     if (kind < 2) {  // q / k: RoPE, fragment-major [quarter][token][8 dims]
       hf* dst = reinterpret_cast<hf*>(kind == 0 ? p.qf : p.kf);
 #pragma unroll
@@ -479,14 +513,22 @@ void gemm3_kernel(const Gemm3P p, int n_tiles, int total_tiles, int per_xcd) {
 #pragma unroll
         for (int a = 0; a < FB; ++a) {
           const int head = (n0 - kind * p.inner + wn * 64 + a * 32) >> 5;
-          hf* blk = dst + (((long)tseq[b] * p.heads + head) * p.nbp + tblk[b]) * 1024;
+          hf* blk = dst + (((long)tseq[b] * p.heads + head) * p.nbp + tblk[b]) * BLK_E;
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             const float e0 = acc[a][b][4 * q] * rs[b], o0 = acc[a][b][4 * q + 1] * rs[b];
             const float e1 = acc[a][b][4 * q + 2] * rs[b], o1 = acc[a][b][4 * q + 3] * rs[b];
-            const u32x2 w = {pk2(e0 * cs[q][0] - o0 * cs[q][1], o0 * cs[q][0] + e0 * cs[q][1]),
-                             pk2(e1 * cs[q][2] - o1 * cs[q][3], o1 * cs[q][2] + e1 * cs[q][3])};
-            *reinterpret_cast<u32x2*>(blk + (q * 32 + lr) * 8 + 4 * g) = w;
+            const float r0 = e0 * cs[q][0] - o0 * cs[q][1], r1 = o0 * cs[q][0] + e0 * cs[q][1];
+            const float r2 = e1 * cs[q][2] - o1 * cs[q][3], r3 = o1 * cs[q][2] + e1 * cs[q][3];
+            if constexpr (X3) {
+              unsigned wh[2], wl[2];
+              split2(r0, r1, wh[0], wl[0], amax);
+              split2(r2, r3, wh[1], wl[1], amax);
+              *reinterpret_cast<u32x2*>(blk + (q * 32 + lr) * 8 + 4 * g) = u32x2{wh[0], wh[1]};
+              *reinterpret_cast<u32x2*>(blk + 1024 + (q * 32 + lr) * 8 + 4 * g) = u32x2{wl[0], wl[1]};
+            } else {
+              *reinterpret_cast<u32x2*>(blk + (q * 32 + lr) * 8 + 4 * g) = u32x2{pk2(r0, r1), pk2(r2, r3)};
+            }
           }
         }
       }
@@ -501,14 +543,18 @@ void gemm3_kernel(const Gemm3P p, int n_tiles, int total_tiles, int per_xcd) {
 #pragma unroll
         for (int b = 0; b < FB; ++b) {  // feature block b (lanes)
           const int head = (n0 - 2 * p.inner + wn * 64 + b * 32) >> 5;
-          hf* blk = dst + (((long)tseq[a] * p.heads + head) * p.nbp + tblk[a]) * 1024;
+          hf* blk = dst + (((long)tseq[a] * p.heads + head) * p.nbp + tblk[a]) * BLK_E;
 #pragma unroll
           for (int s = 0; s < 2; ++s) {
-            u32x4 w;
+            unsigned w[4], wl[4] = {0, 0, 0, 0};
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-              w[i] = pk2(acc[a][b][8 * s + 2 * i] * sk[8 * s + 2 * i], acc[a][b][8 * s + 2 * i + 1] * sk[8 * s + 2 * i + 1]);
-            *reinterpret_cast<u32x4*>(blk + (s * 64 + lane) * 8) = w;
+            for (int i = 0; i < 4; ++i) {
+              const float v0 = acc[a][b][8 * s + 2 * i] * sk[8 * s + 2 * i], v1 = acc[a][b][8 * s + 2 * i + 1] * sk[8 * s + 2 * i + 1];
+              if constexpr (X3) split2(v0, v1, w[i], wl[i], amax);
+              else w[i] = pk2(v0, v1);
+            }
+            *reinterpret_cast<u32x4*>(blk + (s * 64 + lane) * 8) = u32x4{w[0], w[1], w[2], w[3]};
+            if constexpr (X3) *reinterpret_cast<u32x4*>(blk + 1024 + (s * 64 + lane) * 8) = u32x4{wl[0], wl[1], wl[2], wl[3]};
           }
         }
       }
@@ -528,6 +574,7 @@ void gemm3_kernel(const Gemm3P p, int n_tiles, int total_tiles, int per_xcd) {
       }
     }
   }
+  if constexpr (X3) flag_range(p.status, amax);
   if constexpr ((ABL & 8) != 0) {  // development timing dump over the head of the (already written) output
     const long long t_end = clock64();
     __syncthreads();
@@ -539,7 +586,7 @@ void gemm3_kernel(const Gemm3P p, int n_tiles, int total_tiles, int per_xcd) {
   }
 }
 
-template <int EPI, typename CFG, int ABL = 0>
+template <int EPI, typename CFG, bool X3 = false, int ABL = 0>
 void launch_cfg(const Gemm3P& p, hipStream_t s) {
   const int n_tiles = (p.N + CFG::BN - 1) / CFG::BN;
   const long rows = p.epi == G3_QKV ? (long)p.n_seq * p.nblk * 32 : (long)p.M;
@@ -548,24 +595,23 @@ void launch_cfg(const Gemm3P& p, hipStream_t s) {
   long per = (total + 7) / 8;
   per = (per + n_tiles - 1) / n_tiles * n_tiles;
   dim3 grid((unsigned)(per * 8)), block(64 * CFG::WGM * CFG::WGN);
-  hipLaunchKernelGGL((gemm3_kernel<EPI, CFG, ABL>), grid, block, 0, s, p, n_tiles, (int)total, (int)per);
+  hipLaunchKernelGGL((gemm3_kernel<EPI, CFG, X3, ABL>), grid, block, 0, s, p, n_tiles, (int)total, (int)per);
 }
 
 }  // namespace
 
 bool gemm3_supported(const Gemm3P& p) {
-  const int es = p.f8 ? 1 : 2;
-  if (p.M <= 0 || p.K % (p.f8 ? 128 : 64) != 0 || p.K < 128 || p.lda % (16 / es) != 0) return false;
-  if ((long)p.M * p.lda * es >= 0x7fffffffL || (long)(p.N + 255) / 256 * 256 * p.K * es >= 0x7fffffffL) return false;
-  if (p.f8 && (!p.wscale || p.epi == G3_QKV)) return false;
-  if (p.conv_C2 > 0 && (p.epi != G3_RESID || p.f8 || (p.conv_C2 & (p.conv_C2 - 1)) || p.conv_C2 % 32 != 0 || p.lda != p.conv_C2 ||
+  const int eb = p.x3 ? 4 : 2;  // operand bytes per k value (x3: hl32 = a hi and a lo half)
+  if (p.M <= 0 || p.K % 64 != 0 || p.K < 128 || p.lda % 8 != 0) return false;
+  if ((long)p.M * p.lda * eb >= 0x7fffffffL || (long)(p.N + 255) / 256 * 256 * p.K * eb >= 0x7fffffffL) return false;
+  if (p.x3 && BT_HALF_IS_BF16) return false;
+  if (p.conv_C2 > 0 && (p.epi != G3_RESID || (p.conv_C2 & (p.conv_C2 - 1)) || p.conv_C2 % 32 != 0 || p.lda != p.conv_C2 ||
                         p.K != 3 * p.conv_C2 || p.conv_F <= 0 || p.conv_T <= 0 || p.M % (p.conv_T * p.conv_F) != 0 || !p.no_resid))
     return false;
   if (p.epi == G3_RESID && !p.x && !p.xb) return false;
-  if (p.x8 && (p.epi != G3_RESID || !p.ssq_in || !p.ascale_out || p.ldx % 4 != 0)) return false;
   if (p.epi == G3_QKV) return p.inner % 128 == 0 && p.inner == p.heads * 32 && p.L > 0 && p.L <= 1536;
-  if (p.epi == G3_FF1) return p.N % 128 == 0 && p.ldo % (p.f8 ? 16 : 8) == 0;
-  if (p.epi == G3_RESID) return p.N % 64 == 0 && p.ldx % 8 == 0 && (long)(p.M + 256) * p.ldx < 0x7fffffffL &&
+  if (p.epi == G3_FF1) return p.N % 128 == 0 && p.ldo % 8 == 0;
+  if (p.epi == G3_RESID) return p.N % 64 == 0 && p.ldx % 8 == 0 && (long)(p.M + 256) * p.ldx * (p.x3 ? 2 : 1) < 0x7fffffffL &&
                                 (long)(p.N / 64) * p.M < 0x7fffffffL;  // (32-bit element offsets in the epilogue)
   return false;
 }
@@ -588,25 +634,33 @@ int launch_gemm3(const Gemm3P& p, hipStream_t s) {
   // 256 or 192 token rows per tile: fewer (rounds over the 256 CUs) x (rows per tile) wins
   auto cost = [&](int bm) { const long t = ((long)p.M + bm - 1) / bm * (p.N / 256); return (t + 255) / 256 * bm; };
   const bool rows192 = big && p.epi == G3_RESID && force_big != 1 && cost(192) < cost(256);
-  if (p.f8) {
-    if (p.epi == G3_FF1) { if (big) launch_cfg<G3_FF1, CfgB8>(p, s); else launch_cfg<G3_FF1, CfgS8>(p, s); }
-    else if (rows192) launch_cfg<G3_RESID, G3CfgT8>(p, s);
-    else if (big) launch_cfg<G3_RESID, CfgB8>(p, s);
-    else launch_cfg<G3_RESID, CfgS8>(p, s);
+  if (p.x3) {
+    switch (p.epi) {
+      case G3_FF1:
+        if (big) launch_cfg<G3_FF1, G3CfgBX, true>(p, s); else launch_cfg<G3_FF1, G3CfgSX, true>(p, s);
+        break;
+      case G3_RESID:
+        if (rows192) launch_cfg<G3_RESID, G3CfgTX, true>(p, s);
+        else if (big) launch_cfg<G3_RESID, G3CfgBX, true>(p, s);
+        else launch_cfg<G3_RESID, G3CfgSX, true>(p, s);
+        break;
+      case G3_QKV: launch_cfg<G3_QKV, G3CfgSX, true>(p, s); break;
+      default: return -1;
+    }
     return (int)hipGetLastError();
   }
   switch (p.epi) {
     case G3_FF1:
       if (big) launch_cfg<G3_FF1, CfgB>(p, s);
 #ifdef BT_DEV
-      else if (abl == 8) launch_cfg<G3_FF1, CfgS, 8>(p, s);
+      else if (abl == 8) launch_cfg<G3_FF1, CfgS, false, 8>(p, s);
 #endif
       else launch_cfg<G3_FF1, CfgS>(p, s);
       break;
     case G3_RESID:
 #ifdef BT_DEV
-      if (big && abl == 8) { launch_cfg<G3_RESID, CfgB, 8>(p, s); break; }
-      if (!big && abl == 8) { launch_cfg<G3_RESID, CfgS, 8>(p, s); break; }
+      if (big && abl == 8) { launch_cfg<G3_RESID, CfgB, false, 8>(p, s); break; }
+      if (!big && abl == 8) { launch_cfg<G3_RESID, CfgS, false, 8>(p, s); break; }
 #endif
       if (rows192) launch_cfg<G3_RESID, G3CfgT>(p, s);
       else if (big) launch_cfg<G3_RESID, CfgB>(p, s);

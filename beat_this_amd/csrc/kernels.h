@@ -52,7 +52,7 @@ struct GemmP {
 };
 int launch_gemm(const GemmP& p, int prec, hipStream_t s);
 
-// ---- half GEMM of the main layers (gemm3.hip): LDS-DMA ring, transposed product, register epilogues --------
+// ---- half / hi + lo GEMM of the main layers (gemm3.hip): LDS-DMA ring, transposed product, register epilogues --------
 enum { G3_FF1 = 0, G3_RESID = 1, G3_QKV = 2 };
 struct Gemm3P {
   const void* A; long lda; int M, K;   // half [M, lda]
@@ -66,19 +66,19 @@ struct Gemm3P {
   // QKV: rows are (sequence, token) with n_seq sequences of L tokens (M = n_seq * L); columns q | k | v | gates
   int n_seq, L, nblk, nbp, heads, inner;
   const float* rope; void* qf; void* kf; void* vf; float* gates; const float* b_gates;
-  // BT_PREC_FP8: f8 != 0 -> A and W are e4m3 bytes (lda in elements = bytes); wscale[N] = dequantisation factor of
-  // each W row; ascale[M] (FF1 / QKV) = factor the producer multiplied row m of x by before conversion; FF1 then
-  // writes its output as e4m3 as well (unit scale).  RESID (any operand type) with x8 != null also writes the e4m3
-  // shadow x8[m] = e4m3(x_new[m] * c[m]), c = RMSNorm factor of the OLD row from ssq_in, and ascale_out[m] = c[m].
   int no_resid;  // RESID: x = A W^T + bias (x is only written: frontend.linear, frontend convs)
   int gelu;      // RESID: x = gelu(... + bias) (tanh form; frontend convs).  x may be null then (half output xb only)
   // RESID, implicit-GEMM convolution (frontend convs, beat_tracker.py:155-166): conv_C2 > 0 -> A is the half shadow of the
   // (b, t, f, c) activation seen as [M = B T F/2, C2 = 2 C]; K = 3 C2 = the rows m - conv_F, m, m + conv_F (time taps
   // t-1, t, t+1; conv_F = F/2 rows per time step), rows outside 0 <= t < conv_T read as zeros
   int conv_C2, conv_T, conv_F;
-  int f8;
-  const float* wscale; const float* ascale;
-  void* x8; float* ascale_out;
+  // BT_PREC_F32X3: x3 != 0 -> A, W and every activation output (FF1: out; RESID: the shadow xb; QKV: qf / kf / vf) are
+  // fp32 values stored as interleaved hi / lo half planes ("hl32", gemm3.hip header): A = half [M, 2 lda], W = half
+  // [N padded, 2 K], out = half [M, 2 ldo], xb = half [M, 2 ldx], attention blocks of 4 KB ([hi 2 KB | lo 2 KB]); K, lda,
+  // ldo, ldx stay in fp32 elements.  FF1 uses the exact erf GELU.  status (may be null): set to 1 when a value beyond
+  // the fp16 range went through a hi + lo split (the caller then repeats the forward in BT_PREC_F32).
+  int x3;
+  int* status;
 };
 bool gemm3_supported(const Gemm3P& p);
 int launch_gemm3(const Gemm3P& p, hipStream_t s);
@@ -104,6 +104,10 @@ struct AttnFragP {
   int n_seq, L, heads, inner, nbp;
   int o_div;
   long o_outer, o_inner, o_tok;
+  // BT_PREC_F32X3: x3 != 0 -> q, k, v blocks are 4 KB ([hi block | lo block], attn2.hip); out is fp32 [rows, inner]
+  // (out_f32 != 0) or hl32 planes half [rows, 2 inner]; status: range flag of the hl32 output (may be null)
+  int x3, out_f32;
+  int* status;
 };
 int attn_frag_blocks(int L);  // 32-token blocks to allocate per (sequence, head): ceil(L/32) rounded up to a tile
 int launch_attn_frag(const AttnFragP& p, hipStream_t s);
@@ -118,6 +122,10 @@ struct QkvFrontP {
   void* q; void* k; void* v;  // [B * F * heads][nbp][1024] half
   float* gates;          // [B * F * heads][nbp * 32]
   int nbp;
+  // BT_PREC_F32X3: x3 != 0 -> wfrag = bt_pair_weights.w_qkv_frag_x3, output blocks of 4 KB ([hi block | lo block]); status:
+  // range flag (may be null)
+  int x3;
+  int* status;
 };
 int launch_qkv_front(const QkvFrontP& p, hipStream_t s);
 
@@ -178,12 +186,14 @@ struct HeadP {
   float* beat; float* downbeat;  // [M]
   int M, D, sum_head;
   int prenorm;         // x is already normalised (BeatThis.task_heads called on its own)
+  int* status;         // BT_PREC_F32X3 range flag (bit 1 is set when a logit is not finite), may be null
 };
 int launch_head(const HeadP& p, hipStream_t s);
 // transformer_blocks' final RMSNorm as a pass of its own: y = x * sqrt(D) / |x| * gamma   (roformer.py:181, stage exit)
 int launch_norm_out(const float* x, const float* gamma, float* y, long M, int D, hipStream_t s);
 // half shadow and per-64-column sums of squares [D/64][M] of a residual stream handed in from outside (stage entry)
-int launch_shadow_ssq(const float* x, void* xb, float* ssq, long M, int D, hipStream_t s);
+// (hl32 != 0: the shadow in the BT_PREC_F32X3 form, half [M, 2 D] interleaved hi / lo planes)
+int launch_shadow_ssq(const float* x, void* xb, float* ssq, long M, int D, hipStream_t s, int hl32 = 0);
 
 // One track of a batched front-end launch: input samples, their count, and where the track's output starts in the
 // concatenated output buffer (samples for the resampler, frames for the log-mel kernel) / how many outputs it has.

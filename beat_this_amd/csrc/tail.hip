@@ -91,9 +91,14 @@ template <int C>
 struct TRing {
   static constexpr int KT = C / 32;
   static constexpr int STEP_B = 2 * KT * TILE_B;             // a step = 2 KT tiles (C = 512: 64 KB)
-  static constexpr int NST = 128 * 1024 / STEP_B;            // 128 KB ring: 2 stages at C = 512, 4 at C = 256
+  // TWO stages for both widths (C = 512: 2 x 64 KB, C = 256: 2 x 32 KB): every acquire() is then the same branch-free
+  // `vmcnt(0) lgkmcnt(0); barrier; vmcnt(0); burst` sequence.  The 4-stage ring C = 256 had through round 2 chose its
+  // counted vmcnt wait in a branch on the step index and returned NaNs -- the same symptom as the half-step refill
+  // experiments of DESIGN.md section 5 as soon as their wait sat in such a branch (hipcc's code around the pinned inline
+  // assembly, not the hardware: the LDS-DMA order itself is verified by tools/ubench/ldsdma_order.hip).
+  static constexpr int NST = 2;
   static constexpr int CH = STEP_B / 4096;  // buffer loads per thread per step (256 threads x 16 B = 4 KB each)
-  static_assert(NST == 2 || NST == 4, "ring shape");
+  static_assert(NST == 2, "ring shape");
   rsrc_t rs;
   char* lds;
   int tid, wave, total;
@@ -139,11 +144,9 @@ struct TRing {
   }
   // make step s readable by every wave (all older LDS-DMA done in every wave); the stage of step s - 1 is free from here on
   DEVI const char* acquire(int s) {
-    const int ahead = min(NST - 2, total - 1 - s);  // younger steps that may stay in flight
-    // (lgkmcnt(0): this wave's fragment reads of step s - 1 have returned before the barrier: its stage is refilled next)
-    if (NST == 4 && ahead >= 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * CH) : "memory");
-    else if (NST == 4 && ahead == 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(CH) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    // (lgkmcnt(0): this wave's fragment reads of step s - 1 have returned before the barrier: its stage is refilled next;
+    // vmcnt(0): step s -- the only one in flight in a two-stage ring -- has landed)
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 #if BT_TAIL_ISSUE == 2
     // hipcc reloads spilled registers (scratch_load -> VGPR) wherever it likes and waits for them with COUNTED vmcnt
@@ -153,7 +156,7 @@ struct TRing {
     // flight here (2-stage ring: vmcnt(0) above), so draining whatever the compiler has put here costs a reload's latency
     // at most, and nothing can move across: the burst sits between full scheduling barriers.
     __builtin_amdgcn_sched_barrier(0);
-    if (NST == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     issue(s + NST - 1);
     __builtin_amdgcn_sched_barrier(0);
 #endif
@@ -410,9 +413,7 @@ int launch_t(const LayerTailP& p, hipStream_t s) {
 }  // namespace
 
 bool layer_tail_supported(int C, int hidden) {
-  // (the C = 256 instantiation exists but its unit test shows NaNs -- not a race: reproducible -- and it is not dispatched
-  // until that is understood; transformer_dim = 256 models run their tails on gemm3.hip)
-  return C == 512 && hidden % 64 == 0 && hidden >= 128 && hidden <= 4096;
+  return (C == 512 || C == 256) && hidden % 64 == 0 && hidden >= 128 && hidden <= 4096;
 }
 
 int launch_layer_tail(const LayerTailP& p, hipStream_t s) {

@@ -191,8 +191,6 @@ class Spect2Frames:
         self.device = _gpu_device(device)
         self.float16 = bool(float16) and float16 != "f32x3"
         self.model = load_model(checkpoint_path, self.device)
-        if float16 == "fp8":  # extension: float16="fp8" -> autocast + e4m3 feed-forward GEMMs (BT_PREC_FP8)
-            self.model.fp8_weights = True
         if float16 == "f32x3":  # extension: fp32 activations, GEMMs and attention on three fp16 MFMAs per product (BT_PREC_F32X3)
             self.model.fp32_split_gemms = True
 
@@ -214,13 +212,14 @@ class Spect2Frames:
             with torch.autocast(enabled=self.float16, device_type=self.device.type):
                 return forward_chunks_sharded(self.model, spects, 1500, 6, group)
 
-    def spect2frames_batch(self, spect: torch.Tensor, frame_off):
+    def spect2frames_batch(self, spect: torch.Tensor, frame_off, checks=None):
         """Extension: the pieces ``spect[frame_off[k]:frame_off[k+1]]`` of one concatenated (frames, 128) spectrogram
         -> (beat, downbeat) logits concatenated the same way.  One chunk-gather launch per forward slice, one aggregation
-        launch for all pieces (same chunking / keep_first arithmetic as ``spect2frames``, inference.py:188-230)."""
+        launch for all pieces (same chunking / keep_first arithmetic as ``spect2frames``, inference.py:188-230).
+        ``checks``: see ``batch_predict_aggregate``."""
         with torch.inference_mode():
             with torch.autocast(enabled=self.float16, device_type=self.device.type):
-                return batch_predict_aggregate(spect, frame_off, 1500, 6, self.model)
+                return batch_predict_aggregate(spect, frame_off, 1500, 6, self.model, checks=checks)
 
     def __call__(self, spect):
         return self.spect2frames(spect)
@@ -345,7 +344,10 @@ class Audio2Beats(Audio2Frames):
         ``.result()`` of the returned handle waits for the copy and runs the host step.  Submitting batch i + 1 before
         collecting batch i keeps the GPU busy during the host step (bench.py does)."""
         spect, frame_off = self.signal2spect_many(signals, sr)
-        beat, down = self.spect2frames_batch(spect, frame_off)
+        # float16="f32x3": the range flags of the forward slices are collected, not waited for; ``result()`` looks at them
+        # once the batch's device-to-host copy has arrived and repeats the batch on the exact fp32 path if one fired
+        checks = [] if getattr(self.model, "fp32_split_gemms", False) and not self.float16 else None
+        beat, down = self.spect2frames_batch(spect, frame_off, checks=checks)
         if self.frames2beats.type != "minimal":
             class _Done:  # the DBN runs on the host right away (madmom)
                 def __init__(s, out): s.out = out
@@ -354,7 +356,33 @@ class Audio2Beats(Audio2Frames):
                           for k in range(len(signals))])
         pending = self.frames2beats.ragged_async(beat, down, frame_off)
         pending.logits = (beat, down, frame_off)   # framewise logits of the batch (concatenated), for callers that want them
+        if checks:
+            return _GuardedPending(pending, checks, lambda: self._many_exact(signals, sr))
         return pending
+
+    def _many_exact(self, signals, sr):
+        """``many`` on the exact fp32 MFMA path (the repeat of a float16="f32x3" batch whose range flag fired)."""
+        old = self.model.fp32_split_gemms
+        self.model.fp32_split_gemms = False
+        try:
+            return self.many(signals, sr)
+        finally:
+            self.model.fp32_split_gemms = old
+
+
+class _GuardedPending:
+    """A pending ``many_async`` result of the BT_PREC_F32X3 path: ``result()`` also evaluates the forward slices' range
+    flags (they arrived with / before the peak indices) and repeats the batch on the exact path when one fired."""
+
+    def __init__(self, inner, checks, redo):
+        self.inner, self.checks, self.redo = inner, checks, redo
+        self.logits = inner.logits
+
+    def result(self):
+        out = self.inner.result()
+        if any(eng.range_exceeded(chk) for eng, chk in self.checks):
+            return self.redo()
+        return out
 
 
 class File2Beats(Audio2Beats):
@@ -382,12 +410,33 @@ def _resample_filter(up: int, down: int, device):
     return _RESAMPLE_FILTERS[key]
 
 
-def batch_predict_aggregate(spect: torch.Tensor, frame_off, chunk_size: int, border_size: int, model):
+def batch_predict_aggregate(spect: torch.Tensor, frame_off, chunk_size: int, border_size: int, model, checks=None):
     """``split_predict_aggregate`` (keep_first) for several pieces stored back to back in ``spect`` (rows
     ``frame_off[k]:frame_off[k+1]``): -> (beat, downbeat), concatenated like the input.  Pieces longer than
     ``chunk_size - 2 border_size`` frames share one chunk table: their chunks are gathered slice by slice
     (MAX_CHUNKS_PER_LAUNCH) straight into the model and aggregated by one launch; shorter pieces (one odd-length chunk
-    each) go through ``split_predict_aggregate`` one by one."""
+    each) go through ``split_predict_aggregate`` one by one.
+    A ``BeatThis`` with ``fp32_split_gemms`` (BT_PREC_F32X3) runs its forward slices without waiting for their range flags
+    (``Engine.deferred_range_checks``): with ``checks=None`` the flags are looked at before returning and the batch is
+    repeated on the exact fp32 path if one fired; a caller that passes a list gets ``(engine, flags)`` appended instead and
+    evaluates them itself (``Audio2Beats.many_async``)."""
+    guard = isinstance(model, BeatThis) and model.fp32_split_gemms and not torch.is_autocast_enabled("cuda")
+    if guard:
+        eng = model.engine()
+        with eng.deferred_range_checks() as flags:
+            out = batch_predict_aggregate(spect, frame_off, chunk_size, border_size, _Unguarded(model))
+        if checks is not None:
+            checks.append((eng, flags))
+            return out
+        if eng.range_exceeded(flags):
+            model.fp32_split_gemms = False
+            try:
+                return batch_predict_aggregate(spect, frame_off, chunk_size, border_size, model)
+            finally:
+                model.fp32_split_gemms = True
+        return out
+    if isinstance(model, _Unguarded):
+        model = model.model
     _lib.require_gpu(spect, "spectrogram")
     if spect.dim() != 2 or spect.shape[1] != 128:
         raise ValueError(f"expected a (frames, 128) spectrogram, got {tuple(spect.shape)}")
@@ -453,6 +502,13 @@ def batch_predict_aggregate(spect: torch.Tensor, frame_off, chunk_size: int, bor
                                           len(pieces), max_frames, chunk_size, border_size, beat.data_ptr(),
                                           down.data_ptr()))
     return beat, down
+
+
+class _Unguarded:
+    """Marks a model whose range checks the caller has already taken over (batch_predict_aggregate's inner call)."""
+
+    def __init__(self, model):
+        self.model = model
 
 
 def resample_gpu(signal: torch.Tensor, in_rate: int, out_rate: int) -> torch.Tensor:

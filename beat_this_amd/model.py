@@ -75,12 +75,10 @@ class BeatThis(nn.Module):
         for key in state_dict_shapes(self.hparams):
             _attach(self, key, init[key])
         self._engine = None
-        # extension (BASELINE config 5): under autocast, run the main layers' feed-forward GEMMs on e4m3 weights and
-        # activations (BT_PREC_FP8); everything else stays on the bf16 path.  Off by default.
-        self.fp8_weights = False
-        # extension: outside autocast, run the plain GEMMs of the fp32 path on three half MFMAs per product (operands
-        # split into hi + lo halves, BT_PREC_F32X3) instead of fp32 MFMAs: fp32-class results at 16/3 of the matrix rate.
-        # Off by default: the default fp32 path is the exact one.
+        # extension: outside autocast, run every product of the fp32 path on three half MFMAs (operands split into hi + lo
+        # halves, BT_PREC_F32X3) instead of fp32 MFMAs: fp32-class results (1e-5 at the logits, identical beats) at 16/3 of
+        # the matrix rate.  Operands beyond the fp16 range of a hi part are detected and the batch is repeated on the
+        # exact path (Engine.forward_stages).  Off by default: the default fp32 path is the exact one.
         self.fp32_split_gemms = False
         self.eval()
 
@@ -149,7 +147,7 @@ class BeatThis(nn.Module):
             return (empty, empty.clone()) if last == 2 else torch.empty((x.shape[0], x.shape[1], D), dtype=torch.float32, device=x.device)
         half = torch.is_autocast_enabled("cuda") if hasattr(torch, "is_autocast_enabled") else False
         if half:
-            prec = _lib.PREC_FP8 if self.fp8_weights else _lib.PREC_HALF
+            prec = _lib.PREC_HALF
         else:
             prec = _lib.PREC_F32X3 if self.fp32_split_gemms else _lib.PREC_F32
         return self.engine().forward_stages(x, prec, first, last)

@@ -15,7 +15,6 @@ from . import _lib, tables
 
 LOG2E = 1.4426950408889634
 BN_EPS = 1e-5
-E4M3_MAX = 448.0  # largest finite OCP e4m3 (e4m3fn) value
 
 
 def perm32(w: torch.Tensor) -> torch.Tensor:
@@ -136,16 +135,19 @@ class PackedModel:
             w = sd[p + "conv2d.weight"] * sc[:, None, None, None]           # [co, ci, df, dt]
             w = w.permute(0, 3, 2, 1).reshape(2 * dim, 6 * dim)             # [co][dt][df][ci]
             d.conv_w[i][0], d.conv_w[i][1] = self._mat(w)
+            if 2 * dim >= 128:   # (the first convolution, N = 64, stays on the register-staged GEMM)
+                d.conv_w_x3[i] = self._hl32(w)
             d.conv_b[i] = self._f32(sd[p + "norm.bias"] - sd[p + "norm.running_mean"] * sc)
             dim *= 2
         # ---- frontend.linear: reference column = c*4 + f, ours = f*256 + c -----------------
         w = sd["frontend.linear.weight"].view(D, dim, 4).permute(0, 2, 1).reshape(D, 4 * dim)
         d.lin_w[0], d.lin_w[1] = self._mat(w)
+        d.lin_w_x3 = self._hl32(w)
         d.lin_b = self._f32(sd["frontend.linear.bias"])
         # ---- transformer layers ----------------------------------------------------------------
         for l in range(L):
             p = f"transformer_blocks.layers.{l}."
-            self._pair(d.layers[l], sd, p + "0.", p + "1.", D, fp8=True)
+            self._pair(d.layers[l], sd, p + "0.", p + "1.", D, x3=True)
         g = sd["transformer_blocks.norm.gamma"]
         d.head_w = self._f32(sd["task_heads.beat_downbeat_lin.weight"] * g[None, :])
         d.norm_out_g, d.head_w_raw = self._f32(g), self._f32(sd["task_heads.beat_downbeat_lin.weight"])  # (stage calls)
@@ -157,13 +159,6 @@ class PackedModel:
     # ------------------------------------------------------------------------------------------
     def _f32(self, t: torch.Tensor) -> int:
         t = t.to(torch.float32).contiguous().to(self.device)
-        self._keep.append(t)
-        return t.data_ptr()
-
-    def _e4m3(self, w: torch.Tensor) -> int:
-        """fp32 matrix with |w| <= 448 -> OCP e4m3 bytes on the device (round to nearest even)."""
-        t = w.to(torch.float32).clamp(-E4M3_MAX, E4M3_MAX).to(torch.float8_e4m3fn).view(torch.uint8).contiguous()
-        t = t.to(self.device)
         self._keep.append(t)
         return t.data_ptr()
 
@@ -189,7 +184,21 @@ class PackedModel:
         self._keep += [a, b]
         return a.data_ptr(), b.data_ptr()
 
-    def _pair(self, pw, sd, pa: str, pf: str, dim: int, fp8: bool = False) -> None:
+    def _hl32(self, w: torch.Tensor) -> int:
+        """BT_PREC_F32X3 form of a GEMM weight for csrc/gemm3.hip: fp32 [N, K] (K % 32 == 0) -> fp16 [N padded to 256][2 K],
+        per 32 consecutive columns the 32 hi halves (half(w)) followed by the 32 lo halves (half(w - hi)): w = hi + lo to
+        2^-22 (relative) for |w| >= 2^-3 and to 2^-25 absolute below.  0 (NULL) in a bfloat16 build."""
+        if _lib.lib().bt_half_is_bf16():
+            return 0
+        w = _pad_rows(w.to(torch.float32), 256)
+        hi = w.to(torch.float16)
+        lo = (w - hi.to(torch.float32)).to(torch.float16)
+        n, k = w.shape
+        t = torch.stack([hi.reshape(n, k // 32, 32), lo.reshape(n, k // 32, 32)], 2).reshape(n, 2 * k).contiguous().to(self.device)
+        self._keep.append(t)
+        return t.data_ptr()
+
+    def _pair(self, pw, sd, pa: str, pf: str, dim: int, x3: bool = False) -> None:
         heads = dim // 32
         pw.dim, pw.heads = dim, heads
         ga = sd[pa + "norm.gamma"]
@@ -199,11 +208,19 @@ class PackedModel:
         w = torch.cat([wqkv, wg], 0) * ga[None, :]
         pw.w_qkvg[0], pw.w_qkvg[1] = self._mat(w)
         if dim <= 128:
-            qf = qkv_fragment_major(_pad_rows(w.to(torch.float32)), dim).to(_lib.half_torch_dtype()).to(self.device)
+            qflat = qkv_fragment_major(_pad_rows(w.to(torch.float32)), dim)
+            qf = qflat.to(_lib.half_torch_dtype()).to(self.device)
             self._keep.append(qf)
             pw.w_qkv_frag = qf.data_ptr()
+            if not _lib.lib().bt_half_is_bf16():
+                pw.w_qkv_frag_x3 = self._x3_stream(qflat)
         pw.b_gates = self._f32(sd[pa + "to_gates.bias"])
         pw.w_out[0], pw.w_out[1] = self._mat(sd[pa + "to_out.0.weight"])
+        if x3 and dim % 128 == 0:   # main layers: hl32 weights of the LDS-DMA GEMM (csrc/gemm3.hip, BT_PREC_F32X3)
+            pw.w_qkvg_x3 = self._hl32(w)
+            pw.w_out_x3 = self._hl32(sd[pa + "to_out.0.weight"])
+            pw.w_ff1_x3 = self._hl32(sd[pf + "net.1.weight"] * sd[pf + "net.0.gamma"][None, :])
+            pw.w_ff2_x3 = self._hl32(sd[pf + "net.4.weight"])
         # (the register-chained kernels of fused.hip / fused2.hip are built for a hidden width of 4 dim: a main layer with
         # another ff_mult and dim <= 128 runs on the plain GEMM path)
         if dim <= 128 and sd[pf + "net.1.weight"].shape[0] == 4 * dim:
@@ -250,21 +267,13 @@ class PackedModel:
         pw.w_ff2[0], pw.w_ff2[1] = self._mat(sd[pf + "net.4.weight"])
         pw.b_ff2 = self._f32(sd[pf + "net.4.bias"])
         hidden = sd[pf + "net.1.weight"].shape[0]
-        if dim == 512 and hidden % 64 == 0 and 128 <= hidden <= 4096:  # fused layer tail (csrc/tail.hip)
+        if dim in (256, 512) and hidden % 64 == 0 and 128 <= hidden <= 4096:  # fused layer tail (csrc/tail.hip)
             w1 = (sd[pf + "net.1.weight"] * gf[None, :]).to(torch.float32)
             t = tail_fragment_major(sd[pa + "to_out.0.weight"].to(torch.float32), perm32(w1),
                                     perm32(sd[pf + "net.4.weight"].to(torch.float32)))
             t = t.to(_lib.half_torch_dtype()).to(self.device)
             self._keep.append(t)
             pw.w_tail_frag = t.data_ptr()
-        if fp8 and dim % 128 == 0:  # BT_PREC_FP8: e4m3 copies for the main layers' feed-forward GEMMs
-            w1 = _pad_rows((sd[pf + "net.1.weight"] * gf[None, :]).to(torch.float32), 256)
-            s1 = (w1.abs().amax(dim=1) / E4M3_MAX).clamp_min(1e-30)            # one factor per hidden unit
-            pw.w_ff1_f8, pw.s_ff1 = self._e4m3(w1 / s1[:, None]), self._f32(s1)
-            w2 = _pad_rows(sd[pf + "net.4.weight"].to(torch.float32), 256)
-            s2 = (w2.abs().max() / E4M3_MAX).clamp_min(1e-30)                  # one factor for the matrix
-            pw.w_ff2_f8, pw.s_ff2 = self._e4m3(w2 / s2), self._f32(s2.reshape(1))
-            pw.b_ff2_f8 = self._f32(sd[pf + "net.4.bias"] / s2)
 
 
 class PackedPair:
@@ -275,11 +284,11 @@ class PackedPair:
         self._keep: list[torch.Tensor] = []
         self.weights = _lib.PairWeights()
         sd = {k: v.detach().to("cpu", torch.float32) for k, v in sd.items()}
-        PackedModel._pair(self, self.weights, sd, attn_prefix, ff_prefix, dim)
+        PackedModel._pair(self, self.weights, sd, attn_prefix, ff_prefix, dim, x3=True)
 
     _f32 = PackedModel._f32
     _mat = PackedModel._mat
-    _e4m3 = PackedModel._e4m3
+    _hl32 = PackedModel._hl32
     _x3_stream = PackedModel._x3_stream
 
 
@@ -301,6 +310,8 @@ class Engine:
         # Footprint: ~66 MB (fp32) / ~45 MB (half) per chunk and stream; inference.py runs slices of <= 96 chunks
         # (MAX_CHUNKS_PER_LAUNCH) on the caller's stream + CONCURRENT_STREAMS side streams.
         self._ws = collections.OrderedDict()
+        self._deferred = None      # list collecting (pinned flag, event) pairs while deferred_range_checks() is active
+        self.last_fallbacks = 0    # BT_PREC_F32X3 forwards whose range flag fired (and were repeated in exact fp32)
 
     def __del__(self):
         try:
@@ -350,4 +361,48 @@ class Engine:
         with torch.cuda.device(self.device):
             _lib.check(_lib.lib().bt_forward_stages(self._h, _lib.stream_ptr(self.device), prec, first, last, x.data_ptr(), B, T,
                                                     ws.data_ptr(), ws.numel(), _lib.ptr(out), _lib.ptr(beat), _lib.ptr(down)))
+            if prec == _lib.PREC_F32X3:
+                # Range guard of the hi + lo split (include/beat_this_amd.h, BT_PREC_F32X3): the first word of the workspace is
+                # non-zero when an operand left the fp16 range of a hi part (the result then holds inf / NaN).  Default: look at
+                # it now (one stream synchronisation per forward) and repeat the batch on the exact fp32 MFMA path.  A caller
+                # that pipelines several forwards collects the flags instead (deferred_range_checks) and decides later.
+                flag = ws[:4].view(torch.int32)
+                if self._deferred is not None:
+                    host = torch.empty(1, dtype=torch.int32, pin_memory=True)
+                    host.copy_(flag, non_blocking=True)
+                    ev = torch.cuda.Event()
+                    ev.record(torch.cuda.current_stream(self.device))
+                    self._deferred.append((host, ev))
+                elif int(flag.item()) != 0:
+                    self.last_fallbacks += 1
+                    return self.forward_stages(spect, _lib.PREC_F32, first, last)
         return (beat, down) if last == 2 else out
+
+    # -- BT_PREC_F32X3 range guard, deferred form ------------------------------------------------------------------------
+    def deferred_range_checks(self):
+        """Context manager: BT_PREC_F32X3 forwards inside it do not synchronise; their range flags are copied to pinned host
+        memory asynchronously and collected in the list the context yields.  ``Engine.range_exceeded(list)`` (after the
+        work has been waited for, or waiting itself) tells whether any of them fired -- the caller then repeats that
+        work with the model's ``fp32_split_gemms`` off."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def ctx():
+            outer, mine = self._deferred, []
+            self._deferred = mine
+            try:
+                yield mine
+            finally:
+                self._deferred = outer
+                if outer is not None:
+                    outer.extend(mine)
+        return ctx()
+
+    def range_exceeded(self, checks) -> bool:
+        bad = False
+        for host, ev in checks:
+            ev.synchronize()
+            bad = bad or int(host[0]) != 0
+        if bad:
+            self.last_fallbacks += 1
+        return bad

@@ -45,7 +45,9 @@ FRESH_SECONDS_PER_CHUNK = 29.76   # 1488 fresh frames at 50 fps
 TRACK_SECONDS = 300.0
 TRACK_SR = 44100
 TRACKS_PER_GPU = 6
-PEAK_TFLOPS = {"half": 2500.0, "f32": 157.3, "fp8": 5000.0}  # MI355X_MICROARCH.md: dense MFMA peaks
+# MI355X_MICROARCH.md: dense MFMA peaks.  f32x3: every product costs three fp16 MFMAs, so the matrix pipe can deliver at most
+# a third of its fp16 rate in ALGORITHMIC flops on that path
+PEAK_TFLOPS = {"half": 2500.0, "f32": 157.3, "f32x3": 2500.0 / 3}
 PEAK_HBM_GBS = 8000.0
 
 
@@ -105,9 +107,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--model", default="final0")
-    ap.add_argument("--prec", default="half", choices=["half", "f32", "f32x3", "fp8"],
-                    help="half = half-precision MFMA operands (float16=True of the Python API); fp8 = EXPERIMENTAL: half path "
-                         "with the main layers' feed-forward GEMMs on e4m3 (BASELINE config 5)")
+    ap.add_argument("--prec", default="half", choices=["half", "f32", "f32x3"],
+                    help="half = half-precision MFMA operands (float16=True of the Python API); f32 = exact fp32 MFMA; f32x3 = "
+                         "fp32-class results on hi + lo fp16 operands, three MFMAs per product (BT_PREC_F32X3)")
     ap.add_argument("--tracks", type=int, default=TRACKS_PER_GPU, help="5-minute tracks per GPU per step")
     ap.add_argument("--workload", default="tracks", choices=["tracks", "forward"],
                     help="tracks = Audio2Beats on 300 s 44.1 kHz tracks (BASELINE metric); forward = BeatThis.forward on "
@@ -176,7 +178,6 @@ def main():
     model.load_state_dict(sd)
     a2b = Audio2Beats(checkpoint_path=None, device=dev, float16=args.prec not in ("f32", "f32x3"), dbn=False)
     a2b.model = model.to(dev)
-    a2b.model.fp8_weights = args.prec == "fp8"
     a2b.model.fp32_split_gemms = args.prec == "f32x3"
     half = args.prec not in ("f32", "f32x3")
     half_name = _lib.half_dtype_name()
@@ -303,8 +304,7 @@ def main():
             breakdown = profile_forward(step, 3, chunks_per_step)
         dom = max(breakdown, key=lambda k: breakdown[k]["ms_per_step"])
         d = breakdown[dom]
-        peak = PEAK_TFLOPS["fp8" if args.prec == "fp8" and dom in ("ff1_gemm", "ff2_gemm") else
-                           ("f32" if args.prec in ("f32", "f32x3") else "half")]
+        peak = PEAK_TFLOPS[args.prec]
         traffic, traffic_src = None, None
         try:  # HBM bytes per launch of the dominant category: PMC counters of separate rocprofv3 passes, committed
             tj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
@@ -486,8 +486,7 @@ def main():
             "metric": "audio-seconds processed/sec", "value": round(value, 1), "unit": "audio-seconds/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": {"half": half_name, "f32": "f32", "f32x3": "f32 (GEMMs: 3 x f16 MFMA on hi+lo operands)",
-                      "fp8": f"{half_name}+fp8(e4m3 feed-forward GEMMs, experimental)"}[args.prec],
+            "dtype": {"half": half_name, "f32": "f32", "f32x3": "f32 (every product: 3 x f16 MFMA on hi+lo operands)"}[args.prec],
             "data": "synthetic",
             "config": {"workload": workload, "tracks_per_gpu": args.tracks if args.workload == "tracks" else None,
                        "chunks_per_gpu": chunks_per_step, "global_chunks": world * chunks_per_step,

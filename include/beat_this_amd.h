@@ -27,17 +27,24 @@ extern "C" {
 #define BT_PREC_F32 0  /* exact fp32 MFMA (v_mfma_f32_32x32x2_f32), fp32 activations: float16=False */
 #define BT_PREC_HALF 1 /* half-precision MFMA operands (IEEE fp16; bfloat16 in a -DBT_HALF_BF16 build, see bt_half_is_bf16),
                         * fp32 accumulate + fp32 residual stream: float16=True */
-#define BT_PREC_FP8 2  /* BT_PREC_HALF with the main-layer GEMMs that have e4m3 weights (bt_pair_weights *_f8) on OCP e4m3
-                        * operands (2x the bf16 MFMA rate), fp32 accumulate + fp32 residual stream; attention, frontend
-                        * and head as in BT_PREC_HALF */
+/* (2 was BT_PREC_FP8, an experimental e4m3 feed-forward path of rounds 1-2: withdrawn in round 3 -- on every golden case
+ * its logit error stayed far above the reference's own reduced-precision error and it was no faster) */
 
-#define BT_PREC_F32X3 3 /* BT_PREC_F32 with the GEMMs (QKV, out-projection, feed-forward, convolutions, frontend.linear) on
-                        * three half MFMAs per product instead of fp32 MFMAs: every fp32 operand is split on the fly into
-                        * hi + lo halves (a = hi + lo to 2^-22), a.b ~ hi.hi + hi.lo + lo.hi, fp32 accumulate -- 16/3 times
-                        * the fp32 matrix rate at fp32-class accuracy.  Needs the half weight arrays to be followed by their
-                        * lo parts (beat_this_amd/pack.py: [hi | lo], each [N padded to 128][K]); IEEE fp16 builds only.
-                        * The attention (both products) and, when bt_pair_weights.w_*_frag_x3 are set, the register-chained
-                        * frontend halves run the same way; stem, head and every reduction stay fp32. */
+#define BT_PREC_F32X3 3 /* fp32-class results at half-MFMA speed -- the precision that carries the 1e-3 / identical-beats gate:
+                        * every fp32 operand of every product (QKV, attention scores, P.V, out-projection, feed-forward,
+                        * convolutions, frontend.linear) is a hi + lo pair of IEEE fp16 halves (a = hi + lo to 2^-22) and
+                        * a.b ~ lo.hi + hi.lo + hi.hi on three half MFMAs, fp32 accumulate: 16/3 times the fp32 matrix rate.
+                        * Residual stream, statistics, softmax sums, GELU (exact erf form), stem and head stay fp32.
+                        * Activations travel between kernels as interleaved hi / lo half planes ("hl32": per 32 consecutive
+                        * columns 32 hi halves then 32 lo halves), weights come packed the same way (bt_pair_weights.w_*_x3;
+                        * where they are NULL or a shape does not fit, the GEMM falls back to the register-staged kernel on
+                        * [hi | lo] weights, beat_this_amd/pack.py _mat).  IEEE fp16 builds only.
+                        * RANGE: a hi part holds |a| <= 65504 (main layers, like the reference's own fp16 autocast) or
+                        * |a| <= 2047 (register-chained frontend halves, whose operands are pre-scaled by 32).  Beyond that a
+                        * split yields inf.  The first int32 of the workspace is the forward's range flag: bt_forward zeroes it
+                        * and every kernel that splits operands ORs 1 into it when it sees such a value (2: a non-finite
+                        * logit); a caller that finds it non-zero after the forward must repeat the batch in BT_PREC_F32
+                        * (beat_this_amd/pack.py: Engine does). */
 
 #define BT_MAX_LAYERS 32
 
@@ -81,12 +88,6 @@ typedef struct {
    * [gate rows of w_qkvg | zero tiles], per head [q rows | k rows] [v rows | PERM32'd to_out tiles (row block
    * mt, the head's 32 columns)], then the FF steps as in w_outff_frag.  NULL for dim > 128. */
   const void* w_attnff_frag[2];
-  /* BT_PREC_FP8 (main layers only; NULL elsewhere): OCP e4m3 (e4m3fn) copies of the feed-forward weights, row-major
-   * [N padded to a multiple of 256][K] bytes, value = weight / factor rounded to nearest even:
-   *   w_ff1_f8 rows / s_ff1[n] (one factor per hidden unit, fp32 [N padded]);
-   *   w_ff2_f8 / s_ff2[0] (ONE factor for the matrix), b_ff2_f8 = b_ff2 / s_ff2[0]. */
-  const void* w_ff1_f8; const float* s_ff1;
-  const void* w_ff2_f8; const float* s_ff2; const float* b_ff2_f8;
   /* Weights of the fused layer tail (csrc/tail.hip: x += to_out(ao); x += FF(x) in one launch; main layers with
    * dim = 256 / 512, half precision only; NULL elsewhere): fragment-major tiles [half h][lane][8] as above, steps of
    * 2 dim/32 tiles: for st = 0 .. dim/64 - 1 the dim/32 k-tiles of to_out.0.weight's row block 2 st, then of row block
@@ -98,6 +99,14 @@ typedef struct {
    * its lo part, interleaved per 32 x 32 tile ([hi tile 2 KB | lo tile 2 KB]).  NULL: the fp32 kernels run instead. */
   const void* w_outff_frag_x3;
   const void* w_attnff_frag_x3;
+  /* BT_PREC_F32X3 on the LDS-DMA kernels (csrc/gemm3.hip, csrc/qkv_front.hip): the four matrices as hl32 half arrays
+   * [N padded to 256][2 K] (per 32 columns the 32 hi halves, then the 32 lo halves of w - hi), and the hi / lo fragment
+   * stream of w_qkv_frag in the layout of w_outff_frag_x3 (64 x the weight).  NULL: the register-staged GEMM runs. */
+  const void* w_qkvg_x3;
+  const void* w_out_x3;
+  const void* w_ff1_x3;
+  const void* w_ff2_x3;
+  const void* w_qkv_frag_x3;
 } bt_pair_weights;
 
 /* Packed BeatThis weights (beat_tracker.py:38-106).  Host-side packing is done by
@@ -126,6 +135,9 @@ typedef struct {
   /* for bt_forward_stages only: the final RMSNorm's gamma [D] and the task_heads weight [2][D] without it */
   const float* norm_out_g;
   const float* head_w_raw;
+  /* BT_PREC_F32X3: hl32 forms (see bt_pair_weights.w_qkvg_x3) of conv_w / lin_w; NULL: the register-staged GEMM runs */
+  const void* conv_w_x3[3];
+  const void* lin_w_x3;
 } bt_model_desc;
 
 typedef struct {
@@ -138,7 +150,7 @@ typedef struct {
 
 const char* bt_last_error(void);
 int bt_version(void);
-/* operand type of the half-precision path (BT_PREC_HALF / BT_PREC_FP8 slots of the weight arrays) this library was built
+/* operand type of the half-precision path (BT_PREC_HALF slot of the weight arrays) this library was built
  * with: 0 = IEEE fp16 (default), 1 = bfloat16 (-DBT_HALF_BF16) */
 int bt_half_is_bf16(void);
 /* sizeof/offsetof of the structs above as this library was compiled (binding self-check):
@@ -149,7 +161,7 @@ void bt_struct_sizes(int32_t* out);
 /* BeatThis(**hparams) + load_state_dict (inference.py:56-87): keeps a copy of `desc`. */
 int bt_engine_create(const bt_model_desc* desc, bt_engine** out);
 void bt_engine_destroy(bt_engine* e);
-/* bytes of scratch bt_forward needs for a [B,T,128] batch */
+/* bytes of scratch bt_forward needs for a [B,T,128] batch (its first int32 is the BT_PREC_F32X3 range flag) */
 size_t bt_workspace_bytes(const bt_engine* e, int B, int T, int prec);
 
 /* BeatThis.forward (beat_tracker.py:188-192): d_spect [B,T,128] fp32 ->
@@ -257,46 +269,51 @@ typedef struct {
 } bt_attn_args;
 int bt_attention(void* stream, int prec, const bt_attn_args* a);
 
-/* bf16 attention on FRAGMENT-MAJOR operands (csrc/attn2.hip): per (sequence, head) `nbp` blocks of
+/* half-precision attention on FRAGMENT-MAJOR operands (csrc/attn2.hip): per (sequence, head) `nbp` blocks of
  * 32 tokens, 2 KB each.  Q/K block: [quarter a][token][8 dims 8a..8a+7]; V block: [s][lane = 32 g + d]
  * [8 tokens 16 s + 8 (j >> 2) + 4 g + (j & 3)]; gates [n_seq * heads][nbp * 32] fp32.  q must be
- * pre-scaled by log2(e)/sqrt(32).  nbp >= bt_attn_frag_blocks(L).  Output as bt_attention (bf16). */
+ * pre-scaled by log2(e)/sqrt(32).  nbp >= bt_attn_frag_blocks(L).  Output as bt_attention (half).
+ * x3 != 0 (BT_PREC_F32X3): blocks of 4 KB = [hi block | lo block] of the fp32 values, three MFMAs per product; output
+ * fp32 [rows, inner] (out_f32 != 0) or hl32 half [rows, 2 inner]; status (may be NULL) = range flag of the hl32 output. */
 typedef struct {
   const void* q; const void* k; const void* v; const float* gates; void* out;
   int32_t n_seq, L, heads, inner, nbp, o_div; int64_t o_outer, o_inner, o_tok;
+  int32_t x3, out_f32; int32_t* status;
 } bt_attn_frag_args;
-/* bf16 GEMM of the main layers (csrc/gemm3.hip), single-operator entry for the parity tests.
- * epi 0: out[M,ldo] (bf16) = gelu(rms(A) W^T + bias);  epi 1: x[M,ldx] (fp32) += A W^T + bias, bf16 shadow xb,
+/* half GEMM of the main layers (csrc/gemm3.hip), single-operator entry for the parity tests.
+ * epi 0: out[M,ldo] (half) = gelu(rms(A) W^T + bias);  epi 1: x[M,ldx] (fp32) += A W^T + bias, half shadow xb,
  * partial row sums of squares ssq_out[N/64][M];  epi 2: q|k|v|gates = rms(A) W^T with RoPE / sigmoid, written
  * fragment-major (layout of bt_attention_frag) for n_seq sequences of L tokens (M = n_seq L).
  * rms(A) uses ssq_in[ssq_parts][M] (partial row sums of squares of the fp32 source of A), NULL = no RMSNorm.
- * BT_PREC_FP8 (f8 != 0; epi 0 and 1): A and W are OCP e4m3 bytes (v_mfma_scale_f32_32x32x64_f8f6f4 with unit block
- * scales).  epi 0: wscale[N] = dequantisation factor of every W row, ascale[M] = factor row m of A was multiplied by
- * when it was quantised, out = e4m3 bytes [M,ldo] (unit scale, saturating at +-448).  epi 1: wscale[0] = ONE factor for
- * W, bias already divided by it.  epi 1 with x8 != NULL (any operand type, needs ssq_in = statistics of the OLD x):
- * additionally x8[M,ldx] = e4m3(x_new[m] * c[m]) and ascale_out[m] = c[m] = sqrt(N) / ||x_old[m]||. */
+ * x3 != 0 (BT_PREC_F32X3): A half [M, 2 lda], W half [N padded to 256, 2 K], out half [M, 2 ldo], xb half [M, 2 ldx]
+ * are hl32 (interleaved hi / lo planes of the fp32 values; K, lda, ldo, ldx count fp32 elements), q / k / v blocks are
+ * 4 KB, epi 0 uses the exact erf GELU; status (may be NULL) = range flag. */
 typedef struct {
   const void* A; int64_t lda; int32_t M, K; const void* W; int32_t N, epi; const float* bias;
   const float* ssq_in; int32_t ssq_parts; void* out; int64_t ldo; float* x; int64_t ldx; void* xb; float* ssq_out;
   int32_t n_seq, L, nbp, heads; const float* rope; void* qf; void* kf; void* vf; float* gates; const float* b_gates;
-  int32_t f8; const float* wscale; const float* ascale; void* x8; float* ascale_out;
   int32_t no_resid; /* epi 1: x = A W^T + bias, x is only written (frontend.linear) */
   /* epi 1 as the frontend convolution (beat_tracker.py:155-166, BatchNorm folded): gelu != 0 -> x = gelu(.. + bias) (tanh
-   * form), x may be NULL (bf16 output xb only); conv_C2 = 2 C > 0 -> A is the bf16 (b, t, f, c) activation seen as
-   * [M = B T F/2, conv_C2], lda = conv_C2, K = 3 conv_C2: the rows m - conv_F, m, m + conv_F (time taps t-1, t, t+1 with
-   * conv_F = F/2 rows per time step), rows with t outside [0, conv_T) read as zeros.  Needs no_resid. */
+   * form; exact erf form with x3), x may be NULL (shadow output xb only); conv_C2 = 2 C > 0 -> A is the (b, t, f, c)
+   * activation shadow seen as [M = B T F/2, conv_C2], lda = conv_C2, K = 3 conv_C2: the rows m - conv_F, m, m + conv_F
+   * (time taps t-1, t, t+1 with conv_F = F/2 rows per time step), rows with t outside [0, conv_T) read as zeros.  Needs
+   * no_resid. */
   int32_t gelu, conv_C2, conv_T, conv_F;
+  int32_t x3; int32_t* status;
 } bt_gemm3_args;
 int bt_gemm3(void* stream, const bt_gemm3_args* a);
 int bt_attn_frag_blocks(int L);
 int bt_attention_frag(void* stream, const bt_attn_frag_args* a);
-/* Time-direction QKV projection of a frontend block: d_x [B,T,F,C] fp32 -> fragment-major q, k, v, gates */
-int bt_qkv_front(void* stream, const bt_pair_weights* w, const float* d_rope, const float* d_x, int B, int T, int F,
+/* Time-direction QKV projection of a frontend block: d_x [B,T,F,C] fp32 -> fragment-major q, k, v, gates
+ * (prec = BT_PREC_HALF: 2 KB blocks from w_qkv_frag; BT_PREC_F32X3: 4 KB [hi | lo] blocks from w_qkv_frag_x3) */
+int bt_qkv_front(void* stream, int prec, const bt_pair_weights* w, const float* d_rope, const float* d_x, int B, int T, int F,
                  void* d_q, void* d_k, void* d_v, float* d_gates, int nbp);
 /* x[M,C] += FF(x) with one bt_pair_weights, dim = C <= 128 */
 int bt_ff_fused(void* stream, int prec, const bt_pair_weights* w, float* d_x, int64_t M);
-/* fused halves (csrc/fused2.hip): x += to_out(ao) then x += FF(x);  x += AttnF(x) then x += FF(x) */
-int bt_outff_fused(void* stream, int prec, const bt_pair_weights* w, const void* d_ao, float* d_x, int64_t M);
+/* fused halves (csrc/fused2.hip): x += to_out(ao) then x += FF(x);  x += AttnF(x) then x += FF(x).
+ * d_xb (may be NULL): shadow of the new x for the following convolution -- half [M, dim] (BT_PREC_HALF) or hl32 half
+ * [M, 2 dim] (BT_PREC_F32X3) */
+int bt_outff_fused(void* stream, int prec, const bt_pair_weights* w, const void* d_ao, float* d_x, int64_t M, void* d_xb);
 int bt_attnff_fused(void* stream, int prec, const bt_pair_weights* w, const float* d_rope, float* d_x, int64_t M);
 /* fused tail of a main layer (csrc/tail.hip, BT_PREC_HALF, w->dim = 256 / 512, w->w_tail_frag set): d_x [M, dim] fp32
  * += to_out(d_ao [M, dim] half), then += FF(x); optional outputs: d_xb = half copy of the new x, d_ssq_out [dim/64][M] =

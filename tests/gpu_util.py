@@ -117,3 +117,36 @@ def run_attn_frag(qf, kf, vf, gates, out, n_seq, L, heads, nbp, o_div=1, o_outer
     a.o_inner, a.o_tok = o_inner, o_tok
     _lib.check(_lib.lib().bt_attention_frag(_lib.stream_ptr(dev()), C.byref(a)))
     torch.cuda.synchronize()
+
+
+# ---- BT_PREC_F32X3 operand formats (csrc/gemm3.hip, csrc/attn2.hip) --------------------------------------------------
+def to_hl32(x):
+    """fp32 [M, K] (K % 32 == 0) -> fp16 [M, 2 K]: per 32 columns the 32 hi halves, then the 32 lo halves (x = hi + lo)."""
+    x = x.float()
+    m, k = x.shape
+    hi = x.to(torch.float16)
+    lo = (x - hi.float()).to(torch.float16)
+    return torch.stack([hi.view(m, k // 32, 32), lo.view(m, k // 32, 32)], 2).reshape(m, 2 * k).contiguous()
+
+
+def from_hl32(h):
+    """fp16 [M, 2 K] hl32 -> float64 [M, K] = hi + lo"""
+    m, k2 = h.shape
+    t = h.double().view(m, k2 // 64, 2, 32)
+    return (t[:, :, 0] + t[:, :, 1]).reshape(m, k2 // 2)
+
+
+def frag_x3(x, nbp, kind):
+    """[SH, L, 32] fp32-valued -> fp16 [SH, nbp, 2 (hi | lo), 1024]: the 4 KB blocks of the X3 attention operands"""
+    f = frag_qk if kind == "qk" else frag_v
+    x = x.float()
+    hi = x.to(torch.float16)
+    lo = (x - hi.float()).to(torch.float16)
+    SH = x.shape[0]
+    return torch.stack([f(hi.float(), nbp).view(SH, nbp, 1024), f(lo.float(), nbp).view(SH, nbp, 1024)], 2).contiguous()
+
+
+def unfrag_x3(fr, L, kind):
+    """inverse of frag_x3 -> float64 [SH, L, 32]"""
+    u = unfrag_qk if kind == "qk" else unfrag_v
+    return u(fr[:, :, 0].contiguous(), L).double() + u(fr[:, :, 1].contiguous(), L).double()

@@ -139,7 +139,7 @@ def test_qkv_front(C, T):
     kf, vf = qf.clone(), qf.clone()
     gh = torch.zeros((SH, nbp * 32), dtype=torch.float32, device=dev())
     xd = x0.float().to(dev())
-    L.check(L.lib().bt_qkv_front(L.stream_ptr(dev()), Ct.byref(pp.weights), rope.data_ptr(), xd.data_ptr(), B, T, F,
+    L.check(L.lib().bt_qkv_front(L.stream_ptr(dev()), L.PREC_HALF, Ct.byref(pp.weights), rope.data_ptr(), xd.data_ptr(), B, T, F,
                                  qf.data_ptr(), kf.data_ptr(), vf.data_ptr(), gh.data_ptr(), nbp))
     torch.cuda.synchronize()
     x = x0.float().double()
@@ -193,7 +193,7 @@ def test_fused_out_ff(prec, C):
     pp = PackedPair(sd, "a.", "f.", C, dev())
     x = x0.float().to(dev()).clone()
     aod = ao.to(dev())
-    L.check(L.lib().bt_outff_fused(L.stream_ptr(dev()), prec, Ct.byref(pp.weights), aod.data_ptr(), x.data_ptr(), M))
+    L.check(L.lib().bt_outff_fused(L.stream_ptr(dev()), prec, Ct.byref(pp.weights), aod.data_ptr(), x.data_ptr(), M, 0))
     torch.cuda.synchronize()
     x1 = x0.float().double() + ao.double() @ sd["a.to_out.0.weight"].T
     ref = _ff_ref(sd, x1)
@@ -261,7 +261,7 @@ def test_fused_halves_at_scale_are_repeatable(C, prec):
     for _ in range(4):
         xa, xo = x0.clone(), x0.clone()
         L.check(L.lib().bt_attnff_fused(st, prec, Ct.byref(pp.weights), rope.data_ptr(), xa.data_ptr(), M))
-        L.check(L.lib().bt_outff_fused(st, prec, Ct.byref(pp.weights), ao.data_ptr(), xo.data_ptr(), M))
+        L.check(L.lib().bt_outff_fused(st, prec, Ct.byref(pp.weights), ao.data_ptr(), xo.data_ptr(), M, 0))
         outs_a.append(xa)
         outs_o.append(xo)
     torch.cuda.synchronize()
@@ -270,7 +270,7 @@ def test_fused_halves_at_scale_are_repeatable(C, prec):
     assert bad == 0
 
 
-@pytest.mark.parametrize("C,M", [(512, 777), (512, 4096 + 33), (512, 24000)])
+@pytest.mark.parametrize("C,M", [(512, 777), (512, 4096 + 33), (512, 24000), (256, 777), (256, 24000)])
 def test_layer_tail(C, M):
     """Fused tail of a main layer (csrc/tail.hip): x += to_out(ao); x += FF(x), the half shadow and the per-64-column
     partial sums of squares of the new x, against fp64 (exact operands: the tolerance covers half operand rounding)."""

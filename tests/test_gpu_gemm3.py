@@ -124,85 +124,6 @@ def test_gemm3_qkv(n_seq, L, heads):
         assert torch.all(unfrag_v(vf.cpu()[:, nblk - 1:nblk], 32)[:, L % 32:].float() == 0)
 
 
-# ---- BT_PREC_FP8: e4m3 operands (v_mfma_scale_f32_32x32x64_f8f6f4, unit block scales) ---------------------------------
-F8 = torch.float8_e4m3fn
-
-
-def _q8(t):
-    """float tensor -> (e4m3 tensor, its exact float64 values)"""
-    q = t.float().clamp(-448, 448).to(F8)
-    return q, q.to(torch.float64)
-
-
-def _gelu_tanh(u):
-    return 0.5 * u * (1 + torch.tanh(math.sqrt(2 / math.pi) * (u + 0.044715 * u ** 3)))
-
-
-@pytest.mark.parametrize("M,K,N", [(1500, 512, 2048), (333, 128, 512), (24000, 512, 2048)])
-def test_gemm3_f8_ff1(M, K, N):
-    x = _mk((M, K), 21, 2.0).float()
-    c = (0.5 + torch.rand(M, generator=torch.Generator().manual_seed(22))).double() * math.sqrt(K) / x.double().norm(dim=-1)
-    W, b = _mk((N, K), 23, 1 / math.sqrt(K)), _mk((N,), 24)
-    ws = W.abs().amax(dim=1) / 448.0
-    A8, Ad = _q8(x.double() * c[:, None])
-    W8, Wd = _q8(W / ws[:, None])
-    out = torch.zeros((M, N), dtype=torch.uint8, device=dev())
-    _call(A=A8.view(torch.uint8).to(dev()), lda=K, M=M, K=K, W=pad_rows(W8.view(torch.uint8)).to(dev()), N=N, epi=0,
-          bias=b.float().to(dev()), ssq_in=_ssq_parts(x).to(dev()), ssq_parts=K // 64, out=out, ldo=N, f8=1,
-          wscale=ws.float().to(dev()), ascale=c.float().to(dev()))
-    rs = math.sqrt(K) / x.double().norm(dim=-1, keepdim=True)
-    ref = _gelu_tanh(Ad @ Wd.T * (rs / c[:, None]) * ws[None, :] + b)
-    got = out.cpu().view(F8).to(torch.float64)
-    # the stored value is the e4m3 neighbour of the fp32 result: half an ulp = 2^-4 relative (2^-10 absolute below 2^-6)
-    err = ((got - ref).abs() / (ref.abs() * 2 ** -4 + 2 ** -10)).max().item()
-    report("gemm3_f8_ff1", M=M, K=K, N=N, half_ulps=err)
-    assert err < 2.1  # (a result next to a rounding boundary may land on either neighbour)
-
-
-@pytest.mark.parametrize("M,K,N,bias", [(1500, 2048, 512, True), (777, 512, 512, False), (24000, 2048, 512, True),
-                                        (32768, 1024, 512, False)])
-def test_gemm3_f8_resid(M, K, N, bias):
-    A8, Ad = _q8(_mk((M, K), 31).abs() * 0.7)
-    W = _mk((N, K), 32, 0.5 / math.sqrt(K))
-    s = float(W.abs().max() / 448.0)
-    W8, Wd = _q8(W / s)
-    b = _mk((N,), 33)
-    x0 = _mk((M, N), 34).float()
-    x = x0.to(dev()).clone()
-    xb = torch.zeros((M, N), dtype=HALF(), device=dev())
-    ssq = torch.full((N // 64, M), -1.0, dtype=torch.float32, device=dev())
-    _call(A=A8.view(torch.uint8).to(dev()), lda=K, M=M, K=K, W=pad_rows(W8.view(torch.uint8), 256).to(dev()), N=N, epi=1,
-          bias=(b / s).float().to(dev()) if bias else 0, x=x, ldx=N, xb=xb, ssq_out=ssq, f8=1,
-          wscale=torch.tensor([s], dtype=torch.float32, device=dev()))
-    ref = x0.double() + Ad @ Wd.T * s + (b if bias else 0)
-    err, errb = _rel(x, ref), _rel(xb, ref)
-    errs = _rel(ssq, (ref ** 2).view(M, N // 64, 64).sum(-1).T)
-    report("gemm3_f8_resid", M=M, K=K, N=N, rel=err, shadow=errb, ssq=errs)
-    assert err < 1e-5 and errb < 5e-3 and errs < 1e-4
-
-
-@pytest.mark.parametrize("M,K,N", [(1500, 512, 512), (130, 128, 128)])
-def test_gemm3_resid_e4m3_shadow(M, K, N):
-    """bf16 residual GEMM that also emits the e4m3 shadow of the new x, scaled by the RMSNorm factor of the OLD row."""
-    A = _mk((M, K), 41).float().to(HALF())
-    W = _mk((N, K), 42, 0.5 / math.sqrt(K)).float().to(HALF())
-    x0 = _mk((M, N), 43, 3.0).float()
-    x = x0.to(dev()).clone()
-    x8 = torch.zeros((M, N), dtype=torch.uint8, device=dev())
-    asc = torch.zeros((M,), dtype=torch.float32, device=dev())
-    _call(A=A.to(dev()), lda=K, M=M, K=K, W=W.to(dev()), N=N, epi=1, x=x, ldx=N, ssq_in=_ssq_parts(x0).to(dev()),
-          ssq_parts=N // 64, x8=x8, ascale_out=asc)
-    ref = x0.double() + A.double() @ W.double().T
-    c = math.sqrt(N) / x0.double().norm(dim=-1)
-    assert _rel(x, ref) < 1e-5
-    assert _rel(asc, c) < 1e-5
-    got = x8.cpu().view(F8).to(torch.float64)
-    want = ref * c[:, None]
-    err = ((got - want).abs() / (want.abs() * 2 ** -4 + 2 ** -10)).max().item()
-    report("gemm3_resid_e4m3_shadow", M=M, K=K, N=N, half_ulps=err)
-    assert err < 2.1  # (a result next to a rounding boundary may land on either neighbour)
-
-
 def test_gemm3_store_without_residual():
     """epi 1 with no_resid (frontend.linear): x is written, never read (NaN-filled on entry)."""
     M, K, N = 3000, 1024, 512
@@ -219,25 +140,6 @@ def test_gemm3_store_without_residual():
     errs = _rel(ssq, (ref ** 2).view(M, N // 64, 64).sum(-1).T)
     report("gemm3_store", M=M, K=K, N=N, rel=err, shadow=errb, ssq=errs)
     assert err < 1e-5 and errb < 5e-3 and errs < 1e-4
-
-
-def test_gemm3_f8_hidden_saturates_instead_of_overflowing():
-    """e4m3 has no infinity: hidden activations beyond +-448 must saturate (OCP e4m3fn 0x7e / 0xfe), never become NaN (0x7f)."""
-    M, K, N = 256, 128, 128
-    x = _mk((M, K), 61).float()
-    c = torch.ones(M, dtype=torch.float64)
-    A8, _ = _q8(x.double())
-    W8, _ = _q8(_mk((N, K), 62))
-    b = torch.full((N,), 1000.0)
-    b[::2] = -1000.0  # gelu(-1000) = -0: the negative side stays finite as well
-    out = torch.zeros((M, N), dtype=torch.uint8, device=dev())
-    _call(A=A8.view(torch.uint8).to(dev()), lda=K, M=M, K=K, W=pad_rows(W8.view(torch.uint8)).to(dev()), N=N, epi=0,
-          bias=b.float().to(dev()), ssq_in=_ssq_parts(x).to(dev()), ssq_parts=K // 64, out=out, ldo=N, f8=1,
-          wscale=torch.ones(N, device=dev()), ascale=c.float().to(dev()))
-    got = out.cpu()
-    assert not ((got & 0x7F) == 0x7F).any(), "NaN encoding in the e4m3 hidden activation"
-    dec = got.view(F8).float()
-    assert torch.all(dec[:, 1::2] == 448.0) and torch.all(dec[:, 0::2].abs() < 1e-3)
 
 
 @pytest.mark.parametrize("B,T,Fp,C2,N,half_out", [(2, 50, 8, 128, 128, False), (1, 33, 4, 256, 256, True), (3, 7, 16, 64, 128, False),

@@ -1,4 +1,4 @@
-"""Parity AT THE BENCHMARKED BATCH SIZES (BASELINE.json configs 2, 3, 5), not just single chunks: the HIP path against the
+"""Parity AT THE BENCHMARKED BATCH SIZES (BASELINE.json configs 2, 3, 4), not just single chunks: the HIP path against the
 CPU oracle on the same seeded inputs, with beat / downbeat flip counts through the minimal post-processor, plus a
 size-independent property over the WHOLE batch: every chunk of a big batch equals the same chunk forwarded alone
 (rows are independent in every kernel, so a tile-scheduling or LDS-DMA ordering bug that corrupts a few rows only at
@@ -50,12 +50,12 @@ def _oracle(sd, x, idx):
     return out
 
 
-def _check(name, hp_name, B, half, fp8, oracle_idx, tol, flips_allowed):
+def _check(name, hp_name, B, half, x3, oracle_idx, tol, flips_allowed):
     from beat_this_amd.postprocessor import Postprocessor
 
     sd, m, x = _setup(hp_name, B)
     xd = x.to(dev())
-    m.fp8_weights = fp8
+    m.fp32_split_gemms = x3     # BT_PREC_F32X3 (hi + lo operands) instead of the exact fp32 MFMA path
     with torch.inference_mode(), torch.autocast("cuda", enabled=half):
         r = m(xd)
         # every chunk of the batch alone (16 at a time to keep it quick): must reproduce the batched result
@@ -65,6 +65,8 @@ def _check(name, hp_name, B, half, fp8, oracle_idx, tol, flips_allowed):
             worst_alone = max(worst_alone, float((ri["beat"][0] - r["beat"][i]).abs().max()),
                               float((ri["downbeat"][0] - r["downbeat"][i]).abs().max()))
     assert torch.isfinite(r["beat"]).all() and torch.isfinite(r["downbeat"]).all()
+    if x3:
+        assert m.engine().last_fallbacks == 0, "the hi + lo path fell back to exact fp32 (range flag) on ordinary inputs"
     ref = _oracle(sd, x, oracle_idx)
     pp = Postprocessor("minimal")
     err, fb, fd, nb, nd = 0.0, 0, 0, 0, 0
@@ -87,29 +89,39 @@ def _ref_report():
 
 def test_cfg2_final0_16_chunks_fp32_vs_oracle():
     # the parity-gated path: 1e-3 on the logits and IDENTICAL beat / downbeat frames on all 16 chunks
-    _check("cfg2_f32", "final0", 16, half=False, fp8=False, oracle_idx=range(16), tol=1e-3, flips_allowed=(0, 0))
+    _check("cfg2_f32", "final0", 16, half=False, x3=False, oracle_idx=range(16), tol=1e-3, flips_allowed=(0, 0))
 
 
 def test_cfg2_final0_16_chunks_half_vs_oracle():
     # half-precision operands: bounded by the reference's OWN float16-autocast error on the final0 golden case
     # (tests/golden/reference_autocast_report.json, generated from the unmodified reference)
     ref = _ref_report()["final0_lively_T1500_f16"]
-    _check("cfg2_half", "final0", 16, half=True, fp8=False, oracle_idx=range(16),
+    _check("cfg2_half", "final0", 16, half=True, x3=False, oracle_idx=range(16),
            tol=max(ref["max_abs_beat"], ref["max_abs_downbeat"]), flips_allowed=None)
 
 
 def test_cfg3_small0_128_chunks_fp32_vs_oracle():
-    _check("cfg3_small0_f32", "small0", 128, half=False, fp8=False, oracle_idx=[0, 1, 37, 63, 64, 100, 126, 127], tol=1e-3,
+    _check("cfg3_small0_f32", "small0", 128, half=False, x3=False, oracle_idx=[0, 1, 37, 63, 64, 100, 126, 127], tol=1e-3,
            flips_allowed=(0, 0))
 
 
-def test_cfg5_final0_64_chunks_fp8_reported():
-    # EXPERIMENTAL path (e4m3 feed-forward GEMMs): report-only against the oracle, bounded loosely; batch consistency holds
-    _check("cfg5_fp8", "final0", 64, half=True, fp8=True, oracle_idx=[0, 21, 42, 63], tol=0.5, flips_allowed=None)
+def test_cfg2_final0_16_chunks_f32x3_vs_oracle():
+    # BT_PREC_F32X3 (hi + lo operands on the LDS-DMA kernels): the SAME gate as the exact path -- 1e-3, tested at 1e-4, and
+    # IDENTICAL beat / downbeat frames -- on all 16 chunks, plus batch-vs-alone on every chunk
+    _check("cfg2_f32x3", "final0", 16, half=False, x3=True, oracle_idx=range(16), tol=1e-4, flips_allowed=(0, 0))
+
+
+def test_bench_slice_final0_33_chunks_f32x3_vs_oracle():
+    # the benchmark's forward slice (66 chunks as 2 x 33 on two streams): 33 chunks, partial GEMM tiles and CU rounds
+    _check("slice33_f32x3", "final0", 33, half=False, x3=True, oracle_idx=[0, 16, 32], tol=1e-4, flips_allowed=(0, 0))
+
+
+def test_cfg3_small0_128_chunks_f32x3_vs_oracle():
+    _check("cfg3_small0_f32x3", "small0", 128, half=False, x3=True, oracle_idx=[0, 63, 127], tol=1e-4, flips_allowed=(0, 0))
 
 
 def test_cfg4_share_final0_64_chunks_half_batch_consistency():
-    _check("cfg4_share_half", "final0", 64, half=True, fp8=False, oracle_idx=[0, 63], tol=0.05, flips_allowed=None)
+    _check("cfg4_share_half", "final0", 64, half=True, x3=False, oracle_idx=[0, 63], tol=0.05, flips_allowed=None)
 
 
 @pytest.mark.parametrize("case", ["small0_lively_T1500", "small0_lively_T1012", "final0_lively_T1500"])
@@ -143,8 +155,8 @@ def test_half_path_against_reference_autocast_goldens(case):
     assert fb + fd <= r16["flips_beat"] + r16["flips_downbeat"] + 1
 
 
-@pytest.mark.parametrize("half", [False, True])
-@pytest.mark.parametrize("hp_name,B", [("final0", 16), ("small0", 48)])
+@pytest.mark.parametrize("half", [False, True, "f32x3"])
+@pytest.mark.parametrize("hp_name,B", [("final0", 16), ("small0", 48), ("final0", 33)])
 def test_batched_forward_is_repeatable_bit_for_bit(hp_name, B, half):
     """The same batch forwarded five times must give five identical results.  Round 2 found (this way) a write-after-read
     race between a fast wave's LDS-DMA refill and a slow wave's outstanding fragment reads in the weight rings of
@@ -152,7 +164,8 @@ def test_batched_forward_is_repeatable_bit_for_bit(hp_name, B, half):
     different set on every run, invisible to single-chunk goldens."""
     sd, m, x = _setup(hp_name, B)
     xd = x.to(dev())
-    with torch.inference_mode(), torch.autocast("cuda", enabled=half):
+    m.fp32_split_gemms = half == "f32x3"
+    with torch.inference_mode(), torch.autocast("cuda", enabled=half is True):
         outs = [m(xd) for _ in range(5)]
     torch.cuda.synchronize()
     bad = sum(int(not (torch.equal(o["beat"], outs[0]["beat"]) and torch.equal(o["downbeat"], outs[0]["downbeat"])))

@@ -1,0 +1,377 @@
+"""Parity of the BT_PREC_F32X3 kernels (hi + lo fp16 operands, three MFMAs per product) on the MI355X against float64
+restatements: the hl32 GEMM of csrc/gemm3.hip in its three epilogues and as the frontend convolution, the fragment-major
+attention of csrc/attn2.hip on 4 KB [hi | lo] blocks, the frontend's time-direction QKV projection, the hl32 shadow of the
+fused out-projection + FF kernel, and the range flag every operand-splitting kernel raises.  Tolerances are fp32-class
+(1e-6 .. 1e-5 relative): this is the path that carries the 1e-3 logit / identical-beats gate."""
+import ctypes as C
+import math
+
+import pytest
+import torch
+
+from gpu_util import dev, frag_x3, from_hl32, pad_rows, report, to_hl32, unfrag_x3
+
+pytestmark = pytest.mark.gpu
+
+
+def _mk(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(shape, generator=g, dtype=torch.float64) * scale
+
+
+def _rel(a, ref):
+    return float((a.double().cpu() - ref).abs().max() / ref.abs().max().clamp_min(1e-30))
+
+
+def _ssq_parts(x32):
+    M, D = x32.shape
+    return (x32.double() ** 2).view(M, D // 64, 64).sum(-1).T.contiguous().float()
+
+
+def _call(**kw):
+    from beat_this_amd import _lib as L
+
+    a = L.Gemm3Args()
+    for k, v in kw.items():
+        setattr(a, k, v.data_ptr() if isinstance(v, torch.Tensor) else v)
+    a.x3 = 1
+    L.check(L.lib().bt_gemm3(L.stream_ptr(dev()), C.byref(a)))
+    torch.cuda.synchronize()
+
+
+def _status():
+    return torch.zeros(1, dtype=torch.int32, device=dev())
+
+
+@pytest.mark.parametrize("M,K,N", [(1500, 512, 2048), (333, 128, 512), (24000, 512, 2048), (49500, 512, 2048)])
+def test_gemm3_x3_ff1(M, K, N):
+    """out = gelu_erf(rms(A) W^T + b) as hl32 planes; operands are fp32 values (exactly representable as hi + lo)."""
+    x = _mk((M, K), 1, 2.0).float()
+    W, b = _mk((N, K), 2, 1 / math.sqrt(K)).float(), _mk((N,), 3)
+    out = torch.zeros((M, 2 * N), dtype=torch.float16, device=dev())
+    st = _status()
+    _call(A=to_hl32(x).to(dev()), lda=K, M=M, K=K, W=to_hl32(pad_rows(W, 256)).to(dev()), N=N, epi=0, bias=b.float().to(dev()),
+          ssq_in=_ssq_parts(x).to(dev()), ssq_parts=K // 64, out=out, ldo=N, status=st)
+    rs = math.sqrt(K) / x.double().norm(dim=-1, keepdim=True).clamp_min(1e-12)
+    ref = torch.nn.functional.gelu(from_hl32(to_hl32(x)) @ from_hl32(to_hl32(W)).T * rs + b)
+    err = _rel(from_hl32(out.cpu()), ref)
+    report("gemm3_x3_ff1", M=M, K=K, N=N, rel=err)
+    assert err < 3e-6 and int(st.item()) == 0
+
+
+# (M = 24000 runs on the 192 x 256 tiles, M = 32768 on the 256 x 256 ones, the others on 128 x 128)
+@pytest.mark.parametrize("M,K,N,bias", [(1500, 2048, 512, True), (777, 512, 512, False), (130, 128, 128, True),
+                                        (24000, 2048, 512, True), (32768, 1024, 512, False), (49500, 512, 512, True)])
+def test_gemm3_x3_resid(M, K, N, bias):
+    A = _mk((M, K), 4).float()
+    W = _mk((N, K), 5, 0.5 / math.sqrt(K)).float()
+    b = _mk((N,), 6)
+    x0 = _mk((M, N), 7).float()
+    x = x0.to(dev()).clone()
+    xb = torch.full((M, 2 * N), float("nan"), dtype=torch.float16, device=dev())
+    ssq = torch.full((N // 64, M), -1.0, dtype=torch.float32, device=dev())
+    st = _status()
+    _call(A=to_hl32(A).to(dev()), lda=K, M=M, K=K, W=to_hl32(pad_rows(W, 256)).to(dev()), N=N, epi=1,
+          bias=b.float().to(dev()) if bias else 0, x=x, ldx=N, xb=xb, ssq_out=ssq, status=st)
+    ref = x0.double() + from_hl32(to_hl32(A)) @ from_hl32(to_hl32(W)).T + (b if bias else 0)
+    err = _rel(x, ref)
+    xc = x.double().cpu()
+    errb = float((from_hl32(xb.cpu()) - xc).abs().max() / xc.abs().max())   # the shadow IS the new x, to 2^-22
+    errs = _rel(ssq, (ref ** 2).view(M, N // 64, 64).sum(-1).T)
+    report("gemm3_x3_resid", M=M, K=K, N=N, rel=err, shadow=errb, ssq=errs)
+    assert err < 2e-6 and errb < 1e-6 and errs < 1e-5 and int(st.item()) == 0
+
+
+@pytest.mark.parametrize("n_seq,L,heads", [(2, 1500, 4), (3, 77, 4), (1, 1, 4), (5, 130, 8), (16, 1500, 16)])
+def test_gemm3_x3_qkv(n_seq, L, heads):
+    from beat_this_amd import _lib as Lb
+    from beat_this_amd.pack import LOG2E
+    from beat_this_amd.tables import rope_table
+
+    D = heads * 32
+    M = n_seq * L
+    x = _mk((M, D), 10, 1.5).float()
+    Wqkv = _mk((3 * D, D), 11, 1.6 / math.sqrt(D))
+    Wqkv[:D] *= LOG2E / math.sqrt(32.0)
+    Wg, bg = _mk((heads, D), 12, 0.3), _mk((heads,), 13, 0.3)
+    W = pad_rows(torch.cat([Wqkv, Wg]).float(), 256)
+    freqs = 10000.0 ** (-torch.arange(0, 32, 2).float() / 32)
+    rope = torch.from_numpy(rope_table(freqs)).to(dev())
+    nbp = Lb.lib().bt_attn_frag_blocks(L)
+    SH = n_seq * heads
+    qf = torch.full((SH, nbp, 2, 1024), float("nan"), dtype=torch.float16, device=dev())
+    kf, vf = qf.clone(), qf.clone()
+    gh = torch.zeros((SH, nbp * 32), dtype=torch.float32, device=dev())
+    st = _status()
+    _call(A=to_hl32(x).to(dev()), lda=D, M=M, K=D, W=to_hl32(W).to(dev()), N=3 * D + heads, epi=2, ssq_in=_ssq_parts(x).to(dev()),
+          ssq_parts=D // 64, n_seq=n_seq, L=L, nbp=nbp, heads=heads, rope=rope, qf=qf, kf=kf, vf=vf, gates=gh,
+          b_gates=bg.float().to(dev()), status=st)
+    rs = math.sqrt(D) / x.double().norm(dim=-1, keepdim=True).clamp_min(1e-12)
+    Wd, xd = from_hl32(to_hl32(W)), from_hl32(to_hl32(x))
+    qkv = (xd @ Wd[:3 * D].T * rs).view(n_seq, L, 3, heads, 32).permute(2, 0, 3, 1, 4)  # qkv s h t d
+    ang = torch.arange(L, dtype=torch.float64)[:, None] * freqs.double()[None, :]
+    cos, sin = ang.cos().repeat_interleave(2, -1), ang.sin().repeat_interleave(2, -1)
+
+    def rot(t):
+        te, to = t[..., 0::2], t[..., 1::2]
+        return t * cos + torch.stack((-to, te), -1).flatten(-2) * sin
+    q, k, v = rot(qkv[0]).reshape(SH, L, 32), rot(qkv[1]).reshape(SH, L, 32), qkv[2].reshape(SH, L, 32)
+    gates = torch.sigmoid(xd @ Wd[3 * D:3 * D + heads].T * rs + bg).view(n_seq, L, heads).permute(0, 2, 1).reshape(SH, L)
+    nblk = (L + 31) // 32
+    eq = _rel(unfrag_x3(qf.cpu()[:, :nblk], L, "qk"), q)
+    ek = _rel(unfrag_x3(kf.cpu()[:, :nblk], L, "qk"), k)
+    ev = _rel(unfrag_x3(vf.cpu()[:, :nblk], L, "v"), v)
+    eg = _rel(gh.cpu()[:, :L], gates)
+    report("gemm3_x3_qkv", n_seq=n_seq, L=L, heads=heads, q=eq, k=ek, v=ev, gates=eg)
+    assert max(eq, ek, ev) < 3e-6 and eg < 3e-6 and int(st.item()) == 0
+    if L % 32:  # tokens beyond L inside the last block: exact zeros for K and V, hi and lo
+        tail_k = kf.cpu()[:, nblk - 1].view(SH, 2, 4, 32, 8)[:, :, :, L % 32:, :]
+        assert torch.all(tail_k.float() == 0)
+        assert torch.all(unfrag_x3(vf.cpu()[:, nblk - 1:nblk], 32, "v")[:, L % 32:] == 0)
+
+
+@pytest.mark.parametrize("B,T,Fp,C2,N,planes_only", [(2, 50, 8, 128, 128, False), (1, 33, 4, 256, 256, True), (3, 7, 16, 128, 128, False),
+                                                     (16, 1500, 4, 256, 256, True)])
+def test_gemm3_x3_frontend_conv(B, T, Fp, C2, N, planes_only):
+    """epi 1 as the (2,3) / stride (2,1) frontend convolution on the hl32 (b, t, f, c) activation: three time taps gathered
+    by the LDS-DMA loader (zero rows outside 0 <= t < T), bias, exact erf GELU; fp32 output or hl32 planes only."""
+    M = B * T * Fp
+    xin = _mk((M, C2), 20, 1.2).float()
+    W = _mk((N, 3 * C2), 21, 1 / math.sqrt(3 * C2)).float()
+    b = _mk((N,), 22, 0.3)
+    out = torch.full((M, N), float("nan"), dtype=torch.float32, device=dev())
+    outb = torch.full((M, 2 * N), float("nan"), dtype=torch.float16, device=dev())
+    _call(A=to_hl32(xin).to(dev()), lda=C2, M=M, K=3 * C2, W=to_hl32(pad_rows(W, 256)).to(dev()), N=N, epi=1, bias=b.float().to(dev()),
+          x=0 if planes_only else out, ldx=N, xb=outb, no_resid=1, gelu=1, conv_C2=C2, conv_T=T, conv_F=Fp)
+    x4 = xin.double().view(B, T, Fp, C2)
+    pad = torch.zeros((B, 1, Fp, C2), dtype=torch.float64)
+    taps = torch.cat([torch.cat([pad, x4[:, :-1]], 1), x4, torch.cat([x4[:, 1:], pad], 1)], -1).reshape(M, 3 * C2)
+    ref = torch.nn.functional.gelu(taps @ W.double().T + b)
+    errb = _rel(from_hl32(outb.cpu()), ref)
+    err = errb if planes_only else _rel(out, ref)
+    report("gemm3_x3_conv", B=B, T=T, Fp=Fp, C2=C2, N=N, rel=err, planes=errb)
+    assert err < 3e-6 and errb < 3e-6
+
+
+def test_gemm3_x3_range_flag():
+    """A value beyond the fp16 range of a hi part raises the flag (and only then)."""
+    M, K, N = 256, 128, 128
+    A = _mk((M, K), 30).float()
+    W = _mk((N, K), 31, 0.1).float()
+    x0 = torch.zeros((M, N))
+    for boost, expect in ((1.0, 0), (1e6, 1)):
+        x = (x0 + (boost if expect else 0.0)).float().to(dev())
+        xb = torch.zeros((M, 2 * N), dtype=torch.float16, device=dev())
+        st = _status()
+        _call(A=to_hl32(A).to(dev()), lda=K, M=M, K=K, W=to_hl32(pad_rows(W, 256)).to(dev()), N=N, epi=1, x=x, ldx=N, xb=xb, status=st)
+        assert int(st.item()) == expect
+
+
+# ---- attention ----------------------------------------------------------------------------------------------------------
+def _attn_ref(q, k, v, gates):
+    s = q @ k.transpose(-1, -2) * math.log(2.0)  # q carries log2(e)/sqrt(d): softmax in base 2
+    return torch.softmax(s, -1) @ v * gates[..., None]
+
+
+def _run_attn(q, k, v, gates, n_seq, L, heads, out_f32, **omap):
+    from beat_this_amd import _lib as Lb
+
+    nbp = Lb.lib().bt_attn_frag_blocks(L)
+    SH = n_seq * heads
+    gh = torch.zeros((SH, nbp * 32), dtype=torch.float32)
+    gh[:, :L] = gates.float()
+    rows = n_seq * L
+    inner = heads * 32
+    out = torch.zeros((rows, inner), dtype=torch.float32, device=dev()) if out_f32 else \
+        torch.zeros((rows, 2 * inner), dtype=torch.float16, device=dev())
+    qf, kf, vf = frag_x3(q, nbp, "qk"), frag_x3(k, nbp, "qk"), frag_x3(v, nbp, "v")
+    nblk = (L + 31) // 32
+    kf[:, nblk:] = float("nan")   # padding blocks beyond ceil(L / 32) must never be consumed
+    vf[:, nblk:] = float("nan")
+    a = Lb.AttnFragArgs()
+    qd, kd, vd, gd = qf.to(dev()), kf.to(dev()), vf.to(dev()), gh.to(dev())
+    st = _status()
+    a.q, a.k, a.v, a.gates, a.out = qd.data_ptr(), kd.data_ptr(), vd.data_ptr(), gd.data_ptr(), out.data_ptr()
+    a.n_seq, a.L, a.heads, a.inner, a.nbp, a.o_div = n_seq, L, heads, inner, nbp, omap.get("o_div", 1)
+    a.o_outer, a.o_inner, a.o_tok = omap.get("o_outer", L), omap.get("o_inner", 0), omap.get("o_tok", 1)
+    a.x3, a.out_f32, a.status = 1, int(out_f32), st.data_ptr()
+    Lb.check(Lb.lib().bt_attention_frag(Lb.stream_ptr(dev()), C.byref(a)))
+    torch.cuda.synchronize()
+    assert int(st.item()) == 0
+    return out.double().cpu() if out_f32 else from_hl32(out.cpu())
+
+
+@pytest.mark.parametrize("out_f32", [False, True])
+@pytest.mark.parametrize("n_seq,L,heads", [(3, 1500, 2), (2, 77, 1), (1, 128, 4), (5, 1012, 1), (2, 1, 1), (2, 33, 2),
+                                           (1, 1499, 1), (2, 129, 1), (9, 96, 1), (2, 257, 1)])
+def test_attention_frag_x3(n_seq, L, heads, out_f32):
+    SH = n_seq * heads
+    q = _mk((SH, L, 32), 30, 0.6).float().double()
+    k = _mk((SH, L, 32), 31).float().double()
+    v = _mk((SH, L, 32), 32).float().double()
+    k[0, 7 % L] *= 6.0  # one outlier key
+    k = k.float().double()
+    gates = torch.sigmoid(_mk((SH, L), 33)).float().double()
+    out = _run_attn(q, k, v, gates, n_seq, L, heads, out_f32)
+    ref = _attn_ref(q, k, v, gates).view(n_seq, heads, L, 32).permute(0, 2, 1, 3).reshape(n_seq * L, heads * 32)
+    err = _rel(out, ref)
+    report("attn_frag_x3", n_seq=n_seq, L=L, heads=heads, out_f32=out_f32, rel=err)
+    assert err < 4e-6
+
+
+def test_attention_frag_x3_time_direction_rowmap():
+    B, T, F, heads = 2, 150, 4, 1
+    SH = B * F
+    q, k, v = (_mk((SH, T, 32), 40 + i).float().double() for i in range(3))
+    gates = torch.sigmoid(_mk((SH, T), 44)).float().double()
+    out = _run_attn(q, k, v, gates, SH, T, heads, True, o_div=F, o_outer=T * F, o_inner=1, o_tok=F)
+    ref = _attn_ref(q, k, v, gates).view(B, F, T, 32).permute(0, 2, 1, 3).reshape(B * T * F, 32)
+    err = _rel(out, ref)
+    report("attn_frag_x3_rowmap", rel=err)
+    assert err < 4e-6
+
+
+@pytest.mark.parametrize("L", [300, 1500])
+def test_attention_frag_x3_overflow_fallback(L):
+    """Scores that exceed the first key block's maximum by more than the fp16 probabilities can hold force the SAFE
+    (running-max) pass of the workgroup; the result must still be the exact softmax."""
+    SH = 3
+    q = _mk((SH, L, 32), 50, 0.5)
+    k = _mk((SH, L, 32), 51)
+    v = _mk((SH, L, 32), 52)
+    q[1, 5] = 0.0
+    q[1, 5, 0] = 25.0
+    k[1, L - 40] = 0.0
+    k[1, L - 40, 0] = 24.0
+    q, k, v = (t.float().double() for t in (q, k, v))
+    gates = torch.ones((SH, L), dtype=torch.float64)
+    out = _run_attn(q, k, v, gates, SH, L, 1, True)
+    ref = _attn_ref(q, k, v, gates).reshape(SH * L, 32)
+    assert torch.isfinite(out).all()
+    err = _rel(out, ref)
+    report("attn_frag_x3_overflow", L=L, rel=err)
+    assert err < 4e-6
+
+
+def test_attention_frag_x3_at_scale_is_repeatable():
+    """The main-layer launch shape of a 16-chunk batch (256 sequence-heads x 1500 tokens) four times: bit-identical."""
+    n_seq, L, heads = 16, 1500, 16
+    SH = n_seq * heads
+    q, k, v = (_mk((SH, L, 32), 60 + i, 0.7).float() for i in range(3))
+    gates = torch.sigmoid(_mk((SH, L), 63)).float()
+    from beat_this_amd import _lib as Lb
+
+    nbp = Lb.lib().bt_attn_frag_blocks(L)
+    qd, kd, vd = (frag_x3(t, nbp, kind).to(dev()) for t, kind in ((q, "qk"), (k, "qk"), (v, "v")))
+    gh = torch.zeros((SH, nbp * 32), dtype=torch.float32)
+    gh[:, :L] = gates
+    gd = gh.to(dev())
+    outs = []
+    for _ in range(4):
+        out = torch.zeros((n_seq * L, 2 * heads * 32), dtype=torch.float16, device=dev())
+        a = Lb.AttnFragArgs()
+        a.q, a.k, a.v, a.gates, a.out = qd.data_ptr(), kd.data_ptr(), vd.data_ptr(), gd.data_ptr(), out.data_ptr()
+        a.n_seq, a.L, a.heads, a.inner, a.nbp, a.o_div, a.o_outer, a.o_inner, a.o_tok = n_seq, L, heads, heads * 32, nbp, 1, L, 0, 1
+        a.x3, a.out_f32, a.status = 1, 0, 0
+        Lb.check(Lb.lib().bt_attention_frag(Lb.stream_ptr(dev()), C.byref(a)))
+        outs.append(out)
+    torch.cuda.synchronize()
+    assert all(torch.equal(o, outs[0]) for o in outs[1:])
+    # spot check of two sequence-heads against fp64
+    for sh in (0, SH - 1):
+        ref = _attn_ref(q[sh].double(), k[sh].double(), v[sh].double(), gates[sh].double())
+        s_, h_ = divmod(sh, heads)
+        got = from_hl32(outs[0].cpu()[s_ * L:(s_ + 1) * L])[:, h_ * 32:(h_ + 1) * 32]
+        assert _rel(got, ref) < 4e-6
+
+
+# ---- frontend: time-direction QKV projection and the shadow of the fused out-projection + FF kernel -------------------------
+def _pair_sd(Cc, seed):
+    H = Cc // 32
+    g = torch.Generator().manual_seed(seed)
+
+    def rn(*shape, s=1.0):
+        return torch.randn(*shape, generator=g, dtype=torch.float64) * s
+    return {
+        "a.norm.gamma": 1 + 0.1 * rn(Cc), "a.to_qkv.weight": rn(3 * Cc, Cc, s=1.6 / math.sqrt(Cc)),
+        "a.to_gates.weight": rn(H, Cc, s=0.3), "a.to_gates.bias": rn(H, s=0.3),
+        "a.to_out.0.weight": rn(Cc, Cc, s=1 / math.sqrt(Cc)),
+        "f.net.0.gamma": 1 + 0.1 * rn(Cc), "f.net.1.weight": rn(4 * Cc, Cc, s=1 / math.sqrt(Cc)),
+        "f.net.1.bias": rn(4 * Cc, s=0.2), "f.net.4.weight": rn(Cc, 4 * Cc, s=0.5 / math.sqrt(Cc)),
+        "f.net.4.bias": rn(Cc, s=0.2),
+    }
+
+
+@pytest.mark.parametrize("Cc", [32, 64, 128])
+@pytest.mark.parametrize("T", [70, 1500])
+def test_qkv_front_x3(Cc, T):
+    from beat_this_amd import _lib as L
+    from beat_this_amd.pack import LOG2E, PackedPair
+    from beat_this_amd.tables import rope_table
+
+    H, F = Cc // 32, 1024 // Cc
+    B = 2 if T < 1000 else 1
+    if T >= 1000:
+        F = 2
+    sd = {k: v.float().double() for k, v in _pair_sd(Cc, 170 + Cc).items()}   # fp32-representable weights
+    x0 = _mk((B, T, F, Cc), 180 + Cc, 1.5).float()
+    freqs = 10000.0 ** (-torch.arange(0, 32, 2).float() / 32)
+    rope = torch.from_numpy(rope_table(freqs)).to(dev())
+    pp = PackedPair(sd, "a.", "f.", Cc, dev())
+    assert pp.weights.w_qkv_frag_x3
+    nbp = L.lib().bt_attn_frag_blocks(T)
+    SH = B * F * H
+    qf = torch.full((SH, nbp, 2, 1024), float("nan"), dtype=torch.float16, device=dev())
+    kf, vf = qf.clone(), qf.clone()
+    gh = torch.zeros((SH, nbp * 32), dtype=torch.float32, device=dev())
+    xd = x0.to(dev())
+    L.check(L.lib().bt_qkv_front(L.stream_ptr(dev()), L.PREC_F32X3, C.byref(pp.weights), rope.data_ptr(), xd.data_ptr(), B, T, F,
+                                 qf.data_ptr(), kf.data_ptr(), vf.data_ptr(), gh.data_ptr(), nbp))
+    torch.cuda.synchronize()
+    x = x0.double()
+    xn = x / x.norm(dim=-1, keepdim=True).clamp_min(1e-12) * math.sqrt(Cc)
+    wq = (sd["a.to_qkv.weight"] * sd["a.norm.gamma"][None, :]).float().double()   # (gamma is folded at pack time, in fp32)
+    qkv = (xn @ wq.T).reshape(B, T, F, 3, H, 32).permute(3, 0, 2, 4, 1, 5)  # qkv b f h t d
+    ang = torch.arange(T, dtype=torch.float64)[:, None] * freqs.double()[None, :]
+    cos, sin = ang.cos().repeat_interleave(2, -1), ang.sin().repeat_interleave(2, -1)
+
+    def rot(t):
+        te, to = t[..., 0::2], t[..., 1::2]
+        return t * cos + torch.stack((-to, te), -1).flatten(-2) * sin
+    q = rot(qkv[0]).reshape(SH, T, 32) * (LOG2E / math.sqrt(32.0))
+    k = rot(qkv[1]).reshape(SH, T, 32)
+    v = qkv[2].reshape(SH, T, 32)
+    gates = torch.sigmoid(xn @ (sd["a.to_gates.weight"] * sd["a.norm.gamma"][None, :]).T + sd["a.to_gates.bias"])
+    gates = gates.permute(0, 2, 3, 1).reshape(SH, T)
+    nblk = (T + 31) // 32
+    eq = _rel(unfrag_x3(qf.cpu()[:, :nblk], T, "qk"), q)
+    ek = _rel(unfrag_x3(kf.cpu()[:, :nblk], T, "qk"), k)
+    ev = _rel(unfrag_x3(vf.cpu()[:, :nblk], T, "v"), v)
+    eg = _rel(gh.cpu()[:, :T], gates)
+    report("qkv_front_x3", C=Cc, T=T, q=eq, k=ek, v=ev, gates=eg)
+    assert max(eq, ek, ev) < 6e-6 and eg < 6e-6
+    if T % 32:
+        tail_k = kf.cpu()[:, nblk - 1].view(SH, 2, 4, 32, 8)[:, :, :, T % 32:, :]
+        assert torch.all(tail_k.float() == 0)
+
+
+@pytest.mark.parametrize("Cc", [64, 128])
+def test_fused_out_ff_x3_shadow(Cc):
+    """The hl32 shadow the (hi, lo) out-projection + FF kernel leaves for the following convolution equals its fp32 result."""
+    from beat_this_amd import _lib as L
+    from beat_this_amd.pack import PackedPair
+
+    sd = _pair_sd(Cc, 250 + Cc)
+    M = 1000 + Cc
+    x0 = _mk((M, Cc), 260 + Cc, 1.5)
+    ao = _mk((M, Cc), 270 + Cc).float()
+    pp = PackedPair(sd, "a.", "f.", Cc, dev())
+    x = x0.float().to(dev()).clone()
+    xb = torch.full((M, 2 * Cc), float("nan"), dtype=torch.float16, device=dev())
+    L.check(L.lib().bt_outff_fused(L.stream_ptr(dev()), L.PREC_F32X3, C.byref(pp.weights), ao.to(dev()).data_ptr(), x.data_ptr(), M,
+                                   xb.data_ptr()))
+    torch.cuda.synchronize()
+    xc = x.double().cpu()
+    err = float((from_hl32(xb.cpu()) - xc).abs().max() / xc.abs().max())
+    report("outff_x3_shadow", C=Cc, rel=err)
+    assert err < 1e-6
