@@ -501,15 +501,15 @@ __global__ __launch_bounds__(256, (QB == 1 ? 4 : 2)) void attn_frag_kernel(const
 // leaves as fp32 (frontend: consumed by outff_fused_kernel<hl>) or as hl32 planes (main layers: A operand of the
 // out-projection on gemm3.hip).  K / V tiles: 128 keys = 16 KB each, double buffered = 64 KB -> 2 workgroups per CU.
 constexpr int BLKX_BYTES = 2 * BLK_BYTES;
-constexpr int TILEX_BYTES = KB * BLKX_BYTES;
-constexpr int SMEMX_BYTES = 2 * 2 * TILEX_BYTES + 16;
+// (the tile size KBX -- 32-key blocks per LDS tile -- is a template parameter of this path: 4 = 128 keys, 64 KB of LDS,
+// two workgroups per CU; 2 = 64 keys, 32 KB, three workgroups per CU at twice the barriers)
 
 struct QStateX {
   hfx8 q0, q1, q0l, q1l;  // Q^T operand (hi, lo): dims [16g, 16g+8) and [16g+8, 16g+16) of this lane's query
-  f32x16 negm;            // -m - P_SHIFT splat: accumulator input of the first score MFMA (fast pass)
   f32x16 acc;             // O^T accumulator
   float l;                // row sum of this lane's 16 keys per block (the two halves are added at the end)
-  float m;                // running max (SAFE pass) / reference max (fast pass)
+  float m;                // running max (SAFE pass)
+  float nm;               // fast pass: -(reference max) - P_SHIFT, added to every score before the exponential
 };
 struct KFragX { hfx8 k0, k1, k0l, k1l; };
 struct VFragX { hfx8 v0, v1, v0l, v1l; };
@@ -531,54 +531,40 @@ DEVI VFragX ld_vx(const char* vb, int lane) {
 }
 // 8 fp32 probabilities -> packed hi halves and packed lo halves (p = hi + lo)
 DEVI void split8(const f32x16& p, int s, u32x4& whi, u32x4& wlo) {
+  unsigned h[4], l[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    const float a = p[8 * s + 2 * j], b = p[8 * s + 2 * j + 1];
+    const float a = opaque(p[8 * s + 2 * j]), b = opaque(p[8 * s + 2 * j + 1]);   // (common.h: ONE rounded value per split)
     const hf ha = (hf)a, hb = (hf)b;
-    const hfx2 th = {ha, hb};
-    const hfx2 tl = {(hf)(a - (float)ha), (hf)(b - (float)hb)};
-    whi[j] = __builtin_bit_cast(unsigned int, th);
-    wlo[j] = __builtin_bit_cast(unsigned int, tl);
+    h[j] = __builtin_bit_cast(unsigned int, hfx2{ha, hb});
+    l[j] = __builtin_bit_cast(unsigned int, hfx2{(hf)(a - (float)ha), (hf)(b - (float)hb)});
   }
+  whi = u32x4{h[0], h[1], h[2], h[3]};
+  wlo = u32x4{l[0], l[1], l[2], l[3]};
 }
-// scores of one key block: init + K . Q^T on three MFMA pairs, small terms last onto the running value
+// Scores of one key block, S^T = K . Q^T, from a ZERO accumulator with the small terms first (lo . hi, hi . lo, then
+// hi . hi): the reference maximum is subtracted afterwards on the VALU -- riding it on the accumulator input like the half
+// kernel does would round every one of the six partial sums at the magnitude of the maximum (measured: 1.1e-5 instead of
+// 3e-6 relative on the attention output at L = 1500; the matrix pipe, not the VALU, is the busy side of this kernel).
 template <int QB>
-DEVI void score_x(const KFragX& kf, const QStateX (&st)[QB], f32x16 (&sc)[QB], bool safe) {
+DEVI void score_x(const KFragX& kf, const QStateX (&st)[QB], f32x16 (&sc)[QB]) {
 #pragma unroll
   for (int j = 0; j < QB; ++j) {
-    if (safe) zero16(sc[j]); else sc[j] = st[j].negm;
-    sc[j] = MFMA32_H(kf.k0, st[j].q0, sc[j]);
+    zero16(sc[j]);
+    sc[j] = MFMA32_H(kf.k0l, st[j].q0, sc[j]);
   }
-#pragma unroll
-  for (int j = 0; j < QB; ++j) sc[j] = MFMA32_H(kf.k1, st[j].q1, sc[j]);
-#pragma unroll
-  for (int j = 0; j < QB; ++j) sc[j] = MFMA32_H(kf.k0l, st[j].q0, sc[j]);
 #pragma unroll
   for (int j = 0; j < QB; ++j) sc[j] = MFMA32_H(kf.k1l, st[j].q1, sc[j]);
 #pragma unroll
   for (int j = 0; j < QB; ++j) sc[j] = MFMA32_H(kf.k0, st[j].q0l, sc[j]);
 #pragma unroll
   for (int j = 0; j < QB; ++j) sc[j] = MFMA32_H(kf.k1, st[j].q1l, sc[j]);
-}
-// probabilities (already exponentiated, masked) of one key block: row sums, split, O^T += V^T . P^T
-template <int QB>
-DEVI void pv_x(f32x16 (&sc)[QB], const VFragX& vf, QStateX (&st)[QB]) {
 #pragma unroll
-  for (int j = 0; j < QB; ++j) {
-    const float a = (sc[j][0] + sc[j][1]) + (sc[j][2] + sc[j][3]), b = (sc[j][4] + sc[j][5]) + (sc[j][6] + sc[j][7]);
-    const float c = (sc[j][8] + sc[j][9]) + (sc[j][10] + sc[j][11]), d = (sc[j][12] + sc[j][13]) + (sc[j][14] + sc[j][15]);
-    st[j].l += (a + b) + (c + d);
-    u32x4 h0, l0, h1, l1;
-    split8(sc[j], 0, h0, l0);
-    split8(sc[j], 1, h1, l1);
-    st[j].acc = MFMA32_H(vf.v0l, __builtin_bit_cast(hfx8, h0), st[j].acc);
-    st[j].acc = MFMA32_H(vf.v1l, __builtin_bit_cast(hfx8, h1), st[j].acc);
-    st[j].acc = MFMA32_H(vf.v0, __builtin_bit_cast(hfx8, l0), st[j].acc);
-    st[j].acc = MFMA32_H(vf.v1, __builtin_bit_cast(hfx8, l1), st[j].acc);
-    st[j].acc = MFMA32_H(vf.v0, __builtin_bit_cast(hfx8, h0), st[j].acc);
-    st[j].acc = MFMA32_H(vf.v1, __builtin_bit_cast(hfx8, h1), st[j].acc);
-  }
+  for (int j = 0; j < QB; ++j) sc[j] = MFMA32_H(kf.k0, st[j].q0, sc[j]);
+#pragma unroll
+  for (int j = 0; j < QB; ++j) sc[j] = MFMA32_H(kf.k1, st[j].q1, sc[j]);
 }
+// scores -> probabilities -> row sums, split, O^T += V^T . P^T
 template <bool SAFE, bool MASK, int QB>
 DEVI void finish_x(f32x16 (&sc)[QB], const VFragX& vf, int g, QStateX (&st)[QB], int key0, int L) {
 #pragma unroll
@@ -603,98 +589,144 @@ DEVI void finish_x(f32x16 (&sc)[QB], const VFragX& vf, int g, QStateX (&st)[QB],
       for (int r = 0; r < 16; ++r) sc[j][r] = __builtin_amdgcn_exp2f(sc[j][r] - m_new);
     } else {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) sc[j][r] = __builtin_amdgcn_exp2f(sc[j][r]);
+      for (int r = 0; r < 16; ++r) sc[j][r] = __builtin_amdgcn_exp2f(sc[j][r] + st[j].nm);
       if constexpr (MASK) {
 #pragma unroll
         for (int r = 0; r < 16; ++r)
           if (key0 + crow(r, g) >= L) sc[j][r] = 0.f;
       }
     }
+    const float a = (sc[j][0] + sc[j][1]) + (sc[j][2] + sc[j][3]), b = (sc[j][4] + sc[j][5]) + (sc[j][6] + sc[j][7]);
+    const float c = (sc[j][8] + sc[j][9]) + (sc[j][10] + sc[j][11]), d = (sc[j][12] + sc[j][13]) + (sc[j][14] + sc[j][15]);
+    st[j].l += (a + b) + (c + d);
   }
-  pv_x<QB>(sc, vf, st);
+  u32x4 h0[QB], l0[QB], h1[QB], l1[QB];
+#pragma unroll
+  for (int j = 0; j < QB; ++j) {
+    split8(sc[j], 0, h0[j], l0[j]);
+    split8(sc[j], 1, h1[j], l1[j]);
+  }
+  // small terms first; consecutive MFMAs of different query blocks never share an accumulator
+#pragma unroll
+  for (int j = 0; j < QB; ++j) st[j].acc = MFMA32_H(vf.v0l, __builtin_bit_cast(hfx8, h0[j]), st[j].acc);
+#pragma unroll
+  for (int j = 0; j < QB; ++j) st[j].acc = MFMA32_H(vf.v1l, __builtin_bit_cast(hfx8, h1[j]), st[j].acc);
+#pragma unroll
+  for (int j = 0; j < QB; ++j) st[j].acc = MFMA32_H(vf.v0, __builtin_bit_cast(hfx8, l0[j]), st[j].acc);
+#pragma unroll
+  for (int j = 0; j < QB; ++j) st[j].acc = MFMA32_H(vf.v1, __builtin_bit_cast(hfx8, l1[j]), st[j].acc);
+#pragma unroll
+  for (int j = 0; j < QB; ++j) st[j].acc = MFMA32_H(vf.v0, __builtin_bit_cast(hfx8, h0[j]), st[j].acc);
+#pragma unroll
+  for (int j = 0; j < QB; ++j) st[j].acc = MFMA32_H(vf.v1, __builtin_bit_cast(hfx8, h1[j]), st[j].acc);
 }
 
+template <int KBX>
 DEVI void stage_tile_x(rsrc_t rk, rsrc_t rv, int tile, char* smem, int buf, int tid, int wave) {
+  constexpr int TILEX_BYTES = KBX * BLKX_BYTES;
   char* kd = smem + buf * 2 * TILEX_BYTES + wave * 1024;
   char* vd = kd + TILEX_BYTES;
   const int so = tile * TILEX_BYTES;
-  static_assert(TILEX_BYTES == 16384, "stage_tile_x copies four 4 KB pieces per operand");
+  static_assert(TILEX_BYTES % 4096 == 0, "stage_tile_x copies 4 KB pieces");
 #pragma unroll
-  for (int i = 0; i < 4; ++i) __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, (lptr_t)(kd + i * 4096), 16, tid * 16, so + i * 4096, 0, 0);
+  for (int i = 0; i < KBX; ++i) __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, (lptr_t)(kd + i * 4096), 16, tid * 16, so + i * 4096, 0, 0);
 #pragma unroll
-  for (int i = 0; i < 4; ++i) __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (lptr_t)(vd + i * 4096), 16, tid * 16, so + i * 4096, 0, 0);
+  for (int i = 0; i < KBX; ++i) __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (lptr_t)(vd + i * 4096), 16, tid * 16, so + i * 4096, 0, 0);
 }
 
-// One pass over all keys.  Fast pass (SAFE = false): reference maximum from key block 0, scores of block c + 1 issued
-// before the exponentials of block c; SAFE: classic online softmax, unpipelined.  One barrier per 128-key tile.
-template <bool SAFE, int QB>
-DEVI void attn_pass_x(rsrc_t rk, rsrc_t rv, char* smem, int tid, int wave, int lane, int g, int lr, QStateX (&st)[QB], int L,
-                      int nblk) {
-  const int ntiles = (nblk + KB - 1) / KB;
+// Plain pass, one key block at a time (SAFE: classic online softmax over all tiles; fast: only the tiles from `t0` on --
+// the ragged / masked last tile): tile t + 1 is staged while tile t is consumed, one barrier per tile.
+// On entry tile t0 must be readable in buffer t0 & 1 (and tile t0 + 1, if `next_staged`, on its way into the other one).
+template <bool SAFE, int QB, int KBX>
+DEVI void attn_tiles_x(rsrc_t rk, rsrc_t rv, char* smem, int tid, int wave, int lane, int g, int lr, QStateX (&st)[QB], int L,
+                       int nblk, int t0, bool next_staged) {
+  constexpr int TILEX_BYTES = KBX * BLKX_BYTES;
+  const int ntiles = (nblk + KBX - 1) / KBX;
   const bool partial = (L & 31) != 0;
-  stage_tile_x(rk, rv, 0, smem, 0, tid, wave);
+  for (int t = t0; t < ntiles; ++t) {
+    if (t + 1 < ntiles && !(t == t0 && next_staged)) stage_tile_x<KBX>(rk, rv, t + 1, smem, (t + 1) & 1, tid, wave);
+    const char* kb = smem + (t & 1) * 2 * TILEX_BYTES;
+    const char* vb = kb + TILEX_BYTES;
+    const int nb = min(KBX, nblk - t * KBX);
+    for (int c = 0; c < nb; ++c) {
+      const int blk = t * KBX + c;
+      const KFragX kf = ld_kx(kb + c * BLKX_BYTES, g, lr);
+      const VFragX vf = ld_vx(vb + c * BLKX_BYTES, lane);
+      f32x16 sc[QB];
+      score_x<QB>(kf, st, sc);
+      if (partial && blk == nblk - 1) finish_x<SAFE, true, QB>(sc, vf, g, st, blk * 32, L);
+      else finish_x<SAFE, false, QB>(sc, vf, g, st, blk * 32, L);
+    }
+    __syncthreads();  // tile t + 1 has landed (every wave waited for its own copies), tile t is free
+  }
+}
+
+// Fast pass: reference maximum of every query from key block 0, then the key loop software-pipelined by hand over the
+// tiles of KB unmasked blocks: the scores of block c + 1 are issued BEFORE the exponentials of block c (two score
+// buffers alternate: the loop is unrolled over the tile, no register copies), one barrier per tile at its last block.
+template <int QB, int KBX>
+DEVI void attn_fast_x(rsrc_t rk, rsrc_t rv, char* smem, int tid, int wave, int lane, int g, int lr, QStateX (&st)[QB], int L,
+                      int nblk) {
+  constexpr int TILEX_BYTES = KBX * BLKX_BYTES;
+  static_assert(KBX % 2 == 0, "two score buffers alternate over the blocks of a tile");
+  const int ntiles = (nblk + KBX - 1) / KBX;
+  const bool partial = (L & 31) != 0;
+  int nfull = nblk / KBX;  // tiles of KBX unmasked blocks
+  if (partial && nfull * KBX == nblk) --nfull;
+  stage_tile_x<KBX>(rk, rv, 0, smem, 0, tid, wave);
   __syncthreads();
-  if (ntiles > 1) stage_tile_x(rk, rv, 1, smem, 1, tid, wave);
+  if (ntiles > 1) stage_tile_x<KBX>(rk, rv, 1, smem, 1, tid, wave);
 #pragma unroll
   for (int j = 0; j < QB; ++j) {
     zero16(st[j].acc);
-    zero16(st[j].negm);
     st[j].l = 0.f;
     st[j].m = -1e30f;
   }
-  if constexpr (!SAFE) {  // reference max of each query: its scores against key block 0
-    const KFragX k00 = ld_kx(smem, g, lr);
-    f32x16 sc[QB];
-    score_x<QB>(k00, st, sc, true);
-#pragma unroll
-    for (int j = 0; j < QB; ++j) {
-      float bm = -1e30f;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) bm = fmaxf(bm, (crow(r, g) < L) ? sc[j][r] : -1e30f);
-      bm = fmaxf(bm, __shfl_xor(bm, 32));
-      st[j].m = bm;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) st[j].negm[r] = -bm - P_SHIFT;
-    }
-  }
-  f32x16 sc[QB];
+  f32x16 s2[2][QB];  // scores of the current / the next block (indices are compile-time constants: the loop is unrolled)
   KFragX kf = ld_kx(smem, g, lr);
-  score_x<QB>(kf, st, sc, SAFE);
-  for (int t = 0; t < ntiles; ++t) {
+  score_x<QB>(kf, st, s2[0]);
+#pragma unroll
+  for (int j = 0; j < QB; ++j) {  // reference max of each query: its scores against key block 0
+    float bm = -1e30f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) bm = fmaxf(bm, (crow(r, g) < L) ? s2[0][j][r] : -1e30f);
+    bm = fmaxf(bm, __shfl_xor(bm, 32));
+    st[j].nm = -bm - P_SHIFT;
+  }
+  // (s2[0] = scores of block 0 of tile 0: the pipeline's first input, if there is a full tile)
+  for (int t = 0; t < nfull; ++t) {
     const char* kb = smem + (t & 1) * 2 * TILEX_BYTES;
     const char* vb = kb + TILEX_BYTES;
-    const int nb = min(KB, nblk - t * KB);
-    for (int c = 0; c < nb; ++c) {
-      const int blk = t * KB + c;
-      const VFragX vf = ld_vx(vb + c * BLKX_BYTES, lane);
-      const bool last_of_tile = c + 1 == nb;
-      const bool more = blk + 1 < nblk;  // (uniform)
-      f32x16 sn[QB];
-      if (last_of_tile) {
-        // every wave has issued and received its last fragment reads of tile t (vf above, kf earlier): after the barrier the
-        // buffer of tile t is free for tile t + 2, and tile t + 1 has landed in every wave (vmcnt(0) in __syncthreads)
-        __syncthreads();
-        if (t + 2 < ntiles) stage_tile_x(rk, rv, t + 2, smem, t & 1, tid, wave);
-        if (more) kf = ld_kx(smem + ((t + 1) & 1) * 2 * TILEX_BYTES, g, lr);
-      } else {
-        kf = ld_kx(kb + (c + 1) * BLKX_BYTES, g, lr);
-      }
-      if (more) score_x<QB>(kf, st, sn, SAFE);
-      if (partial && blk == nblk - 1) finish_x<SAFE, true, QB>(sc, vf, g, st, blk * 32, L);
-      else finish_x<SAFE, false, QB>(sc, vf, g, st, blk * 32, L);
-      if (more) {
+    const char* kb_next = smem + ((t + 1) & 1) * 2 * TILEX_BYTES;
 #pragma unroll
-        for (int j = 0; j < QB; ++j) sc[j] = sn[j];
+    for (int c = 0; c < KBX; ++c) {
+      const VFragX vf = ld_vx(vb + c * BLKX_BYTES, lane);
+      if (c + 1 < KBX) {
+        kf = ld_kx(kb + (c + 1) * BLKX_BYTES, g, lr);
+        score_x<QB>(kf, st, s2[(c + 1) & 1]);
+      } else {
+        // the tile's last fragment reads are issued (vf) / have arrived (kf): barrier, refill, first block of tile t + 1
+        __syncthreads();  // tile t + 1 has landed in every wave; nobody reads tile t any more
+        if (t + 2 < ntiles) stage_tile_x<KBX>(rk, rv, t + 2, smem, t & 1, tid, wave);
+        if (t + 1 < nfull) {  // (uniform)
+          kf = ld_kx(kb_next, g, lr);
+          score_x<QB>(kf, st, s2[0]);
+        }
       }
+      finish_x<false, false, QB>(s2[c & 1], vf, g, st, 0, L);
     }
   }
-  __syncthreads();
+  if (nfull < ntiles)  // last tile: fewer than KBX blocks and / or a masked last block (staged by the loop / the prologue)
+    attn_tiles_x<false, QB, KBX>(rk, rv, smem, tid, wave, lane, g, lr, st, L, nblk, nfull, true);
+  else
+    __syncthreads();
 }
 
 // OUT: 0 = hl32 planes [rows, 2 inner] (main layers), 1 = fp32 [rows, inner] (frontend)
-template <int QB, int OUT>
-__global__ __launch_bounds__(256, 2) void attn_frag_x3_kernel(const AttnFragP p, int nqt, int sh_total) {
-  __shared__ __attribute__((aligned(16))) char smem[SMEMX_BYTES];
+template <int QB, int OUT, int KBX>
+__global__ __launch_bounds__(256, (KBX == 2 ? 3 : 2)) void attn_frag_x3_kernel(const AttnFragP p, int nqt, int sh_total) {
+  constexpr int TILEX_BYTES = KBX * BLKX_BYTES;
+  __shared__ __attribute__((aligned(16))) char smem[2 * 2 * TILEX_BYTES + 16];
   const int bid = blockIdx.x;
   const int idx = bid >> 3;
   const int sh = (idx / nqt) * 8 + (bid & 7);
@@ -728,7 +760,7 @@ __global__ __launch_bounds__(256, 2) void attn_frag_x3_kernel(const AttnFragP p,
   const unsigned seq_bytes = (unsigned)p.nbp * BLKX_BYTES;
   const rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(kseq), 0, seq_bytes, 0x00020000);
   const rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(vseq), 0, seq_bytes, 0x00020000);
-  attn_pass_x<false, QB>(rk, rv, smem, tid, wave, lane, g, lr, st, L, nblk);
+  attn_fast_x<QB, KBX>(rk, rv, smem, tid, wave, lane, g, lr, st, L, nblk);
   float l_tot[QB];
   bool bad = false;
 #pragma unroll
@@ -744,7 +776,15 @@ __global__ __launch_bounds__(256, 2) void attn_frag_x3_kernel(const AttnFragP p,
   __syncthreads();
   if (*flag) {  // workgroup-uniform
     __syncthreads();
-    attn_pass_x<true, QB>(rk, rv, smem, tid, wave, lane, g, lr, st, L, nblk);
+#pragma unroll
+    for (int j = 0; j < QB; ++j) {
+      zero16(st[j].acc);
+      st[j].l = 0.f;
+      st[j].m = -1e30f;
+    }
+    stage_tile_x<KBX>(rk, rv, 0, smem, 0, tid, wave);
+    __syncthreads();
+    attn_tiles_x<true, QB, KBX>(rk, rv, smem, tid, wave, lane, g, lr, st, L, nblk, 0, false);
 #pragma unroll
     for (int j = 0; j < QB; ++j) l_tot[j] = st[j].l + __shfl_xor(st[j].l, 32);
   }
@@ -776,8 +816,9 @@ __global__ __launch_bounds__(256, 2) void attn_frag_x3_kernel(const AttnFragP p,
         unsigned xh[2], xl[2], yh[2], yl[2];
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-          const float a0 = st[j].acc[8 * k + 2 * i] * scale, a1 = st[j].acc[8 * k + 2 * i + 1] * scale;
-          const float b0 = st[j].acc[8 * k + 4 + 2 * i] * scale, b1 = st[j].acc[8 * k + 4 + 2 * i + 1] * scale;
+          // (opaque, common.h: the split must see ONE rounded fp32 product, not a multiply contracted into the conversions)
+          const float a0 = opaque(st[j].acc[8 * k + 2 * i] * scale), a1 = opaque(st[j].acc[8 * k + 2 * i + 1] * scale);
+          const float b0 = opaque(st[j].acc[8 * k + 4 + 2 * i] * scale), b1 = opaque(st[j].acc[8 * k + 4 + 2 * i + 1] * scale);
           const hf ha0 = (hf)a0, ha1 = (hf)a1, hb0 = (hf)b0, hb1 = (hf)b1;
           xh[i] = __builtin_bit_cast(unsigned, hfx2{ha0, ha1});
           xl[i] = __builtin_bit_cast(unsigned, hfx2{(hf)(a0 - (float)ha0), (hf)(a1 - (float)ha1)});
@@ -812,13 +853,13 @@ static void launch_v(const AttnFragP& p, hipStream_t s) {
   hipLaunchKernelGGL((attn_frag_kernel<ABL, QB>), dim3((unsigned)grid), dim3(256), 0, s, p, nqt, (int)sh);
 }
 
-template <int QB, int OUT>
+template <int QB, int OUT, int KBX>
 static void launch_x3(const AttnFragP& p, hipStream_t s) {
   const int nblk = (p.L + 31) / 32;
   const int nqt = (nblk + 4 * QB - 1) / (4 * QB);
   const long sh = (long)p.n_seq * p.heads;
   const long grid = (sh + 7) / 8 * 8 * nqt;
-  hipLaunchKernelGGL((attn_frag_x3_kernel<QB, OUT>), dim3((unsigned)grid), dim3(256), 0, s, p, nqt, (int)sh);
+  hipLaunchKernelGGL((attn_frag_x3_kernel<QB, OUT, KBX>), dim3((unsigned)grid), dim3(256), 0, s, p, nqt, (int)sh);
 }
 
 int launch_attn_frag(const AttnFragP& p, hipStream_t s) {
@@ -826,7 +867,12 @@ int launch_attn_frag(const AttnFragP& p, hipStream_t s) {
   if ((long)p.n_seq * p.heads * ((p.L + 127) / 128) > 0x3fffffffL) return -3;
   if (p.x3) {
     if (BT_HALF_IS_BF16 || (long)p.nbp * 4096 >= 0x7fffffffL) return -2;
-    if (p.out_f32) launch_x3<1, 1>(p, s); else launch_x3<1, 0>(p, s);
+    // x3 selects the variant (bt_attention_frag; the engine passes 1): 1 = one query block per wave, 128-key tiles;
+    // 2 = two query blocks per wave (half the fragment reads per MFMA, two independent accumulation chains);
+    // 3 = one query block per wave, 64-key tiles (32 KB of LDS: three workgroups per CU)
+    if (p.x3 == 2) { if (p.out_f32) launch_x3<2, 1, 4>(p, s); else launch_x3<2, 0, 4>(p, s); }
+    else if (p.x3 == 3) { if (p.out_f32) launch_x3<1, 1, 2>(p, s); else launch_x3<1, 0, 2>(p, s); }
+    else { if (p.out_f32) launch_x3<1, 1, 4>(p, s); else launch_x3<1, 0, 4>(p, s); }
     return (int)hipGetLastError();
   }
   // (Two query blocks per wave -- QB = 2, half the fragment reads per MFMA at half the occupancy -- measured equal.)

@@ -130,6 +130,16 @@ template <typename T> DEVI T from_f32(float x);
 template <> DEVI float from_f32<float>(float x) { return x; }
 template <> DEVI hf from_f32<hf>(float x) { return (hf)x; }
 
+// A value that is about to be split into hi + lo halves must be ONE materialised fp32 number: with fp contraction hipcc
+// folds the arithmetic that produced it into the conversions (v_fma_mixlo_f16 hi = half(a * b) from the EXACT product, lo =
+// half(a * b - hi) likewise) while the stored hi comes from a separately rounded fp32 product -- the two hi parts differ by
+// one fp16 ulp where the double rounding bites, and hi + lo is then 2^-11 off (found by the unit tests of round 3:
+// 2.5e-4 .. 5e-4 relative on 0.1 % of the elements).  An empty asm makes the value opaque at no cost.
+DEVI float opaque(float v) {
+  asm("" : "+v"(v));
+  return v;
+}
+
 DEVI void st16(float* dst, const float* v) {  // 16 floats, 64 B aligned enough for 16 B stores
   f32x4* d = reinterpret_cast<f32x4*>(dst);
 #pragma unroll

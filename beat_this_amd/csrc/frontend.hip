@@ -120,7 +120,7 @@ __global__ __launch_bounds__(256) void shadow_ssq_kernel(const float* __restrict
   for (int g = 0; g < D / 64; ++g) {
     const float v = x[row * D + g * 64 + lane];
     if (hl32) {
-      const hf h = (hf)v;
+      const hf h = (hf)v;   // (v is a loaded value: nothing to contract into the conversions)
       hf* d = xb + (row * D + g * 64) * 2 + (lane >> 5) * 64 + (lane & 31);
       d[0] = h;
       d[32] = (hf)(v - (float)h);

@@ -154,7 +154,8 @@ DEVI void ff_tail(WRing<T, C>& ws, int step0, float (&xn)[C / 32][16], const flo
           unsigned xh[2], xl[2], yh[2], yl[2];
 #pragma unroll
           for (int i = 0; i < 2; ++i) {
-            const float a0 = v[2 * k][2 * i], a1 = v[2 * k][2 * i + 1], b0 = v[2 * k + 1][2 * i], b1 = v[2 * k + 1][2 * i + 1];
+            const float a0 = opaque(v[2 * k][2 * i]), a1 = opaque(v[2 * k][2 * i + 1]);   // (common.h: ONE rounded value per split)
+            const float b0 = opaque(v[2 * k + 1][2 * i]), b1 = opaque(v[2 * k + 1][2 * i + 1]);
             const hf ha0 = (hf)a0, ha1 = (hf)a1, hb0 = (hf)b0, hb1 = (hf)b1;
             xh[i] = __builtin_bit_cast(unsigned, hfx2{ha0, ha1});
             xl[i] = __builtin_bit_cast(unsigned, hfx2{(hf)(a0 - (float)ha0), (hf)(a1 - (float)ha1)});

@@ -123,7 +123,9 @@ def test_gemm3_x3_qkv(n_seq, L, heads):
     ev = _rel(unfrag_x3(vf.cpu()[:, :nblk], L, "v"), v)
     eg = _rel(gh.cpu()[:, :L], gates)
     report("gemm3_x3_qkv", n_seq=n_seq, L=L, heads=heads, q=eq, k=ek, v=ev, gates=eg)
-    assert max(eq, ek, ev) < 3e-6 and eg < 3e-6 and int(st.item()) == 0
+    # (q, k: the rotary angles pos * freq are fp32 products like rotary-embedding-torch's -- 1e-4 rad at position 1500 -- so
+    # against this float64 restatement the rotated values are 2e-5 off at L = 1500; v has no rotation)
+    assert max(eq, ek) < (3e-6 if L < 200 else 4e-5) and ev < 3e-6 and eg < 3e-6 and int(st.item()) == 0
     if L % 32:  # tokens beyond L inside the last block: exact zeros for K and V, hi and lo
         tail_k = kf.cpu()[:, nblk - 1].view(SH, 2, 4, 32, 8)[:, :, :, L % 32:, :]
         assert torch.all(tail_k.float() == 0)
@@ -173,7 +175,7 @@ def _attn_ref(q, k, v, gates):
     return torch.softmax(s, -1) @ v * gates[..., None]
 
 
-def _run_attn(q, k, v, gates, n_seq, L, heads, out_f32, **omap):
+def _run_attn(q, k, v, gates, n_seq, L, heads, out_f32, variant=1, **omap):
     from beat_this_amd import _lib as Lb
 
     nbp = Lb.lib().bt_attn_frag_blocks(L)
@@ -194,17 +196,18 @@ def _run_attn(q, k, v, gates, n_seq, L, heads, out_f32, **omap):
     a.q, a.k, a.v, a.gates, a.out = qd.data_ptr(), kd.data_ptr(), vd.data_ptr(), gd.data_ptr(), out.data_ptr()
     a.n_seq, a.L, a.heads, a.inner, a.nbp, a.o_div = n_seq, L, heads, inner, nbp, omap.get("o_div", 1)
     a.o_outer, a.o_inner, a.o_tok = omap.get("o_outer", L), omap.get("o_inner", 0), omap.get("o_tok", 1)
-    a.x3, a.out_f32, a.status = 1, int(out_f32), st.data_ptr()
+    a.x3, a.out_f32, a.status = variant, int(out_f32), st.data_ptr()
     Lb.check(Lb.lib().bt_attention_frag(Lb.stream_ptr(dev()), C.byref(a)))
     torch.cuda.synchronize()
     assert int(st.item()) == 0
     return out.double().cpu() if out_f32 else from_hl32(out.cpu())
 
 
+@pytest.mark.parametrize("variant", [1, 2, 3])   # bt_attn_frag_args.x3: query blocks per wave / keys per LDS tile (attn2.hip)
 @pytest.mark.parametrize("out_f32", [False, True])
 @pytest.mark.parametrize("n_seq,L,heads", [(3, 1500, 2), (2, 77, 1), (1, 128, 4), (5, 1012, 1), (2, 1, 1), (2, 33, 2),
-                                           (1, 1499, 1), (2, 129, 1), (9, 96, 1), (2, 257, 1)])
-def test_attention_frag_x3(n_seq, L, heads, out_f32):
+                                           (1, 1499, 1), (2, 129, 1), (9, 96, 1), (2, 257, 1), (2, 250, 1), (1, 64, 1)])
+def test_attention_frag_x3(n_seq, L, heads, out_f32, variant):
     SH = n_seq * heads
     q = _mk((SH, L, 32), 30, 0.6).float().double()
     k = _mk((SH, L, 32), 31).float().double()
@@ -212,10 +215,10 @@ def test_attention_frag_x3(n_seq, L, heads, out_f32):
     k[0, 7 % L] *= 6.0  # one outlier key
     k = k.float().double()
     gates = torch.sigmoid(_mk((SH, L), 33)).float().double()
-    out = _run_attn(q, k, v, gates, n_seq, L, heads, out_f32)
+    out = _run_attn(q, k, v, gates, n_seq, L, heads, out_f32, variant)
     ref = _attn_ref(q, k, v, gates).view(n_seq, heads, L, 32).permute(0, 2, 1, 3).reshape(n_seq * L, heads * 32)
     err = _rel(out, ref)
-    report("attn_frag_x3", n_seq=n_seq, L=L, heads=heads, out_f32=out_f32, rel=err)
+    report("attn_frag_x3", n_seq=n_seq, L=L, heads=heads, out_f32=out_f32, variant=variant, rel=err)
     assert err < 4e-6
 
 
@@ -231,8 +234,9 @@ def test_attention_frag_x3_time_direction_rowmap():
     assert err < 4e-6
 
 
+@pytest.mark.parametrize("variant", [1, 2, 3])
 @pytest.mark.parametrize("L", [300, 1500])
-def test_attention_frag_x3_overflow_fallback(L):
+def test_attention_frag_x3_overflow_fallback(L, variant):
     """Scores that exceed the first key block's maximum by more than the fp16 probabilities can hold force the SAFE
     (running-max) pass of the workgroup; the result must still be the exact softmax."""
     SH = 3
@@ -245,7 +249,7 @@ def test_attention_frag_x3_overflow_fallback(L):
     k[1, L - 40, 0] = 24.0
     q, k, v = (t.float().double() for t in (q, k, v))
     gates = torch.ones((SH, L), dtype=torch.float64)
-    out = _run_attn(q, k, v, gates, SH, L, 1, True)
+    out = _run_attn(q, k, v, gates, SH, L, 1, True, variant)
     ref = _attn_ref(q, k, v, gates).reshape(SH * L, 32)
     assert torch.isfinite(out).all()
     err = _rel(out, ref)
@@ -349,7 +353,7 @@ def test_qkv_front_x3(Cc, T):
     ev = _rel(unfrag_x3(vf.cpu()[:, :nblk], T, "v"), v)
     eg = _rel(gh.cpu()[:, :T], gates)
     report("qkv_front_x3", C=Cc, T=T, q=eq, k=ek, v=ev, gates=eg)
-    assert max(eq, ek, ev) < 6e-6 and eg < 6e-6
+    assert max(eq, ek) < (6e-6 if T < 200 else 4e-5) and ev < 6e-6 and eg < 6e-6   # (q, k at T = 1500: fp32 rotary angles, see above)
     if T % 32:
         tail_k = kf.cpu()[:, nblk - 1].view(SH, 2, 4, 32, 8)[:, :, :, T % 32:, :]
         assert torch.all(tail_k.float() == 0)

@@ -1,0 +1,109 @@
+#!/usr/bin/env python
+"""Time the BT_PREC_F32X3 kernels in isolation at the final0 / 16-chunk launch shapes (GPU box):
+  * attention variants of csrc/attn2.hip (bt_attn_frag_args.x3 = 1 / 2 / 3) on the main-layer and frontend shapes, with
+    a bit-for-bit comparison of the variants' results;
+  * the hl32 GEMM of csrc/gemm3.hip on the main-layer shapes (QKV, out-projection, FF1, FF2) and frontend.linear.
+    python tools/x3_probe.py [chunks]"""
+import ctypes as C
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+from beat_this_amd import _lib as L  # noqa: E402
+from gpu_util import frag_x3, pad_rows, to_hl32  # noqa: E402
+
+dev = torch.device("cuda:0")
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+lib = L.lib()
+
+
+def timeit(fn, n=20):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(n):
+        fn()
+    b.record()
+    b.synchronize()
+    return a.elapsed_time(b) / n * 1e3   # us
+
+
+def attention(n_seq, heads, Lq, label):
+    g = torch.Generator().manual_seed(1)
+    SH = n_seq * heads
+    nbp = lib.bt_attn_frag_blocks(Lq)
+    # (random operands straight in the block layout: every 16-byte entry is an arbitrary hi / lo pair, like real data)
+    mk = lambda s: (torch.randn((SH, nbp, 2, 1024), generator=g) * s).to(torch.float16)  # noqa: E731
+    q, k, v = mk(0.6), mk(1.0), mk(1.0)
+    q[:, :, 1] *= 2.0 ** -11
+    k[:, :, 1] *= 2.0 ** -11
+    v[:, :, 1] *= 2.0 ** -11
+    qd, kd, vd = q.to(dev), k.to(dev), v.to(dev)
+    gates = torch.rand((SH, nbp * 32), generator=g).to(dev)
+    outs = {}
+    for variant in (1, 2, 3):
+        out = torch.zeros((n_seq * Lq, 2 * heads * 32), dtype=torch.float16, device=dev)
+        a = L.AttnFragArgs()
+        a.q, a.k, a.v, a.gates, a.out = qd.data_ptr(), kd.data_ptr(), vd.data_ptr(), gates.data_ptr(), out.data_ptr()
+        a.n_seq, a.L, a.heads, a.inner, a.nbp, a.o_div, a.o_outer, a.o_inner, a.o_tok = n_seq, Lq, heads, heads * 32, nbp, 1, Lq, 0, 1
+        a.x3, a.out_f32, a.status = variant, 0, 0
+        st = L.stream_ptr(dev)
+        us = timeit(lambda: L.check(lib.bt_attention_frag(st, C.byref(a))))
+        flop = 2 * 2 * SH * Lq * Lq * 32
+        outs[variant] = out.clone()
+        print(f"attention x3 variant {variant} {label}: {us:8.1f} us  {flop / us / 1e6:7.1f} TFLOP/s algorithmic "
+              f"({3 * flop / us / 1e6:7.1f} on the matrix pipe)  same as variant 1: {torch.equal(outs[variant], outs[1])}", flush=True)
+
+
+def gemm(M, K, N, epi, label, heads=0, n_seq=0, Lq=0):
+    g = torch.Generator().manual_seed(2)
+    A = to_hl32(torch.randn((M, K), generator=g)).to(dev)
+    W = to_hl32(pad_rows(torch.randn((N, K), generator=g) / K ** 0.5, 256)).to(dev)
+    a = L.Gemm3Args()
+    a.A, a.lda, a.M, a.K, a.W, a.N, a.epi, a.x3 = A.data_ptr(), K, M, K, W.data_ptr(), N, epi, 1
+    keep = []
+    if epi == 0:
+        bias = torch.zeros(N, device=dev); out = torch.zeros((M, 2 * N), dtype=torch.float16, device=dev)
+        ssq = torch.ones((K // 64, M), device=dev)
+        a.bias, a.out, a.ldo, a.ssq_in, a.ssq_parts = bias.data_ptr(), out.data_ptr(), N, ssq.data_ptr(), K // 64
+        keep += [bias, out, ssq]
+    elif epi == 1:
+        x = torch.zeros((M, N), device=dev); xb = torch.zeros((M, 2 * N), dtype=torch.float16, device=dev)
+        ssq = torch.zeros((N // 64, M), device=dev)
+        a.x, a.ldx, a.xb, a.ssq_out = x.data_ptr(), N, xb.data_ptr(), ssq.data_ptr()
+        keep += [x, xb, ssq]
+    else:
+        from beat_this_amd.tables import rope_table
+        nbp = lib.bt_attn_frag_blocks(Lq)
+        SH = n_seq * heads
+        qf = torch.zeros((SH, nbp, 2, 1024), dtype=torch.float16, device=dev)
+        kf, vf = qf.clone(), qf.clone()
+        gh = torch.zeros((SH, nbp * 32), device=dev)
+        rope = torch.from_numpy(rope_table(10000.0 ** (-torch.arange(0, 32, 2).float() / 32))).to(dev)
+        ssq = torch.ones((K // 64, M), device=dev); bg = torch.zeros(heads, device=dev)
+        a.N = 3 * K + heads
+        a.ssq_in, a.ssq_parts, a.n_seq, a.L, a.nbp, a.heads, a.rope = ssq.data_ptr(), K // 64, n_seq, Lq, nbp, heads, rope.data_ptr()
+        a.qf, a.kf, a.vf, a.gates, a.b_gates = qf.data_ptr(), kf.data_ptr(), vf.data_ptr(), gh.data_ptr(), bg.data_ptr()
+        keep += [qf, kf, vf, gh, rope, ssq, bg]
+    st = L.stream_ptr(dev)
+    us = timeit(lambda: L.check(lib.bt_gemm3(st, C.byref(a))))
+    flop = 2.0 * M * K * a.N
+    print(f"gemm3 x3 {label} M={M} K={K} N={a.N}: {us:8.1f} us  {flop / us / 1e6:7.1f} TFLOP/s algorithmic "
+          f"({3 * flop / us / 1e6:7.1f} on the matrix pipe)", flush=True)
+
+
+T = 1500
+attention(B, 16, T, f"main layer ({B} chunks x 16 heads)")
+attention(B * 32, 1, T, f"frontend block 0 ({B * 32} sequences x 1 head)")
+attention(B * 8, 4, T, f"frontend block 2 ({B * 8} sequences x 4 heads)")
+M = B * T
+gemm(M, 512, 0, 2, "QKV", heads=16, n_seq=B, Lq=T)
+gemm(M, 512, 512, 1, "out-projection")
+gemm(M, 512, 2048, 0, "FF1")
+gemm(M, 2048, 512, 1, "FF2")
+gemm(M, 1024, 512, 1, "frontend.linear")
