@@ -617,6 +617,11 @@ bool gemm3_supported(const Gemm3P& p) {
   return false;
 }
 
+// BT_PREC_F32X3, FF1 of the main layers on the 256 x 256 tiles (half the L2 -> LDS bytes per flop of the 128 x 128 ones)
+#ifndef X3_BIG_FF1
+#define X3_BIG_FF1 0
+#endif
+
 int launch_gemm3(const Gemm3P& p, hipStream_t s) {
   if (!gemm3_supported(p)) return -2;
 #ifdef BT_DEV
@@ -631,10 +636,13 @@ int launch_gemm3(const Gemm3P& p, hipStream_t s) {
   // k-loop); for the long-K residual GEMM (FF2, K = 4 D: half the operand traffic per flop, epilogue amortised over 32
   // k-steps) it wins inside the forward as well, 0.452 vs 0.487 ms per step.
   const bool big_ok = p.epi != G3_QKV && p.N % 256 == 0;
-  const bool big = big_ok && (force_big == 1 || (force_big != 0 && p.epi == G3_RESID && p.K >= 1024 && p.M >= 4096));
+  // (x3 = 2 / 3 through the single-operator entry bt_gemm3 forces the 256-row / the 128-row configuration: tools/x3_probe.py)
+  const int force = p.x3 == 2 ? 1 : p.x3 == 3 ? 0 : force_big;
+  const bool big = big_ok && (force == 1 || (force != 0 && p.epi == G3_RESID && p.K >= 1024 && p.M >= 4096) ||
+                              (force != 0 && p.x3 && X3_BIG_FF1 && p.epi == G3_FF1 && p.M >= 4096));
   // 256 or 192 token rows per tile: fewer (rounds over the 256 CUs) x (rows per tile) wins
   auto cost = [&](int bm) { const long t = ((long)p.M + bm - 1) / bm * (p.N / 256); return (t + 255) / 256 * bm; };
-  const bool rows192 = big && p.epi == G3_RESID && force_big != 1 && cost(192) < cost(256);
+  const bool rows192 = big && p.epi == G3_RESID && force != 1 && cost(192) < cost(256);
   if (p.x3) {
     switch (p.epi) {
       case G3_FF1:

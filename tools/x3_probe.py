@@ -46,7 +46,7 @@ def attention(n_seq, heads, Lq, label):
     qd, kd, vd = q.to(dev), k.to(dev), v.to(dev)
     gates = torch.rand((SH, nbp * 32), generator=g).to(dev)
     outs = {}
-    for variant in (1, 2, 3):
+    for variant in (1, 2, 3, 4):
         out = torch.zeros((n_seq * Lq, 2 * heads * 32), dtype=torch.float16, device=dev)
         a = L.AttnFragArgs()
         a.q, a.k, a.v, a.gates, a.out = qd.data_ptr(), kd.data_ptr(), vd.data_ptr(), gates.data_ptr(), out.data_ptr()
@@ -60,12 +60,12 @@ def attention(n_seq, heads, Lq, label):
               f"({3 * flop / us / 1e6:7.1f} on the matrix pipe)  same as variant 1: {torch.equal(outs[variant], outs[1])}", flush=True)
 
 
-def gemm(M, K, N, epi, label, heads=0, n_seq=0, Lq=0):
+def gemm(M, K, N, epi, label, heads=0, n_seq=0, Lq=0, force=1):
     g = torch.Generator().manual_seed(2)
     A = to_hl32(torch.randn((M, K), generator=g)).to(dev)
     W = to_hl32(pad_rows(torch.randn((N, K), generator=g) / K ** 0.5, 256)).to(dev)
     a = L.Gemm3Args()
-    a.A, a.lda, a.M, a.K, a.W, a.N, a.epi, a.x3 = A.data_ptr(), K, M, K, W.data_ptr(), N, epi, 1
+    a.A, a.lda, a.M, a.K, a.W, a.N, a.epi, a.x3 = A.data_ptr(), K, M, K, W.data_ptr(), N, epi, force
     keep = []
     if epi == 0:
         bias = torch.zeros(N, device=dev); out = torch.zeros((M, 2 * N), dtype=torch.float16, device=dev)
@@ -86,14 +86,13 @@ def gemm(M, K, N, epi, label, heads=0, n_seq=0, Lq=0):
         gh = torch.zeros((SH, nbp * 32), device=dev)
         rope = torch.from_numpy(rope_table(10000.0 ** (-torch.arange(0, 32, 2).float() / 32))).to(dev)
         ssq = torch.ones((K // 64, M), device=dev); bg = torch.zeros(heads, device=dev)
-        a.N = 3 * K + heads
         a.ssq_in, a.ssq_parts, a.n_seq, a.L, a.nbp, a.heads, a.rope = ssq.data_ptr(), K // 64, n_seq, Lq, nbp, heads, rope.data_ptr()
         a.qf, a.kf, a.vf, a.gates, a.b_gates = qf.data_ptr(), kf.data_ptr(), vf.data_ptr(), gh.data_ptr(), bg.data_ptr()
         keep += [qf, kf, vf, gh, rope, ssq, bg]
     st = L.stream_ptr(dev)
     us = timeit(lambda: L.check(lib.bt_gemm3(st, C.byref(a))))
     flop = 2.0 * M * K * a.N
-    print(f"gemm3 x3 {label} M={M} K={K} N={a.N}: {us:8.1f} us  {flop / us / 1e6:7.1f} TFLOP/s algorithmic "
+    print(f"gemm3 x3 {label} [{ {1: 'auto', 2: '256-row tiles', 3: '128-row tiles'}[force] }] M={M} K={K} N={a.N}: {us:8.1f} us  {flop / us / 1e6:7.1f} TFLOP/s algorithmic "
           f"({3 * flop / us / 1e6:7.1f} on the matrix pipe)", flush=True)
 
 
@@ -102,8 +101,10 @@ attention(B, 16, T, f"main layer ({B} chunks x 16 heads)")
 attention(B * 32, 1, T, f"frontend block 0 ({B * 32} sequences x 1 head)")
 attention(B * 8, 4, T, f"frontend block 2 ({B * 8} sequences x 4 heads)")
 M = B * T
-gemm(M, 512, 0, 2, "QKV", heads=16, n_seq=B, Lq=T)
-gemm(M, 512, 512, 1, "out-projection")
-gemm(M, 512, 2048, 0, "FF1")
-gemm(M, 2048, 512, 1, "FF2")
-gemm(M, 1024, 512, 1, "frontend.linear")
+gemm(M, 512, 3 * 512 + 16, 2, "QKV", heads=16, n_seq=B, Lq=T)
+for f in (3, 2):
+    gemm(M, 512, 512, 1, "out-projection", force=f)
+    gemm(M, 512, 2048, 0, "FF1", force=f)
+    gemm(M, 2048, 512, 1, "FF2", force=f)
+    gemm(M, 1024, 512, 1, "frontend.linear", force=f)
+gemm(M, 2048, 512, 1, "FF2 (auto)")
