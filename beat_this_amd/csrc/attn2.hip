@@ -564,13 +564,13 @@ DEVI void score_x(const KFragX& kf, const QStateX (&st)[QB], f32x16 (&sc)[QB]) {
 #pragma unroll
   for (int j = 0; j < QB; ++j) sc[j] = MFMA32_H(kf.k1, st[j].q1, sc[j]);
 }
-// scores -> probabilities -> row sums, split, T^T (+)= V^T . P^T.
-// The matrix pipe's fp32 accumulation is not round-to-nearest: 282 accumulations of a 1500-key row straight into one
-// accumulator left the output 1.1e-5 (relative) off at L = 1500 -- growing with L, identical whatever the score path did --
-// where the fp32-MFMA kernel is at 2.7e-6.  So the products of at most one LDS tile (FIRST starts from a zero accumulator
-// input) go into `tacc`, and the caller adds `tacc` to the running fp32 output with VALU adds (flush_x) once per tile.
-template <bool SAFE, bool MASK, bool FIRST, int QB>
-DEVI void finish_x(f32x16 (&sc)[QB], const VFragX& vf, int g, QStateX (&st)[QB], f32x16 (&tacc)[QB], int key0, int L) {
+// scores -> probabilities -> row sums, split, O^T += V^T . P^T
+// (Measured and rejected: accumulating each LDS tile's products in a fresh accumulator and adding it to the running output
+// with VALU adds -- the attention output's 1.1e-5 relative error at L = 1500 on the outlier-key test did not move, nor did
+// it when the scores stopped riding on the reference maximum: it is the 22-bit operand representation, 2^-22 |q| |k|
+// per score, amplified by scores of magnitude 60, not the accumulation.)
+template <bool SAFE, bool MASK, int QB>
+DEVI void finish_x(f32x16 (&sc)[QB], const VFragX& vf, int g, QStateX (&st)[QB], int key0, int L) {
 #pragma unroll
   for (int j = 0; j < QB; ++j) {
     if constexpr (SAFE) {
@@ -588,7 +588,7 @@ DEVI void finish_x(f32x16 (&sc)[QB], const VFragX& vf, int g, QStateX (&st)[QB],
       st[j].m = m_new;
       st[j].l *= alpha;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) st[j].acc[r] *= alpha;   // (SAFE callers flush tacc after every block: nothing pending)
+      for (int r = 0; r < 16; ++r) st[j].acc[r] *= alpha;
 #pragma unroll
       for (int r = 0; r < 16; ++r) sc[j][r] = __builtin_amdgcn_exp2f(sc[j][r] - m_new);
     } else {
@@ -612,27 +612,17 @@ DEVI void finish_x(f32x16 (&sc)[QB], const VFragX& vf, int g, QStateX (&st)[QB],
   }
   // small terms first; consecutive MFMAs of different query blocks never share an accumulator
 #pragma unroll
-  for (int j = 0; j < QB; ++j) {
-    if constexpr (FIRST) zero16(tacc[j]);   // (a constant-zero accumulator input: no register traffic)
-    tacc[j] = MFMA32_H(vf.v0l, __builtin_bit_cast(hfx8, h0[j]), tacc[j]);
-  }
+  for (int j = 0; j < QB; ++j) st[j].acc = MFMA32_H(vf.v0l, __builtin_bit_cast(hfx8, h0[j]), st[j].acc);
 #pragma unroll
-  for (int j = 0; j < QB; ++j) tacc[j] = MFMA32_H(vf.v1l, __builtin_bit_cast(hfx8, h1[j]), tacc[j]);
+  for (int j = 0; j < QB; ++j) st[j].acc = MFMA32_H(vf.v1l, __builtin_bit_cast(hfx8, h1[j]), st[j].acc);
 #pragma unroll
-  for (int j = 0; j < QB; ++j) tacc[j] = MFMA32_H(vf.v0, __builtin_bit_cast(hfx8, l0[j]), tacc[j]);
+  for (int j = 0; j < QB; ++j) st[j].acc = MFMA32_H(vf.v0, __builtin_bit_cast(hfx8, l0[j]), st[j].acc);
 #pragma unroll
-  for (int j = 0; j < QB; ++j) tacc[j] = MFMA32_H(vf.v1, __builtin_bit_cast(hfx8, l1[j]), tacc[j]);
+  for (int j = 0; j < QB; ++j) st[j].acc = MFMA32_H(vf.v1, __builtin_bit_cast(hfx8, l1[j]), st[j].acc);
 #pragma unroll
-  for (int j = 0; j < QB; ++j) tacc[j] = MFMA32_H(vf.v0, __builtin_bit_cast(hfx8, h0[j]), tacc[j]);
+  for (int j = 0; j < QB; ++j) st[j].acc = MFMA32_H(vf.v0, __builtin_bit_cast(hfx8, h0[j]), st[j].acc);
 #pragma unroll
-  for (int j = 0; j < QB; ++j) tacc[j] = MFMA32_H(vf.v1, __builtin_bit_cast(hfx8, h1[j]), tacc[j]);
-}
-template <int QB>
-DEVI void flush_x(QStateX (&st)[QB], const f32x16 (&tacc)[QB]) {
-#pragma unroll
-  for (int j = 0; j < QB; ++j)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) st[j].acc[r] += tacc[j][r];
+  for (int j = 0; j < QB; ++j) st[j].acc = MFMA32_H(vf.v1, __builtin_bit_cast(hfx8, h1[j]), st[j].acc);
 }
 
 template <int KBX>
@@ -666,11 +656,10 @@ DEVI void attn_tiles_x(rsrc_t rk, rsrc_t rv, char* smem, int tid, int wave, int 
       const int blk = t * KBX + c;
       const KFragX kf = ld_kx(kb + c * BLKX_BYTES, g, lr);
       const VFragX vf = ld_vx(vb + c * BLKX_BYTES, lane);
-      f32x16 sc[QB], tacc[QB];
+      f32x16 sc[QB];
       score_x<QB>(kf, st, sc);
-      if (partial && blk == nblk - 1) finish_x<SAFE, true, true, QB>(sc, vf, g, st, tacc, blk * 32, L);
-      else finish_x<SAFE, false, true, QB>(sc, vf, g, st, tacc, blk * 32, L);
-      flush_x<QB>(st, tacc);
+      if (partial && blk == nblk - 1) finish_x<SAFE, true, QB>(sc, vf, g, st, blk * 32, L);
+      else finish_x<SAFE, false, QB>(sc, vf, g, st, blk * 32, L);
     }
     __syncthreads();  // tile t + 1 has landed (every wave waited for its own copies), tile t is free
   }
@@ -697,12 +686,7 @@ DEVI void attn_fast_x(rsrc_t rk, rsrc_t rv, char* smem, int tid, int wave, int l
     st[j].l = 0.f;
     st[j].m = -1e30f;
   }
-  // PIPE (one query block per wave): the scores of block c + 1 are issued before the exponentials of block c, two score
-  // buffers alternate.  Two query blocks per wave are two independent chains already (and the second buffer would not
-  // fit the register file): score and finish of a block follow each other.
-  constexpr bool PIPE = QB == 1;
-  f32x16 s2[PIPE ? 2 : 1][QB];  // scores of the current / the next block (compile-time indices: the tile loop is unrolled)
-  f32x16 tacc[QB];              // V^T . P^T of the current tile (finish_x)
+  f32x16 s2[2][QB];  // scores of the current / the next block (compile-time indices: the tile loop is unrolled)
   KFragX kf = ld_kx(smem, g, lr);
   score_x<QB>(kf, st, s2[0]);
 #pragma unroll
@@ -720,35 +704,21 @@ DEVI void attn_fast_x(rsrc_t rk, rsrc_t rv, char* smem, int tid, int wave, int l
     const char* kb_next = smem + ((t + 1) & 1) * 2 * TILEX_BYTES;
 #pragma unroll
     for (int c = 0; c < KBX; ++c) {
-      // (two query blocks per wave: keep the scheduler from interleaving the unrolled blocks -- it runs out of registers)
-      if (!PIPE) __builtin_amdgcn_sched_barrier(0);
       const VFragX vf = ld_vx(vb + c * BLKX_BYTES, lane);
-      constexpr int NXT = PIPE ? 1 : 0;
-      const int cur = PIPE ? (c & 1) : 0, nxt = PIPE ? ((c + 1) & 1) : 0;
       if (c + 1 < KBX) {
         kf = ld_kx(kb + (c + 1) * BLKX_BYTES, g, lr);
-        if (PIPE) score_x<QB>(kf, st, s2[nxt]);
+        score_x<QB>(kf, st, s2[(c + 1) & 1]);
       } else {
         // the tile's last fragment reads are issued (vf) / have arrived (kf): barrier, refill, first block of tile t + 1
         __syncthreads();  // tile t + 1 has landed in every wave; nobody reads tile t any more
         if (t + 2 < ntiles) stage_tile_x<KBX>(rk, rv, t + 2, smem, t & 1, tid, wave);
         if (t + 1 < nfull) {  // (uniform)
           kf = ld_kx(kb_next, g, lr);
-          if (PIPE) score_x<QB>(kf, st, s2[0]);
+          score_x<QB>(kf, st, s2[0]);
         }
       }
-      (void)NXT;
-      // (two query blocks per wave: the tile accumulator is flushed after every block -- kept across the tile it does not
-      // fit next to the second block's state: 44 scratch accesses per tile in the generated code)
-      if (c == 0 || !PIPE) finish_x<false, false, true, QB>(s2[cur], vf, g, st, tacc, 0, L);
-      else finish_x<false, false, false, QB>(s2[cur], vf, g, st, tacc, 0, L);
-      if (!PIPE) {
-        flush_x<QB>(st, tacc);
-        __builtin_amdgcn_sched_barrier(0);   // (the next block's score MFMAs stay behind this block's: register pressure)
-        if (c + 1 < KBX || t + 1 < nfull) score_x<QB>(kf, st, s2[0]);   // (the next block's scores, kf read above)
-      }
+      finish_x<false, false, QB>(s2[c & 1], vf, g, st, 0, L);
     }
-    if (PIPE) flush_x<QB>(st, tacc);
   }
   if (nfull < ntiles)  // last tile: fewer than KBX blocks and / or a masked last block (staged by the loop / the prologue)
     attn_tiles_x<false, QB, KBX>(rk, rv, smem, tid, wave, lane, g, lr, st, L, nblk, nfull, true);
@@ -760,7 +730,10 @@ DEVI void attn_fast_x(rsrc_t rk, rsrc_t rv, char* smem, int tid, int wave, int l
 template <int QB, int OUT, int KBX, int MINW>
 __global__ __launch_bounds__(256, MINW) void attn_frag_x3_kernel(const AttnFragP p, int nqt, int sh_total) {
   constexpr int TILEX_BYTES = KBX * BLKX_BYTES;
-  __shared__ __attribute__((aligned(16))) char smem[2 * 2 * TILEX_BYTES + 16];
+  // (MINW = 3 with the 32 KB tiles: the declaration is padded past 160 KB / 4 so that THREE workgroups share a CU -- four fit
+  // by registers and LDS, and measured slower on the main-layer shape: 289 vs 269 us per 16-chunk launch)
+  constexpr int SMEM_X = 2 * 2 * TILEX_BYTES + 16;
+  __shared__ __attribute__((aligned(16))) char smem[(MINW == 3 && SMEM_X < 41 * 1024) ? 41 * 1024 : SMEM_X];
   const int bid = blockIdx.x;
   const int idx = bid >> 3;
   const int sh = (idx / nqt) * 8 + (bid & 7);
@@ -901,15 +874,14 @@ int launch_attn_frag(const AttnFragP& p, hipStream_t s) {
   if ((long)p.n_seq * p.heads * ((p.L + 127) / 128) > 0x3fffffffL) return -3;
   if (p.x3) {
     if (BT_HALF_IS_BF16 || (long)p.nbp * 4096 >= 0x7fffffffL) return -2;
-    // x3 selects the variant (single-operator entry bt_attention_frag; measured by tools/x3_probe.py):
-    //   1 = one query block per wave, 128-key LDS tiles (64 KB: two workgroups per CU);
-    //   2 = two query blocks per wave (half the fragment reads per MFMA, two independent accumulation chains; spills);
-    //   3 = one query block per wave, 64-key tiles (32 KB), registers capped for four workgroups per CU;
-    //   4 = as 3 with the register cap of three workgroups per CU (no spills)
-    if (p.x3 == 2) { if (p.out_f32) launch_x3<2, 1, 4, 2>(p, s); else launch_x3<2, 0, 4, 2>(p, s); }
+    // x3 selects the variant (single-operator entry bt_attention_frag; measured by tools/x3_probe.py; the engine passes 1):
+    //   1 = 64-key LDS tiles (32 KB), registers capped for three workgroups per CU;
+    //   2 = 128-key tiles (64 KB: two workgroups per CU);   3 = 64-key tiles, registers capped for four workgroups per CU
+    // (two query blocks per wave -- half the fragment reads per MFMA -- were 15 % faster on the main-layer shape until the
+    // kernel grew past 256 registers per lane; with spills they are 3x slower and were removed)
+    if (p.x3 == 2) { if (p.out_f32) launch_x3<1, 1, 4, 2>(p, s); else launch_x3<1, 0, 4, 2>(p, s); }
     else if (p.x3 == 3) { if (p.out_f32) launch_x3<1, 1, 2, 4>(p, s); else launch_x3<1, 0, 2, 4>(p, s); }
-    else if (p.x3 == 4) { if (p.out_f32) launch_x3<1, 1, 2, 3>(p, s); else launch_x3<1, 0, 2, 3>(p, s); }
-    else { if (p.out_f32) launch_x3<1, 1, 4, 2>(p, s); else launch_x3<1, 0, 4, 2>(p, s); }
+    else { if (p.out_f32) launch_x3<1, 1, 2, 3>(p, s); else launch_x3<1, 0, 2, 3>(p, s); }
     return (int)hipGetLastError();
   }
   // (Two query blocks per wave -- QB = 2, half the fragment reads per MFMA at half the occupancy -- measured equal.)
