@@ -730,10 +730,7 @@ DEVI void attn_fast_x(rsrc_t rk, rsrc_t rv, char* smem, int tid, int wave, int l
 template <int QB, int OUT, int KBX, int MINW>
 __global__ __launch_bounds__(256, MINW) void attn_frag_x3_kernel(const AttnFragP p, int nqt, int sh_total) {
   constexpr int TILEX_BYTES = KBX * BLKX_BYTES;
-  // (MINW = 3 with the 32 KB tiles: the declaration is padded past 160 KB / 4 so that THREE workgroups share a CU -- four fit
-  // by registers and LDS, and measured slower on the main-layer shape: 289 vs 269 us per 16-chunk launch)
-  constexpr int SMEM_X = 2 * 2 * TILEX_BYTES + 16;
-  __shared__ __attribute__((aligned(16))) char smem[(MINW == 3 && SMEM_X < 41 * 1024) ? 41 * 1024 : SMEM_X];
+  __shared__ __attribute__((aligned(16))) char smem[2 * 2 * TILEX_BYTES + 16];
   const int bid = blockIdx.x;
   const int idx = bid >> 3;
   const int sh = (idx / nqt) * 8 + (bid & 7);
@@ -874,14 +871,14 @@ int launch_attn_frag(const AttnFragP& p, hipStream_t s) {
   if ((long)p.n_seq * p.heads * ((p.L + 127) / 128) > 0x3fffffffL) return -3;
   if (p.x3) {
     if (BT_HALF_IS_BF16 || (long)p.nbp * 4096 >= 0x7fffffffL) return -2;
-    // x3 selects the variant (single-operator entry bt_attention_frag; measured by tools/x3_probe.py; the engine passes 1):
-    //   1 = 64-key LDS tiles (32 KB), registers capped for three workgroups per CU;
-    //   2 = 128-key tiles (64 KB: two workgroups per CU);   3 = 64-key tiles, registers capped for four workgroups per CU
-    // (two query blocks per wave -- half the fragment reads per MFMA -- were 15 % faster on the main-layer shape until the
-    // kernel grew past 256 registers per lane; with spills they are 3x slower and were removed)
-    if (p.x3 == 2) { if (p.out_f32) launch_x3<1, 1, 4, 2>(p, s); else launch_x3<1, 0, 4, 2>(p, s); }
-    else if (p.x3 == 3) { if (p.out_f32) launch_x3<1, 1, 2, 4>(p, s); else launch_x3<1, 0, 2, 4>(p, s); }
-    else { if (p.out_f32) launch_x3<1, 1, 2, 3>(p, s); else launch_x3<1, 0, 2, 3>(p, s); }
+    // x3 selects the LDS tile (measured per launch shape by tools/x3_probe.py, 16 chunks, +-3 % run to run):
+    //   1 = 128-key tiles, 64 KB, two workgroups per CU: main layers (256 sequence-heads: 269 vs 283 us);
+    //   2 = 64-key tiles, 32 KB, four workgroups per CU: frontend (512 sequence-heads: 480 vs 525 us).
+    // (Two query blocks per wave -- half the fragment reads per MFMA -- were 15 % faster still on the main-layer shape
+    // until the kernel grew past 256 registers per lane; with spills they are 3x slower and were removed.  Three
+    // workgroups per CU with the 64-key tiles were not better than four.)
+    if (p.x3 == 2) { if (p.out_f32) launch_x3<1, 1, 2, 4>(p, s); else launch_x3<1, 0, 2, 4>(p, s); }
+    else { if (p.out_f32) launch_x3<1, 1, 4, 2>(p, s); else launch_x3<1, 0, 4, 2>(p, s); }
     return (int)hipGetLastError();
   }
   // (Two query blocks per wave -- QB = 2, half the fragment reads per MFMA at half the occupancy -- measured equal.)

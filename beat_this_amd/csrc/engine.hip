@@ -241,7 +241,7 @@ int run_pair(prof::State* pf, const bt_pair_weights& pw, const float* rope, floa
     memset(&a, 0, sizeof a);
     a.q = ws.qf; a.k = ws.kf; a.v = ws.vf; a.gates = ws.gates_h; a.out = ws.ao; a.n_seq = B * F; a.L = T; a.heads = H;
     a.inner = C; a.nbp = ws.nbp; a.o_div = F; a.o_outer = (long)T * F; a.o_inner = 1; a.o_tok = F;
-    a.x3 = t2x3; a.out_f32 = 1; a.status = ws.status;
+    a.x3 = t2x3 ? 2 : 0; a.out_f32 = 1; a.status = ws.status;   // (x3 = 2: the 64-key LDS tiles, attn2.hip)
     LAUNCH_CAT(CAT_ATTN_FLASH, s, launch_attn_frag(a, s), "time attention");
     if (fused2_ok) return outff();
     memset(&g, 0, sizeof g);

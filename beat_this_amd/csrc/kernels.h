@@ -105,7 +105,8 @@ struct AttnFragP {
   int o_div;
   long o_outer, o_inner, o_tok;
   // BT_PREC_F32X3: x3 != 0 -> q, k, v blocks are 4 KB ([hi block | lo block], attn2.hip); out is fp32 [rows, inner]
-  // (out_f32 != 0) or hl32 planes half [rows, 2 inner]; status: range flag of the hl32 output (may be null)
+  // (out_f32 != 0) or hl32 planes half [rows, 2 inner]; status: range flag of the hl32 output (may be null).
+  // x3 = 1: 128-key LDS tiles, x3 = 2: 64-key tiles (same results)
   int x3, out_f32;
   int* status;
 };

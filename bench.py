@@ -22,8 +22,15 @@ Extra objects on the JSON line:
                 ALGORITHMIC bytes (3.41 MB per chunk for the log-mel).
   forward_only  BASELINE config 2 (16 chunks through BeatThis.forward, spectrograms resident), for continuity with round 1.
   fp32_path     the same headline workload on the exact-fp32 MFMA path (the one under the 1e-3 gate), fewer steps.
-  f32x3_path    the fp32 path with its GEMMs and attention on three fp16 MFMAs per product (hi + lo operand split): the
-                same 1e-3 / identical-beats gate at about twice the fp32-MFMA rate.
+  f32x3_path    the same headline workload in BT_PREC_F32X3 (every product on three fp16 MFMAs over hi + lo operands, the
+                LDS-DMA kernels): the 1e-3 / identical-beats gate at several times the fp32-MFMA rate, with its own
+                `roofline` object (dominant kernel category against a third of the fp16 matrix peak) and breakdown.
+  configs       the other BASELINE.json configurations as short legs: cfg2 (final0 half, 16 chunks = forward_only), cfg3
+                (small0 exact fp32, 128 chunks: fp32-FLOP fraction AND counter-measured HBM GB/s), cfg4_share (final0 half,
+                64 chunks = one GPU's share of the 512-chunk job), cfg5 (withdrawn: no fp8 path is offered).
+  strong_scaling_cfg4  BASELINE config 4 itself: 512 chunks sharded over the N ranks (512 / N each), logits all-gathered.
+  timed_region  the K steps are repeated until the timed region holds >= 2 s of GPU work (clocks and temperatures settle);
+                ms_per_step = region / (K x repeats).  rccl_ranks = ranks counted by an RCCL all-reduce.
   host_inclusive  the headline job with the waveforms starting in pinned HOST memory (PCIe-inclusive rate; never `value`).
   cpu_baseline  the CPU oracle's Audio2Beats (torch fp32, SDPA attention like the reference) on ONE 300 s track on this
                 host, thread count probed and stated (rank 0, N = 1 only).
@@ -119,6 +126,8 @@ def main():
     ap.add_argument("--streams", type=int, default=0, help="streams the forward slices of a step run on (0 = the library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the forward_only / fp32_path / frontend legs")
+    ap.add_argument("--min-seconds", type=float, default=2.0,
+                    help="the K timed steps are repeated until the timed region is at least this long (0: exactly K steps)")
     ap.add_argument("--watchdog", type=int, default=900, help="seconds after which a stuck run dumps its stacks and exits")
     args = ap.parse_args()
     import faulthandler
@@ -157,6 +166,12 @@ def main():
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)
+    rccl_ranks = None
+    if use_dist:   # proof of N ranks: an RCCL all-reduce counts them
+        one = torch.ones(1, dtype=torch.int32, device=dev)
+        dist.all_reduce(one)
+        rccl_ranks = int(one.item())
+        assert rccl_ranks == dist.get_world_size()
 
     from beat_this_amd import _lib
     from beat_this_amd import inference as _inf
@@ -249,24 +264,71 @@ def main():
     drain()
     fence()
     log("warm-up")
+    tw = time.perf_counter()
     for _ in range(args.warmup):
         step()
     drain()
     fence()
-    log("timed region")
+    tw = (time.perf_counter() - tw) / max(1, args.warmup)
+    # The K steps are timed `repeats` times back to back so that the region holds >= --min-seconds of GPU work (0.3 s of
+    # a 20-step default run is over before clocks and temperatures have settled); every rank uses the same count.
+    repeats = 1
+    if args.min_seconds > 0 and args.warmup > 0:
+        est = torch.tensor([tw * args.steps], dtype=torch.float64, device=dev)
+        if use_dist:
+            dist.all_reduce(est, op=dist.ReduceOp.MIN)
+        repeats = max(1, int(-(-args.min_seconds // max(float(est.item()), 1e-6))))
+    log(f"timed region: {args.steps} steps x {repeats}")
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(args.steps * repeats):
         step()
     last = drain()
     fence()
     elapsed = time.perf_counter() - t0
-    log(f"timed region done: {1e3 * elapsed / args.steps:.3f} ms / step")
+    n_timed = args.steps * repeats
+    log(f"timed region done: {1e3 * elapsed / n_timed:.3f} ms / step over {elapsed:.2f} s")
     if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    ms_per_step = 1e3 * elapsed / args.steps
-    value = units_per_step / (elapsed / args.steps)
+    ms_per_step = 1e3 * elapsed / n_timed
+    value = units_per_step / (elapsed / n_timed)
+
+    # ---- BASELINE config 4 as written: 512 chunks sharded over the ranks, logits all-gathered (strong scaling) ------------
+    strong = None
+    if args.workload == "tracks" and not args.no_extras:
+        log("strong-scaling leg (512 chunks / N)")
+        per = 512 // world
+        xs = torch.from_numpy(np.stack([W.synthetic_spect(CHUNK_FRAMES, seed=50000 + 512 * rank + i) for i in range(min(per, 64))])).to(dev)
+        xs = xs.repeat(-(-per // xs.shape[0]), 1, 1)[:per]   # (per-rank share; distinct seeds for the first 64, repeated beyond)
+        g512 = torch.empty((world * per, 2, CHUNK_FRAMES), dtype=torch.float32, device=dev) if use_dist else None
+
+        def sstep():
+            with torch.inference_mode(), torch.autocast("cuda", enabled=half):
+                outs = [a2b.model(xs[i: i + 64]) for i in range(0, per, 64)]
+                r = torch.stack((torch.cat([o["beat"] for o in outs]), torch.cat([o["downbeat"] for o in outs])), 1)
+            if use_dist:
+                dist.all_gather_into_tensor(g512, r)
+            return r
+        for _ in range(2):
+            sstep()
+        fence()
+        ts = time.perf_counter()
+        n_s = 3 if world == 1 else 6
+        for _ in range(n_s):
+            sstep()
+        fence()
+        ts = time.perf_counter() - ts
+        if use_dist:
+            t = torch.tensor([ts], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            ts = float(t.item())
+        ts /= n_s
+        strong = {"workload": f"BASELINE config 4: 512 x 1500-frame chunks, {per} per GPU in slices of 64, {args.prec} forward, "
+                              "logits all-gathered (RCCL)" + ("" if use_dist else " -- one GPU: no collective"),
+                  "global_chunks": world * per, "chunks_per_gpu": per, "ms_per_step": round(ts * 1e3, 3),
+                  "audio_seconds_per_s": round(world * per * FRESH_SECONDS_PER_CHUNK / ts, 1), "scaling": "strong"}
+        del xs, g512
 
     out = None
     if rank == 0:
@@ -302,27 +364,35 @@ def main():
             breakdown = profile_forward(lambda: a2b.many(tracks, TRACK_SR), 2, chunks_per_step)
         else:
             breakdown = profile_forward(step, 3, chunks_per_step)
-        dom = max(breakdown, key=lambda k: breakdown[k]["ms_per_step"])
-        d = breakdown[dom]
-        peak = PEAK_TFLOPS[args.prec]
-        traffic, traffic_src = None, None
-        try:  # HBM bytes per launch of the dominant category: PMC counters of separate rocprofv3 passes, committed
-            tj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-            if tj["workload"]["model"] == args.model and tj["workload"]["prec"] == args.prec and dom in tj:
-                traffic = tj[dom]["bytes_per_launch"] * chunks_per_step / tj["workload"]["chunks"] / (
-                    d["launches_per_step"] / tj[dom]["launches_per_forward"])
-                traffic_src = f"profiles/pmc_traffic.json ({tj['workload']['chunks']}-chunk forward, scaled per launch)"
-        except (OSError, ValueError, KeyError, ZeroDivisionError):
-            pass
-        roofline = {"kernel": dom, "bound": "mfma", "achieved": d["tflops"], "peak": peak, "unit": "TFLOP/s",
+        def roofline_of(bd, prec, chunks):
+            """roofline object of a profiled forward: its dominant launch category against the matrix peak of `prec`"""
+            dom = max(bd, key=lambda k: bd[k]["ms_per_step"])
+            d = bd[dom]
+            peak = PEAK_TFLOPS[prec]
+            traffic, traffic_src = None, None
+            try:  # HBM bytes per launch of the dominant category: PMC counters of separate rocprofv3 passes, committed
+                name = "pmc_traffic.json" if prec == "half" else f"pmc_traffic_{prec}.json"
+                tj = json.load(open(os.path.join(ROOT, "profiles", name)))
+                if tj["workload"]["model"] == args.model and tj["workload"]["prec"] == prec and dom in tj:
+                    traffic = tj[dom]["bytes_per_launch"] * chunks / tj["workload"]["chunks"] / (
+                        d["launches_per_step"] / tj[dom]["launches_per_forward"])
+                    traffic_src = f"profiles/{name} ({tj['workload']['chunks']}-chunk forward, scaled per launch)"
+            except (OSError, ValueError, KeyError, ZeroDivisionError):
+                pass
+            tot = sum(v["ms_per_step"] for v in bd.values())
+            return {"kernel": dom, "bound": "mfma", "achieved": d["tflops"], "peak": round(peak, 1), "unit": "TFLOP/s",
                     "frac": round(d["tflops"] / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
                     "avg_launch_ms": round(d["ms_per_step"] / d["launches_per_step"], 4),
-                    "flop_per_launch": fl[dom] * chunks_per_step / d["launches_per_step"],
-                    "forward_ms_per_step": round(sum(v["ms_per_step"] for v in breakdown.values()), 3),
-                    "whole_forward_tflops": round(FLOP_PER_CHUNK * chunks_per_step /
-                                                  (sum(v["ms_per_step"] for v in breakdown.values()) * 1e-3) / 1e12, 2)}
+                    "flop_per_launch": fl[dom] * chunks / d["launches_per_step"],
+                    "forward_ms_per_step": round(tot, 3),
+                    "whole_forward_tflops": round(FLOP_PER_CHUNK * chunks / (tot * 1e-3) / 1e12, 2),
+                    "whole_forward_frac": round(FLOP_PER_CHUNK * chunks / (tot * 1e-3) / 1e12 / peak, 4),
+                    "peak_note": {"half": "dense fp16 MFMA peak", "f32": "fp32 MFMA peak",
+                                  "f32x3": "a third of the dense fp16 MFMA peak: every product is three fp16 MFMAs"}[prec]}
 
-        frontend = forward_only = fp32_path = f32x3_path = host_inclusive = None
+        roofline = roofline_of(breakdown, args.prec, chunks_per_step)
+
+        frontend = forward_only = fp32_path = f32x3_path = host_inclusive = configs = None
         if args.workload == "tracks" and not args.no_extras:
             # ---- HBM-bound stages: events around each stage on torch's current stream (the launch stream) -------------
             def timed(fn, reps=5):
@@ -370,6 +440,54 @@ def main():
             forward_only = {"workload": "BASELINE config 2: 16 chunks x 1500 frames, BeatThis.forward, spectrograms resident",
                             "ms_per_step": round(tf * 1e3, 3), "audio_seconds_per_s": round(16 * FRESH_SECONDS_PER_CHUNK / tf, 1),
                             "whole_forward_tflops": round(FLOP_PER_CHUNK * 16 / tf / 1e12, 1)}
+
+            # ---- the other BASELINE configurations as short legs ------------------------------------------------------
+            def time_forward(model_, xin, half_, n_warm, n_time):
+                def f():
+                    with torch.inference_mode(), torch.autocast("cuda", enabled=half_):
+                        return model_(xin)
+                for _ in range(n_warm):
+                    f()
+                torch.cuda.synchronize(dev)
+                t_ = time.perf_counter()
+                for _ in range(n_time):
+                    f()
+                torch.cuda.synchronize(dev)
+                return (time.perf_counter() - t_) / n_time
+
+            log("config legs (cfg3, cfg4 share)")
+            x64 = torch.from_numpy(np.stack([W.synthetic_spect(CHUNK_FRAMES, seed=2000 + i) for i in range(64)])).to(dev)
+            t64 = time_forward(a2b.model, x64, half, 3, 5)
+            hp_s = W.resolve_hparams("small0")
+            m_s = BeatThis(**{k: hp_s[k] for k in ("spect_dim", "transformer_dim", "ff_mult", "n_layers", "head_dim", "stem_dim")})
+            m_s.load_state_dict(W.random_state_dict(hp_s, seed=1, style="lively"))
+            m_s = m_s.to(dev)
+            x128 = x64.repeat(2, 1, 1)
+            t128 = time_forward(m_s, x128, False, 2, 3)
+            fl_s = flops_per_chunk(hp_s["transformer_dim"], ff_mult=hp_s["ff_mult"])
+            flop_s = sum(v for k, v in fl_s.items() if k != "layer_tail")   # 59.57 GFLOP / chunk
+            cfg3 = {"workload": "BASELINE config 3: small0, exact fp32 MFMA, 128 chunks x 1500 frames resident",
+                    "ms_per_step": round(t128 * 1e3, 2), "audio_seconds_per_s": round(128 * FRESH_SECONDS_PER_CHUNK / t128, 1),
+                    "tflops_fp32": round(flop_s * 128 / t128 / 1e12, 1),
+                    "frac_of_fp32_matrix_peak": round(flop_s * 128 / t128 / 1e12 / PEAK_TFLOPS["f32"], 4),
+                    "hbm_GBps_counters": None, "frac_of_hbm_peak": None}
+            try:  # HBM bytes of one such forward from the committed counter passes (FETCH_SIZE x 2 + WRITE_SIZE, separate runs)
+                tj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_cfg3.json")))
+                gb = tj["bytes_per_forward"] / 1e9
+                cfg3.update(hbm_GB_per_forward=round(gb, 2), hbm_GBps_counters=round(gb / t128, 1),
+                            frac_of_hbm_peak=round(gb / t128 / PEAK_HBM_GBS, 4), hbm_source="profiles/pmc_traffic_cfg3.json "
+                            "(rocprofv3 PMC passes of this configuration; bytes per forward / this run's time)")
+            except (OSError, ValueError, KeyError):
+                pass
+            configs = {
+                "cfg2": "= forward_only",
+                "cfg3": cfg3,
+                "cfg4_share": {"workload": "BASELINE config 4, one GPU's share: final0, half operands, 64 chunks x 1500 frames resident",
+                               "ms_per_step": round(t64 * 1e3, 3), "audio_seconds_per_s": round(64 * FRESH_SECONDS_PER_CHUNK / t64, 1),
+                               "whole_forward_tflops": round(FLOP_PER_CHUNK * 64 / t64 / 1e12, 1)},
+                "cfg5": "withdrawn: no fp8 path is offered (rounds 1-2: e4m3 feed-forward GEMMs moved 47 of 194 beats at 0.28 "
+                        "logit error and were no faster than the half path; DESIGN.md)"}
+            del m_s, x64, x128
 
             # ---- the same job from HOST buffers (PCIe-inclusive; never `value`): waveforms in pinned host memory, uploaded
             # on a copy stream by Audio2Beats.many_async while the previous step computes -----------------------------------
@@ -467,18 +585,23 @@ def main():
                     # ... and with its GEMMs and attention on three fp16 MFMAs per product (BT_PREC_F32X3): same gate
                     log("f32x3 path leg")
                     a2b.model.fp32_split_gemms = True
-                    for _ in range(2):
+                    for _ in range(3):
                         a2b.many(tracks, TRACK_SR)
                     torch.cuda.synchronize(dev)
+                    n3 = max(10, int(1.0 / max(ms_per_step * 3e-3, 1e-3)))   # ~1 s of steps
                     t3 = time.perf_counter()
-                    for _ in range(3):
+                    for _ in range(n3):
                         step()
                     drain()
                     torch.cuda.synchronize(dev)
-                    t3 = (time.perf_counter() - t3) / 3
+                    t3 = (time.perf_counter() - t3) / n3
+                    fb0 = eng.last_fallbacks
+                    bd3 = profile_forward(lambda: a2b.many(tracks, TRACK_SR), 2, chunks_per_step)
                     f32x3_path = {"ms_per_step": round(t3 * 1e3, 2), "audio_seconds_per_s": round(units_per_step / t3, 1),
-                                  "dtype": "f32 activations; GEMMs and attention: 3 x v_mfma_f32_32x32x16_f16 on hi + lo operands",
-                                  "parity": parity_of(a2b)}
+                                  "steps": n3,
+                                  "dtype": "f32 activations; every product: 3 x v_mfma_f32_32x32x16_f16 on hi + lo operands (BT_PREC_F32X3)",
+                                  "parity": parity_of(a2b), "roofline": roofline_of(bd3, "f32x3", chunks_per_step),
+                                  "breakdown": bd3, "range_fallbacks": eng.last_fallbacks - fb0}
                     a2b.model.fp32_split_gemms = False
                 a2b.float16 = True
 
@@ -493,7 +616,10 @@ def main():
                        "parallelism": f"track-sharded x{world}, framewise logits all-gathered" if args.workload == "tracks"
                        else f"chunk-sharded x{world}, logits all-gathered"},
             "parity": parity, "roofline": roofline, "cpu_baseline": cpu, "frontend": frontend, "forward_only": forward_only,
-            "fp32_path": fp32_path, "f32x3_path": f32x3_path, "host_inclusive": host_inclusive, "breakdown": breakdown,
+            "fp32_path": fp32_path, "f32x3_path": f32x3_path, "host_inclusive": host_inclusive, "configs": configs,
+            "strong_scaling_cfg4": strong, "rccl_ranks": rccl_ranks,
+            "timed_region": {"steps": args.steps, "repeats": repeats, "steps_timed": n_timed, "seconds": round(elapsed, 3)},
+            "breakdown": breakdown,
         }
         if last is not None and args.workload == "tracks":
             out["config"]["beats_in_last_track"] = int(len(last[-1][0]))

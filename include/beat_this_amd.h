@@ -274,7 +274,8 @@ int bt_attention(void* stream, int prec, const bt_attn_args* a);
  * [8 tokens 16 s + 8 (j >> 2) + 4 g + (j & 3)]; gates [n_seq * heads][nbp * 32] fp32.  q must be
  * pre-scaled by log2(e)/sqrt(32).  nbp >= bt_attn_frag_blocks(L).  Output as bt_attention (half).
  * x3 != 0 (BT_PREC_F32X3): blocks of 4 KB = [hi block | lo block] of the fp32 values, three MFMAs per product; output
- * fp32 [rows, inner] (out_f32 != 0) or hl32 half [rows, 2 inner]; status (may be NULL) = range flag of the hl32 output. */
+ * fp32 [rows, inner] (out_f32 != 0) or hl32 half [rows, 2 inner]; status (may be NULL) = range flag of the hl32 output;
+ * x3 = 1: 128-key LDS tiles (main layers), x3 = 2: 64-key tiles (frontend) -- same results. */
 typedef struct {
   const void* q; const void* k; const void* v; const float* gates; void* out;
   int32_t n_seq, L, heads, inner, nbp, o_div; int64_t o_outer, o_inner, o_tok;

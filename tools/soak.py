@@ -2,7 +2,8 @@
 """Development tool (GPU): soak of the pipelined multi-track path in the bench configuration -- N batches of 6 x 300 s
 tracks through Audio2Beats.many_async (two forward streams, pinned host uploads on the copy stream, two batches in flight),
 every batch's framewise logits and beats compared bit for bit with the first batch's.
-    python tools/soak.py [batches] [device|pinned]"""
+    python tools/soak.py [batches] [device|pinned] [half|f32|f32x3]
+(f32x3: BT_PREC_F32X3 with its deferred range flags -- the soak also asserts that no batch fell back to exact fp32)"""
 import os
 import sys
 import time
@@ -17,12 +18,14 @@ from beat_this_amd.model import BeatThis
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 mode = sys.argv[2] if len(sys.argv) > 2 else "pinned"
+prec = sys.argv[3] if len(sys.argv) > 3 else "half"
 dev = torch.device("cuda:0")
 hp = W.resolve_hparams("final0")
-a2b = Audio2Beats(checkpoint_path=None, device=dev, float16=True)
+a2b = Audio2Beats(checkpoint_path=None, device=dev, float16={"half": True, "f32": False, "f32x3": "f32x3"}[prec])
 m = BeatThis(**hp)
 m.load_state_dict(W.random_state_dict(hp, seed=1, style="lively"))
 a2b.model = m.to(dev).eval()
+a2b.model.fp32_split_gemms = prec == "f32x3"
 tracks = [torch.from_numpy(W.synthetic_audio(300.0, seed=i, sr=44100)) for i in range(6)]
 tracks = [t.pin_memory() for t in tracks] if mode == "pinned" else [t.to(dev) for t in tracks]
 ref = None
@@ -49,6 +52,7 @@ for i in range(n):
 while pend:
     collect(pend.pop(0))
 dt = time.perf_counter() - t0
-print(f"soak ({mode} inputs): {n} batches of 6 tracks in {dt:.1f} s ({n * 1800 / dt / 1e3:.1f} k audio-s/s incl. the comparisons), "
-      f"{bad} batch(es) differ from the first")
-sys.exit(1 if bad else 0)
+fallbacks = a2b.model.engine().last_fallbacks
+print(f"soak ({mode} inputs, {prec}): {n} batches of 6 tracks in {dt:.1f} s ({n * 1800 / dt / 1e3:.1f} k audio-s/s incl. the comparisons), "
+      f"{bad} batch(es) differ from the first, {fallbacks} range fallback(s)")
+sys.exit(1 if bad or fallbacks else 0)
