@@ -173,7 +173,7 @@ DEVI void do_block(const KFrag& kf, const VFrag& vf, int g, QState (&st)[QB], in
       for (int r = 0; r < 16; ++r) sc[j][r] = __builtin_amdgcn_exp2f(sc[j][r] - m_new);
     } else {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) sc[j][r] = __builtin_amdgcn_exp2f(sc[j][r]);
+      for (int r = 0; r < 16; ++r) sc[j][r] = __builtin_amdgcn_exp2f(QB == 1 ? sc[j][r] : sc[j][r] + st[j].negm[0]);
       if constexpr (MASK) {
 #pragma unroll
         for (int r = 0; r < 16; ++r)
@@ -509,7 +509,9 @@ struct QStateX {
   f32x16 acc;             // O^T accumulator
   float l;                // row sum of this lane's 16 keys per block (the two halves are added at the end)
   float m;                // running max (SAFE pass)
-  float nm;               // fast pass: -(reference max) - P_SHIFT, added to every score before the exponential
+  f32x16 negm;            // fast pass, one query block per wave: -(reference max) - P_SHIFT splat = accumulator input of
+                          // the first score MFMA;  two query blocks per wave (no registers for a splat): only negm[0] is
+                          // used, added to every score on the VALU
 };
 struct KFragX { hfx8 k0, k1, k0l, k1l; };
 struct VFragX { hfx8 v0, v1, v0l, v1l; };
@@ -542,15 +544,14 @@ DEVI void split8(const f32x16& p, int s, u32x4& whi, u32x4& wlo) {
   whi = u32x4{h[0], h[1], h[2], h[3]};
   wlo = u32x4{l[0], l[1], l[2], l[3]};
 }
-// Scores of one key block, S^T = K . Q^T, from a ZERO accumulator with the small terms first (lo . hi, hi . lo, then
-// hi . hi): the reference maximum is subtracted afterwards on the VALU -- riding it on the accumulator input like the half
-// kernel does would round every one of the six partial sums at the magnitude of the maximum (measured: 1.1e-5 instead of
-// 3e-6 relative on the attention output at L = 1500; the matrix pipe, not the VALU, is the busy side of this kernel).
-template <int QB>
+// Scores of one key block, S^T = K . Q^T (+ st.negm when INIT: the subtraction of the reference maximum rides on the
+// accumulator input like in the half kernel -- starting from zero and subtracting on the VALU costs 16 adds and 16
+// register clears per block and changed nothing measurable in the result), small terms first.
+template <bool INIT, int QB>
 DEVI void score_x(const KFragX& kf, const QStateX (&st)[QB], f32x16 (&sc)[QB]) {
 #pragma unroll
   for (int j = 0; j < QB; ++j) {
-    zero16(sc[j]);
+    if constexpr (INIT) sc[j] = st[j].negm; else zero16(sc[j]);
     sc[j] = MFMA32_H(kf.k0l, st[j].q0, sc[j]);
   }
 #pragma unroll
@@ -593,7 +594,7 @@ DEVI void finish_x(f32x16 (&sc)[QB], const VFragX& vf, int g, QStateX (&st)[QB],
       for (int r = 0; r < 16; ++r) sc[j][r] = __builtin_amdgcn_exp2f(sc[j][r] - m_new);
     } else {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) sc[j][r] = __builtin_amdgcn_exp2f(sc[j][r] + st[j].nm);
+      for (int r = 0; r < 16; ++r) sc[j][r] = __builtin_amdgcn_exp2f(QB == 1 ? sc[j][r] : sc[j][r] + st[j].negm[0]);
       if constexpr (MASK) {
 #pragma unroll
         for (int r = 0; r < 16; ++r)
@@ -657,7 +658,7 @@ DEVI void attn_tiles_x(rsrc_t rk, rsrc_t rv, char* smem, int tid, int wave, int 
       const KFragX kf = ld_kx(kb + c * BLKX_BYTES, g, lr);
       const VFragX vf = ld_vx(vb + c * BLKX_BYTES, lane);
       f32x16 sc[QB];
-      score_x<QB>(kf, st, sc);
+      score_x<!SAFE && QB == 1, QB>(kf, st, sc);
       if (partial && blk == nblk - 1) finish_x<SAFE, true, QB>(sc, vf, g, st, blk * 32, L);
       else finish_x<SAFE, false, QB>(sc, vf, g, st, blk * 32, L);
     }
@@ -686,18 +687,24 @@ DEVI void attn_fast_x(rsrc_t rk, rsrc_t rv, char* smem, int tid, int wave, int l
     st[j].l = 0.f;
     st[j].m = -1e30f;
   }
-  f32x16 s2[2][QB];  // scores of the current / the next block (compile-time indices: the tile loop is unrolled)
+  // PIPE (one query block per wave): the scores of block c + 1 are issued before the exponentials of block c, two score
+  // buffers alternate.  Two query blocks per wave are two independent chains already (and a second score buffer does not
+  // fit the register file): there the scores of the next block follow the current block's products.
+  constexpr bool PIPE = QB == 1;
+  f32x16 s2[PIPE ? 2 : 1][QB];  // scores of the current / the next block (compile-time indices: the tile loop is unrolled)
   KFragX kf = ld_kx(smem, g, lr);
-  score_x<QB>(kf, st, s2[0]);
+  score_x<false, QB>(kf, st, s2[0]);
 #pragma unroll
   for (int j = 0; j < QB; ++j) {  // reference max of each query: its scores against key block 0
     float bm = -1e30f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) bm = fmaxf(bm, (crow(r, g) < L) ? s2[0][j][r] : -1e30f);
     bm = fmaxf(bm, __shfl_xor(bm, 32));
-    st[j].nm = -bm - P_SHIFT;
+#pragma unroll
+    for (int r = 0; r < (QB == 1 ? 16 : 1); ++r) st[j].negm[r] = -bm - P_SHIFT;
   }
-  // (s2[0] = scores of block 0 of tile 0: the pipeline's first input, if there is a full tile)
+  // (one query block per wave: the scores of block 0 of tile 0 again, now on the reference maximum)
+  if (QB == 1 && nfull > 0) score_x<true, QB>(kf, st, s2[0]);
   for (int t = 0; t < nfull; ++t) {
     const char* kb = smem + (t & 1) * 2 * TILEX_BYTES;
     const char* vb = kb + TILEX_BYTES;
@@ -705,19 +712,20 @@ DEVI void attn_fast_x(rsrc_t rk, rsrc_t rv, char* smem, int tid, int wave, int l
 #pragma unroll
     for (int c = 0; c < KBX; ++c) {
       const VFragX vf = ld_vx(vb + c * BLKX_BYTES, lane);
+      const int cur = PIPE ? (c & 1) : 0, nxt = PIPE ? ((c + 1) & 1) : 0;
+      bool have_next = true;
       if (c + 1 < KBX) {
         kf = ld_kx(kb + (c + 1) * BLKX_BYTES, g, lr);
-        score_x<QB>(kf, st, s2[(c + 1) & 1]);
       } else {
         // the tile's last fragment reads are issued (vf) / have arrived (kf): barrier, refill, first block of tile t + 1
         __syncthreads();  // tile t + 1 has landed in every wave; nobody reads tile t any more
         if (t + 2 < ntiles) stage_tile_x<KBX>(rk, rv, t + 2, smem, t & 1, tid, wave);
-        if (t + 1 < nfull) {  // (uniform)
-          kf = ld_kx(kb_next, g, lr);
-          score_x<QB>(kf, st, s2[0]);
-        }
+        have_next = t + 1 < nfull;  // (uniform)
+        if (have_next) kf = ld_kx(kb_next, g, lr);
       }
-      finish_x<false, false, QB>(s2[c & 1], vf, g, st, 0, L);
+      if (PIPE && have_next) score_x<true, QB>(kf, st, s2[nxt]);
+      finish_x<false, false, QB>(s2[cur], vf, g, st, 0, L);
+      if (!PIPE && have_next) score_x<false, QB>(kf, st, s2[0]);
     }
   }
   if (nfull < ntiles)  // last tile: fewer than KBX blocks and / or a masked last block (staged by the loop / the prologue)
@@ -871,13 +879,12 @@ int launch_attn_frag(const AttnFragP& p, hipStream_t s) {
   if ((long)p.n_seq * p.heads * ((p.L + 127) / 128) > 0x3fffffffL) return -3;
   if (p.x3) {
     if (BT_HALF_IS_BF16 || (long)p.nbp * 4096 >= 0x7fffffffL) return -2;
-    // x3 selects the LDS tile (measured per launch shape by tools/x3_probe.py, 16 chunks, +-3 % run to run):
-    //   1 = 128-key tiles, 64 KB, two workgroups per CU: main layers (256 sequence-heads: 269 vs 283 us);
-    //   2 = 64-key tiles, 32 KB, four workgroups per CU: frontend (512 sequence-heads: 480 vs 525 us).
-    // (Two query blocks per wave -- half the fragment reads per MFMA -- were 15 % faster still on the main-layer shape
-    // until the kernel grew past 256 registers per lane; with spills they are 3x slower and were removed.  Three
-    // workgroups per CU with the 64-key tiles were not better than four.)
+    // x3 selects the variant (measured per launch shape by tools/x3_probe.py, 16 chunks, +-3 % run to run):
+    //   1 = 128-key LDS tiles, 64 KB, two workgroups per CU: main layers (256 sequence-heads: 269 vs 283 us);
+    //   2 = 64-key tiles, 32 KB, four workgroups per CU: frontend (512 sequence-heads: 480 vs 525 us);
+    //   3 = two query blocks per wave on 128-key tiles (half the fragment reads per MFMA, no score pipelining).
     if (p.x3 == 2) { if (p.out_f32) launch_x3<1, 1, 2, 4>(p, s); else launch_x3<1, 0, 2, 4>(p, s); }
+    else if (p.x3 == 3) { if (p.out_f32) launch_x3<2, 1, 4, 2>(p, s); else launch_x3<2, 0, 4, 2>(p, s); }
     else { if (p.out_f32) launch_x3<1, 1, 4, 2>(p, s); else launch_x3<1, 0, 4, 2>(p, s); }
     return (int)hipGetLastError();
   }
