@@ -170,7 +170,7 @@ int run_layer_x3(prof::State* pf, const bt_pair_weights& pw, const float* rope, 
   memset(&a, 0, sizeof a);
   a.q = ws.qf; a.k = ws.kf; a.v = ws.vf; a.gates = ws.gates_h; a.out = ws.ao; a.n_seq = B; a.L = T; a.heads = H;
   a.inner = D; a.nbp = ws.nbp; a.o_div = 1; a.o_outer = T; a.o_inner = 0; a.o_tok = 1;
-  a.x3 = 1; a.out_f32 = 0; a.status = ws.status;
+  a.x3 = 2; a.out_f32 = 0; a.status = ws.status;   // (x3 = 2: the 64-key LDS tiles, four workgroups per CU -- attn2.hip)
   LAUNCH_CAT(CAT_ATTN_FLASH, s, launch_attn_frag(a, s), "attention (hi + lo)");
   memset(&g, 0, sizeof g);
   g.A = ws.ao; g.lda = D; g.M = M; g.K = D; g.W = pw.w_out_x3; g.N = D; g.epi = G3_RESID; g.x3 = 1; g.status = ws.status;
