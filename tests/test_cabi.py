@@ -127,3 +127,35 @@ def test_host_peak_mask_and_cpu_logits_postprocessor():
     mb, md = pp(rb, rd, mask)
     ob, od = O.postp_minimal(rb[:2500].clone().masked_fill(~mask[:2500], -1000.0), rd[:2500])
     assert np.array_equal(mb, ob) and np.array_equal(md, od)
+
+
+def test_hl32_format_round_trips_and_matches_the_packer():
+    """The hi / lo plane format of BT_PREC_F32X3 (csrc/gemm3.hip): x = hi + lo to 2^-22 relative (2^-25 absolute for tiny
+    values), the layout is [32 hi | 32 lo] per 32 columns, and beat_this_amd.pack's weight packer and the tests' helper
+    produce the same bytes."""
+    import sys
+
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from gpu_util import from_hl32, to_hl32
+
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn((70, 96), generator=g) * torch.logspace(-6, 3, 96)[None, :]
+    h = to_hl32(x)
+    assert h.shape == (70, 192) and h.dtype == torch.float16
+    err = (from_hl32(h) - x.double()).abs()
+    assert float((err / x.double().abs().clamp_min(2.0 ** -3)).max()) <= 2.0 ** -21   # 22 bits above 2^-3, 2^-24 absolute below
+    assert torch.equal(h.view(70, 3, 2, 32)[:, :, 0].reshape(70, 96), x.to(torch.float16))   # hi plane = half(x)
+
+    class _P:   # PackedModel._hl32 without a device
+        device = torch.device("cpu")
+        _keep = []
+    from beat_this_amd.pack import PackedModel
+
+    L = _lib()
+    if not L.lib().bt_half_is_bf16():
+        w = torch.randn((130, 64), generator=g) * 0.05
+        p = _P()
+        assert PackedModel._hl32(p, w) != 0
+        packed = p._keep[-1]
+        assert packed.shape == (256, 128)   # rows padded to a multiple of 256
+        assert torch.equal(packed[:130], to_hl32(w)) and torch.all(packed[130:] == 0)
