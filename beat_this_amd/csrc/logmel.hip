@@ -14,6 +14,13 @@
 
 namespace {
 
+// Every LDS array of this kernel is private to ONE wave (index [wave]): the stages of a frame's FFT exchange data between
+// the lanes of that wave only.  LDS instructions of a wave execute in issue order, so a write followed by another lane's
+// read needs no s_barrier -- only that the compiler keeps the order (it must: the accesses may alias) and does not move
+// them across the stage boundary.  Through round 2 each of the seven exchanges was a workgroup-wide __syncthreads() that
+// made four unrelated frames wait for each other (log-mel 301 -> see DESIGN.md section 5 for the measured gain).
+#define WAVE_SYNC() __builtin_amdgcn_wave_barrier()
+
 struct cplx { float re, im; };
 DEVI cplx cadd(cplx a, cplx b) { return {a.re + b.re, a.im + b.im}; }
 DEVI cplx csub(cplx a, cplx b) { return {a.re - b.re, a.im - b.im}; }
@@ -89,7 +96,7 @@ __global__ __launch_bounds__(256) void logmel_kernel(const LogmelP p) {
       im[q * 72 + b * 9 + c] = x[q].im;
     }
   }
-  __syncthreads();
+  WAVE_SYNC();
   // ---- stage 2: DFT over b; lane = (p, c) ------------------------------------------------
   {
     const int pp = lane >> 3, c = lane & 7;
@@ -104,14 +111,14 @@ __global__ __launch_bounds__(256) void logmel_kernel(const LogmelP p) {
       f32x2 t = tw[64 + c * 64 + pp + 8 * q];
       x[q] = cmul(x[q], cplx{t.x, t.y});
     }
-    __syncthreads();
+    WAVE_SYNC();
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
       re[q * 72 + pp * 9 + c] = x[q].re;
       im[q * 72 + pp * 9 + c] = x[q].im;
     }
   }
-  __syncthreads();
+  WAVE_SYNC();
   // ---- stage 3: DFT over c; lane = (q, p) = (lane >> 3, lane & 7); Z[p + 8q + 64r] ---------
   {
     const int q = lane >> 3, pp = lane & 7;
@@ -121,14 +128,14 @@ __global__ __launch_bounds__(256) void logmel_kernel(const LogmelP p) {
       x[c].im = im[q * 72 + pp * 9 + c];
     }
     dft8(x);
-    __syncthreads();
+    WAVE_SYNC();
 #pragma unroll
     for (int r = 0; r < 8; ++r) {  // k = (p + 8 q) + 64 r = lane + 64 r
       re[lane + 64 * r] = x[r].re;
       im[lane + 64 * r] = x[r].im;
     }
   }
-  __syncthreads();
+  WAVE_SYNC();
   // ---- split step: X[k], k = 0..512, magnitude / sqrt(1024) --------------------------------
 #pragma unroll
   for (int j = 0; j < 9; ++j) {
@@ -144,7 +151,7 @@ __global__ __launch_bounds__(256) void logmel_kernel(const LogmelP p) {
       mag[k] = sqrtf(xr * xr + xi * xi) * 0.03125f;
     }
   }
-  __syncthreads();
+  WAVE_SYNC();
   // ---- banded mel projection + log1p(1000 x) ------------------------------------------------
   if (active) {
 #pragma unroll
