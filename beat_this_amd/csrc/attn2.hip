@@ -879,12 +879,12 @@ int launch_attn_frag(const AttnFragP& p, hipStream_t s) {
   if ((long)p.n_seq * p.heads * ((p.L + 127) / 128) > 0x3fffffffL) return -3;
   if (p.x3) {
     if (BT_HALF_IS_BF16 || (long)p.nbp * 4096 >= 0x7fffffffL) return -2;
-    // x3 selects the variant (measured per launch shape by tools/x3_probe.py, 16 chunks, +-3 % run to run):
-    //   1 = 128-key LDS tiles, 64 KB, two workgroups per CU: main layers (256 sequence-heads: 269 vs 283 us);
-    //   2 = 64-key tiles, 32 KB, four workgroups per CU: frontend (512 sequence-heads: 480 vs 525 us);
-    //   3 = two query blocks per wave on 128-key tiles (half the fragment reads per MFMA, no score pipelining).
+    // x3 selects the LDS tile (tools/x3_probe.py, 16 chunks, +-3 % run to run):
+    //   1 = 128-key tiles, 64 KB, two workgroups per CU:   main-layer shape 290 us, frontend shapes 590 us per launch;
+    //   2 = 64-key tiles, 32 KB, four workgroups per CU:   main-layer shape 250 us, frontend shapes 485 us -- the engine's choice.
+    // (Two query blocks per wave -- QB = 2: half the fragment reads per MFMA, no score pipelining, 256 registers -- measured
+    // 323 us on the main-layer shape and is not dispatched.)
     if (p.x3 == 2) { if (p.out_f32) launch_x3<1, 1, 2, 4>(p, s); else launch_x3<1, 0, 2, 4>(p, s); }
-    else if (p.x3 == 3) { if (p.out_f32) launch_x3<2, 1, 4, 2>(p, s); else launch_x3<2, 0, 4, 2>(p, s); }
     else { if (p.out_f32) launch_x3<1, 1, 4, 2>(p, s); else launch_x3<1, 0, 4, 2>(p, s); }
     return (int)hipGetLastError();
   }

@@ -203,7 +203,7 @@ def _run_attn(q, k, v, gates, n_seq, L, heads, out_f32, variant=1, **omap):
     return out.double().cpu() if out_f32 else from_hl32(out.cpu())
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3])   # bt_attn_frag_args.x3: query blocks per wave / keys per LDS tile (attn2.hip)
+@pytest.mark.parametrize("variant", [1, 2])   # bt_attn_frag_args.x3: query blocks per wave / keys per LDS tile (attn2.hip)
 @pytest.mark.parametrize("out_f32", [False, True])
 @pytest.mark.parametrize("n_seq,L,heads", [(3, 1500, 2), (2, 77, 1), (1, 128, 4), (5, 1012, 1), (2, 1, 1), (2, 33, 2),
                                            (1, 1499, 1), (2, 129, 1), (9, 96, 1), (2, 257, 1), (2, 250, 1), (1, 64, 1)])
@@ -237,7 +237,7 @@ def test_attention_frag_x3_time_direction_rowmap():
     assert err < 4e-6
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3])
+@pytest.mark.parametrize("variant", [1, 2])
 @pytest.mark.parametrize("L", [300, 1500])
 def test_attention_frag_x3_overflow_fallback(L, variant):
     """Scores that exceed the first key block's maximum by more than the fp16 probabilities can hold force the SAFE
