@@ -53,7 +53,7 @@ class ModelDesc(C.Structure):
                 ("layers", PairWeights * MAX_LAYERS),
                 ("head_w", C.c_void_p), ("head_b", C.c_float * 2), ("rope", C.c_void_p), ("ff_mult", C.c_int32),
                 ("norm_out_g", C.c_void_p), ("head_w_raw", C.c_void_p),
-                ("conv_w_x3", C.c_void_p * 3), ("lin_w_x3", C.c_void_p)]
+                ("conv_w_x3", C.c_void_p * 3), ("lin_w_x3", C.c_void_p), ("rope_len", C.c_int32)]
 
 
 class LogmelTables(C.Structure):

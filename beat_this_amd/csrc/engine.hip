@@ -345,7 +345,9 @@ int bt_forward_stages(bt_engine* e, void* stream, int prec, int first, int last,
   if (!e || !d_spect || !d_ws) return bt_set_error(BT_ERR_ARG, "null argument");
   if (first < 0 || last > 2 || first > last) return bt_set_error(BT_ERR_ARG, "stages: need 0 <= first <= last <= 2");
   if (last == 2 ? (!d_beat || !d_downbeat) : !d_out) return bt_set_error(BT_ERR_ARG, "null output");
-  if (B <= 0 || T <= 0 || T > 1536) return bt_set_error(BT_ERR_ARG, "need B >= 1 and 1 <= T <= 1536");
+  const int max_T = e->d.rope_len > 0 ? e->d.rope_len : 1536;   // rows of the rotary table
+  if (B <= 0 || T <= 0 || T > max_T)
+    return bt_set_error(BT_ERR_ARG, "need B >= 1 and 1 <= T <= " + std::to_string(max_T) + " (bt_model_desc.rope_len: rows of the rotary table)");
   if (prec != BT_PREC_F32 && prec != BT_PREC_HALF && prec != BT_PREC_F32X3)
     return bt_set_error(BT_ERR_ARG, "unknown precision");
   const bt_model_desc& d = e->d;

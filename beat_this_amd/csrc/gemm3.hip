@@ -610,7 +610,7 @@ bool gemm3_supported(const Gemm3P& p) {
                         p.K != 3 * p.conv_C2 || p.conv_F <= 0 || p.conv_T <= 0 || p.M % (p.conv_T * p.conv_F) != 0 || !p.no_resid))
     return false;
   if (p.epi == G3_RESID && !p.x && !p.xb) return false;
-  if (p.epi == G3_QKV) return p.inner % 128 == 0 && p.inner == p.heads * 32 && p.L > 0 && p.L <= 1536;
+  if (p.epi == G3_QKV) return p.inner % 128 == 0 && p.inner == p.heads * 32 && p.L > 0 && (long)p.n_seq * ((p.L + 31) / 32 * 32) < 0x7fffffffL;   // (p.rope must have L rows)
   if (p.epi == G3_FF1) return p.N % 128 == 0 && p.ldo % 8 == 0;
   if (p.epi == G3_RESID) return p.N % 64 == 0 && p.ldx % 8 == 0 && (long)(p.M + 256) * p.ldx * (p.x3 ? 2 : 1) < 0x7fffffffL &&
                                 (long)(p.N / 64) * p.M < 0x7fffffffL;  // (32-bit element offsets in the epilogue)

@@ -12,8 +12,6 @@ Differences that matter for speed, not for results:
 
 Limits of the drop-in (there is no CPU implementation in this package):
   * ``device`` must be a ROCm GPU; the default is "cuda" (the reference's default "cpu" raises here, in ``__init__``);
-  * ``BeatThis.forward`` takes at most 1536 frames per item (the reference's chunk length is 1500; its module accepts any
-    length); longer spectrograms go through ``split_predict_aggregate`` like in the reference's own inference classes;
   * the resampler is a Kaiser-windowed-sinc polyphase FIR built to libsoxr's HQ specification, not libsoxr.
 """
 from __future__ import annotations

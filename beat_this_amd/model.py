@@ -121,11 +121,6 @@ class BeatThis(nn.Module):
         if x.dim() != 3:
             raise ValueError(f"expected (batch, time, {self.hparams['spect_dim']}) input, got {tuple(x.shape)}")
         _lib.require_gpu(x, "model input")
-        if x.shape[1] > 1536:
-            raise ValueError(
-                f"beat_this_amd.BeatThis.forward takes at most 1536 frames per item (got {x.shape[1]}): the kernels are "
-                "built for the reference's 1500-frame chunks.  Feed longer spectrograms through "
-                "beat_this_amd.inference.split_predict_aggregate / Spect2Frames, as the reference's inference classes do.")
         if x.shape[0] == 0 or x.shape[1] == 0:
             empty = torch.empty((x.shape[0], x.shape[1]), dtype=torch.float32, device=x.device)
             return {"beat": empty, "downbeat": empty.clone()}
@@ -138,8 +133,8 @@ class BeatThis(nn.Module):
 
     def _run(self, x: torch.Tensor, first: int, last: int):
         """Stages first..last in the engine; precision follows autocast like the whole forward."""
-        if x.dim() != 3 or x.shape[1] > 1536:
-            raise ValueError(f"expected a (batch, time <= 1536, features) input, got {tuple(x.shape)}")
+        if x.dim() != 3:
+            raise ValueError(f"expected a (batch, time, features) input, got {tuple(x.shape)}")
         _lib.require_gpu(x, "stage input")
         if x.shape[0] == 0 or x.shape[1] == 0:
             D = self.hparams["transformer_dim"]

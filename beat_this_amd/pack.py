@@ -153,8 +153,13 @@ class PackedModel:
         d.norm_out_g, d.head_w_raw = self._f32(g), self._f32(sd["task_heads.beat_downbeat_lin.weight"])  # (stage calls)
         hb = sd["task_heads.beat_downbeat_lin.bias"]
         d.head_b[0], d.head_b[1] = float(hb[0]), float(hb[1])
-        freqs = next(v for k, v in sd.items() if k.endswith("rotary_embed.freqs"))
-        d.rope = self._f32(torch.from_numpy(tables.rope_table(freqs)))
+        self._freqs = next(v for k, v in sd.items() if k.endswith("rotary_embed.freqs"))
+        self.set_positions(1536)
+
+    def set_positions(self, n_pos: int) -> None:
+        """(Re)build the rotary table for sequences of up to ``n_pos`` frames (bt_model_desc.rope / rope_len)."""
+        self.desc.rope = self._f32(torch.from_numpy(tables.rope_table(self._freqs, n_pos)))
+        self.desc.rope_len = int(n_pos)
 
     # ------------------------------------------------------------------------------------------
     def _f32(self, t: torch.Tensor) -> int:
@@ -323,6 +328,18 @@ class Engine:
 
     MAX_WORKSPACES = 4
 
+    def ensure_positions(self, T: int) -> None:
+        """Sequences longer than the rotary table (1536 rows by default: the reference's chunks are 1500 frames, but its module
+        takes any length, beat_tracker.py:188-192): grow the table to the next multiple of 512 and re-create the handle."""
+        if T <= self.packed.desc.rope_len:
+            return
+        torch.cuda.synchronize(self.device)   # (nothing may still be reading the old table when it is released)
+        self.packed.set_positions(-(-T // 512) * 512)
+        _lib.lib().bt_engine_destroy(self._h)
+        h = C.c_void_p()
+        _lib.check(_lib.lib().bt_engine_create(C.byref(self.packed.desc), C.byref(h)))
+        self._h = h
+
     def _workspace(self, need: int) -> torch.Tensor:
         key = torch.cuda.current_stream(self.device)
         ws = self._ws.pop(key, None)
@@ -348,6 +365,7 @@ class Engine:
         if M != (128 if first == 0 else D):
             raise ValueError(f"expected {128 if first == 0 else D} input features, got {M}")
         x = spect.to(torch.float32).contiguous()
+        self.ensure_positions(T)
         need = _lib.lib().bt_workspace_bytes(self._h, B, T, prec)
         if need == 0:
             raise ValueError("empty batch")

@@ -129,7 +129,7 @@ typedef struct {
   bt_pair_weights layers[BT_MAX_LAYERS];
   const float* head_w; /* [2][D] task_heads weight * final RMSNorm gamma */
   float head_b[2];
-  const float* rope;   /* [1536][16][2] cos/sin of pos * freqs (rotary-embedding-torch) */
+  const float* rope;   /* [rope_len][16][2] cos/sin of pos * freqs (rotary-embedding-torch), fp32 products like the reference's */
   int32_t ff_mult;     /* hidden width of the main layers' FeedForward = ff_mult * transformer_dim (the frontend's partial
                         * transformers always use 4, beat_tracker.py:279,288) */
   /* for bt_forward_stages only: the final RMSNorm's gamma [D] and the task_heads weight [2][D] without it */
@@ -138,6 +138,7 @@ typedef struct {
   /* BT_PREC_F32X3: hl32 forms (see bt_pair_weights.w_qkvg_x3) of conv_w / lin_w; NULL: the register-staged GEMM runs */
   const void* conv_w_x3[3];
   const void* lin_w_x3;
+  int32_t rope_len;    /* rows of `rope` = the longest sequence (frames per item) bt_forward accepts; 0 means 1536 */
 } bt_model_desc;
 
 typedef struct {
@@ -165,7 +166,8 @@ void bt_engine_destroy(bt_engine* e);
 size_t bt_workspace_bytes(const bt_engine* e, int B, int T, int prec);
 
 /* BeatThis.forward (beat_tracker.py:188-192): d_spect [B,T,128] fp32 ->
- * d_beat, d_downbeat [B,T] fp32 logits (SumHead applied). T <= 1500. */
+ * d_beat, d_downbeat [B,T] fp32 logits (SumHead applied).  Any T <= bt_model_desc.rope_len (the reference's chunks have
+ * T = 1500; its module takes any length, and so does this one given a rotary table that long). */
 int bt_forward(bt_engine* e, void* stream, int prec, const float* d_spect, int B, int T, void* d_ws,
                size_t ws_bytes, float* d_beat, float* d_downbeat);
 

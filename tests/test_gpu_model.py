@@ -501,14 +501,35 @@ def test_f32x3_range_guard_falls_back_to_exact_fp32(name):
         assert np.array_equal(gb, wb) and np.array_equal(gd, wd)
 
 
-def test_empty_and_oversize_inputs():
+@pytest.mark.parametrize("mode", ["fp32", "half", "f32x3"])
+def test_forward_takes_sequences_longer_than_a_chunk(mode):
+    """BeatThis.forward on 2100 frames in one item (the reference's module takes any length, beat_tracker.py:188-192; its
+    inference classes only ever feed 1500): the rotary table grows on demand, every kernel is length-agnostic."""
+    from beat_this_amd import weights as W
+    from oracle import beat_this_oracle as O
+
+    hp = W.resolve_hparams("small0")
+    sd = W.random_state_dict(hp, seed=2, style="lively")
+    m = _model("small0", 2, "lively")
+    m.fp32_split_gemms = mode == "f32x3"
+    x = torch.from_numpy(W.synthetic_spect(2100, seed=41))[None]
+    with torch.inference_mode(), torch.autocast("cuda", enabled=mode == "half"):
+        r = m(x.to(dev()))
+        r1500 = m(x[:, :1500].to(dev()))   # (and the ordinary length still works on the grown table)
+    with torch.inference_mode():
+        ob, od = O.model_forward(sd, x)
+    err = max(float((r["beat"].cpu() - ob).abs().max()), float((r["downbeat"].float().cpu() - od).abs().max()))
+    report("long_sequence", mode=mode, T=2100, max_abs_logit=err)
+    assert r["beat"].shape == (1, 2100) and r1500["beat"].shape == (1, 1500)
+    assert err < (2e-2 if mode == "half" else LOGIT_TOL_F32 if mode == "fp32" else 1e-4)
+
+
+def test_empty_inputs_and_cpu_device():
     from beat_this_amd.inference import Spect2Frames
 
     s2f = Spect2Frames(checkpoint_path=None, device="cuda:0")
     b, d = s2f(torch.zeros((0, 128), device=dev()))
     assert b.shape == (0,) and d.shape == (0,) and b.dtype == torch.float32
-    with pytest.raises(ValueError, match="at most 1536 frames"):
-        s2f.model(torch.zeros((1, 2000, 128), device=dev()))
     with pytest.raises(RuntimeError, match="no CPU implementation"):
         Spect2Frames(checkpoint_path=None, device="cpu")
 
