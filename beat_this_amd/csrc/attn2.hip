@@ -881,10 +881,14 @@ int launch_attn_frag(const AttnFragP& p, hipStream_t s) {
     if (BT_HALF_IS_BF16 || (long)p.nbp * 4096 >= 0x7fffffffL) return -2;
     // x3 selects the LDS tile (tools/x3_probe.py, 16 chunks, +-3 % run to run):
     //   1 = 128-key tiles, 64 KB, two workgroups per CU:   main-layer shape 290 us, frontend shapes 590 us per launch;
-    //   2 = 64-key tiles, 32 KB, four workgroups per CU:   main-layer shape 250 us, frontend shapes 485 us -- the engine's choice.
+    //   2 = 64-key tiles, 32 KB, three / four workgroups per CU (registers / LDS): main-layer shape 250 us, frontend shapes
+    //       485 us -- the engine's choice.
     // (Two query blocks per wave -- QB = 2: half the fragment reads per MFMA, no score pipelining, 256 registers -- measured
     // 323 us on the main-layer shape and is not dispatched.)
-    if (p.x3 == 2) { if (p.out_f32) launch_x3<1, 1, 2, 4>(p, s); else launch_x3<1, 0, 2, 4>(p, s); }
+    // (register cap of THREE workgroups per CU: capped for four, the kernel spilled two registers around the key loop and
+    // their reloads raced the LDS-DMA in flight -- different results on every run of a 16-chunk forward; the ISA lint's
+    // fourth rule now rejects any scratch access in a kernel with LDS-DMA)
+    if (p.x3 == 2) { if (p.out_f32) launch_x3<1, 1, 2, 3>(p, s); else launch_x3<1, 0, 2, 3>(p, s); }
     else { if (p.out_f32) launch_x3<1, 1, 4, 2>(p, s); else launch_x3<1, 0, 4, 2>(p, s); }
     return (int)hipGetLastError();
   }

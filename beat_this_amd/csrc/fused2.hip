@@ -370,7 +370,12 @@ __global__ __launch_bounds__(256) void attnff_fused_kernel(const FusedAttnFFP p)
       f32x16 ao;
       zero16(ao);
       mma32(ao, pack_frag<T>(v), pack_frag<T>(pr));
-      const float fin = gate[hd] / l * PA;
+      // (gate[hd] by selects: a run-time index into the register array put it into scratch memory -- three scratch accesses
+      // in a kernel whose weight ring is LDS-DMA; tools/isa_lint.py, fourth rule)
+      float gsel = gate[0];
+#pragma unroll
+      for (int k = 1; k < H; ++k) gsel = hd == k ? gate[k] : gsel;
+      const float fin = gsel / l * PA;
       float o[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) o[r] = ao[r] * fin;

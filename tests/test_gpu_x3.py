@@ -260,8 +260,11 @@ def test_attention_frag_x3_overflow_fallback(L, variant):
     assert err < 6e-6
 
 
-def test_attention_frag_x3_at_scale_is_repeatable():
-    """The main-layer launch shape of a 16-chunk batch (256 sequence-heads x 1500 tokens) four times: bit-identical."""
+@pytest.mark.parametrize("variant", [1, 2])
+def test_attention_frag_x3_at_scale_is_repeatable(variant):
+    """The main-layer launch shape of a 16-chunk batch (256 sequence-heads x 1500 tokens) four times: bit-identical.
+    (Round 3: the 64-key variant, capped to 128 registers, spilled two of them around the key loop; the reloads raced the
+    LDS-DMA in flight and a 16-chunk forward differed from run to run -- the single-launch parity tests never saw it.)"""
     n_seq, L, heads = 16, 1500, 16
     SH = n_seq * heads
     q, k, v = (_mk((SH, L, 32), 60 + i, 0.7).float() for i in range(3))
@@ -279,7 +282,7 @@ def test_attention_frag_x3_at_scale_is_repeatable():
         a = Lb.AttnFragArgs()
         a.q, a.k, a.v, a.gates, a.out = qd.data_ptr(), kd.data_ptr(), vd.data_ptr(), gd.data_ptr(), out.data_ptr()
         a.n_seq, a.L, a.heads, a.inner, a.nbp, a.o_div, a.o_outer, a.o_inner, a.o_tok = n_seq, L, heads, heads * 32, nbp, 1, L, 0, 1
-        a.x3, a.out_f32, a.status = 1, 0, 0
+        a.x3, a.out_f32, a.status = variant, 0, 0
         Lb.check(Lb.lib().bt_attention_frag(Lb.stream_ptr(dev()), C.byref(a)))
         outs.append(out)
     torch.cuda.synchronize()

@@ -46,5 +46,13 @@ def test_lint_sees_the_pattern(tmp_path):
         assert len(isa_lint.lint("x.hip")) == 1
         isa_lint.asm_of = lambda src: racy.replace("\ts_waitcnt vmcnt(0)\n\ts_barrier", "\ts_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier")
         assert isa_lint.lint("x.hip") == []
+        # fourth rule: scratch in a kernel with LDS-DMA (allowed only on the allow list)
+        spilly = "\n".join(["_Zk:", "\tscratch_store_dword off, v1, off", "\tbuffer_load_dwordx4 v1, s[12:15], s4 offen lds",
+                            "\ts_waitcnt vmcnt(0)", "\tscratch_load_dword v1, off, off", "\ts_waitcnt vmcnt(0)", "\tv_add_u32_e32 v2, s1, v1",
+                            "\ts_endpgm"])
+        isa_lint.asm_of = lambda src: spilly
+        assert len(isa_lint.lint("x.hip")) == 1
+        isa_lint.asm_of = lambda src: spilly.replace("_Zk:", "_Z17layer_tail_kernelILi512EEv:")
+        assert isa_lint.lint("x.hip") == []
     finally:
         isa_lint.asm_of = orig

@@ -18,6 +18,12 @@ Third rule (the race of DESIGN.md section 3): in a kernel that issues LDS-DMA, n
 the nearest wait in front of it that drains the wave's LDS counter (lgkmcnt(0)) -- otherwise a
 fast wave's refill of a ring stage can overtake a slow wave's outstanding fragment reads of that stage.
 
+Fourth rule (round 3: a BT_PREC_F32X3 attention variant with 12 bytes of scratch gave different results on every run --
+two registers spilled in front of the key loop and reloaded behind it, next to LDS-DMA still in flight, the covering
+vmcnt(0) in a conditionally skipped block, which the straight-line scan of the first rule took for a guard): a kernel
+that issues LDS-DMA must not use scratch memory at all, unless it is on the allow list below (tail.hip's 512-register
+kernel, whose reloads are drained by an explicit vmcnt(0) in front of every LDS-DMA burst).
+
     python tools/isa_lint.py [source.hip ...]        exit status 1 if anything is reported
 """
 import concurrent.futures
@@ -112,12 +118,31 @@ def lint_barriers(lines, src):
     return findings
 
 
+SCRATCH_OK = ("layer_tail_kernel",)   # kernels with LDS-DMA that may spill (their bursts sit behind explicit vmcnt(0) drains)
+
+
+def lint_scratch(lines, src):
+    findings = []
+    bounds = [i for i, l in enumerate(lines) if re.match(r"^_Z\w+:", l)] + [len(lines)]
+    for a, b in zip(bounds, bounds[1:]):
+        body = lines[a:b]
+        kernel = body[0].split(":")[0]
+        if not any("buffer_load" in x and " lds" in x for x in body) or any(k in kernel for k in SCRATCH_OK):
+            continue
+        n = sum(1 for x in body if re.match(r"\s*scratch_(load|store)", x))
+        if n:
+            findings.append(f"{os.path.basename(src)}: {kernel}: {n} scratch access(es) in a kernel that issues LDS-DMA "
+                            f"(spill reloads are waited for with counted vmcnt values that LDS-DMA invalidates)")
+    return findings
+
+
 def lint(src):
     findings = []
     kernel = "?"
     lines = asm_of(src).split("\n")
     findings += lint_mfma(lines, src)
     findings += lint_barriers(lines, src)
+    findings += lint_scratch(lines, src)
     for i, line in enumerate(lines):
         m = re.match(r"^(_Z\w+):", line)
         if m:
