@@ -20,7 +20,7 @@ def test_no_counted_wait_guards_a_load_across_lds_dma(capsys):
 def test_lint_sees_the_pattern(tmp_path):
     """The detector itself: a hand-written listing with the hazard (the round-2 build of tail.hip had exactly this)."""
     import isa_lint
-    listing = "\n".join(["_Zk:", "\ts_waitcnt vmcnt(0) lgkmcnt(0)", "\ts_barrier", "\tscratch_load_dword v48, off, off offset:16",
+    listing = "\n".join(["_Zk:", "\ts_waitcnt vmcnt(0) lgkmcnt(0)", "\ts_barrier", "\tglobal_load_dword v48, v[2:3], off offset:16",
                          *["\tbuffer_load_dwordx4 v1, s[12:15], s4 offen lds"] * 16, "\ts_waitcnt vmcnt(16)", "\tv_add_u32_e32 v47, s1, v48",
                          "\ts_endpgm"])
     safe = listing.replace("s_waitcnt vmcnt(16)", "s_waitcnt vmcnt(0)")
