@@ -50,6 +50,11 @@ struct G3CfgSX { static constexpr int BM = 128, BN = 128, BK = 64, WGM = 2, WGN 
 struct G3CfgBX { static constexpr int BM = 256, BN = 256, BK = 64, WGM = 2, WGN = 4, NST = 2, OCC = 1; };
 struct G3CfgTX { static constexpr int BM = 192, BN = 256, BK = 64, WGM = 2, WGN = 4, NST = 2, OCC = 1; };
 
+// BT_PREC_F32X3: XCD groups a large weight matrix is split over (1 = off; launch_cfg)
+#ifndef X3_NSPLIT
+#define X3_NSPLIT 1
+#endif
+
 namespace {
 
 typedef G3CfgS CfgS;
@@ -117,7 +122,7 @@ DEVI void flag_range(int* status, float amax) {
 // bits 0 - 2 (no LDS-DMA after the prologue / no GELU / no MFMAs) are ablations that can be instantiated by hand
 template <int EPI, typename CFG, bool X3 = false, int ABL = 0>
 __global__ __launch_bounds__(64 * CFG::WGM * CFG::WGN, (CFG::OCC * CFG::WGM * CFG::WGN + 3) / 4)
-void gemm3_kernel(const Gemm3P p, int n_tiles, int total_tiles, int per_xcd) {
+void gemm3_kernel(const Gemm3P p, int n_tiles, int total_tiles, int per_xcd, int nsplit) {
   constexpr int BM = CFG::BM, BN = CFG::BN, BK = CFG::BK, NST = CFG::NST;
   constexpr int NW = CFG::WGM * CFG::WGN, NT = 64 * NW;
   constexpr int TB = BM / CFG::WGM / 32;       // 32-token blocks per wave
@@ -134,11 +139,27 @@ void gemm3_kernel(const Gemm3P p, int n_tiles, int total_tiles, int per_xcd) {
   static_assert(!X3 || ROWB == 128, "hl32: one k-step of 32 = 64 hi + 64 lo bytes per row");
   static_assert(NST * ST_BYTES >= NW * 8192, "the epilogues stage 8 KB per wave in the ring's LDS");
   __shared__ __attribute__((aligned(16))) char smem[NST * ST_BYTES];
-  // XCD-aware tile order: the n-tiles sharing one 128-row A panel run on the same XCD (block b -> XCD b % 8)
+  // XCD-aware tile order (block b -> XCD b % 8).  nsplit = 1: the n-tiles sharing one A panel run on the same XCD, an XCD
+  // walks whole panels -- every XCD streams ALL of W once per panel, which is free while W stays in its 4 MB L2 (half
+  // precision) and is not when W is an hl32 matrix of 3 - 4 MB (x3 FF1: 7x the algorithmic fetch bytes, the kernel bound
+  // by that stream at ~10 TB/s).  nsplit = 2 / 4: the XCDs form nsplit groups, group g owns the n-tiles
+  // [g, g + 1) * n_tiles / nsplit (its slice of W stays in L2), the 8 / nsplit XCDs of a group share out the A panels;
+  // an A panel is then fetched by nsplit XCDs instead of one.
   const int bid = blockIdx.x;
-  const int tile = (bid & 7) * per_xcd + (bid >> 3);
-  if (tile >= total_tiles) return;
-  const int m_tile = tile / n_tiles, n_tile = tile - m_tile * n_tiles;
+  int m_tile, n_tile;
+  if (nsplit <= 1) {
+    const int tile = (bid & 7) * per_xcd + (bid >> 3);
+    if (tile >= total_tiles) return;
+    m_tile = tile / n_tiles;
+    n_tile = tile - m_tile * n_tiles;
+  } else {
+    const int xcd = bid & 7, slot = bid >> 3;
+    const int g = xcd % nsplit, j = xcd / nsplit, per_m = 8 / nsplit, nt = n_tiles / nsplit;
+    const int m_local = slot / nt;
+    m_tile = m_local * per_m + j;
+    n_tile = g * nt + (slot - m_local * nt);
+    if ((long)m_tile * n_tiles >= total_tiles) return;   // (total_tiles = m_tiles * n_tiles)
+  }
   const int m0 = m_tile * BM, n0 = n_tile * BN;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // (wave index in an SGPR: uniform index math stays scalar)
   const int g = lane >> 5, lr = lane & 31;
@@ -593,10 +614,22 @@ void launch_cfg(const Gemm3P& p, hipStream_t s) {
   const long rows = p.epi == G3_QKV ? (long)p.n_seq * p.nblk * 32 : (long)p.M;
   const long m_tiles = (rows + CFG::BM - 1) / CFG::BM;
   const long total = m_tiles * n_tiles;
-  long per = (total + 7) / 8;
-  per = (per + n_tiles - 1) / n_tiles * n_tiles;
+  // W split over XCD groups (see the kernel): forced through x3 >> 4 by tools/x3_probe.py, otherwise for an x3 weight matrix
+  // beyond ~2.5 MB whose n-tiles divide evenly
+  int nsplit = p.x3 >> 4;
+  if (nsplit == 0) nsplit = (X3 && X3_NSPLIT > 1 && (long)n_tiles * CFG::BN * p.K * 4 > (5L << 19) && n_tiles % X3_NSPLIT == 0) ? X3_NSPLIT : 1;
+  if (nsplit != 2 && nsplit != 4 && nsplit != 8) nsplit = 1;
+  if (n_tiles % nsplit) nsplit = 1;
+  long per;
+  if (nsplit == 1) {
+    per = (total + 7) / 8;
+    per = (per + n_tiles - 1) / n_tiles * n_tiles;
+  } else {
+    const long per_m = 8 / nsplit;
+    per = (m_tiles + per_m - 1) / per_m * (n_tiles / nsplit);
+  }
   dim3 grid((unsigned)(per * 8)), block(64 * CFG::WGM * CFG::WGN);
-  hipLaunchKernelGGL((gemm3_kernel<EPI, CFG, X3, ABL>), grid, block, 0, s, p, n_tiles, (int)total, (int)per);
+  hipLaunchKernelGGL((gemm3_kernel<EPI, CFG, X3, ABL>), grid, block, 0, s, p, n_tiles, (int)total, (int)per, nsplit);
 }
 
 }  // namespace
@@ -637,13 +670,25 @@ int launch_gemm3(const Gemm3P& p, hipStream_t s) {
   // k-steps) it wins inside the forward as well, 0.452 vs 0.487 ms per step.
   const bool big_ok = p.epi != G3_QKV && p.N % 256 == 0;
   // (x3 = 2 / 3 through the single-operator entry bt_gemm3 forces the 256-row / the 128-row configuration: tools/x3_probe.py)
-  const int force = p.x3 == 2 ? 1 : p.x3 == 3 ? 0 : force_big;
+  const int force = (p.x3 & 15) == 2 ? 1 : (p.x3 & 15) == 3 ? 0 : force_big;
   const bool big = big_ok && (force == 1 || (force != 0 && p.epi == G3_RESID && p.K >= 1024 && p.M >= 4096) ||
                               (force != 0 && p.x3 && X3_BIG_FF1 && p.epi == G3_FF1 && p.M >= 4096));
   // 256 or 192 token rows per tile: fewer (rounds over the 256 CUs) x (rows per tile) wins
   auto cost = [&](int bm) { const long t = ((long)p.M + bm - 1) / bm * (p.N / 256); return (t + 255) / 256 * bm; };
   const bool rows192 = big && p.epi == G3_RESID && force != 1 && cost(192) < cost(256);
   if (p.x3) {
+#ifdef BT_DEV
+    // development: ablations of the x3 kernel (results are garbage): BT_G3_ABL = 1 no LDS-DMA after the prologue, 4 no MFMAs
+    if (abl == 1 || abl == 4) {
+      const bool b = big || rows192;
+      if (p.epi == G3_FF1) { if (abl == 1) { if (b) launch_cfg<G3_FF1, G3CfgBX, true, 1>(p, s); else launch_cfg<G3_FF1, G3CfgSX, true, 1>(p, s); }
+                             else { if (b) launch_cfg<G3_FF1, G3CfgBX, true, 4>(p, s); else launch_cfg<G3_FF1, G3CfgSX, true, 4>(p, s); } }
+      else if (p.epi == G3_RESID) { if (abl == 1) { if (b) launch_cfg<G3_RESID, G3CfgBX, true, 1>(p, s); else launch_cfg<G3_RESID, G3CfgSX, true, 1>(p, s); }
+                                    else { if (b) launch_cfg<G3_RESID, G3CfgBX, true, 4>(p, s); else launch_cfg<G3_RESID, G3CfgSX, true, 4>(p, s); } }
+      else { if (abl == 1) launch_cfg<G3_QKV, G3CfgSX, true, 1>(p, s); else launch_cfg<G3_QKV, G3CfgSX, true, 4>(p, s); }
+      return (int)hipGetLastError();
+    }
+#endif
     switch (p.epi) {
       case G3_FF1:
         if (big) launch_cfg<G3_FF1, G3CfgBX, true>(p, s); else launch_cfg<G3_FF1, G3CfgSX, true>(p, s);

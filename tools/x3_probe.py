@@ -60,12 +60,12 @@ def attention(n_seq, heads, Lq, label):
               f"({3 * flop / us / 1e6:7.1f} on the matrix pipe)  same as variant 1: {torch.equal(outs[variant], outs[1])}", flush=True)
 
 
-def gemm(M, K, N, epi, label, heads=0, n_seq=0, Lq=0, force=1):
+def gemm(M, K, N, epi, label, heads=0, n_seq=0, Lq=0, force=1, nsplit=0):
     g = torch.Generator().manual_seed(2)
     A = to_hl32(torch.randn((M, K), generator=g)).to(dev)
     W = to_hl32(pad_rows(torch.randn((N, K), generator=g) / K ** 0.5, 256)).to(dev)
     a = L.Gemm3Args()
-    a.A, a.lda, a.M, a.K, a.W, a.N, a.epi, a.x3 = A.data_ptr(), K, M, K, W.data_ptr(), N, epi, force
+    a.A, a.lda, a.M, a.K, a.W, a.N, a.epi, a.x3 = A.data_ptr(), K, M, K, W.data_ptr(), N, epi, force | (nsplit << 4)
     keep = []
     if epi == 0:
         bias = torch.zeros(N, device=dev); out = torch.zeros((M, 2 * N), dtype=torch.float16, device=dev)
@@ -92,7 +92,7 @@ def gemm(M, K, N, epi, label, heads=0, n_seq=0, Lq=0, force=1):
     st = L.stream_ptr(dev)
     us = timeit(lambda: L.check(lib.bt_gemm3(st, C.byref(a))))
     flop = 2.0 * M * K * a.N
-    print(f"gemm3 x3 {label} [{ {1: 'auto', 2: '256-row tiles', 3: '128-row tiles'}[force] }] M={M} K={K} N={a.N}: {us:8.1f} us  {flop / us / 1e6:7.1f} TFLOP/s algorithmic "
+    print(f"gemm3 x3 {label} [{ {1: 'auto', 2: '256-row tiles', 3: '128-row tiles'}[force] }, W over {nsplit or 'auto'} XCD groups] M={M} K={K} N={a.N}: {us:8.1f} us  {flop / us / 1e6:7.1f} TFLOP/s algorithmic "
           f"({3 * flop / us / 1e6:7.1f} on the matrix pipe)", flush=True)
 
 
@@ -108,3 +108,10 @@ for f in (3, 2):
     gemm(M, 2048, 512, 1, "FF2", force=f)
     gemm(M, 1024, 512, 1, "frontend.linear", force=f)
 gemm(M, 2048, 512, 1, "FF2 (auto)")
+for ns in (1, 2, 4):
+    gemm(M, 512, 2048, 0, "FF1", force=3, nsplit=ns)
+    gemm(M, 512, 2048, 0, "FF1", force=2, nsplit=ns)
+    gemm(M, 2048, 512, 1, "FF2", force=1, nsplit=ns)
+    gemm(M, 1024, 512, 1, "frontend.linear", force=1, nsplit=ns)
+    if ns < 4:
+        gemm(M, 512, 512, 1, "out-projection", force=3, nsplit=ns)
