@@ -50,9 +50,11 @@ struct G3CfgSX { static constexpr int BM = 128, BN = 128, BK = 64, WGM = 2, WGN 
 struct G3CfgBX { static constexpr int BM = 256, BN = 256, BK = 64, WGM = 2, WGN = 4, NST = 2, OCC = 1; };
 struct G3CfgTX { static constexpr int BM = 192, BN = 256, BK = 64, WGM = 2, WGN = 4, NST = 2, OCC = 1; };
 
-// BT_PREC_F32X3: XCD groups a large weight matrix is split over (1 = off; launch_cfg)
+// BT_PREC_F32X3: XCD groups a large weight matrix is split over (1 = off; launch_cfg).  tools/x3_probe.py, M = 24000:
+// FF1 (W = 4 MB of hl32) 206 / 189 / 202 us with 1 / 2 / 4 groups, FF2 175 / 165 / 164, frontend.linear and the
+// out-projection (W <= 2 MB: below the threshold) unchanged.
 #ifndef X3_NSPLIT
-#define X3_NSPLIT 1
+#define X3_NSPLIT 2
 #endif
 
 namespace {
