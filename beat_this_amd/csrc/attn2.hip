@@ -535,12 +535,8 @@ DEVI VFragX ld_vx(const char* vb, int lane) {
 DEVI void split8(const f32x16& p, int s, u32x4& whi, u32x4& wlo) {
   unsigned h[4], l[4];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const float a = opaque(p[8 * s + 2 * j]), b = opaque(p[8 * s + 2 * j + 1]);   // (common.h: ONE rounded value per split)
-    const hf ha = (hf)a, hb = (hf)b;
-    h[j] = __builtin_bit_cast(unsigned int, hfx2{ha, hb});
-    l[j] = __builtin_bit_cast(unsigned int, hfx2{(hf)(a - (float)ha), (hf)(b - (float)hb)});
-  }
+  for (int j = 0; j < 4; j += 2)   // (common.h)
+    split_hl4(p[8 * s + 2 * j], p[8 * s + 2 * j + 1], p[8 * s + 2 * j + 2], p[8 * s + 2 * j + 3], h[j], l[j], h[j + 1], l[j + 1]);
   whi = u32x4{h[0], h[1], h[2], h[3]};
   wlo = u32x4{l[0], l[1], l[2], l[3]};
 }
@@ -828,14 +824,9 @@ __global__ __launch_bounds__(256, MINW) void attn_frag_x3_kernel(const AttnFragP
         unsigned xh[2], xl[2], yh[2], yl[2];
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-          // (opaque, common.h: the split must see ONE rounded fp32 product, not a multiply contracted into the conversions)
-          const float a0 = opaque(st[j].acc[8 * k + 2 * i] * scale), a1 = opaque(st[j].acc[8 * k + 2 * i + 1] * scale);
-          const float b0 = opaque(st[j].acc[8 * k + 4 + 2 * i] * scale), b1 = opaque(st[j].acc[8 * k + 4 + 2 * i + 1] * scale);
-          const hf ha0 = (hf)a0, ha1 = (hf)a1, hb0 = (hf)b0, hb1 = (hf)b1;
-          xh[i] = __builtin_bit_cast(unsigned, hfx2{ha0, ha1});
-          xl[i] = __builtin_bit_cast(unsigned, hfx2{(hf)(a0 - (float)ha0), (hf)(a1 - (float)ha1)});
-          yh[i] = __builtin_bit_cast(unsigned, hfx2{hb0, hb1});
-          yl[i] = __builtin_bit_cast(unsigned, hfx2{(hf)(b0 - (float)hb0), (hf)(b1 - (float)hb1)});
+          const float a0 = st[j].acc[8 * k + 2 * i] * scale, a1 = st[j].acc[8 * k + 2 * i + 1] * scale;
+          const float b0 = st[j].acc[8 * k + 4 + 2 * i] * scale, b1 = st[j].acc[8 * k + 4 + 2 * i + 1] * scale;
+          split_hl4(a0, a1, b0, b1, xh[i], xl[i], yh[i], yl[i]);   // (common.h)
           amax = fmaxf(amax, fmaxf(fmaxf(fabsf(a0), fabsf(a1)), fmaxf(fabsf(b0), fabsf(b1))));
         }
         auto h0 = __builtin_amdgcn_permlane32_swap(xh[0], yh[0], false, false);

@@ -130,14 +130,43 @@ template <typename T> DEVI T from_f32(float x);
 template <> DEVI float from_f32<float>(float x) { return x; }
 template <> DEVI hf from_f32<hf>(float x) { return (hf)x; }
 
-// A value that is about to be split into hi + lo halves must be ONE materialised fp32 number: with fp contraction hipcc
-// folds the arithmetic that produced it into the conversions (v_fma_mixlo_f16 hi = half(a * b) from the EXACT product, lo =
-// half(a * b - hi) likewise) while the stored hi comes from a separately rounded fp32 product -- the two hi parts differ by
-// one fp16 ulp where the double rounding bites, and hi + lo is then 2^-11 off (found by the unit tests of round 3:
-// 2.5e-4 .. 5e-4 relative on 0.1 % of the elements).  An empty asm makes the value opaque at no cost.
-DEVI float opaque(float v) {
-  asm("" : "+v"(v));
-  return v;
+// hi + lo split of fp32 values (BT_PREC_F32X3): per pair (a, b)  whi = packed (half(a), half(b)),  wlo = packed
+// (half(a - hi_a), half(b - hi_b)), in THREE instructions -- one v_cvt_pk_f16_f32 and, per lo half, one
+// v_fma_mix{lo,hi}_f16 that reads its hi part straight out of the packed word (op_sel), multiplies it by -1 (an SGPR: the
+// operand is read as fp32), adds the fp32 value and rounds the exact difference to fp16 into its half of the destination.
+// Inline assembly for two reasons: (1) hipcc's own sequence is eight instructions per pair (two single conversions, two
+// conversions back, two subtractions, two packed conversions), which made the split the largest VALU item of the x3
+// attention loop; (2) a value that is about to be split must be ONE materialised fp32 number -- with fp contraction hipcc
+// folds the arithmetic that produced it into the conversions (hi = half(x * y) from the EXACT product, the stored hi from a
+// separately rounded one: the two differ by one fp16 ulp where the double rounding bites and hi + lo is then 2^-11 off;
+// found by the unit tests of round 3 as 2.5e-4 .. 5e-4 relative on 0.1 % of the elements) -- and an asm operand is that.
+// The hazard recogniser does not look into inline assembly, so the blocks carry their own wait states (gfx940 rules, one
+// wait state each): a transcendental's result read by a non-transcendental VALU (the inputs may be v_exp results: leading
+// s_nop), and a half-register write (mixlo / mixhi) followed by a read of that register (two pairs interleaved, trailing
+// s_nop).  Inputs are always VALU results here, never raw MFMA accumulators.
+DEVI void split_hl4(float a0, float b0, float a1, float b1, unsigned& h0, unsigned& l0, unsigned& h1, unsigned& l1) {
+  const float m1 = -1.0f;
+  asm("s_nop 0\n\t"
+      "v_cvt_pk_f16_f32 %0, %4, %5\n\t"
+      "v_cvt_pk_f16_f32 %2, %6, %7\n\t"
+      "v_fma_mixlo_f16 %1, %0, %8, %4 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mixlo_f16 %3, %2, %8, %6 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mixhi_f16 %1, %0, %8, %5 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mixhi_f16 %3, %2, %8, %7 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+      "s_nop 0"
+      : "=&v"(h0), "=&v"(l0), "=&v"(h1), "=&v"(l1)
+      : "v"(a0), "v"(b0), "v"(a1), "v"(b1), "s"(m1));
+}
+DEVI void split_hl(float a, float b, unsigned& whi, unsigned& wlo) {
+  const float m1 = -1.0f;
+  asm("s_nop 0\n\t"
+      "v_cvt_pk_f16_f32 %0, %2, %3\n\t"
+      "v_fma_mixlo_f16 %1, %0, %4, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+      "s_nop 0\n\t"
+      "v_fma_mixhi_f16 %1, %0, %4, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+      "s_nop 0"
+      : "=&v"(whi), "=&v"(wlo)
+      : "v"(a), "v"(b), "s"(m1));
 }
 
 DEVI void st16(float* dst, const float* v) {  // 16 floats, 64 B aligned enough for 16 B stores

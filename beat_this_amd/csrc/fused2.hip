@@ -154,13 +154,7 @@ DEVI void ff_tail(WRing<T, C>& ws, int step0, float (&xn)[C / 32][16], const flo
           unsigned xh[2], xl[2], yh[2], yl[2];
 #pragma unroll
           for (int i = 0; i < 2; ++i) {
-            const float a0 = opaque(v[2 * k][2 * i]), a1 = opaque(v[2 * k][2 * i + 1]);   // (common.h: ONE rounded value per split)
-            const float b0 = opaque(v[2 * k + 1][2 * i]), b1 = opaque(v[2 * k + 1][2 * i + 1]);
-            const hf ha0 = (hf)a0, ha1 = (hf)a1, hb0 = (hf)b0, hb1 = (hf)b1;
-            xh[i] = __builtin_bit_cast(unsigned, hfx2{ha0, ha1});
-            xl[i] = __builtin_bit_cast(unsigned, hfx2{(hf)(a0 - (float)ha0), (hf)(a1 - (float)ha1)});
-            yh[i] = __builtin_bit_cast(unsigned, hfx2{hb0, hb1});
-            yl[i] = __builtin_bit_cast(unsigned, hfx2{(hf)(b0 - (float)hb0), (hf)(b1 - (float)hb1)});
+            split_hl4(v[2 * k][2 * i], v[2 * k][2 * i + 1], v[2 * k + 1][2 * i], v[2 * k + 1][2 * i + 1], xh[i], xl[i], yh[i], yl[i]);   // (common.h)
           }
           auto h0 = __builtin_amdgcn_permlane32_swap(xh[0], yh[0], false, false);
           auto h1 = __builtin_amdgcn_permlane32_swap(xh[1], yh[1], false, false);

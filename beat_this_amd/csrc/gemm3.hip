@@ -90,12 +90,7 @@ DEVI void pack_row_hf(const float (&v)[16], u32x4 (&piece)[2]) {
 // (a, b) -> packed hi halves and packed lo halves of the hi + lo split: hi = half(v), lo = half(v - hi); amax tracks the
 // largest magnitude that went through a split (range guard of BT_PREC_F32X3: a hi part beyond the fp16 range is inf)
 DEVI void split2(float a, float b, unsigned& whi, unsigned& wlo, float& amax) {
-  a = opaque(a); b = opaque(b);   // (common.h: the split must see ONE rounded fp32 value)
-  const hf ha = (hf)a, hb = (hf)b;
-  const hfx2 th = {ha, hb};
-  const hfx2 tl = {(hf)(a - (float)ha), (hf)(b - (float)hb)};
-  whi = __builtin_bit_cast(unsigned, th);
-  wlo = __builtin_bit_cast(unsigned, tl);
+  split_hl(a, b, whi, wlo);   // (common.h)
   amax = fmaxf(amax, fmaxf(fabsf(a), fabsf(b)));
 }
 // pack_row_hf for both parts of the split

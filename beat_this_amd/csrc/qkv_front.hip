@@ -19,10 +19,7 @@ typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
 DEVI void split2q(float a, float b, unsigned& whi, unsigned& wlo, float& amax) {
-  a = opaque(a); b = opaque(b);   // (common.h: the split must see ONE rounded fp32 value)
-  const hf ha = (hf)a, hb = (hf)b;
-  whi = __builtin_bit_cast(unsigned, hfx2{ha, hb});
-  wlo = __builtin_bit_cast(unsigned, hfx2{(hf)(a - (float)ha), (hf)(b - (float)hb)});
+  split_hl(a, b, whi, wlo);   // (common.h)
   amax = fmaxf(amax, fmaxf(fabsf(a), fabsf(b)));
 }
 
