@@ -37,6 +37,14 @@ constexpr int SMEM_BYTES = 2 * 2 * TILE_BYTES + 16;  // [buffer][K | V] + fallba
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
+// The lane index again, from an operand hipcc cannot see through: values derived from it are recomputed where they are
+// used instead of being kept live (or spilled -- the kernels here allow no scratch next to LDS-DMA) across a key loop that
+// has no register to spare.
+DEVI int lane_id_fresh() {
+  int z;
+  asm volatile("s_mov_b32 %0, 0" : "=s"(z));
+  return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, z));
+}
 DEVI unsigned pk2(float a, float b) {
   const hfx2 t = {(hf)a, (hf)b};
   return __builtin_bit_cast(unsigned, t);
@@ -50,15 +58,20 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 // 8 probabilities -> 4 dwords of packed half (one v_cvt_pk_bf16_f32 each).  Operands are assembled from
 // these dwords by bit casts only: half-vector shuffles make hipcc (ROCm 7.2) emit 3x the conversions.
+#ifndef BT_ATTN_PKRTZ
+#define BT_ATTN_PKRTZ 0
+#endif
+constexpr float L_OVERFLOW = (BT_ATTN_PKRTZ && !BT_HALF_IS_BF16) ? 65504.f : 1e30f;  // fast pass: row sums from here on re-run
 DEVI u32x4 pack8(const f32x16& p, int s) {
   u32x4 w;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-#if defined(BT_ATTN_PKRTZ) && !BT_HALF_IS_BF16
-    // EXPERIMENT, off: round-toward-zero packing (v_cvt_pkrtz_f16_f32) issues faster than the round-to-nearest
-    // v_cvt_pk_f16_f32 (A/B on one box, 16 chunks: attention 1.188 vs 1.242 ms; 1.143 ms for the bfloat16 build), but it
-    // SATURATES at 65504 instead of producing inf, so the overflow test that triggers the SAFE pass never fires and the
-    // logit error doubled on the sharp-softmax goldens (1.6e-2 vs 0.7e-2).  Round to nearest stays.
+#if BT_ATTN_PKRTZ && !BT_HALF_IS_BF16
+    // Round-toward-zero packing (v_cvt_pkrtz_f16_f32) issues faster than the round-to-nearest v_cvt_pk_f16_f32.  It is as
+    // accurate for a softmax: numerator (P.V) and denominator (the row sums, taken from the same packed words) carry the
+    // same mean relative bias of -2^-11, which cancels in O / l, and the spread around it is that of round-to-nearest.  But
+    // it SATURATES at 65504 instead of producing inf, so the overflow test of the fast pass is "row sum >= 65504" here (one
+    // saturated probability makes the sum at least that; a sum that large without one only costs the re-run).
     w[j] = __builtin_bit_cast(unsigned int, __builtin_amdgcn_cvt_pkrtz(p[8 * s + 2 * j], p[8 * s + 2 * j + 1]));
 #else
     const hfx2 t = {(hf)p[8 * s + 2 * j], (hf)p[8 * s + 2 * j + 1]};
@@ -109,6 +122,12 @@ DEVI void rowsum16_valu(f32x4& l, const f32x16& p) {
 // error of 2^-10 in the row sum only if ALL 1500 keys sit there).  The common factor cancels in O / l.  bfloat16 has
 // the fp32 exponent range and needs no shift.
 constexpr float P_SHIFT = BT_HALF_IS_BF16 ? 0.f : 4.f;
+// BT_ATTN_EXPT (development, variant builds only -- results are WRONG): what the key loop of the fast pass spends where.
+//   1 = no exponentials, 2 = no packing either (VALU-free), 4 = no row-sum MFMAs, 8 = no fragment reads from LDS in the loop,
+//   16 = no LDS-DMA / barriers after the prologue, 32 = one score MFMA per block instead of two, 64 = one P.V MFMA instead of two
+#ifndef BT_ATTN_EXPT
+#define BT_ATTN_EXPT 0
+#endif
 
 // Per-query-block softmax state of a wave (QB query blocks of 32 queries share every K / V fragment read).
 struct QState {
@@ -285,24 +304,39 @@ DEVI void score_fast(const KFrag& kf, const QState (&st)[QB], f32x16 (&sc)[QB]) 
 #pragma unroll
   for (int j = 0; j < QB; ++j) {
     sc[j] = MFMA32_H(kf.k0, st[j].q0, st[j].negm);
+#if !(BT_ATTN_EXPT & 32)
     sc[j] = MFMA32_H(kf.k1, st[j].q1, sc[j]);
+#endif
   }
 }
 template <int QB>
 DEVI void finish_fast(f32x16 (&sc)[QB], const VFrag& vf, QState (&st)[QB]) {
 #pragma unroll
   for (int j = 0; j < QB; ++j) {
+#if !(BT_ATTN_EXPT & 3)
 #pragma unroll
     for (int r = 0; r < 16; ++r) sc[j][r] = __builtin_amdgcn_exp2f(sc[j][r]);
+#endif
+#if BT_ATTN_EXPT & 2
+    const u32x4 w0 = {__builtin_bit_cast(unsigned, sc[j][0]), __builtin_bit_cast(unsigned, sc[j][1]), __builtin_bit_cast(unsigned, sc[j][2]), __builtin_bit_cast(unsigned, sc[j][3])};
+    const u32x4 w1 = {__builtin_bit_cast(unsigned, sc[j][8]), __builtin_bit_cast(unsigned, sc[j][9]), __builtin_bit_cast(unsigned, sc[j][10]), __builtin_bit_cast(unsigned, sc[j][11])};
+#else
     const u32x4 w0 = pack8(sc[j], 0), w1 = pack8(sc[j], 1);
-#if BT_ATTN_ROWSUM == 1
+#endif
+#if BT_ATTN_EXPT & 4
+    st[j].l[0] += __builtin_bit_cast(float, w0[0]);
+#elif BT_ATTN_ROWSUM == 1
     rowsum16_valu(st[j].l, sc[j]);
 #else
     rowsum8(st[j].l, w0);
     rowsum8(st[j].l, w1);
 #endif
+#if BT_ATTN_EXPT & 64
+    st[j].acc = MFMA32_H(vf.v0, __builtin_bit_cast(hfx8, w0 ^ w1), st[j].acc);
+#else
     st[j].acc = MFMA32_H(vf.v0, __builtin_bit_cast(hfx8, w0), st[j].acc);
     st[j].acc = MFMA32_H(vf.v1, __builtin_bit_cast(hfx8, w1), st[j].acc);
+#endif
   }
 }
 
@@ -313,6 +347,7 @@ DEVI void attn_pass_pipe(rsrc_t rk, rsrc_t rv, char* smem, int tid, int wave, in
   const bool partial = (L & 31) != 0;
   int nfull = nblk / KB;  // tiles of KB unmasked blocks
   if (partial && nfull * KB == nblk) --nfull;
+  nfull = __builtin_amdgcn_readfirstlane(nfull);  // (hipcc kept the loop bound in a VGPR -- and spilled it across the loop)
   stage_tile(rk, rv, 0, smem, 0, tid, wave);
   __syncthreads();
   if (ntiles > 1) stage_tile(rk, rv, 1, smem, 1, tid, wave);
@@ -344,29 +379,59 @@ DEVI void attn_pass_pipe(rsrc_t rk, rsrc_t rv, char* smem, int tid, int wave, in
     KFrag kn = ld_k(smem, g, lr);
     score_fast<QB>(kn, st, sc);
     kn = ld_k(smem + BLK_BYTES, g, lr);
+#if BT_ATTN_EXPT & 8
+    const VFrag vf0 = ld_v(smem + TILE_BYTES, lane);
+#define LD_V(addr, lane) vf0
+#define LD_K(addr, g, lr) kn
+#else
+#define LD_V(addr, lane) ld_v(addr, lane)
+#define LD_K(addr, g, lr) ld_k(addr, g, lr)
+#endif
+    // BT_ATTN_VPRE = 1: the V fragments are read one block ahead like the K fragments (two V register sets).  Measured on
+    // one box against the default (tools/attn_ab.sh): main-layer shape 104.8 / 103.2 vs 108.9 / 105.0 us, frontend shape
+    // 237 / 235 vs 228 / 231 us, the x3 kernel 2 % slower -- the fragment reads cost LDS issue and energy (removing them
+    // entirely, BT_ATTN_EXPT = 8, is worth 30 %), not exposed latency.  Off.
+#ifndef BT_ATTN_VPRE
+#define BT_ATTN_VPRE 0
+#endif
+#if BT_ATTN_VPRE
+    VFrag vn = LD_V(smem + TILE_BYTES, lane);
+#endif
     for (int t = 0; t < nfull; ++t) {
       const char* kb = smem + (t & 1) * 2 * TILE_BYTES;
       const char* vb = kb + TILE_BYTES;
       const char* kb_next = smem + ((t + 1) & 1) * 2 * TILE_BYTES;
 #pragma unroll
       for (int c = 0; c < KB; ++c) {
-        const VFrag vf = ld_v(vb + c * BLK_BYTES, lane);
+#if BT_ATTN_VPRE
+        const VFrag vf = vn;
+#else
+        const VFrag vf = LD_V(vb + c * BLK_BYTES, lane);
+#endif
         if (c + 1 < KB) {
           f32x16 sn[QB];
+#if BT_ATTN_VPRE
+          vn = LD_V(vb + (c + 1) * BLK_BYTES, lane);
+#endif
           score_fast<QB>(kn, st, sn);
-          if (c + 2 < KB) kn = ld_k(kb + (c + 2) * BLK_BYTES, g, lr);
+          if (c + 2 < KB) kn = LD_K(kb + (c + 2) * BLK_BYTES, g, lr);
           __builtin_amdgcn_sched_barrier(0);
           finish_fast<QB>(sc, vf, st);
 #pragma unroll
           for (int j = 0; j < QB; ++j) sc[j] = sn[j];
         } else {
-          __syncthreads();  // tile t+1 has landed; nobody reads tile t any more (vf above has arrived)
+#if !(BT_ATTN_EXPT & 16)
+          __syncthreads();  // tile t+1 has landed; nobody reads tile t any more (every fragment read of it has arrived)
           if (t + 2 < ntiles) stage_tile(rk, rv, t + 2, smem, t & 1, tid, wave);
+#endif
           const bool more = t + 1 < nfull;  // (uniform)
           KFrag k0n = kn;
           if (more) {
-            k0n = ld_k(kb_next, g, lr);
-            kn = ld_k(kb_next + BLK_BYTES, g, lr);
+            k0n = LD_K(kb_next, g, lr);
+            kn = LD_K(kb_next + BLK_BYTES, g, lr);
+#if BT_ATTN_VPRE
+            vn = LD_V(kb_next + TILE_BYTES, lane);
+#endif
           }
           __builtin_amdgcn_sched_barrier(0);
           finish_fast<QB>(sc, vf, st);
@@ -379,14 +444,15 @@ DEVI void attn_pass_pipe(rsrc_t rk, rsrc_t rv, char* smem, int tid, int wave, in
     const char* kb = smem + (nfull & 1) * 2 * TILE_BYTES;
     const char* vb = kb + TILE_BYTES;
     const int nb = nblk - nfull * KB;
+    const int lane2 = lane_id_fresh(), g2 = lane2 >> 5, lr2 = lane2 & 31;  // (not kept live across the key loop)
     for (int c = 0; c < nb; ++c) {
       const int blk = nfull * KB + c;
-      const VFrag vf = ld_v(vb + c * BLK_BYTES, lane);
-      const KFrag kf = ld_k(kb + c * BLK_BYTES, g, lr);
+      const VFrag vf = ld_v(vb + c * BLK_BYTES, lane2);
+      const KFrag kf = ld_k(kb + c * BLK_BYTES, g2, lr2);
       if (partial && blk == nblk - 1)
-        do_block<false, true, QB>(kf, vf, g, st, blk * 32, L);
+        do_block<false, true, QB>(kf, vf, g2, st, blk * 32, L);
       else
-        do_block<false, false, QB>(kf, vf, g, st, blk * 32, L);
+        do_block<false, false, QB>(kf, vf, g2, st, blk * 32, L);
     }
   }
   __syncthreads();
@@ -403,15 +469,15 @@ __global__ __launch_bounds__(256, (QB == 1 ? 4 : 2)) void attn_frag_kernel(const
   const int sh = (idx / nqt) * 8 + (bid & 7);
   const int qt = idx % nqt;
   if (sh >= sh_total) return;
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // (wave index in an SGPR: uniform index math stays scalar)
-  const int g = lane >> 5, lr = lane & 31;
+  const int tid0 = threadIdx.x, lane0 = tid0 & 63, wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);  // (wave index in an SGPR: uniform index math stays scalar)
+  const int g0 = lane0 >> 5, lr0 = lane0 & 31;
   const int L = p.L;
   const int nblk = (L + 31) >> 5;
   const long seq_off = (long)sh * p.nbp * BLK_BYTES;
   const char* kseq = reinterpret_cast<const char*>(p.k) + seq_off;
   const char* vseq = reinterpret_cast<const char*>(p.v) + seq_off;
   int* flag = reinterpret_cast<int*>(smem + 4 * TILE_BYTES);
-  if (tid == 0) *flag = 0;
+  if (tid0 == 0) *flag = 0;
 
   QState st[QB];
   const int qb0 = (qt * 4 + wave) * QB;  // this wave's first query block
@@ -419,15 +485,17 @@ __global__ __launch_bounds__(256, (QB == 1 ? 4 : 2)) void attn_frag_kernel(const
   for (int j = 0; j < QB; ++j) {
     const int qbc = min(qb0 + j, nblk - 1);
     const char* qblk = reinterpret_cast<const char*>(p.q) + seq_off + (long)qbc * BLK_BYTES;
-    st[j].q0 = *reinterpret_cast<const hfx8*>(qblk + ((2 * g) * 32 + lr) * 16);
-    st[j].q1 = *reinterpret_cast<const hfx8*>(qblk + ((2 * g + 1) * 32 + lr) * 16);
+    st[j].q0 = *reinterpret_cast<const hfx8*>(qblk + ((2 * g0) * 32 + lr0) * 16);
+    st[j].q1 = *reinterpret_cast<const hfx8*>(qblk + ((2 * g0 + 1) * 32 + lr0) * 16);
   }
   const unsigned seq_bytes = (unsigned)p.nbp * BLK_BYTES;
   const rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(kseq), 0, seq_bytes, 0x00020000);
   const rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(vseq), 0, seq_bytes, 0x00020000);
   const long long tc0 = clock64(), tw0 = wall_clock64();
   long long t_loop = tw0;
-  attn_pass_pipe<QB>(rk, rv, smem, tid, wave, lane, g, lr, st, L, nblk, (ABL & 128) ? &t_loop : nullptr);
+  attn_pass_pipe<QB>(rk, rv, smem, tid0, wave, lane0, g0, lr0, st, L, nblk, (ABL & 128) ? &t_loop : nullptr);
+  // (lane-derived values again: nothing but the softmax state stays live across the key loop)
+  const int lane = lane_id_fresh(), tid = wave * 64 + lane, g = lane >> 5, lr = lane & 31;
   if constexpr ((ABL & 128) != 0) {  // development: shader-clock ticks vs 100 MHz wall ticks of the pass
     if (lane == 0) {
       long long* dbg = reinterpret_cast<long long*>(const_cast<float*>(p.gates));
@@ -443,7 +511,7 @@ __global__ __launch_bounds__(256, (QB == 1 ? 4 : 2)) void attn_frag_kernel(const
   for (int j = 0; j < QB; ++j) {
     l_tot[j] = st[j].l[0] + __shfl_xor(st[j].l[0], 32);
     const bool valid = qb0 + j < nblk && (qb0 + j) * 32 + lr < L;
-    bad = bad || (valid && !(l_tot[j] < 1e30f));  // overflow / NaN: this query needs the running-max pass
+    bad = bad || (valid && !(l_tot[j] < L_OVERFLOW));  // overflow / NaN: this query needs the running-max pass
   }
   if (__any(bad) && lane == 0) *flag = 1;
   __syncthreads();
@@ -701,23 +769,39 @@ DEVI void attn_fast_x(rsrc_t rk, rsrc_t rv, char* smem, int tid, int wave, int l
   }
   // (one query block per wave: the scores of block 0 of tile 0 again, now on the reference maximum)
   if (QB == 1 && nfull > 0) score_x<true, QB>(kf, st, s2[0]);
+  // (the V fragments are read one block ahead, like the K fragments: two V register sets)
+#if BT_ATTN_VPRE
+  VFragX vn = ld_vx(smem + TILEX_BYTES, lane);
+#endif
   for (int t = 0; t < nfull; ++t) {
     const char* kb = smem + (t & 1) * 2 * TILEX_BYTES;
     const char* vb = kb + TILEX_BYTES;
     const char* kb_next = smem + ((t + 1) & 1) * 2 * TILEX_BYTES;
 #pragma unroll
     for (int c = 0; c < KBX; ++c) {
+#if BT_ATTN_VPRE
+      const VFragX vf = vn;
+#else
       const VFragX vf = ld_vx(vb + c * BLKX_BYTES, lane);
+#endif
       const int cur = PIPE ? (c & 1) : 0, nxt = PIPE ? ((c + 1) & 1) : 0;
       bool have_next = true;
       if (c + 1 < KBX) {
         kf = ld_kx(kb + (c + 1) * BLKX_BYTES, g, lr);
+#if BT_ATTN_VPRE
+        vn = ld_vx(vb + (c + 1) * BLKX_BYTES, lane);
+#endif
       } else {
-        // the tile's last fragment reads are issued (vf) / have arrived (kf): barrier, refill, first block of tile t + 1
+        // every fragment read of tile t has arrived (the barrier's wait): barrier, refill, first block of tile t + 1
         __syncthreads();  // tile t + 1 has landed in every wave; nobody reads tile t any more
         if (t + 2 < ntiles) stage_tile_x<KBX>(rk, rv, t + 2, smem, t & 1, tid, wave);
         have_next = t + 1 < nfull;  // (uniform)
-        if (have_next) kf = ld_kx(kb_next, g, lr);
+        if (have_next) {
+          kf = ld_kx(kb_next, g, lr);
+#if BT_ATTN_VPRE
+          vn = ld_vx(kb_next + TILEX_BYTES, lane);
+#endif
+        }
       }
       if (PIPE && have_next) score_x<true, QB>(kf, st, s2[nxt]);
       finish_x<false, false, QB>(s2[cur], vf, g, st, 0, L);

@@ -19,8 +19,9 @@ namespace {
 // read needs no s_barrier -- only that the compiler keeps the order (it must: the accesses may alias) and does not move
 // them across the stage boundary.  Through round 2 each of the six exchanges was a workgroup-wide __syncthreads() that
 // made four unrelated frames wait for each other; removing them changed nothing measurable (0.308 vs 0.311 ms for 6 x 300 s):
-// the kernel is bound by its ~1700 VALU instructions per frame (598 of them the FFT's arithmetic; precise sqrtf / log1pf
-// expansions, 64-bit reflect index math and the variable-length mel loop are the rest), 24 waves per CU hide every wait.
+// the kernel is bound by its VALU instructions per frame (~1700 then, 598 of them the FFT's arithmetic; precise sqrtf /
+// log1pf expansions, 64-bit reflect index math and a one-tap-per-iteration mel loop were the rest and are gone since),
+// 24 waves per CU hide every wait.
 #define WAVE_SYNC() __builtin_amdgcn_wave_barrier()
 
 struct cplx { float re, im; };
@@ -72,16 +73,31 @@ __global__ __launch_bounds__(256) void logmel_kernel(const LogmelP p) {
   const long s0 = (active ? frame : 0) * 441 - 512;
 
   // ---- load + window: lane holds z[64 a + lane], z[n] = x[2n] + i x[2n+1] -------------
+  // Interior frames (all but the first two and the last two of a track; wave-uniform test): the 1024 samples are one
+  // contiguous run, 32-bit indices, one 8-byte load per complex value (4-byte aligned: s0 is odd for odd frames).  Edge
+  // frames take the reflecting path (center=True, pad_mode="reflect").
+  typedef float f32x2u __attribute__((ext_vector_type(2), aligned(4)));
   cplx x[8];
+  if (s0 >= 0 && s0 + 1024 <= N) {
+    const float* __restrict__ a0 = audio + s0 + 2 * lane;
 #pragma unroll
-  for (int a = 0; a < 8; ++a) {
-    const int n = 64 * a + lane;
-    long j0 = s0 + 2 * n, j1 = j0 + 1;
-    j0 = j0 < 0 ? -j0 : (j0 >= N ? 2 * (N - 1) - j0 : j0);
-    j1 = j1 < 0 ? -j1 : (j1 >= N ? 2 * (N - 1) - j1 : j1);
-    const f32x2 w = *reinterpret_cast<const f32x2*>(p.window + 2 * n);
-    x[a].re = audio[j0] * w.x;
-    x[a].im = audio[j1] * w.y;
+    for (int a = 0; a < 8; ++a) {
+      const f32x2 w = *reinterpret_cast<const f32x2*>(p.window + 128 * a + 2 * lane);
+      const f32x2u v = *reinterpret_cast<const f32x2u*>(a0 + 128 * a);
+      x[a].re = v.x * w.x;
+      x[a].im = v.y * w.y;
+    }
+  } else {
+#pragma unroll
+    for (int a = 0; a < 8; ++a) {
+      const int n = 64 * a + lane;
+      long j0 = s0 + 2 * n, j1 = j0 + 1;
+      j0 = j0 < 0 ? -j0 : (j0 >= N ? 2 * (N - 1) - j0 : j0);
+      j1 = j1 < 0 ? -j1 : (j1 >= N ? 2 * (N - 1) - j1 : j1);
+      const f32x2 w = *reinterpret_cast<const f32x2*>(p.window + 2 * n);
+      x[a].re = audio[j0] * w.x;
+      x[a].im = audio[j1] * w.y;
+    }
   }
   // ---- stage 1: DFT over a; lane = (b, c) = (lane >> 3, lane & 7) -----------------------
   dft8(x);
@@ -139,6 +155,9 @@ __global__ __launch_bounds__(256) void logmel_kernel(const LogmelP p) {
   }
   WAVE_SYNC();
   // ---- split step: X[k], k = 0..512, magnitude / sqrt(1024) --------------------------------
+  // (v_sqrt_f32 / v_log_f32 below are the 1-ulp hardware forms: the precise sqrtf / log1pf expansions were 200 of the
+  // kernel's instructions per frame; log(1 + y) loses nothing that matters for y >= 0 -- its absolute error is one rounding
+  // of 1 + y, 6e-8)
 #pragma unroll
   for (int j = 0; j < 9; ++j) {
     const int k = lane + 64 * j;
@@ -150,19 +169,30 @@ __global__ __launch_bounds__(256) void logmel_kernel(const LogmelP p) {
       const f32x2 t = tw[576 + k];  // (cos, -sin)
       const float xr = er + (t.x * oi + t.y * orr);
       const float xi = ei - (t.x * orr - t.y * oi);
-      mag[k] = sqrtf(xr * xr + xi * xi) * 0.03125f;
+      mag[k] = __builtin_amdgcn_sqrtf(xr * xr + xi * xi) * 0.03125f;
+    } else if (k < 520) {
+      mag[k] = 0.f;  // (the mel loop reads whole groups of four bins: up to three past a filter's last one, times weight 0)
     }
   }
   WAVE_SYNC();
   // ---- banded mel projection + log1p(1000 x) ------------------------------------------------
+  // four taps per iteration: one 16-byte load of the filter's weight row (zero beyond its length), four LDS reads
   if (active) {
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const int m = lane + 64 * h;
       const int st = p.mel_start[m], len = p.mel_len[m];
+      const f32x4* wrow = reinterpret_cast<const f32x4*>(p.mel_w + m * 32);
+      const float* mg = mag + st;
       float acc = 0.f;
-      for (int i = 0; i < len; ++i) acc = fmaf(mag[st + i], p.mel_w[m * 32 + i], acc);
-      p.spect[(tr.out_off + frame) * 128 + m] = log1pf(1000.0f * acc);
+      for (int i = 0; i < len; i += 4) {
+        const f32x4 w = wrow[i >> 2];
+        acc = fmaf(mg[i], w[0], acc);
+        acc = fmaf(mg[i + 1], w[1], acc);
+        acc = fmaf(mg[i + 2], w[2], acc);
+        acc = fmaf(mg[i + 3], w[3], acc);
+      }
+      p.spect[(tr.out_off + frame) * 128 + m] = __builtin_amdgcn_logf(fmaf(1000.0f, acc, 1.0f)) * 0.69314718055994531f;
     }
   }
 }

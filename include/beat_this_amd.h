@@ -146,7 +146,7 @@ typedef struct {
   const float* twiddle;  /* [1089][2]  (see csrc/logmel.hip) */
   const int32_t* mel_start; /* [128] first FFT bin of each mel filter */
   const int32_t* mel_len;   /* [128] */
-  const float* mel_w;       /* [128][32] */
+  const float* mel_w;       /* [128][32], 16-byte aligned; a row is ZERO beyond the filter's mel_len (the kernel reads it four taps at a time) */
 } bt_logmel_tables;
 
 const char* bt_last_error(void);

@@ -17,11 +17,11 @@ nbp = _lib.lib().bt_attn_frag_blocks(L)
 for name, n_seq, heads in (("front", 512, 1), ("main", 16, 16)):
     SH = n_seq * heads
     g = torch.Generator(device="cpu").manual_seed(0)
-    q = (torch.randn((SH, nbp, 1024), generator=g) * 0.6).to(torch.bfloat16).to(dev)
-    k = torch.randn((SH, nbp, 1024), generator=g).to(torch.bfloat16).to(dev)
-    v = torch.randn((SH, nbp, 1024), generator=g).to(torch.bfloat16).to(dev)
+    q = (torch.randn((SH, nbp, 1024), generator=g) * 0.3).to(torch.float16).to(dev)
+    k = torch.randn((SH, nbp, 1024), generator=g).to(torch.float16).to(dev)
+    v = torch.randn((SH, nbp, 1024), generator=g).to(torch.float16).to(dev)
     gates = torch.rand((SH, nbp * 32), generator=g).to(dev)
-    out = torch.zeros((n_seq * L, heads * 32), dtype=torch.bfloat16, device=dev)
+    out = torch.zeros((n_seq * L, heads * 32), dtype=torch.float16, device=dev)
     a = _lib.AttnFragArgs()
     a.q, a.k, a.v, a.gates, a.out = q.data_ptr(), k.data_ptr(), v.data_ptr(), gates.data_ptr(), out.data_ptr()
     a.n_seq, a.L, a.heads, a.inner, a.nbp, a.o_div = n_seq, L, heads, heads * 32, nbp, 1

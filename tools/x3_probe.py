@@ -3,7 +3,7 @@
   * attention variants of csrc/attn2.hip (bt_attn_frag_args.x3 = 1 / 2 / 3) on the main-layer and frontend shapes, with
     a bit-for-bit comparison of the variants' results;
   * the hl32 GEMM of csrc/gemm3.hip on the main-layer shapes (QKV, out-projection, FF1, FF2) and frontend.linear.
-    python tools/x3_probe.py [chunks]"""
+    python tools/x3_probe.py [chunks] [attn]"""
 import ctypes as C
 import os
 import sys
@@ -100,6 +100,8 @@ T = 1500
 attention(B, 16, T, f"main layer ({B} chunks x 16 heads)")
 attention(B * 32, 1, T, f"frontend block 0 ({B * 32} sequences x 1 head)")
 attention(B * 8, 4, T, f"frontend block 2 ({B * 8} sequences x 4 heads)")
+if len(sys.argv) > 2 and sys.argv[2] == "attn":
+    sys.exit(0)
 M = B * T
 gemm(M, 512, 3 * 512 + 16, 2, "QKV", heads=16, n_seq=B, Lq=T)
 for f in (3, 2):
