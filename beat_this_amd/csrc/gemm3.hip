@@ -277,13 +277,36 @@ void gemm3_kernel(const Gemm3P p, int n_tiles, int total_tiles, int per_xcd, int
     for (int q = 0; q < 8; ++q)
       part[j][q] = (EPI != G3_RESID && p.ssq_in && trow[j] >= 0 && q < p.ssq_parts) ? p.ssq_in[(long)q * p.M + trow[j]] : 0.f;
   }
+  // FF1: this lane's bias values (MFMA layout: 4-feature runs 8 q + 4 g of each 32-feature block), requested here for the
+  // same reason -- in the epilogue each block's four loads were a memory round trip in front of its GELU
+  f32x4 bqv[EPI == G3_FF1 ? FB : 1][4];
+  if constexpr (EPI == G3_FF1) {
+#pragma unroll
+    for (int a = 0; a < FB; ++a)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) bqv[a][q] = *reinterpret_cast<const f32x4*>(p.bias + n0 + wn * 64 + a * 32 + 8 * q + 4 * g);
+  }
+  // QKV, q / k tiles: (cos, sin) of this lane's token for its pairs 4 q + 2 g, + 1 (the same for every head), likewise
+  f32x4 csv[EPI == G3_QKV ? TB : 1][4];
+  if constexpr (EPI == G3_QKV) {
+    if (kind < 2) {
+#pragma unroll
+      for (int b = 0; b < TB; ++b)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          csv[b][q] = tseq[b] < p.n_seq ? *reinterpret_cast<const f32x4*>(p.rope + ((long)(tblk[b] * 32 + lr) * 16 + 4 * q + 2 * g) * 2)
+                                        : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
   constexpr int LPS = APC + WPC;  // LDS-DMA instructions per thread and k-step
 #pragma unroll
   for (int s0 = 0; s0 < NST - 1; ++s0)
     if (s0 < nk) G3_ISSUE(s0, s0);
-  if (EPI != G3_RESID && p.ssq_in) {
+  if (EPI == G3_FF1 || EPI == G3_QKV || (EPI != G3_RESID && p.ssq_in)) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
+  }
+  if (EPI != G3_RESID && p.ssq_in) {
 #pragma unroll
     for (int j = 0; j < TB; ++j) {
       float sum = 0.f;
@@ -377,12 +400,9 @@ void gemm3_kernel(const Gemm3P p, int n_tiles, int total_tiles, int per_xcd, int
     for (int b = 0; b < TB; ++b) {
 #pragma unroll
       for (int a = 0; a < FB; ++a) {
-        f32x4 bq[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) bq[q] = *reinterpret_cast<const f32x4*>(p.bias + nb0 + a * 32 + 8 * q + 4 * g);
         float v[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) v[r] = gelu_erf(fmaf(acc[a][b][r], rs[b], bq[r >> 2][r & 3]));
+        for (int r = 0; r < 16; ++r) v[r] = gelu_erf(fmaf(acc[a][b][r], rs[b], bqv[a][r >> 2][r & 3]));
         u32x4 hi[2], lo[2];
         pack_row_hl(v, hi, lo, amax);
 #pragma unroll
@@ -407,13 +427,10 @@ void gemm3_kernel(const Gemm3P p, int n_tiles, int total_tiles, int per_xcd, int
     for (int b = 0; b < TB; ++b) {
 #pragma unroll
       for (int a = 0; a < FB; ++a) {
-        f32x4 bq[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) bq[q] = *reinterpret_cast<const f32x4*>(p.bias + nb0 + a * 32 + 8 * q + 4 * g);
         float v[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const float u = fmaf(acc[a][b][r], rs[b], bq[r >> 2][r & 3]);
+          const float u = fmaf(acc[a][b][r], rs[b], bqv[a][r >> 2][r & 3]);
           v[r] = (ABL & 2) ? u : gelu_tanh(u);
         }
         u32x4 piece[2];
@@ -525,10 +542,7 @@ void gemm3_kernel(const Gemm3P p, int n_tiles, int total_tiles, int per_xcd, int
 #pragma unroll
       for (int b = 0; b < TB; ++b) {
         if (tseq[b] >= p.n_seq) continue;  // wave-uniform
-        const int pos = tblk[b] * 32 + lr;
-        f32x4 cs[4];  // (cos, sin) of this token's pairs 4 q + 2 g, +1: the same for every head, requested up front
-#pragma unroll
-        for (int q = 0; q < 4; ++q) cs[q] = *reinterpret_cast<const f32x4*>(p.rope + ((long)pos * 16 + 4 * q + 2 * g) * 2);
+        const f32x4 (&cs)[4] = csv[b];  // (cos, sin) of this token's pairs 4 q + 2 g, +1: loaded before the k-loop
 #pragma unroll
         for (int a = 0; a < FB; ++a) {
           const int head = (n0 - kind * p.inner + wn * 64 + a * 32) >> 5;
@@ -676,6 +690,7 @@ int launch_gemm3(const Gemm3P& p, hipStream_t s) {
   if (p.x3) {
 #ifdef BT_DEV
     // development: ablations of the x3 kernel (results are garbage): BT_G3_ABL = 1 no LDS-DMA after the prologue, 4 no MFMAs
+    if (abl == 8 && p.epi == G3_FF1) { launch_cfg<G3_FF1, G3CfgSX, true, 8>(p, s); return (int)hipGetLastError(); }
     if (abl == 1 || abl == 4) {
       const bool b = big || rows192;
       if (p.epi == G3_FF1) { if (abl == 1) { if (b) launch_cfg<G3_FF1, G3CfgBX, true, 1>(p, s); else launch_cfg<G3_FF1, G3CfgSX, true, 1>(p, s); }

@@ -14,7 +14,7 @@ M, D = 24000, 512
 g = torch.Generator().manual_seed(0)
 
 
-def rnd(*shape, scale=1.0, dtype=torch.bfloat16):
+def rnd(*shape, scale=1.0, dtype=torch.float16):
     return (torch.randn(shape, generator=g) * scale).to(dtype).to(dev)
 
 
@@ -39,7 +39,7 @@ ssq = torch.rand((D // 64, M), generator=g).to(dev) * 64
 xf = torch.randn((M, D), generator=g).to(dev)
 if "ff1" in which:
     a = _lib.Gemm3Args()
-    W, b, out = rnd(4 * D, D, scale=0.05), rnd(4 * D, dtype=torch.float32), torch.empty((M, 4 * D), dtype=torch.bfloat16, device=dev)
+    W, b, out = rnd(4 * D, D, scale=0.05), rnd(4 * D, dtype=torch.float32), torch.empty((M, 4 * D), dtype=torch.float16, device=dev)
     a.A, a.lda, a.M, a.K, a.W, a.N, a.epi = x.data_ptr(), D, M, D, W.data_ptr(), 4 * D, 0
     a.bias, a.ssq_in, a.ssq_parts, a.out, a.ldo = b.data_ptr(), ssq.data_ptr(), D // 64, out.data_ptr(), 4 * D
     if os.environ.get("BT_G3_ABL") == "8":
@@ -54,7 +54,7 @@ if "ff1" in which:
 if "ff2" in which:
     a = _lib.Gemm3Args()
     h, W, b = rnd(M, 4 * D), rnd(D, 4 * D, scale=0.02), rnd(D, dtype=torch.float32)
-    xb, so = torch.empty((M, D), dtype=torch.bfloat16, device=dev), torch.empty((D // 64, M), device=dev)
+    xb, so = torch.empty((M, D), dtype=torch.float16, device=dev), torch.empty((D // 64, M), device=dev)
     a.A, a.lda, a.M, a.K, a.W, a.N, a.epi = h.data_ptr(), 4 * D, M, 4 * D, W.data_ptr(), D, 1
     a.bias, a.x, a.ldx, a.xb, a.ssq_out = b.data_ptr(), xf.data_ptr(), D, xb.data_ptr(), so.data_ptr()
     if os.environ.get("BT_G3_ABL") == "8":
@@ -69,7 +69,7 @@ if "ff2" in which:
 if "out" in which:
     a = _lib.Gemm3Args()
     W = rnd(D, D, scale=0.02)
-    xb, so = torch.empty((M, D), dtype=torch.bfloat16, device=dev), torch.empty((D // 64, M), device=dev)
+    xb, so = torch.empty((M, D), dtype=torch.float16, device=dev), torch.empty((D // 64, M), device=dev)
     a.A, a.lda, a.M, a.K, a.W, a.N, a.epi = x.data_ptr(), D, M, D, W.data_ptr(), D, 1
     a.x, a.ldx, a.xb, a.ssq_out = xf.data_ptr(), D, xb.data_ptr(), so.data_ptr()
     timeit("out (N=512,K=512)", a, 2.0 * M * D * D)
@@ -80,7 +80,7 @@ if "qkv" in which:
     nbp = _lib.lib().bt_attn_frag_blocks(L)
     W = rnd(3 * D + 128, D, scale=0.05)
     rope = torch.from_numpy(rope_table(10000.0 ** (-torch.arange(0, 32, 2).float() / 32))).to(dev)
-    qf = torch.empty((B * H, nbp, 1024), dtype=torch.bfloat16, device=dev)
+    qf = torch.empty((B * H, nbp, 1024), dtype=torch.float16, device=dev)
     kf, vf = torch.empty_like(qf), torch.empty_like(qf)
     gh, bg = torch.empty((B * H, nbp * 32), device=dev), rnd(H, dtype=torch.float32)
     a.A, a.lda, a.M, a.K, a.W, a.N, a.epi = x.data_ptr(), D, M, D, W.data_ptr(), 3 * D + H, 2
@@ -88,26 +88,19 @@ if "qkv" in which:
     a.rope, a.qf, a.kf, a.vf, a.gates, a.b_gates = rope.data_ptr(), qf.data_ptr(), kf.data_ptr(), vf.data_ptr(), gh.data_ptr(), bg.data_ptr()
     a.M = B * L
     timeit(f"qkv (N=1552,K=512,B={B})", a, 2.0 * B * L * D * (3 * D + H))
-if "ff1_f8" in which or "ff2_f8" in which:
-    F8 = torch.float8_e4m3fn
-    x8 = (torch.randn((M, D), generator=g)).to(F8).view(torch.uint8).to(dev)
-    asc = torch.ones((M,), device=dev)
-if "ff1_f8" in which:
+if "ff1x3" in which:   # BT_PREC_F32X3 FF1 (hl32 operands); BT_G3_ABL=8 on a -DBT_DEV build dumps the per-wave timing
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
+    from gpu_util import pad_rows, to_hl32
     a = _lib.Gemm3Args()
-    W = (torch.randn((4 * D, D), generator=g) * 20).to(F8).view(torch.uint8).to(dev)
-    b, wsc = rnd(4 * D, dtype=torch.float32), torch.full((4 * D,), 0.002, device=dev)
-    out = torch.empty((M, 4 * D), dtype=torch.uint8, device=dev)
-    a.A, a.lda, a.M, a.K, a.W, a.N, a.epi = x8.data_ptr(), D, M, D, W.data_ptr(), 4 * D, 0
-    a.bias, a.ssq_in, a.ssq_parts, a.out, a.ldo = b.data_ptr(), ssq.data_ptr(), D // 64, out.data_ptr(), 4 * D
-    a.f8, a.wscale, a.ascale = 1, wsc.data_ptr(), asc.data_ptr()
-    timeit("ff1 e4m3 (N=2048,K=512)", a, 2.0 * M * D * 4 * D)
-if "ff2_f8" in which:
-    a = _lib.Gemm3Args()
-    h = (torch.randn((M, 4 * D), generator=g)).to(F8).view(torch.uint8).to(dev)
-    W = (torch.randn((D, 4 * D), generator=g) * 20).to(F8).view(torch.uint8).to(dev)
-    b, wsc = rnd(D, dtype=torch.float32), torch.full((1,), 0.001, device=dev)
-    xb, so = torch.empty((M, D), dtype=torch.bfloat16, device=dev), torch.empty((D // 64, M), device=dev)
-    a.A, a.lda, a.M, a.K, a.W, a.N, a.epi = h.data_ptr(), 4 * D, M, 4 * D, W.data_ptr(), D, 1
-    a.bias, a.x, a.ldx, a.xb, a.ssq_out = b.data_ptr(), xf.data_ptr(), D, xb.data_ptr(), so.data_ptr()
-    a.f8, a.wscale = 1, wsc.data_ptr()
-    timeit("ff2 e4m3 (N=512,K=2048)", a, 2.0 * M * D * 4 * D)
+    A3 = to_hl32(torch.randn((M, D), generator=g)).to(dev)
+    W3 = to_hl32(pad_rows(torch.randn((4 * D, D), generator=g) / D ** 0.5, 256)).to(dev)
+    b3, out3 = torch.zeros(4 * D, device=dev), torch.empty((M, 8 * D), dtype=torch.float16, device=dev)
+    dbg3 = torch.ones((8 * 1024 * 1024,), device=dev)
+    a.A, a.lda, a.M, a.K, a.W, a.N, a.epi, a.x3 = A3.data_ptr(), D, M, D, W3.data_ptr(), 4 * D, 0, 3
+    a.bias, a.ssq_in, a.ssq_parts, a.out, a.ldo = b3.data_ptr(), dbg3.data_ptr(), D // 64, out3.data_ptr(), 4 * D
+    timeit("ff1 x3 (N=2048,K=512)", a, 2.0 * M * D * 4 * D)
+    if os.environ.get("BT_G3_ABL") == "8":
+        torch.cuda.synchronize()
+        nw = 3008 * 4
+        d = dbg3.view(torch.int64)[: nw * 4].view(-1, 4).cpu().double()
+        print(f"   per wave: loop {d[:,0].mean():.0f} cyc (vmcnt wait {d[:,1].mean():.0f}, barrier {d[:,2].mean():.0f}), epilogue {d[:,3].mean():.0f}")
