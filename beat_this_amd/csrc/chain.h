@@ -18,21 +18,26 @@ template <> DEVI Frag<hf> ldg_frag<hf>(const hf* p) {
   return f;
 }
 
-// an fp32 activation -> the (hi, lo) half pair of Frag<hl> (pre-scaled, common.h: OpScale): element j of half-fragment h
-DEVI void split_hl(Frag<hl>& f, int h, int j, float v) {
-  v *= OpScale<hl>::ACT;
-  const hf hi = (hf)v;
-  f.v[h][j] = hi;
-  f.v[2 + h][j] = (hf)(v - (float)hi);
+// eight fp32 activations -> half-fragment h of Frag<hl>: the (hi, lo) half pairs, pre-scaled (common.h: OpScale), on the
+// three-instructions-per-pair split of common.h (split_hl4)
+DEVI void split_hl8(Frag<hl>& f, int h, const float (&v)[8]) {
+  typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+  unsigned hi[4], lo[4];
+#pragma unroll
+  for (int j = 0; j < 4; j += 2)
+    split_hl4(v[2 * j] * OpScale<hl>::ACT, v[2 * j + 1] * OpScale<hl>::ACT, v[2 * j + 2] * OpScale<hl>::ACT,
+              v[2 * j + 3] * OpScale<hl>::ACT, hi[j], lo[j], hi[j + 1], lo[j + 1]);
+  f.v[h] = __builtin_bit_cast(hfx8, u32x4{hi[0], hi[1], hi[2], hi[3]});
+  f.v[2 + h] = __builtin_bit_cast(hfx8, u32x4{lo[0], lo[1], lo[2], lo[3]});
 }
 template <> DEVI Frag<hl> ldg_frag<hl>(const hl* p) {   // (memory holds fp32: hl is the operand type, not a storage type)
   Frag<hl> f;
   const f32x4* q = reinterpret_cast<const f32x4*>(p);
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const f32x4 v = q[i];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) split_hl(f, i >> 1, 4 * (i & 1) + j, v[j]);
+  for (int h = 0; h < 2; ++h) {
+    const f32x4 a = q[2 * h], b = q[2 * h + 1];
+    const float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    split_hl8(f, h, v);
   }
   return f;
 }
@@ -70,13 +75,13 @@ template <> DEVI Frag<hf> ldx_frag<hf>(const float* p, bool ok, float& ss) {
 template <> DEVI Frag<hl> ldx_frag<hl>(const float* p, bool ok, float& ss) {
   Frag<hl> f;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const f32x4 v = ok ? reinterpret_cast<const f32x4*>(p)[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int h = 0; h < 2; ++h) {
+    const f32x4 a = ok ? reinterpret_cast<const f32x4*>(p)[2 * h] : f32x4{0.f, 0.f, 0.f, 0.f};
+    const f32x4 b = ok ? reinterpret_cast<const f32x4*>(p)[2 * h + 1] : f32x4{0.f, 0.f, 0.f, 0.f};
+    const float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      ss = fmaf(v[j], v[j], ss);
-      split_hl(f, i >> 1, 4 * (i & 1) + j, v[j]);
-    }
+    for (int j = 0; j < 8; ++j) ss = fmaf(v[j], v[j], ss);
+    split_hl8(f, h, v);
   }
   return f;
 }
@@ -101,9 +106,10 @@ template <> DEVI Frag<hf> pack_frag<hf>(const float (&h)[16]) {
 template <> DEVI Frag<hl> pack_frag<hl>(const float (&h)[16]) {
   Frag<hl> f;
 #pragma unroll
-  for (int s = 0; s < 2; ++s)
-#pragma unroll
-    for (int j = 0; j < 8; ++j) split_hl(f, s, j, h[8 * s + j]);
+  for (int s = 0; s < 2; ++s) {
+    const float v[8] = {h[8 * s], h[8 * s + 1], h[8 * s + 2], h[8 * s + 3], h[8 * s + 4], h[8 * s + 5], h[8 * s + 6], h[8 * s + 7]};
+    split_hl8(f, s, v);
+  }
   return f;
 }
 
