@@ -972,6 +972,8 @@ int launch_attn_frag(const AttnFragP& p, hipStream_t s) {
   // development builds only: BT_ATTN_ABL=128 dumps per-wave phase timings over the gates buffer (tools/attn_probe.py)
   static const int abl = getenv("BT_ATTN_ABL") ? atoi(getenv("BT_ATTN_ABL")) : 0;
   if (abl == 128) { launch_v<128, 1>(p, s); return (int)hipGetLastError(); }
+  static const int qb = getenv("BT_ATTN_QB") ? atoi(getenv("BT_ATTN_QB")) : 1;   // two query blocks per wave (A/B only)
+  if (qb == 2) { launch_v<0, 2>(p, s); return (int)hipGetLastError(); }
 #endif
   launch_v<0, 1>(p, s);
   return (int)hipGetLastError();
