@@ -387,32 +387,18 @@ DEVI void attn_pass_pipe(rsrc_t rk, rsrc_t rv, char* smem, int tid, int wave, in
 #define LD_V(addr, lane) ld_v(addr, lane)
 #define LD_K(addr, g, lr) ld_k(addr, g, lr)
 #endif
-    // BT_ATTN_VPRE = 1: the V fragments are read one block ahead like the K fragments (two V register sets).  Measured on
-    // one box against the default (tools/attn_ab.sh): main-layer shape 104.8 / 103.2 vs 108.9 / 105.0 us, frontend shape
-    // 237 / 235 vs 228 / 231 us, the x3 kernel 2 % slower -- the fragment reads cost LDS issue and energy (removing them
-    // entirely, BT_ATTN_EXPT = 8, is worth 30 %), not exposed latency.  Off.
-#ifndef BT_ATTN_VPRE
-#define BT_ATTN_VPRE 0
-#endif
-#if BT_ATTN_VPRE
-    VFrag vn = LD_V(smem + TILE_BYTES, lane);
-#endif
+    // (Reading the V fragments one block ahead as well -- a second V register set, 127 VGPRs -- was measured and dropped:
+    // main-layer shape 104.8 / 103.2 vs 108.9 / 105.0 us, frontend shape 237 / 235 vs 228 / 231 us, the x3 kernel 2 % slower:
+    // the fragment reads cost LDS issue slots and energy, not exposed latency.)
     for (int t = 0; t < nfull; ++t) {
       const char* kb = smem + (t & 1) * 2 * TILE_BYTES;
       const char* vb = kb + TILE_BYTES;
       const char* kb_next = smem + ((t + 1) & 1) * 2 * TILE_BYTES;
 #pragma unroll
       for (int c = 0; c < KB; ++c) {
-#if BT_ATTN_VPRE
-        const VFrag vf = vn;
-#else
         const VFrag vf = LD_V(vb + c * BLK_BYTES, lane);
-#endif
         if (c + 1 < KB) {
           f32x16 sn[QB];
-#if BT_ATTN_VPRE
-          vn = LD_V(vb + (c + 1) * BLK_BYTES, lane);
-#endif
           score_fast<QB>(kn, st, sn);
           if (c + 2 < KB) kn = LD_K(kb + (c + 2) * BLK_BYTES, g, lr);
           __builtin_amdgcn_sched_barrier(0);
@@ -429,9 +415,6 @@ DEVI void attn_pass_pipe(rsrc_t rk, rsrc_t rv, char* smem, int tid, int wave, in
           if (more) {
             k0n = LD_K(kb_next, g, lr);
             kn = LD_K(kb_next + BLK_BYTES, g, lr);
-#if BT_ATTN_VPRE
-            vn = LD_V(kb_next + TILE_BYTES, lane);
-#endif
           }
           __builtin_amdgcn_sched_barrier(0);
           finish_fast<QB>(sc, vf, st);
@@ -457,6 +440,9 @@ DEVI void attn_pass_pipe(rsrc_t rk, rsrc_t rv, char* smem, int tid, int wave, in
   }
   __syncthreads();
 }
+
+#undef LD_V
+#undef LD_K
 
 template <int ABL, int QB>
 __global__ __launch_bounds__(256, (QB == 1 ? 4 : 2)) void attn_frag_kernel(const AttnFragP p, int nqt, int sh_total) {
@@ -769,39 +755,23 @@ DEVI void attn_fast_x(rsrc_t rk, rsrc_t rv, char* smem, int tid, int wave, int l
   }
   // (one query block per wave: the scores of block 0 of tile 0 again, now on the reference maximum)
   if (QB == 1 && nfull > 0) score_x<true, QB>(kf, st, s2[0]);
-  // (the V fragments are read one block ahead, like the K fragments: two V register sets)
-#if BT_ATTN_VPRE
-  VFragX vn = ld_vx(smem + TILEX_BYTES, lane);
-#endif
   for (int t = 0; t < nfull; ++t) {
     const char* kb = smem + (t & 1) * 2 * TILEX_BYTES;
     const char* vb = kb + TILEX_BYTES;
     const char* kb_next = smem + ((t + 1) & 1) * 2 * TILEX_BYTES;
 #pragma unroll
     for (int c = 0; c < KBX; ++c) {
-#if BT_ATTN_VPRE
-      const VFragX vf = vn;
-#else
       const VFragX vf = ld_vx(vb + c * BLKX_BYTES, lane);
-#endif
       const int cur = PIPE ? (c & 1) : 0, nxt = PIPE ? ((c + 1) & 1) : 0;
       bool have_next = true;
       if (c + 1 < KBX) {
         kf = ld_kx(kb + (c + 1) * BLKX_BYTES, g, lr);
-#if BT_ATTN_VPRE
-        vn = ld_vx(vb + (c + 1) * BLKX_BYTES, lane);
-#endif
       } else {
         // every fragment read of tile t has arrived (the barrier's wait): barrier, refill, first block of tile t + 1
         __syncthreads();  // tile t + 1 has landed in every wave; nobody reads tile t any more
         if (t + 2 < ntiles) stage_tile_x<KBX>(rk, rv, t + 2, smem, t & 1, tid, wave);
         have_next = t + 1 < nfull;  // (uniform)
-        if (have_next) {
-          kf = ld_kx(kb_next, g, lr);
-#if BT_ATTN_VPRE
-          vn = ld_vx(kb_next + TILEX_BYTES, lane);
-#endif
-        }
+        if (have_next) kf = ld_kx(kb_next, g, lr);
       }
       if (PIPE && have_next) score_x<true, QB>(kf, st, s2[nxt]);
       finish_x<false, false, QB>(s2[cur], vf, g, st, 0, L);
