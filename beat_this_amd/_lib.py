@@ -95,6 +95,7 @@ class Gemm3Args(C.Structure):
 
 
 G3_FF1, G3_RESID, G3_QKV = 0, 1, 2
+UNIT_STEM, UNIT_PARTIAL, UNIT_CONV, UNIT_LINEAR, UNIT_ATTN, UNIT_FF, UNIT_NORM = range(7)
 
 EXPORTS = {
     "bt_last_error": (C.c_char_p, []),
@@ -108,6 +109,8 @@ EXPORTS = {
                              C.c_void_p, C.c_void_p]),
     "bt_forward_stages": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
                                     C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "bt_forward_unit": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                  C.c_void_p, C.c_size_t]),
     "bt_split_chunks": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "bt_aggregate": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int64,
                                C.c_void_p, C.c_void_p]),

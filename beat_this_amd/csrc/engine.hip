@@ -193,9 +193,11 @@ inline bool pair_fused2_ok(const bt_pair_weights& pw, int prec) {
   return pw.dim <= 128 && pw.w_ff_frag[prec] && pw.w_outff_frag[prec] && pw.w_attnff_frag[prec];
 }
 
+// part (mode 0 only; bt_forward_unit): 0 = the whole pair, 1 = the attention half (x += Attention(x)) only, 2 = the
+// feed-forward half (x += FeedForward(x)) only
 int run_pair(prof::State* pf, const bt_pair_weights& pw, const float* rope, float* x, void* xshadow, const Workspace& ws,
              int B, int T, int F, int mode, int prec, hipStream_t s, void* out_shadow = nullptr, int ff_mult = 4,
-             bool x3 = false) {
+             bool x3 = false, int part = 0) {
   const int C = pw.dim, H = pw.heads, HID = ff_mult * C;
   // BT_PREC_F32X3: prec is BT_PREC_F32 for everything but the plain GEMMs, which take the [hi | lo] half weights
   const int gp = x3 ? BT_PREC_F32X3 : prec, wp = x3 ? BT_PREC_HALF : prec;
@@ -228,7 +230,9 @@ int run_pair(prof::State* pf, const bt_pair_weights& pw, const float* rope, floa
   // BT_PREC_F32X3 time direction on the fragment-major kernels: hi + lo QKV blocks straight from the projection, the
   // attention's fp32 output feeds the (hi, lo) out-projection + FF kernel
   const bool t2x3 = mode == 2 && f2x3 && fused2_ok && pw.w_qkv_frag_x3 && ws.qf;
-  if (mode == 2 && fused_ok && ((prec == BT_PREC_HALF && pw.w_qkv_frag) || t2x3)) {
+  if (part == 2) {
+    // (feed-forward half only: nothing of the attention half runs)
+  } else if (mode == 2 && fused_ok && ((prec == BT_PREC_HALF && pw.w_qkv_frag) || t2x3)) {
     // time direction: fragment-major QKV straight from the projection, flash attention on it
     QkvFrontP qp;
     memset(&qp, 0, sizeof qp);
@@ -277,6 +281,7 @@ int run_pair(prof::State* pf, const bt_pair_weights& pw, const float* rope, floa
   g.epi = GEMM_EPI_RESID; g.flags = 0; g.x = x; g.ldx = C; g.xb = shadow ? xshadow : nullptr;
   LAUNCH_CAT(CAT_OUT, s, launch_gemm(g, gp, s), "out-proj gemm");
   }
+  if (part == 1) return BT_OK;
   if (fused_ok) {
     FusedFFP ff;
     ff.x = x; ff.M = M; ff.C = C; ff.wfrag = pw.w_ff_frag[prec]; ff.b1 = pw.b_ff1; ff.b2 = pw.b_ff2;
@@ -491,6 +496,78 @@ int bt_forward_stages(bt_engine* e, void* stream, int prec, int first, int last,
   hp.status = x3 ? ws.status : nullptr;
   LAUNCH_CAT(CAT_HEAD, s, launch_head(hp, s), "head");
   return BT_OK;
+}
+
+int bt_forward_unit(bt_engine* e, void* stream, int prec, int unit, int index, const float* d_in, float* d_out, int B, int T,
+                    void* d_ws, size_t ws_bytes) {
+  if (!e || !d_in || !d_out || !d_ws) return bt_set_error(BT_ERR_ARG, "null argument");
+  const bt_model_desc& d = e->d;
+  const int max_T = d.rope_len > 0 ? d.rope_len : 1536;
+  if (B <= 0 || T <= 0 || T > max_T) return bt_set_error(BT_ERR_ARG, "need B >= 1 and 1 <= T <= bt_model_desc.rope_len");
+  if (prec == BT_PREC_F32X3) prec = BT_PREC_F32;   // (sub-modules: the exact path)
+  if (prec != BT_PREC_F32 && prec != BT_PREC_HALF) return bt_set_error(BT_ERR_ARG, "unknown precision");
+  prof::State* pf = &e->prof;
+  const int D = d.transformer_dim;
+  Workspace ws = carve((char*)d_ws, B, T, D, d.ff_mult, prec);
+  if (ws.total > ws_bytes) return bt_set_error(BT_ERR_WORKSPACE, "workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  const bool block_unit = unit == BT_UNIT_PARTIAL || unit == BT_UNIT_CONV;
+  const bool layer_unit = unit == BT_UNIT_ATTN || unit == BT_UNIT_FF;
+  if (block_unit && (index < 0 || index > 2)) return bt_set_error(BT_ERR_ARG, "frontend block index out of range");
+  if (layer_unit && (index < 0 || index >= d.n_layers)) return bt_set_error(BT_ERR_ARG, "layer index out of range");
+  auto copy_in = [&](size_t bytes) -> int {
+    if (d_in != d_out && hipMemcpyAsync(d_out, d_in, bytes, hipMemcpyDeviceToDevice, s) != hipSuccess)
+      return bt_set_error(BT_ERR_HIP, "copy of the unit's input");
+    return BT_OK;
+  };
+  switch (unit) {
+    case BT_UNIT_STEM: {
+      StemP sp;
+      sp.spect = d_in; sp.x = d_out; sp.bn1_scale = d.bn1_scale; sp.bn1_shift = d.bn1_shift;
+      sp.w = d.stem_w; sp.bias = d.stem_b; sp.B = B; sp.T = T;
+      LAUNCH_CAT(CAT_STEM, s, launch_stem(sp, s), "stem");
+      return BT_OK;
+    }
+    case BT_UNIT_PARTIAL: {
+      if (!d.partial_transformers) return bt_set_error(BT_ERR_ARG, "this model has no partial transformers");
+      const int F = 32 >> index;
+      if (int rc = copy_in((size_t)B * T * 1024 * 4)) return rc;
+      if (int rc = run_pair(pf, d.front[index][0], d.rope, d_out, nullptr, ws, B, T, F, 1, prec, s)) return rc;
+      return run_pair(pf, d.front[index][1], d.rope, d_out, nullptr, ws, B, T, F, 2, prec, s);
+    }
+    case BT_UNIT_CONV: {
+      const int C = 32 << index, F = 32 >> index;
+      GemmP g;
+      memset(&g, 0, sizeof g);
+      g.A = d_in; g.W = d.conv_w[index][prec]; g.M = B * T * (F / 2); g.N = 2 * C; g.K = 6 * C;
+      g.epi = GEMM_EPI_STORE; g.flags = GEMM_F_CONV | GEMM_F_A_F32 | GEMM_F_BIAS | GEMM_F_GELU | GEMM_F_OUT_F32;
+      g.bias = d.conv_b[index]; g.out = d_out; g.ldo = 2 * C;
+      g.conv_C2 = 2 * C; g.conv_T = T; g.conv_F = F / 2;
+      LAUNCH_CAT(CAT_CONV, s, launch_gemm(g, prec, s), "frontend conv gemm");
+      return BT_OK;
+    }
+    case BT_UNIT_LINEAR: {
+      GemmP g;
+      memset(&g, 0, sizeof g);
+      g.A = d_in; g.lda = 1024; g.W = d.lin_w[prec]; g.M = B * T; g.N = D; g.K = 1024;
+      g.epi = GEMM_EPI_STORE; g.flags = GEMM_F_A_F32 | GEMM_F_BIAS | GEMM_F_OUT_F32;
+      g.bias = d.lin_b; g.out = d_out; g.ldo = D;
+      LAUNCH_CAT(CAT_LINEAR, s, launch_gemm(g, prec, s), "frontend linear gemm");
+      return BT_OK;
+    }
+    case BT_UNIT_ATTN:
+    case BT_UNIT_FF: {
+      if (int rc = copy_in((size_t)B * T * D * 4)) return rc;
+      return run_pair(pf, d.layers[index], d.rope, d_out, nullptr, ws, B, T, 1, 0, prec, s, nullptr, d.ff_mult, false,
+                      unit == BT_UNIT_ATTN ? 1 : 2);
+    }
+    case BT_UNIT_NORM:
+      if (!d.norm_out_g) return bt_set_error(BT_ERR_ARG, "bt_model_desc.norm_out_g is not set");
+      LAUNCH_CAT(CAT_HEAD, s, launch_norm_out(d_in, d.norm_out_g, d_out, (long)B * T, D, s), "final norm");
+      return BT_OK;
+    default:
+      return bt_set_error(BT_ERR_ARG, "unknown unit");
+  }
 }
 
 int bt_split_chunks(void* stream, const float* d_spect, int64_t n_frames, const int32_t* d_starts, int B, int T,

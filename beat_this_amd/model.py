@@ -22,7 +22,48 @@ _BUFFER_LEAVES = ("running_mean", "running_var", "num_batches_tracked")
 
 
 class _Node(nn.Module):
-    """Plain container; exists only so parameters carry the reference's dotted names."""
+    """Container that carries the reference's dotted parameter names.  The nodes that are callable sub-modules in the
+    reference -- ``frontend.stem``, ``.blocks``, ``.blocks[i]``, ``.blocks[i].partial``, ``.concat``, ``.linear``,
+    ``transformer_blocks.layers[l][0]`` (Attention), ``[l][1]`` (FeedForward), ``.norm`` (beat_tracker.py:54-80,108-168,
+    roformer.py:138-181) -- are bound to a unit of the owning model's engine (BeatThis._bind_units, bt_forward_unit) and can
+    be called with the reference's tensor layouts: (b, c, f, t) inside the frontend, (b, n, dim) in the transformer.  They
+    run on the generic kernels (exact fp32, or half operands under autocast), one launch group per call; the fused fast
+    path is ``BeatThis.forward`` / the three stages.  Nodes below them (``partial.attnF`` ...) hold parameters only.
+    Digit-named children index like the reference's ModuleList / Sequential (``layers[3][0]``, ``blocks[1]``)."""
+
+    _unit = None   # (kind, index) once bound
+
+    def __getstate__(self):  # (copy.deepcopy / pickle: the owner re-binds itself, BeatThis.__setstate__)
+        state = self.__dict__.copy()
+        state.pop("_root", None)
+        return state
+
+    def _indexed(self):
+        keys = [k for k in self._modules if k.isdigit()]
+        return sorted(keys, key=int)
+
+    def __len__(self):
+        return len(self._indexed())
+
+    def __bool__(self):   # (a module is truthy whatever its number of indexed children)
+        return True
+
+    def __getitem__(self, i: int):
+        keys = self._indexed()
+        if not keys:
+            raise TypeError(f"{type(self).__name__} node is not indexable")
+        return self._modules[keys[i]]
+
+    def __iter__(self):
+        return iter(self._modules[k] for k in self._indexed())
+
+    def forward(self, x: torch.Tensor):
+        if self._unit is None:
+            raise NotImplementedError(
+                "this node only carries parameters under the reference's names; the callable sub-modules are frontend.stem / "
+                ".blocks / .blocks[i] / .blocks[i].partial / .concat / .linear, transformer_blocks.layers[l][0] / [l][1] / .norm "
+                "and the three stages")
+        return self._root()._run_unit(x, *self._unit)
 
 
 class _Stage(_Node):
@@ -74,6 +115,7 @@ class BeatThis(nn.Module):
             self.add_module(name, _Stage(self, i))
         for key in state_dict_shapes(self.hparams):
             _attach(self, key, init[key])
+        self._bind_units()
         self._engine = None
         # extension: outside autocast, run every product of the fp32 path on three half MFMAs (operands split into hi + lo
         # halves, BT_PREC_F32X3) instead of fp32 MFMAs: fp32-class results (1e-5 at the logits, identical beats) at 16/3 of
@@ -91,6 +133,28 @@ class BeatThis(nn.Module):
         super().__setstate__(state)
         for name in ("frontend", "transformer_blocks", "task_heads"):
             object.__setattr__(self._modules[name], "_root", weakref.ref(self))
+        self._bind_units()
+
+    def _bind_units(self) -> None:
+        """Make the reference's callable sub-modules callable here (see _Node)."""
+        def bind(node, kind, index=0):
+            object.__setattr__(node, "_root", weakref.ref(self))
+            node._unit = (kind, index)
+        fr = self.frontend
+        if "concat" not in fr._modules:   # (parameter-free in the reference: Rearrange("b c f t -> b t (c f)"))
+            fr.add_module("concat", _Node())
+        bind(fr.stem, "stem")
+        bind(fr.blocks, "blocks")
+        for i, blk in enumerate(fr.blocks):
+            bind(blk, "block", i)
+            if "partial" in blk._modules:
+                bind(blk.partial, "partial", i)
+        bind(fr.concat, "concat")
+        bind(fr.linear, "linear")
+        for l, layer in enumerate(self.transformer_blocks.layers):
+            bind(layer[0], "attn", l)
+            bind(layer[1], "ff", l)
+        bind(self.transformer_blocks.norm, "norm")
 
     # -- state dict plumbing (beat_tracker.py:194-203: strip torch.compile's "_orig_mod.") ----
     def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False):
@@ -146,3 +210,61 @@ class BeatThis(nn.Module):
         else:
             prec = _lib.PREC_F32X3 if self.fp32_split_gemms else _lib.PREC_F32
         return self.engine().forward_stages(x, prec, first, last)
+
+    def _run_unit(self, x: torch.Tensor, kind: str, index: int):
+        """A sub-module call (see _Node): reference layouts in and out, fp32 results; precision follows autocast (the hi + lo
+        mode of ``fp32_split_gemms`` is the exact fp32 path here)."""
+        _lib.require_gpu(x, "sub-module input")
+        half = torch.is_autocast_enabled("cuda") if hasattr(torch, "is_autocast_enabled") else False
+        prec = _lib.PREC_HALF if half else _lib.PREC_F32
+        eng = self.engine()
+        D = self.hparams["transformer_dim"]
+
+        def to_btfc(t, i):   # (b, c, f, t) of frontend block i's input -> this library's (b, t, f, c)
+            c, f = 32 << i, 32 >> i
+            if t.dim() != 4 or t.shape[1] != c or t.shape[2] != f:
+                raise ValueError(f"expected a (batch, {c}, {f}, time) input, got {tuple(t.shape)}")
+            return t.permute(0, 3, 2, 1).contiguous()
+
+        def partial(t, i):   # (b, t, f, c) -> (b, t, f, c)
+            if not self.hparams["partial_transformers"]:
+                return t
+            return eng.forward_unit(t, prec, _lib.UNIT_PARTIAL, i, t.shape)
+
+        def conv(t, i):      # (b, t, f, c) -> (b, t, f / 2, 2 c)
+            b, n, f, c = t.shape
+            return eng.forward_unit(t, prec, _lib.UNIT_CONV, i, (b, n, f // 2, 2 * c))
+
+        if kind == "stem":
+            if x.dim() != 3 or x.shape[2] != 128:
+                raise ValueError(f"expected a (batch, time, 128) input, got {tuple(x.shape)}")
+            return eng.forward_unit(x, prec, _lib.UNIT_STEM, 0, (x.shape[0], x.shape[1], 32, 32)).permute(0, 3, 2, 1)
+        if kind == "partial":
+            return partial(to_btfc(x, index), index).permute(0, 3, 2, 1)
+        if kind == "block":
+            return conv(partial(to_btfc(x, index), index), index).permute(0, 3, 2, 1)
+        if kind == "blocks":
+            t = to_btfc(x, 0)
+            for i in range(3):
+                t = conv(partial(t, i), i)
+            return t.permute(0, 3, 2, 1)
+        if kind == "concat":
+            if x.dim() != 4:
+                raise ValueError(f"expected a (batch, channels, freq, time) input, got {tuple(x.shape)}")
+            b, c, f, n = x.shape
+            return x.permute(0, 3, 1, 2).reshape(b, n, c * f)
+        if kind == "linear":
+            if x.dim() != 3 or x.shape[2] != 1024:
+                raise ValueError(f"expected a (batch, time, 1024) input, got {tuple(x.shape)}")
+            b, n, _ = x.shape
+            t = x.reshape(b, n, 256, 4).transpose(2, 3).contiguous()   # (c f) -> (f c): the packed weight's column order
+            return eng.forward_unit(t, prec, _lib.UNIT_LINEAR, 0, (b, n, D))
+        if x.dim() != 3 or x.shape[2] != D:
+            raise ValueError(f"expected a (batch, time, {D}) input, got {tuple(x.shape)}")
+        if kind == "norm":
+            return eng.forward_unit(x, prec, _lib.UNIT_NORM, 0, x.shape)
+        # Attention / FeedForward return their branch WITHOUT the residual (roformer.py:176-181 adds it); the engine computes
+        # the residual form x + f(x) in fp32, so f(x) is that minus x (exact to the rounding of the fp32 sum)
+        xf = x.to(torch.float32).contiguous()
+        y = eng.forward_unit(xf, prec, _lib.UNIT_ATTN if kind == "attn" else _lib.UNIT_FF, index, xf.shape)
+        return y - xf

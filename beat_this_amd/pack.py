@@ -396,6 +396,24 @@ class Engine:
                     return self.forward_stages(spect, _lib.PREC_F32, first, last)
         return (beat, down) if last == 2 else out
 
+    def forward_unit(self, x: torch.Tensor, prec: int, unit: int, index: int, out_shape) -> torch.Tensor:
+        """One sub-module of the model (bt_forward_unit; the _lib.UNIT_* constants): fp32 (B, T, ...) tensor in this
+        library's activation layout in, a new fp32 tensor of ``out_shape`` out.  Generic kernels, exact fp32 or half operands."""
+        _lib.require_gpu(x, "sub-module input")
+        B, T = int(x.shape[0]), int(x.shape[1])
+        if B == 0 or T == 0:
+            raise ValueError("empty batch")
+        if prec == _lib.PREC_F32X3:
+            prec = _lib.PREC_F32
+        x = x.to(torch.float32).contiguous()
+        self.ensure_positions(T)
+        ws = self._workspace(_lib.lib().bt_workspace_bytes(self._h, B, T, prec))
+        out = torch.empty(tuple(out_shape), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().bt_forward_unit(self._h, _lib.stream_ptr(self.device), prec, unit, index, x.data_ptr(),
+                                                  out.data_ptr(), B, T, ws.data_ptr(), ws.numel()))
+        return out
+
     # -- BT_PREC_F32X3 range guard, deferred form ------------------------------------------------------------------------
     def deferred_range_checks(self):
         """Context manager: BT_PREC_F32X3 forwards inside it do not synchronise; their range flags are copied to pinned host

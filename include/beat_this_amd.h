@@ -179,6 +179,22 @@ int bt_forward(bt_engine* e, void* stream, int prec, const float* d_spect, int B
 int bt_forward_stages(bt_engine* e, void* stream, int prec, int first, int last, const float* d_in, int B, int T, void* d_ws,
                       size_t ws_bytes, float* d_out, float* d_beat, float* d_downbeat);
 
+/* The sub-modules below the three stages (what a caller of the reference reaches as model.frontend.stem, .blocks[i],
+ * .blocks[i].partial, .linear, model.transformer_blocks.layers[l][0] / [1], .norm -- beat_tracker.py:54-80,108-168,
+ * roformer.py:138-181), one unit per call, fp32 tensors in THIS library's activation layout, on the generic kernels (not
+ * the fused fast path of bt_forward): BT_PREC_F32 or BT_PREC_HALF (BT_PREC_F32X3 is taken as BT_PREC_F32).
+ *   BT_UNIT_STEM     d_in spect [B,T,128]              -> d_out [B,T,32,32]   (b, t, f, c)
+ *   BT_UNIT_PARTIAL  index = block: d_in [B,T,F,C]     -> d_out [B,T,F,C]     PartialFTTransformer (F = 32 >> index, C = 32 << index)
+ *   BT_UNIT_CONV     index = block: d_in [B,T,F,C]     -> d_out [B,T,F/2,2C]  conv (2,3) / stride (2,1) + BatchNorm + GELU
+ *   BT_UNIT_LINEAR   d_in [B,T,8,128] (= (f c) order)  -> d_out [B,T,D]
+ *   BT_UNIT_ATTN     index = layer: d_in [B,T,D]       -> d_out = x + Attention(x)      (the residual form the layer computes)
+ *   BT_UNIT_FF       index = layer: d_in [B,T,D]       -> d_out = x + FeedForward(x)
+ *   BT_UNIT_NORM     d_in [B,T,D]                      -> d_out = RMSNorm(x)
+ * d_out may equal d_in for the in-place units (PARTIAL, ATTN, FF).  Workspace as for bt_forward. */
+enum { BT_UNIT_STEM = 0, BT_UNIT_PARTIAL = 1, BT_UNIT_CONV = 2, BT_UNIT_LINEAR = 3, BT_UNIT_ATTN = 4, BT_UNIT_FF = 5, BT_UNIT_NORM = 6 };
+int bt_forward_unit(bt_engine* e, void* stream, int prec, int unit, int index, const float* d_in, float* d_out, int B, int T,
+                    void* d_ws, size_t ws_bytes);
+
 /* split_piece + zeropad (inference.py:90-135): d_chunks[b,t,:] = d_spect[d_starts[b]+t,:] or 0 */
 int bt_split_chunks(void* stream, const float* d_spect, int64_t n_frames, const int32_t* d_starts, int B, int T,
                     float* d_chunks);

@@ -159,3 +159,29 @@ def test_hl32_format_round_trips_and_matches_the_packer():
         packed = p._keep[-1]
         assert packed.shape == (256, 128)   # rows padded to a multiple of 256
         assert torch.equal(packed[:130], to_hl32(w)) and torch.all(packed[130:] == 0)
+
+
+def test_submodule_tree_mirrors_the_reference_containers():
+    """CPU: the nodes the reference exposes as callable sub-modules are bound to engine units, index like its ModuleList /
+    Sequential, survive deepcopy, leave the state dict alone and fail loudly on CPU tensors / on parameter-only nodes."""
+    import copy
+
+    import pytest
+    import torch
+
+    from beat_this_amd.model import BeatThis
+
+    m = BeatThis(transformer_dim=128, n_layers=3)
+    keys = set(m.state_dict())
+    assert len(m.frontend.blocks) == 3 and len(m.transformer_blocks.layers) == 3 and len(m.transformer_blocks.layers[0]) == 2
+    assert [b._unit for b in m.frontend.blocks] == [("block", 0), ("block", 1), ("block", 2)]
+    assert m.transformer_blocks.layers[2][0]._unit == ("attn", 2) and m.transformer_blocks.layers[2][1]._unit == ("ff", 2)
+    assert m.frontend.stem._unit == ("stem", 0) and m.frontend.concat._unit == ("concat", 0) and bool(m.frontend.concat)
+    pairs = [(a._unit, f._unit) for a, f in m.transformer_blocks.layers]
+    assert pairs == [(("attn", l), ("ff", l)) for l in range(3)]
+    m2 = copy.deepcopy(m)
+    assert m2.frontend.linear._root() is m2 and set(m2.state_dict()) == keys
+    with pytest.raises(RuntimeError, match="ROCm GPUs only"):
+        m.frontend.stem(torch.zeros(1, 10, 128))
+    with pytest.raises(NotImplementedError):
+        m.frontend.blocks[0].partial.attnF(torch.zeros(1))

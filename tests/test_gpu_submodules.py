@@ -1,0 +1,114 @@
+"""The callable sub-modules below the three stages (model.frontend.stem / .blocks / .blocks[i] / .blocks[i].partial / .concat /
+.linear, model.transformer_blocks.layers[l][0] / [l][1] / .norm; reference: beat_tracker.py:54-80,108-168,
+roformer.py:138-181) against the oracle's functions of the same names, in the reference's tensor layouts."""
+import pytest
+import torch
+
+from gpu_util import dev, report
+
+pytestmark = pytest.mark.gpu
+HP = dict(transformer_dim=256, n_layers=2)   # (small model: the sub-module entry runs the generic kernels)
+
+
+def _model(style="lively", **hp):
+    from beat_this_amd import weights as W
+    from beat_this_amd.model import BeatThis
+
+    h = W.resolve_hparams(dict(HP, **hp))
+    sd = W.random_state_dict(h, seed=5, style=style)
+    m = BeatThis(**h)
+    m.load_state_dict(sd)
+    return m.to(dev()).eval(), {k: v.double() if v.is_floating_point() else v for k, v in sd.items()}, h
+
+
+def _rel(a, ref):
+    return float((a.double().cpu() - ref).abs().max() / ref.abs().max().clamp_min(1e-30))
+
+
+def test_frontend_submodules_match_the_oracle():
+    from beat_this_amd import weights as W
+    from oracle import beat_this_oracle as O
+
+    m, sd, _ = _model()
+    x = torch.from_numpy(W.synthetic_spect(200, seed=2))[None].repeat(2, 1, 1)
+    x[1] = x[1].flip(0)
+    with torch.inference_mode():
+        s_ref = O.stem(x.double(), sd)
+        s = m.frontend.stem(x.to(dev()))
+        assert s.shape == s_ref.shape == (2, 32, 32, 200)
+        errs = {"stem": _rel(s, s_ref)}
+        cur_ref, cur = s_ref, s
+        for i in range(3):
+            p = f"frontend.blocks.{i}."
+            pr = O.partial_ft(cur_ref, sd, p + "partial.")
+            errs[f"partial{i}"] = _rel(m.frontend.blocks[i].partial(cur_ref.float().to(dev())), pr)
+            br = torch.nn.functional.gelu(O.batchnorm(torch.nn.functional.conv2d(pr, sd[p + "conv2d.weight"], stride=(2, 1), padding=(0, 1)),
+                                                      sd, p + "norm.", 1))
+            errs[f"block{i}"] = _rel(m.frontend.blocks[i](cur_ref.float().to(dev())), br)
+            cur_ref = br
+        errs["blocks"] = _rel(m.frontend.blocks(s_ref.float().to(dev())), cur_ref)
+        cat_ref = cur_ref.permute(0, 3, 1, 2).reshape(2, 200, 1024)
+        cat = m.frontend.concat(cur_ref.float().to(dev()))
+        assert torch.equal(cat.cpu().double(), cat_ref.float().double())
+        lin_ref = cat_ref @ sd["frontend.linear.weight"].T + sd["frontend.linear.bias"]
+        errs["linear"] = _rel(m.frontend.linear(cat), lin_ref)
+        # composed like the reference's Sequential: equals the frontend stage
+        whole = m.frontend.linear(m.frontend.concat(m.frontend.blocks(m.frontend.stem(x.to(dev())))))
+        errs["composed_vs_stage"] = _rel(whole, m.frontend(x.to(dev())).double().cpu())
+    report("submodules_frontend", **errs)
+    assert max(errs.values()) < 2e-5, errs
+
+
+def test_transformer_submodules_match_the_oracle():
+    from oracle import beat_this_oracle as O
+
+    m, sd, h = _model()
+    D = h["transformer_dim"]
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn((2, 333, D), generator=g)
+    errs = {}
+    with torch.inference_mode():
+        for l in range(h["n_layers"]):
+            p = f"transformer_blocks.layers.{l}."
+            a_ref = O.attention(x.double(), sd, p + "0.", D // 32)
+            f_ref = O.feedforward(x.double(), sd, p + "1.")
+            errs[f"attn{l}"] = _rel(m.transformer_blocks.layers[l][0](x.to(dev())), a_ref)
+            errs[f"ff{l}"] = _rel(m.transformer_blocks.layers[l][1](x.to(dev())), f_ref)
+        errs["norm"] = _rel(m.transformer_blocks.norm(x.to(dev())), O.rmsnorm(x.double(), sd["transformer_blocks.norm.gamma"]))
+        # the reference's loop over the ModuleList, written against this model
+        y = x.to(dev())
+        for attn, ff in m.transformer_blocks.layers:
+            y = attn(y) + y
+            y = ff(y) + y
+        y = m.transformer_blocks.norm(y)
+        errs["loop_vs_stage"] = _rel(y, m.transformer_blocks(x.to(dev())).double().cpu())
+    report("submodules_transformer", **errs)
+    assert max(errs.values()) < 2e-5, errs
+
+
+def test_submodules_under_autocast_and_without_partial_transformers():
+    from oracle import beat_this_oracle as O
+
+    m, sd, h = _model()
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn((1, 96, h["transformer_dim"]), generator=g)
+    with torch.inference_mode(), torch.autocast("cuda"):
+        a = m.transformer_blocks.layers[0][0](x.to(dev()))
+        f = m.transformer_blocks.layers[0][1](x.to(dev()))
+    ea = _rel(a, O.attention(x.double(), sd, "transformer_blocks.layers.0.0.", h["transformer_dim"] // 32))
+    ef = _rel(f, O.feedforward(x.double(), sd, "transformer_blocks.layers.0.1."))
+    m2, sd2, _ = _model(partial_transformers=False)
+    s = torch.randn((1, 32, 32, 50), generator=g)
+    with torch.inference_mode():
+        assert "partial" not in m2.frontend.blocks[0]._modules
+        b0 = m2.frontend.blocks[0](s.to(dev()))
+    p = "frontend.blocks.0."
+    ref = torch.nn.functional.gelu(O.batchnorm(torch.nn.functional.conv2d(s.double(), sd2[p + "conv2d.weight"], stride=(2, 1), padding=(0, 1)),
+                                               sd2, p + "norm.", 1))
+    eb = _rel(b0, ref)
+    report("submodules_misc", attn_half=ea, ff_half=ef, block_without_partial=eb)
+    assert ea < 2e-2 and ef < 2e-2 and eb < 2e-5
+    with pytest.raises(ValueError):
+        m.frontend.blocks[1](s.to(dev()))            # block 1 takes (b, 64, 16, t)
+    with pytest.raises(NotImplementedError):
+        m.frontend.blocks[0].partial.attnF(s.to(dev()))
