@@ -84,8 +84,22 @@ class _Stage(_Node):
         return state
 
     def forward(self, x: torch.Tensor):
+        if self._stage < 2 and _hooked_below(self):
+            # somebody hooked a sub-module of this stage: run it through the sub-modules, like the reference's containers
+            # (beat_tracker.py:77-80, roformer.py:176-181), so that the hook fires
+            if self._stage == 0:
+                return self.linear(self.concat(self.blocks(self.stem(x))))
+            for attn, ff in self.layers:
+                x = attn(x) + x
+                x = ff(x) + x
+            return self.norm(x)
         out = self._root()._run(x, self._stage, self._stage)
         return {"beat": out[0], "downbeat": out[1]} if self._stage == 2 else out
+
+
+def _hooked_below(node: nn.Module) -> bool:
+    """A forward (pre-)hook is registered on a sub-module of ``node`` (not on ``node`` itself)."""
+    return any(m is not node and (m._forward_hooks or m._forward_pre_hooks) for m in node.modules())
 
 
 def _attach(root: nn.Module, key: str, value: torch.Tensor) -> None:
@@ -188,8 +202,7 @@ class BeatThis(nn.Module):
         if x.shape[0] == 0 or x.shape[1] == 0:
             empty = torch.empty((x.shape[0], x.shape[1]), dtype=torch.float32, device=x.device)
             return {"beat": empty, "downbeat": empty.clone()}
-        stages = (self.frontend, self.transformer_blocks, self.task_heads)
-        if any(st._forward_hooks or st._forward_pre_hooks for st in stages):
+        if _hooked_below(self):
             # somebody hooked a sub-module: run the stages through the modules so the hooks fire (beat_tracker.py:188-192)
             return self.task_heads(self.transformer_blocks(self.frontend(x)))
         beat, down = self._run(x, 0, 2)
@@ -242,8 +255,15 @@ class BeatThis(nn.Module):
         if kind == "partial":
             return partial(to_btfc(x, index), index).permute(0, 3, 2, 1)
         if kind == "block":
+            blk = self.frontend.blocks[index]
+            if _hooked_below(blk) and "partial" in blk._modules:   # (through the module: a hook on .partial fires)
+                return conv(to_btfc(blk.partial(x), index), index).permute(0, 3, 2, 1)
             return conv(partial(to_btfc(x, index), index), index).permute(0, 3, 2, 1)
         if kind == "blocks":
+            if _hooked_below(self.frontend.blocks):
+                for blk in self.frontend.blocks:
+                    x = blk(x)
+                return x
             t = to_btfc(x, 0)
             for i in range(3):
                 t = conv(partial(t, i), i)

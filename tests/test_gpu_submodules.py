@@ -112,3 +112,35 @@ def test_submodules_under_autocast_and_without_partial_transformers():
         m.frontend.blocks[1](s.to(dev()))            # block 1 takes (b, 64, 16, t)
     with pytest.raises(NotImplementedError):
         m.frontend.blocks[0].partial.attnF(s.to(dev()))
+
+
+def test_hooks_on_deep_submodules_fire_in_the_whole_forward():
+    """A forward hook on a sub-module below the stages (here: the FeedForward of layer 1, the partial transformer of frontend
+    block 2, the whole block 0) makes BeatThis.forward run through the sub-modules, so the hook fires once per forward with
+    the reference's tensor shapes, and the result is that of the whole-forward call (fp32: the same kernels up to the fused norm + head)."""
+    from beat_this_amd import weights as W
+
+    m, _, h = _model()
+    x = torch.from_numpy(W.synthetic_spect(150, seed=7))[None].to(dev())
+    with torch.inference_mode():
+        plain = m(x)
+    seen = {}
+    def rec(name):
+        def hook(mod, inp, out):   # (returns None: a forward hook that returns something replaces the output)
+            seen.setdefault(name, (tuple(inp[0].shape), tuple(out.shape)))
+        return hook
+    hs = [m.transformer_blocks.layers[1][1].register_forward_hook(rec("ff1")),
+          m.frontend.blocks[2].partial.register_forward_hook(rec("partial2")),
+          m.frontend.blocks[0].register_forward_hook(rec("block0"))]
+    with torch.inference_mode():
+        hooked = m(x)
+    for hd in hs:
+        hd.remove()
+    D = h["transformer_dim"]
+    assert seen == {"ff1": ((1, 150, D), (1, 150, D)), "partial2": ((1, 128, 8, 150), (1, 128, 8, 150)),
+                    "block0": ((1, 32, 32, 150), (1, 64, 16, 150))}, seen
+    # (stage by stage the final RMSNorm and the head are two kernels instead of one: agreement to fp32 rounding)
+    assert float((hooked["beat"] - plain["beat"]).abs().max()) < 1e-5 and float((hooked["downbeat"] - plain["downbeat"]).abs().max()) < 1e-5
+    with torch.inference_mode():
+        again = m(x)   # hooks removed: the fast path again
+    assert torch.equal(again["beat"], plain["beat"])
