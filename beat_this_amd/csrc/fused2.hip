@@ -50,8 +50,17 @@ struct WRing {
   static constexpr int KT = C / 32;
   static constexpr int TILE_B = 32 * 32 * (int)sizeof(T);
   static constexpr int STEP_B = 2 * KT * TILE_B;
-  static constexpr int NST = C == 128 ? 3 : 4;  // (C = 128: 3 stages = 51 KB, out-projection + FF halves 4 % faster inside the forward;
-                                                 //  C = 64: 3 stages only help back to back with itself; 3 workgroups per CU at C = 128: spills)
+#ifndef BT_F2_NST_HL128
+#define BT_F2_NST_HL128 2   // (1.01 ms with two stages vs 1.13 with three, same measurement)
+#endif
+  // (C = 128: 3 stages = 51 KB, out-projection + FF halves 4 % faster inside the forward; C = 64: 3 stages only help back to
+  //  back with itself; 3 workgroups per CU at C = 128: spills.  (hi, lo) operands at C = 128: a stage is 32 KB -- three of
+  //  them leave ONE workgroup per CU, i.e. one wave per SIMD; two stages = two workgroups per CU)
+#ifndef BT_F2_NST_HL64
+#define BT_F2_NST_HL64 2   // (A/B on one box, x3 forward of 16 chunks: frequency + time halves 1.045 / 1.05 / 1.075 ms with 2 / 3 / 4 stages)
+#endif
+  static constexpr bool HL = sizeof(T) == 4 && !std::is_same<T, float>::value;
+  static constexpr int NST = C == 128 ? (HL ? BT_F2_NST_HL128 : 3) : (HL && C == 64 ? BT_F2_NST_HL64 : 4);
   static constexpr int CH = STEP_B / 4096;  // buffer loads per thread per step (256 threads x 16 B = 4 KB each)
   rsrc_t rs;
   char* lds;
