@@ -24,7 +24,7 @@ DEVI void split2q(float a, float b, unsigned& whi, unsigned& wlo, float& amax) {
 }
 
 template <typename T, int C>
-__global__ __launch_bounds__(256, (sizeof(T) == 2 ? (C == 32 ? 4 : C == 64 ? 3 : 2) : (C == 32 ? 3 : C == 64 ? 2 : 1)))
+__global__ __launch_bounds__(256, (sizeof(T) == 2 ? (C == 32 ? 4 : C == 64 ? 3 : 2) : (C == 32 ? 3 : 2)))
 void qkv_front_kernel(const QkvFrontP p) {
   constexpr bool X3 = sizeof(T) == 4;    // T = hl
   constexpr int KT = C / 32;             // k-tiles
@@ -33,7 +33,10 @@ void qkv_front_kernel(const QkvFrontP p) {
   constexpr int BLK_E = X3 ? 2048 : 1024;        // half elements per 32-token output block (X3: [hi block | lo block])
   constexpr int STEP_B = 3 * KT * TILE_B;  // q, k, v tiles of one head (the gate step uses the first KT)
   constexpr int NCH = STEP_B / 16;       // 16-byte chunks per step
-  __shared__ __attribute__((aligned(16))) char wl[2 * STEP_B];
+  // (hi, lo) operands at C = 128: a step is 48 KB -- double buffered that is ONE workgroup (one wave per SIMD) per CU for a
+  // kernel that lives on loads in flight; single buffered (stage, barrier, multiply, barrier) two workgroups cover each other
+  constexpr int NBUF = (X3 && C == 128) ? 1 : 2;
+  __shared__ __attribute__((aligned(16))) char wl[NBUF * STEP_B];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // (wave index in an SGPR: uniform index math stays scalar)
   const int g = lane >> 5, lr = lane & 31;
   const int nblk = (p.T + 31) >> 5;
@@ -58,7 +61,7 @@ void qkv_front_kernel(const QkvFrontP p) {
                                          (lptr_t)(wl + buf * STEP_B + c0 * 16), 16, 0, 0);
     }
   };
-  stage(0, 0);
+  if (NBUF == 2) stage(0, 0);
 
   float ss = 0.f, amax = 0.f;
   Frag<T> xf[KT];
@@ -85,8 +88,13 @@ void qkv_front_kernel(const QkvFrontP p) {
   __syncthreads();
 #pragma unroll 1
   for (int step = 0; step <= H; ++step) {
-    const char* wb = wl + (step & 1) * STEP_B;
-    if (step < H) stage(step + 1, (step + 1) & 1);
+    const char* wb = wl + (NBUF == 2 ? (step & 1) * STEP_B : 0);
+    if (NBUF == 2) {
+      if (step < H) stage(step + 1, (step + 1) & 1);
+    } else {
+      stage(step, 0);
+      __syncthreads();   // (this step's tiles have landed in every wave)
+    }
     if (step < H) {
       const int hd = step;
       f32x16 aq, ak, av;
