@@ -329,7 +329,7 @@ __global__ __launch_bounds__(256) void decimate_kernel(const bt_span_t one, cons
     const float* ur = us + r * UW + 8 * tid + QP;   // hi block of tap group 0: u_r[mb + 8 tid .. + 7]
     const float* hr = hs + r * QP;
     f32x4 hi0 = *reinterpret_cast<const f32x4*>(ur), hi1 = *reinterpret_cast<const f32x4*>(ur + 4);
-#pragma unroll 1
+#pragma unroll 2   // (two groups per iteration: the hi <- lo hand-over becomes a renaming instead of four v_mov_b64 per 64 FMAs)
     for (int G = 0; G < groups; ++G) {
       const f32x4 lo0 = *reinterpret_cast<const f32x4*>(ur - 8 * (G + 1)), lo1 = *reinterpret_cast<const f32x4*>(ur - 8 * (G + 1) + 4);
       const f32x4 ha = *reinterpret_cast<const f32x4*>(hr + 8 * G), hb = *reinterpret_cast<const f32x4*>(hr + 8 * G + 4);
