@@ -22,6 +22,7 @@ SOURCES = ["gemm.hip", "gemm2.hip", "gemm3.hip", "attn.hip", "attn2.hip", "fused
 HEADERS = ["common.h", "chain.h", "kernels.h", os.path.join("..", "..", "include", "beat_this_amd.h")]
 
 BT_OK, BT_ERR_ARG, BT_ERR_HIP, BT_ERR_WORKSPACE = 0, -1, -2, -3
+ABI_VERSION = 400   # BT_ABI_VERSION of include/beat_this_amd.h this binding was written against
 PREC_F32, PREC_HALF, PREC_F32X3 = 0, 1, 3   # (2 was the withdrawn e4m3 experiment)
 MAX_LAYERS = 32
 PROFILE_CATEGORIES = ["stem", "qkv_gemm", "attn_freq", "attn_flash", "out_gemm", "ff1_gemm", "ff2_gemm", "conv_gemm",
@@ -193,6 +194,7 @@ def build(force: bool = False, verbose: bool = False, lib_path: str | None = Non
         objs.append(obj)
         if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_time):
             todo.append((src, obj))
+    build.last_rebuilt = [os.path.basename(j[0]) for j in todo]   # (sources recompiled by this call: __graft_entry__ lints those)
     if not todo and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(o) for o in objs):
         return LIB_PATH
     os.makedirs(obj_dir, exist_ok=True)
@@ -223,6 +225,17 @@ def build(force: bool = False, verbose: bool = False, lib_path: str | None = Non
     return LIB_PATH
 
 
+build.last_rebuilt = []
+
+
+def device_asm_command(src: str, out: str, defines=()) -> list:
+    """The hipcc command line that regenerates the device ISA of ``src`` exactly as ``build`` compiles it (same flags, same
+    defines) -- what tools/isa_lint.py reads."""
+    flags = FLAGS_BY_SOURCE.get(os.path.basename(src), HIPCC_FLAGS)
+    return [os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", *flags,
+            *EXTRA_DEFINES, *defines, "-S", "--cuda-device-only", src, "-o", out]
+
+
 _lib = None
 
 
@@ -235,6 +248,10 @@ def lib():
                 f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(needs hipcc); beat_this_amd has no CPU/PyTorch fallback")
         handle = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+        handle.bt_version.restype = C.c_int
+        if handle.bt_version() != ABI_VERSION:   # (a stale .so from another revision: signatures / struct layouts differ)
+            raise ImportError(f"{LIB_PATH} has ABI version {handle.bt_version()}, this binding needs {ABI_VERSION}: rebuild it "
+                              "(python -c 'import __graft_entry__ as g; g.build()')")
         for name, (res, args) in EXPORTS.items():
             fn = getattr(handle, name)
             fn.restype = res

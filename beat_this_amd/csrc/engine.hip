@@ -308,7 +308,7 @@ int run_pair(prof::State* pf, const bt_pair_weights& pw, const float* rope, floa
 extern "C" {
 
 const char* bt_last_error(void) { return g_err.c_str(); }
-int bt_version(void) { return 200; }
+int bt_version(void) { return BT_ABI_VERSION; }
 int bt_half_is_bf16(void) { return BT_HALF_IS_BF16; }
 void bt_struct_sizes(int32_t* out) {
   out[0] = (int32_t)sizeof(bt_pair_weights); out[1] = (int32_t)sizeof(bt_model_desc);
@@ -365,7 +365,9 @@ int bt_forward_stages(bt_engine* e, void* stream, int prec, int first, int last,
   if (x3) {
     if (BT_HALF_IS_BF16) return bt_set_error(BT_ERR_ARG, "BT_PREC_F32X3 needs an IEEE fp16 build");
     prec = BT_PREC_F32;
-    // range flag of this forward (first word of the workspace): cleared here, ORed by every kernel that splits operands
+    // range flag of this forward (first word of the workspace): cleared here; bit 0 is ORed by the gemm3 / attention / QKV
+    // kernels when a value beyond the fp16 range goes through a split, bit 1 by whatever ends the call (head, final norm,
+    // stage exit) when its output is not finite -- which is where an overflow in any other splitting kernel ends up
     if (hipMemsetAsync(ws.status, 0, 4, s) != hipSuccess) return bt_set_error(BT_ERR_HIP, "clearing the range flag");
   }
   const int gp = x3 ? BT_PREC_F32X3 : prec, wp = x3 ? BT_PREC_HALF : prec;   // plain GEMMs: launch / weight precision
@@ -476,6 +478,9 @@ int bt_forward_stages(bt_engine* e, void* stream, int prec, int first, int last,
   if (last == 0) {
     if (hipMemcpyAsync(d_out, ws.xm, xm_bytes, hipMemcpyDeviceToDevice, s) != hipSuccess)
       return bt_set_error(BT_ERR_HIP, "copy of the stage output");
+    // (x3: not every operand-splitting kernel of the frontend raises the flag itself -- what they all do is turn an operand
+    // beyond the fp16 range into inf / NaN, which the stage's exit looks for like the head does for the logits)
+    if (x3) LAUNCH_CAT(CAT_HEAD, s, launch_finite_rows(ws.xm, (long)B * T, D, ws.status, s), "range check of the stage output");
     return BT_OK;
   }
   for (int l = 0; l < d.n_layers; ++l) {
@@ -487,7 +492,7 @@ int bt_forward_stages(bt_engine* e, void* stream, int prec, int first, int last,
   }
   if (last == 1) {
     if (!d.norm_out_g) return bt_set_error(BT_ERR_ARG, "stage exit after transformer_blocks needs norm_out_g");
-    LAUNCH_CAT(CAT_HEAD, s, launch_norm_out(ws.xm, d.norm_out_g, d_out, (long)B * T, D, s), "final norm");
+    LAUNCH_CAT(CAT_HEAD, s, launch_norm_out(ws.xm, d.norm_out_g, d_out, (long)B * T, D, s, x3 ? ws.status : nullptr), "final norm");
     return BT_OK;
   }
   HeadP hp;

@@ -96,8 +96,10 @@ __global__ __launch_bounds__(256) void head_kernel(const HeadP p) {
 }
 
 // one wave per token row: y = x * sqrt(D) / max(|x|, 1e-12) * gamma (F.normalize semantics, roformer.py:20-30)
+// status (BT_PREC_F32X3 stage exit, may be null): bit 1 is set when a row's sum of squares is not finite (an operand that
+// left the fp16 range of a hi half upstream reaches every token of its chunk as inf / NaN)
 __global__ __launch_bounds__(256) void norm_out_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
-                                                       float* __restrict__ y, long M, int D) {
+                                                       float* __restrict__ y, long M, int D, int* __restrict__ status) {
   const int lane = threadIdx.x & 63;
   const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
@@ -108,6 +110,19 @@ __global__ __launch_bounds__(256) void norm_out_kernel(const float* __restrict__
   for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
   const float sc = sqrtf((float)D) / fmaxf(sqrtf(ss), 1e-12f);
   for (int k = lane; k < D; k += 64) y[row * D + k] = xr[k] * sc * gamma[k];
+  if (status && lane == 0 && !(ss <= 3.0e38f)) atomicOr(status, 2);
+}
+
+// BT_PREC_F32X3 stage exit after the frontend: the same test on the rows of the residual stream handed out as they are
+__global__ __launch_bounds__(256) void finite_rows_kernel(const float* __restrict__ x, long M, int D, int* __restrict__ status) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  float ss = 0.f;
+  for (int k = lane; k < D; k += 64) ss = fmaf(x[row * D + k], x[row * D + k], ss);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+  if (lane == 0 && !(ss <= 3.0e38f)) atomicOr(status, 2);
 }
 
 // one wave per token row, lane = column of a 64-column group: the half shadow of x and the group's sum of squares
@@ -385,8 +400,12 @@ int launch_head(const HeadP& p, hipStream_t s) {
   hipLaunchKernelGGL(head_kernel, dim3((unsigned)((p.M + 3) / 4)), dim3(256), 0, s, p);
   return (int)hipGetLastError();
 }
-int launch_norm_out(const float* x, const float* gamma, float* y, long M, int D, hipStream_t s) {
-  hipLaunchKernelGGL(norm_out_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, x, gamma, y, M, D);
+int launch_norm_out(const float* x, const float* gamma, float* y, long M, int D, hipStream_t s, int* status) {
+  hipLaunchKernelGGL(norm_out_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, x, gamma, y, M, D, status);
+  return (int)hipGetLastError();
+}
+int launch_finite_rows(const float* x, long M, int D, int* status, hipStream_t s) {
+  hipLaunchKernelGGL(finite_rows_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, x, M, D, status);
   return (int)hipGetLastError();
 }
 int launch_shadow_ssq(const float* x, void* xb, float* ssq, long M, int D, hipStream_t s, int hl32) {

@@ -191,7 +191,8 @@ struct HeadP {
 };
 int launch_head(const HeadP& p, hipStream_t s);
 // transformer_blocks' final RMSNorm as a pass of its own: y = x * sqrt(D) / |x| * gamma   (roformer.py:181, stage exit)
-int launch_norm_out(const float* x, const float* gamma, float* y, long M, int D, hipStream_t s);
+int launch_norm_out(const float* x, const float* gamma, float* y, long M, int D, hipStream_t s, int* status = nullptr);
+int launch_finite_rows(const float* x, long M, int D, int* status, hipStream_t s);
 // half shadow and per-64-column sums of squares [D/64][M] of a residual stream handed in from outside (stage entry)
 // (hl32 != 0: the shadow in the BT_PREC_F32X3 form, half [M, 2 D] interleaved hi / lo planes)
 int launch_shadow_ssq(const float* x, void* xb, float* ssq, long M, int D, hipStream_t s, int hl32 = 0);

@@ -10,6 +10,14 @@ Differences that matter for speed, not for results:
     a whole list of tracks per call -- ONE launch per stage (resample, log-mel, chunk gather, forward slices,
     aggregation, peak picking) and ONE device-to-host copy for all tracks.
 
+Precision (the ``float16`` argument of the inference classes):
+  * ``False`` (the reference's default): fp32 activations and fp32-class results -- framewise logits within 1e-3 of the
+    reference's CPU fp32 path (measured 1e-5 .. 2e-5), identical beats -- with every product of the forward on three fp16
+    MFMAs over hi + lo operand halves (BT_PREC_F32X3; ``BeatThis.fp32_split_gemms``).  A batch whose operands leave the
+    fp16 range of a hi half is detected and repeated on the exact fp32 MFMA path (``Engine.last_fallbacks``).
+  * ``True``: the reference's float16 autocast -- fp16 MFMA operands, fp32 accumulation; not under the 1e-3 gate.
+  * ``"exact"``: every product on exact fp32 MFMAs (``v_mfma_f32_32x32x2_f32``), a third of the default's speed.
+
 Limits of the drop-in (there is no CPU implementation in this package):
   * ``device`` must be a ROCm GPU; the default is "cuda" (the reference's default "cpu" raises here, in ``__init__``);
   * the resampler is a Kaiser-windowed-sinc polyphase FIR built to libsoxr's HQ specification, not libsoxr.
@@ -181,16 +189,40 @@ def split_predict_aggregate(spect: torch.Tensor, chunk_size: int, border_size: i
     return {"beat": beat, "downbeat": down}
 
 
+def _precision_mode(float16) -> str:
+    """The ``float16`` argument of the inference classes -> "half" | "f32x3" | "exact" (module docstring)."""
+    if isinstance(float16, str):
+        mode = {"f32x3": "f32x3", "exact": "exact", "fp32": "exact", "f32": "exact", "half": "half", "fp16": "half",
+                "float16": "half"}.get(float16.lower())
+        if mode is None:
+            raise ValueError(f"unknown precision float16={float16!r}: use False (fp32-class results, the default), True "
+                             "(fp16 autocast) or 'exact' (exact fp32 MFMAs)")
+        return mode
+    return "half" if float16 else "f32x3"
+
+
 class Spect2Frames:
     """Framewise beat/downbeat logits from a spectrogram (inference.py:233-257)."""
 
     def __init__(self, checkpoint_path="final0", device="cuda", float16=False):
         super().__init__()
         self.device = _gpu_device(device)
-        self.float16 = bool(float16) and float16 != "f32x3"
+        mode = _precision_mode(float16)
+        self.float16 = mode == "half"
+        # what ``float16=False`` means for a BeatThis model assigned to ``.model``: hi + lo fp16 operands (BT_PREC_F32X3, the
+        # default) or exact fp32 MFMAs ("exact"); ``self.model.fp32_split_gemms`` remains the switch afterwards
+        self.fp32_mode = "exact" if mode == "exact" or _lib.lib().bt_half_is_bf16() else "f32x3"
         self.model = load_model(checkpoint_path, self.device)
-        if float16 == "f32x3":  # extension: fp32 activations, GEMMs and attention on three fp16 MFMAs per product (BT_PREC_F32X3)
-            self.model.fp32_split_gemms = True
+
+    @property
+    def model(self):
+        return self._model
+
+    @model.setter
+    def model(self, m):
+        if isinstance(m, BeatThis):
+            m.fp32_split_gemms = self.fp32_mode == "f32x3"
+        self._model = m
 
     def spect2frames(self, spect):
         with torch.inference_mode():
@@ -272,8 +304,9 @@ class Audio2Frames(Spect2Frames):
             w = waves[k]
             if w is None:
                 w = sig.to(dev) if isinstance(sig, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(sig)).to(dev)
-            w = w.to(torch.float32)
-            waves[k] = (w.mean(1) if w.dim() == 2 else w).contiguous()
+            if w.dim() == 2:   # mono mix in the signal's own type (float64 for float64 / integer input), like numpy's mean(1)
+                w = (w if w.dtype in (torch.float32, torch.float64) else w.to(torch.float64)).mean(1)   # in the reference (inference.py:270-271)
+            waves[k] = w.to(torch.float32).contiguous()
         n = len(waves)
         if n == 0:
             return torch.empty((0, 128), dtype=torch.float32, device=dev), np.zeros(1, dtype=np.int64)
@@ -344,26 +377,30 @@ class Audio2Beats(Audio2Frames):
         spect, frame_off = self.signal2spect_many(signals, sr)
         # float16="f32x3": the range flags of the forward slices are collected, not waited for; ``result()`` looks at them
         # once the batch's device-to-host copy has arrived and repeats the batch on the exact fp32 path if one fired
-        checks = [] if getattr(self.model, "fp32_split_gemms", False) and not self.float16 else None
-        beat, down = self.spect2frames_batch(spect, frame_off, checks=checks)
         if self.frames2beats.type != "minimal":
-            class _Done:  # the DBN runs on the host right away (madmom)
-                def __init__(s, out): s.out = out
+            # the DBN (madmom) runs on the host right away and needs final logits: the range flags are looked at -- and the
+            # batch repeated on the exact path if one fired -- before it sees them (checks=None: the synchronous guard)
+            beat, down = self.spect2frames_batch(spect, frame_off)
+
+            class _Done:
+                def __init__(s, out): s.out, s.logits = out, (beat, down, frame_off)
                 def result(s): return s.out
             return _Done([self.frames2beats(beat[frame_off[k]: frame_off[k + 1]], down[frame_off[k]: frame_off[k + 1]])
                           for k in range(len(signals))])
+        checks = [] if getattr(self.model, "fp32_split_gemms", False) and not self.float16 else None
+        beat, down = self.spect2frames_batch(spect, frame_off, checks=checks)
         pending = self.frames2beats.ragged_async(beat, down, frame_off)
         pending.logits = (beat, down, frame_off)   # framewise logits of the batch (concatenated), for callers that want them
         if checks:
-            return _GuardedPending(pending, checks, lambda: self._many_exact(signals, sr))
+            return _GuardedPending(pending, checks, lambda: self._many_exact_async(signals, sr))
         return pending
 
-    def _many_exact(self, signals, sr):
-        """``many`` on the exact fp32 MFMA path (the repeat of a float16="f32x3" batch whose range flag fired)."""
+    def _many_exact_async(self, signals, sr):
+        """``many_async`` on the exact fp32 MFMA path (the repeat of a BT_PREC_F32X3 batch whose range flag fired)."""
         old = self.model.fp32_split_gemms
         self.model.fp32_split_gemms = False
         try:
-            return self.many(signals, sr)
+            return self.many_async(signals, sr)
         finally:
             self.model.fp32_split_gemms = old
 
@@ -378,8 +415,11 @@ class _GuardedPending:
 
     def result(self):
         out = self.inner.result()
-        if any(eng.range_exceeded(chk) for eng, chk in self.checks):
-            return self.redo()
+        if self.checks and any(eng.range_exceeded(chk) for eng, chk in self.checks):
+            self.inner = self.redo()           # (the exact path: no flags of its own)
+            self.logits = self.inner.logits    # ... and its logits replace the overflowed ones
+            out = self.inner.result()
+        self.checks = None
         return out
 
 

@@ -5,7 +5,8 @@ Same constructor signature, same ``state_dict`` keys (so reference checkpoints l
 the arithmetic runs in the hand-written HIP kernels of libbeat_this_amd.so.  Precision
 follows the caller exactly like the reference: under ``torch.autocast`` (what
 ``Spect2Frames(float16=True)`` enters, inference.py:246) the half-precision (fp16 MFMA operand) path runs, otherwise
-the exact-fp32 MFMA path.  There is no CPU implementation here.
+an fp32-class path: exact fp32 MFMAs, or -- ``fp32_split_gemms``, what the inference classes select for
+``float16=False`` -- three fp16 MFMAs per product on hi + lo operand halves.  There is no CPU implementation here.
 """
 from __future__ import annotations
 
@@ -131,10 +132,11 @@ class BeatThis(nn.Module):
             _attach(self, key, init[key])
         self._bind_units()
         self._engine = None
-        # extension: outside autocast, run every product of the fp32 path on three half MFMAs (operands split into hi + lo
-        # halves, BT_PREC_F32X3) instead of fp32 MFMAs: fp32-class results (1e-5 at the logits, identical beats) at 16/3 of
-        # the matrix rate.  Operands beyond the fp16 range of a hi part are detected and the batch is repeated on the
-        # exact path (Engine.forward_stages).  Off by default: the default fp32 path is the exact one.
+        # outside autocast: True = every product of the forward on three half MFMAs over hi + lo operand halves
+        # (BT_PREC_F32X3: fp32-class results -- 1e-5 at the logits, identical beats -- at 16/3 of the fp32 matrix rate; operands
+        # beyond the fp16 range of a hi half are detected and the batch is repeated on the exact path, Engine.forward_stages);
+        # False = exact fp32 MFMAs.  A bare module starts on the exact path; the inference classes (Spect2Frames ...,
+        # ``float16=False``) switch the model they are given to the hi + lo path, which is the API's default precision.
         self.fp32_split_gemms = False
         self.eval()
 

@@ -157,9 +157,13 @@ class PackedModel:
         self.set_positions(1536)
 
     def set_positions(self, n_pos: int) -> None:
-        """(Re)build the rotary table for sequences of up to ``n_pos`` frames (bt_model_desc.rope / rope_len)."""
-        self.desc.rope = self._f32(torch.from_numpy(tables.rope_table(self._freqs, n_pos)))
+        """(Re)build the rotary table for sequences of up to ``n_pos`` frames (bt_model_desc.rope / rope_len); a previous
+        table is released (the caller makes sure nothing still reads it: Engine.ensure_positions)."""
+        old = getattr(self, "_rope_t", None)
+        self._rope_t = torch.from_numpy(tables.rope_table(self._freqs, n_pos)).to(torch.float32).contiguous().to(self.device)
+        self.desc.rope = self._rope_t.data_ptr()
         self.desc.rope_len = int(n_pos)
+        del old
 
     # ------------------------------------------------------------------------------------------
     def _f32(self, t: torch.Tensor) -> int:
@@ -310,8 +314,8 @@ class Engine:
         # (torch hands out its streams from a fixed pool, so equal keys are the same HIP stream, and a workspace is
         # allocated under the stream that uses it: the caching allocator's stream-ordered reuse covers its release).  At
         # most MAX_WORKSPACES are kept (least recently used goes first: callers that cycle through many streams do not
-        # leak one workspace each), and a workspace far larger than the current need (> 4x) is dropped instead of
-        # pinning e.g. 6.7 GB of a past 96-chunk fp32 batch for the engine's lifetime.
+        # leak one workspace each), and a workspace far larger than what the stream's recent calls need (> 4x, SHRINK_AFTER
+        # times in a row) is dropped instead of pinning e.g. 6.7 GB of a past 96-chunk fp32 batch for the engine's lifetime.
         # Footprint: ~66 MB (fp32) / ~45 MB (half) per chunk and stream; inference.py runs slices of <= 96 chunks
         # (MAX_CHUNKS_PER_LAUNCH) on the caller's stream + CONCURRENT_STREAMS side streams.
         self._ws = collections.OrderedDict()
@@ -327,27 +331,44 @@ class Engine:
             pass
 
     MAX_WORKSPACES = 4
+    SHRINK_AFTER = 8   # consecutive requests of < 1/4 of a stream's workspace before it is given back
 
     def ensure_positions(self, T: int) -> None:
         """Sequences longer than the rotary table (1536 rows by default: the reference's chunks are 1500 frames, but its module
         takes any length, beat_tracker.py:188-192): grow the table to the next multiple of 512 and re-create the handle."""
         if T <= self.packed.desc.rope_len:
             return
+        if self._deferred is not None:
+            raise RuntimeError("the rotary table cannot grow while range checks of earlier forwards are pending")
         torch.cuda.synchronize(self.device)   # (nothing may still be reading the old table when it is released)
+        old_rope, old_len, old_t = self.packed.desc.rope, self.packed.desc.rope_len, self.packed._rope_t
         self.packed.set_positions(-(-T // 512) * 512)
-        _lib.lib().bt_engine_destroy(self._h)
         h = C.c_void_p()
-        _lib.check(_lib.lib().bt_engine_create(C.byref(self.packed.desc), C.byref(h)))
-        self._h = h
+        try:
+            _lib.check(_lib.lib().bt_engine_create(C.byref(self.packed.desc), C.byref(h)))
+        except Exception:   # the old handle (and its table) stay valid
+            self.packed.desc.rope, self.packed.desc.rope_len, self.packed._rope_t = old_rope, old_len, old_t
+            raise
+        old_h, self._h = self._h, h       # swap first, then release: self._h never dangles
+        _lib.lib().bt_engine_destroy(old_h)   # (its profiling records, if a bench leg had some open, go with it)
 
     def _workspace(self, need: int) -> torch.Tensor:
         key = torch.cuda.current_stream(self.device)
-        ws = self._ws.pop(key, None)
-        if ws is not None and (ws.numel() < need or ws.numel() > 4 * need):
+        ws, small = self._ws.pop(key, (None, 0))
+        if ws is not None and ws.numel() < need:
             ws = None
+        elif ws is not None and ws.numel() > 4 * need:
+            # far larger than this call needs: kept while big and small batches alternate on the stream (a 96-chunk slice
+            # next to short pieces would otherwise free and re-allocate gigabytes every call), dropped after
+            # SHRINK_AFTER consecutive small requests
+            small += 1
+            if small >= self.SHRINK_AFTER:
+                ws = None
+        else:
+            small = 0
         if ws is None:
-            ws = torch.empty(need, dtype=torch.uint8, device=self.device)
-        self._ws[key] = ws            # (most recently used last)
+            ws, small = torch.empty(need, dtype=torch.uint8, device=self.device), 0
+        self._ws[key] = (ws, small)   # (most recently used last)
         while len(self._ws) > self.MAX_WORKSPACES:
             self._ws.popitem(last=False)
         return ws

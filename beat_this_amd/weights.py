@@ -97,8 +97,18 @@ def random_state_dict(hp=None, seed: int = 0, style: str = "lively") -> "Ordered
     style="lively": fan-in scaled weights so that attention logits and the output
                     logits have O(1) spread (peaks, sign changes) -- a stricter
                     numerical test than "init", same FLOPs.
+    style="outlier": "lively" with what trained transformers add to it (no checkpoint can be
+                    fetched here, so the stress is synthesised): a few OUTLIER CHANNELS of the
+                    residual stream carrying activations of 10^2 .. 10^3 (rows of
+                    frontend.linear / to_out / net.4 scaled up, the RMSNorm gammas of those
+                    channels scaled down, as trained models do), heavy-tailed (Student-t, 4
+                    degrees of freedom) matrix entries, sharper attention (q / k rows x 2), and
+                    frontend BatchNorm scales that push some channels to |a| ~ 10^2.  Exercises
+                    the fp16 range and the hi + lo representation of BT_PREC_F32X3.
     """
     hp = resolve_hparams(hp)
+    if style == "outlier":
+        return _outlier_state_dict(hp, seed)
     rng = np.random.default_rng(seed)
     sd: "OrderedDict[str, torch.Tensor]" = OrderedDict()
     hd = hp["head_dim"]
@@ -139,6 +149,49 @@ def random_state_dict(hp=None, seed: int = 0, style: str = "lively") -> "Ordered
                 std = 1.0 / math.sqrt(shape[1])
             v = std * rng.standard_normal(shape)
         sd[key] = torch.from_numpy(np.asarray(v, dtype=np.float32).reshape(shape).copy())
+    return sd
+
+
+OUTLIER_GAIN = 400.0   # residual-stream magnitude of the outlier channels of style="outlier" (ordinary channels: O(1 .. 10))
+
+
+def _outlier_state_dict(hp: dict, seed: int) -> "OrderedDict[str, torch.Tensor]":
+    """style="outlier" of ``random_state_dict`` (see there)."""
+    sd = random_state_dict(hp, seed=seed, style="lively")
+    rng = np.random.default_rng(seed + 7919)
+    D, L = hp["transformer_dim"], hp["n_layers"]
+    # heavy-tailed matrix entries: every 2-D weight of the transformer parts times |t_4| / E|t_4| element by element (mean 1,
+    # occasional x5 .. x10)
+    for key, v in sd.items():
+        if v.dim() == 2 and "task_heads" not in key:
+            t = np.abs(rng.standard_t(4, size=tuple(v.shape))).astype(np.float32)
+            sd[key] = v * torch.from_numpy(t / 0.75)
+    # sharper attention: q and k rows of every to_qkv x 1.5 (scores x 2.25)
+    for key, v in sd.items():
+        if key.endswith("to_qkv.weight"):
+            v[: 2 * v.shape[1]] *= 1.5
+    # outlier channels of the main residual stream: a large, nearly token-independent component (what "massive activations"
+    # of trained transformers look like) that the layers keep feeding, and RMSNorm gammas that undo what it does to the norm
+    n_out = max(2, D // 128)
+    out_ch = rng.choice(D, size=n_out, replace=False)
+    gain = OUTLIER_GAIN
+    sd["frontend.linear.weight"][out_ch] *= 4.0
+    sd["frontend.linear.bias"][out_ch] = torch.from_numpy((gain * rng.choice([-1.0, 1.0], n_out)).astype(np.float32))
+    comp = gain * float(np.sqrt(n_out / D)) / 4     # ~ (row norm with outliers) / (row norm without)
+    gammas = ["transformer_blocks.norm.gamma"]
+    for l in range(L):
+        p = f"transformer_blocks.layers.{l}."
+        sd[p + "0.to_out.0.weight"][out_ch] *= 4.0
+        sd[p + "1.net.4.weight"][out_ch] *= 4.0
+        gammas += [p + "0.norm.gamma", p + "1.net.0.gamma"]
+    for g in gammas:
+        sd[g] *= comp
+        sd[g][out_ch] *= 1.0 / (comp * gain / 8)
+    sd["task_heads.beat_downbeat_lin.weight"] *= 0.15   # (logits back to a spread of ~2: peaks on both sides of 0)
+    # frontend: two BatchNorm channels per block with a large scale (activations of ~10^2 inside the partial transformers)
+    for i in range(3):
+        w = sd[f"frontend.blocks.{i}.norm.weight"]
+        w[rng.choice(w.shape[0], size=2, replace=False)] *= 6.0
     return sd
 
 

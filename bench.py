@@ -4,10 +4,12 @@
     python bench.py --gpus N --steps K --warmup W        (N > 1 re-launches itself under torch.distributed.run)
 
 Headline workload = BASELINE.json's metric: final0-shaped BeatThis, 5-minute (300 s) synthetic 44.1 kHz mono tracks
-through ``Audio2Beats`` -- GPU resampler -> log-mel -> chunk gather -> BeatThis.forward (half-precision MFMA operands,
-fp32 accumulate) -> keep_first aggregation -> peak picking -> device-to-host copy of the peak indices -> C++ host
-post-processing -- audio in, beat / downbeat times out.  One step = one batch of TRACKS_PER_GPU = 6 tracks (66 chunks of
-1500 frames; BASELINE config 4's per-GPU share is 64) on every rank, waveforms resident in HBM when the timed region
+through ``Audio2Beats`` -- GPU resampler -> log-mel -> chunk gather -> BeatThis.forward -> keep_first aggregation -> peak
+picking -> device-to-host copy of the peak indices -> C++ host post-processing -- audio in, beat / downbeat times out, in the
+precision of the API's DEFAULT (``float16=False``): BT_PREC_F32X3, fp32 activations with every product on three fp16 MFMAs
+over hi + lo operand halves -- the path that carries north_star's gate (logits within 1e-3 of the CPU reference, identical
+beats), which the in-run `parity` object shows on every run.  One step = one batch of TRACKS_PER_GPU = 6 tracks (66 chunks
+of 1500 frames; BASELINE config 4's per-GPU share is 64) on every rank, waveforms resident in HBM when the timed region
 starts; step i + 1 is enqueued before the host part of step i is collected (Audio2Beats.many_async).  For N > 1 every
 rank processes its own tracks and the framewise logits are all-gathered (RCCL) inside the step -- weak scaling.
 value = N * 6 * 300 audio-seconds / step time (max over ranks).
@@ -17,23 +19,30 @@ Extra objects on the JSON line:
                 max |logit difference|, beat / downbeat frame flips.
   roofline      dominant launch category of the forward (attention, MFMA bound): algorithmic FLOP per launch / average
                 launch duration from HIP events on the launch stream (bt_profile_*, a profiled pass of the same workload
-                right after the timed region); traffic = HBM bytes per launch from the committed PMC passes (labelled).
+                right after the timed region); peak = a third of the dense fp16 MFMA peak (three MFMAs per product);
+                traffic = HBM bytes per launch from the committed PMC passes (labelled).
+  half_path     the same workload with float16=True (fp16 MFMA operands, what BASELINE configs 2 / 4 call bf16): NOT under the
+                gate -- its parity object says by how much, next to the reference's own fp16-autocast error -- with its own
+                roofline (dense fp16 peak) and breakdown.
+  fp32_exact_path  the same workload on exact fp32 MFMAs (float16="exact"), the fallback of the default path.
+  latency       single-file latency (BASELINE config 1: File2Beats on one 30 s track, and one 300 s track), host waveform in
+                -> beat times out, one call at a time, in the three precisions, next to the CPU oracle on the same inputs.
+  stress_weights  the default path on trained-like "outlier" weights (residual outlier channels of ~10^3, heavy-tailed
+                matrices): throughput, parity, and how many batches fell back to the exact path (range guard).
   frontend      the HBM-bound stages (resample, log-mel, chunk gather, aggregation, peak picking): ms per step and GB/s of
                 ALGORITHMIC bytes (3.41 MB per chunk for the log-mel).
-  forward_only  BASELINE config 2 (16 chunks through BeatThis.forward, spectrograms resident), for continuity with round 1.
-  fp32_path     the same headline workload on the exact-fp32 MFMA path (the one under the 1e-3 gate), fewer steps.
-  f32x3_path    the same headline workload in BT_PREC_F32X3 (every product on three fp16 MFMAs over hi + lo operands, the
-                LDS-DMA kernels): the 1e-3 / identical-beats gate at several times the fp32-MFMA rate, with its own
-                `roofline` object (dominant kernel category against a third of the fp16 matrix peak) and breakdown.
-  configs       the other BASELINE.json configurations as short legs: cfg2 (final0 half, 16 chunks = forward_only), cfg3
-                (small0 exact fp32, 128 chunks: fp32-FLOP fraction AND counter-measured HBM GB/s), cfg4_share (final0 half,
-                64 chunks = one GPU's share of the 512-chunk job), cfg5 (withdrawn: no fp8 path is offered).
+  forward_only  BASELINE config 2 (16 chunks through BeatThis.forward, spectrograms resident) in the headline precision and
+                in half precision.
+  configs       the other BASELINE.json configurations as short legs: cfg3 (small0 exact fp32, 128 chunks: fp32-FLOP
+                fraction AND counter-measured HBM GB/s), cfg4_share (final0, 64 chunks = one GPU's share of the 512-chunk
+                job, both precisions), cfg5 (withdrawn: no fp8 path is offered).
   strong_scaling_cfg4  BASELINE config 4 itself: 512 chunks sharded over the N ranks (512 / N each), logits all-gathered.
   timed_region  the K steps are repeated until the timed region holds >= 2 s of GPU work (clocks and temperatures settle);
-                ms_per_step = region / (K x repeats).  rccl_ranks = ranks counted by an RCCL all-reduce.
+                ms_per_step = region / (K x repeats).  rccl_ranks = ranks counted by an RCCL all-reduce (the process group
+                is brought up at N = 1 as well, so every run exercises the N > 1 code path).
   host_inclusive  the headline job with the waveforms starting in pinned HOST memory (PCIe-inclusive rate; never `value`).
   cpu_baseline  the CPU oracle's Audio2Beats (torch fp32, SDPA attention like the reference) on ONE 300 s track on this
-                host, thread count probed and stated (rank 0, N = 1 only).
+                host, three repeats (value = the fastest, median beside it), thread count probed and stated (rank 0, N = 1).
 """
 import argparse
 import ctypes as C
@@ -114,9 +123,10 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--model", default="final0")
-    ap.add_argument("--prec", default="half", choices=["half", "f32", "f32x3"],
-                    help="half = half-precision MFMA operands (float16=True of the Python API); f32 = exact fp32 MFMA; f32x3 = "
-                         "fp32-class results on hi + lo fp16 operands, three MFMAs per product (BT_PREC_F32X3)")
+    ap.add_argument("--prec", default="f32x3", choices=["half", "f32", "f32x3"],
+                    help="f32x3 (default, = float16=False of the Python API) = fp32-class results on hi + lo fp16 operands, three "
+                         "MFMAs per product (BT_PREC_F32X3): the path under the 1e-3 / identical-beats gate; half = fp16 MFMA "
+                         "operands (float16=True); f32 = exact fp32 MFMA (float16='exact')")
     ap.add_argument("--tracks", type=int, default=TRACKS_PER_GPU, help="5-minute tracks per GPU per step")
     ap.add_argument("--workload", default="tracks", choices=["tracks", "forward"],
                     help="tracks = Audio2Beats on 300 s 44.1 kHz tracks (BASELINE metric); forward = BeatThis.forward on "
@@ -125,7 +135,8 @@ def main():
     ap.add_argument("--slice", type=int, default=0, help="chunks per forward launch (0 = the library default)")
     ap.add_argument("--streams", type=int, default=0, help="streams the forward slices of a step run on (0 = the library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extras", action="store_true", help="skip the forward_only / fp32_path / frontend legs")
+    ap.add_argument("--no-extras", action="store_true", help="skip the side legs (other precisions, latency, configs, frontend)")
+    ap.add_argument("--no-dist", action="store_true", help="N = 1 without bringing up the RCCL process group")
     ap.add_argument("--min-seconds", type=float, default=2.0,
                     help="the K timed steps are repeated until the timed region is at least this long (0: exactly K steps)")
     ap.add_argument("--watchdog", type=int, default=900, help="seconds after which a stuck run dumps its stacks and exits")
@@ -157,15 +168,23 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    # (BT_BENCH_FORCE_DIST=1: run the RCCL code path -- process group, logits all-gather, barrier, all-reduce of the time --
-    # with a world of ONE, the only way to exercise it on a single-GPU box; never set by the driver)
-    use_dist = world > 1 or os.environ.get("BT_BENCH_FORCE_DIST") == "1"
+    # N = 1 brings the RCCL process group up as well (a world of one): the logits all-gather, the barriers and the
+    # all-reduced time of the N > 1 path then run on every driver invocation; --no-dist (or a group that fails to come up)
+    # gives the plain single-process run, rccl_ranks = null
+    use_dist = world > 1 or not args.no_dist
+    dist_note = None
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", str(_free_port()))
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=dev)
+        try:
+            dist.init_process_group("nccl", device_id=dev)
+        except Exception as e:  # noqa: BLE001
+            if world > 1:
+                raise
+            use_dist, dist_note = False, f"RCCL group of one did not come up ({type(e).__name__}): single-process run"
+            log(dist_note)
     rccl_ranks = None
     if use_dist:   # proof of N ranks: an RCCL all-reduce counts them
         one = torch.ones(1, dtype=torch.int32, device=dev)
@@ -191,11 +210,18 @@ def main():
     sd = W.random_state_dict(hp, seed=1, style="lively")
     model = BeatThis(**{k: hp[k] for k in ("spect_dim", "transformer_dim", "ff_mult", "n_layers", "head_dim", "stem_dim")})
     model.load_state_dict(sd)
-    a2b = Audio2Beats(checkpoint_path=None, device=dev, float16=args.prec not in ("f32", "f32x3"), dbn=False)
+    a2b = Audio2Beats(checkpoint_path=None, device=dev, float16={"half": True, "f32": "exact", "f32x3": False}[args.prec], dbn=False)
     a2b.model = model.to(dev)
-    a2b.model.fp32_split_gemms = args.prec == "f32x3"
-    half = args.prec not in ("f32", "f32x3")
     half_name = _lib.half_dtype_name()
+    DTYPE = {"half": half_name, "f32": "f32 (v_mfma_f32_32x32x2_f32)",
+             "f32x3": "f32 activations; every product: 3 x v_mfma_f32_32x32x16_f16 on hi + lo operands (BT_PREC_F32X3)"}
+
+    def set_prec(prec):
+        """precision of everything that follows: the API's float16=True / False (default, f32x3) / "exact" """
+        a2b.float16 = prec == "half"
+        a2b.model.fp32_split_gemms = prec == "f32x3"
+    set_prec(args.prec)
+    half = args.prec == "half"
 
     def fence():
         if use_dist:
@@ -392,7 +418,7 @@ def main():
 
         roofline = roofline_of(breakdown, args.prec, chunks_per_step)
 
-        frontend = forward_only = fp32_path = f32x3_path = host_inclusive = configs = None
+        frontend = forward_only = host_inclusive = configs = None
         if args.workload == "tracks" and not args.no_extras:
             # ---- HBM-bound stages: events around each stage on torch's current stream (the launch stream) -------------
             def timed(fn, reps=5):
@@ -423,28 +449,13 @@ def main():
                 "resample_GBps_algorithmic": round(res_bytes / (max(t_front - t_mel, 1e-6) * 1e-3) / 1e9, 1),
                 "peaks+d2h+host_post_ms": round(t_post, 4),
                 "note": "python launch overhead included (stage wall time between stream events); bytes = SURVEY 8d algorithmic"}
-            # ---- BASELINE config 2: forward only, 16 resident chunks --------------------------------------------------
-            x16 = torch.from_numpy(np.stack([W.synthetic_spect(CHUNK_FRAMES, seed=1000 + i) for i in range(16)])).to(dev)
+            # ---- BASELINE configs 2 / 3 / 4 (share): forward only, chunks resident ---------------------------------------
+            def time_forward(model_, xin, prec_, n_warm, n_time):
+                keep = model_.fp32_split_gemms
+                model_.fp32_split_gemms = prec_ == "f32x3"
 
-            def fwd():
-                with torch.inference_mode(), torch.autocast("cuda", enabled=half):
-                    return a2b.model(x16)
-            for _ in range(20):
-                fwd()
-            torch.cuda.synchronize(dev)
-            tf = time.perf_counter()
-            for _ in range(30):
-                fwd()
-            torch.cuda.synchronize(dev)
-            tf = (time.perf_counter() - tf) / 30
-            forward_only = {"workload": "BASELINE config 2: 16 chunks x 1500 frames, BeatThis.forward, spectrograms resident",
-                            "ms_per_step": round(tf * 1e3, 3), "audio_seconds_per_s": round(16 * FRESH_SECONDS_PER_CHUNK / tf, 1),
-                            "whole_forward_tflops": round(FLOP_PER_CHUNK * 16 / tf / 1e12, 1)}
-
-            # ---- the other BASELINE configurations as short legs ------------------------------------------------------
-            def time_forward(model_, xin, half_, n_warm, n_time):
                 def f():
-                    with torch.inference_mode(), torch.autocast("cuda", enabled=half_):
+                    with torch.inference_mode(), torch.autocast("cuda", enabled=prec_ == "half"):
                         return model_(xin)
                 for _ in range(n_warm):
                     f()
@@ -453,24 +464,39 @@ def main():
                 for _ in range(n_time):
                     f()
                 torch.cuda.synchronize(dev)
+                model_.fp32_split_gemms = keep
                 return (time.perf_counter() - t_) / n_time
+
+            def fwd_obj(t_, chunks):
+                return {"ms_per_step": round(t_ * 1e3, 3), "audio_seconds_per_s": round(chunks * FRESH_SECONDS_PER_CHUNK / t_, 1),
+                        "whole_forward_tflops": round(FLOP_PER_CHUNK * chunks / t_ / 1e12, 1)}
+
+            other = "half" if args.prec != "half" else "f32x3"
+            x16 = torch.from_numpy(np.stack([W.synthetic_spect(CHUNK_FRAMES, seed=1000 + i) for i in range(16)])).to(dev)
+            forward_only = {"workload": "BASELINE config 2: 16 chunks x 1500 frames, BeatThis.forward, spectrograms resident",
+                            **fwd_obj(time_forward(a2b.model, x16, args.prec, 20, 30), 16), "dtype": args.prec,
+                            other: fwd_obj(time_forward(a2b.model, x16, other, 20, 30), 16)}
 
             log("config legs (cfg3, cfg4 share)")
             x64 = torch.from_numpy(np.stack([W.synthetic_spect(CHUNK_FRAMES, seed=2000 + i) for i in range(64)])).to(dev)
-            t64 = time_forward(a2b.model, x64, half, 3, 5)
+            t64 = time_forward(a2b.model, x64, args.prec, 3, 5)
+            t64o = time_forward(a2b.model, x64, other, 3, 5)
             hp_s = W.resolve_hparams("small0")
             m_s = BeatThis(**{k: hp_s[k] for k in ("spect_dim", "transformer_dim", "ff_mult", "n_layers", "head_dim", "stem_dim")})
             m_s.load_state_dict(W.random_state_dict(hp_s, seed=1, style="lively"))
             m_s = m_s.to(dev)
             x128 = x64.repeat(2, 1, 1)
-            t128 = time_forward(m_s, x128, False, 2, 3)
+            t128 = time_forward(m_s, x128, "f32", 2, 3)
+            t128x = time_forward(m_s, x128, "f32x3", 2, 3)
             fl_s = flops_per_chunk(hp_s["transformer_dim"], ff_mult=hp_s["ff_mult"])
             flop_s = sum(v for k, v in fl_s.items() if k != "layer_tail")   # 59.57 GFLOP / chunk
             cfg3 = {"workload": "BASELINE config 3: small0, exact fp32 MFMA, 128 chunks x 1500 frames resident",
                     "ms_per_step": round(t128 * 1e3, 2), "audio_seconds_per_s": round(128 * FRESH_SECONDS_PER_CHUNK / t128, 1),
                     "tflops_fp32": round(flop_s * 128 / t128 / 1e12, 1),
                     "frac_of_fp32_matrix_peak": round(flop_s * 128 / t128 / 1e12 / PEAK_TFLOPS["f32"], 4),
-                    "hbm_GBps_counters": None, "frac_of_hbm_peak": None}
+                    "hbm_GBps_counters": None, "frac_of_hbm_peak": None,
+                    "f32x3": {"ms_per_step": round(t128x * 1e3, 2), "audio_seconds_per_s": round(128 * FRESH_SECONDS_PER_CHUNK / t128x, 1),
+                              "note": "the same batch in the API's default precision (fp32-class results on hi + lo fp16 operands)"}}
             try:  # HBM bytes of one such forward from the committed counter passes (FETCH_SIZE x 2 + WRITE_SIZE, separate runs)
                 tj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_cfg3.json")))
                 gb = tj["bytes_per_forward"] / 1e9
@@ -482,11 +508,11 @@ def main():
             configs = {
                 "cfg2": "= forward_only",
                 "cfg3": cfg3,
-                "cfg4_share": {"workload": "BASELINE config 4, one GPU's share: final0, half operands, 64 chunks x 1500 frames resident",
-                               "ms_per_step": round(t64 * 1e3, 3), "audio_seconds_per_s": round(64 * FRESH_SECONDS_PER_CHUNK / t64, 1),
-                               "whole_forward_tflops": round(FLOP_PER_CHUNK * 64 / t64 / 1e12, 1)},
+                "cfg4_share": {"workload": "BASELINE config 4, one GPU's share: final0, 64 chunks x 1500 frames resident",
+                               **fwd_obj(t64, 64), "dtype": args.prec, other: fwd_obj(t64o, 64)},
                 "cfg5": "withdrawn: no fp8 path is offered (rounds 1-2: e4m3 feed-forward GEMMs moved 47 of 194 beats at 0.28 "
-                        "logit error and were no faster than the half path; DESIGN.md)"}
+                        "logit error and were no faster than the half path; round 4's study of narrow formats for the hi + lo "
+                        "correction terms only: DESIGN.md)"}
             del m_s, x64, x128
 
             # ---- the same job from HOST buffers (PCIe-inclusive; never `value`): waveforms in pinned host memory, uploaded
@@ -517,7 +543,7 @@ def main():
             del htracks
 
         # ---- CPU baseline + in-run parity: the oracle's Audio2Beats on track 0, bounded sample ------------------------
-        cpu = parity = None
+        cpu = parity = half_path = fp32_exact_path = f32x3_path = latency = stress = None
         if world == 1 and not args.no_cpu_baseline and args.workload == "tracks":
             from oracle import beat_this_oracle as O
 
@@ -526,7 +552,7 @@ def main():
             with torch.inference_mode():
                 # torch's default (one thread per logical core) oversubscribes big hosts badly: probe on one chunk
                 xc = torch.from_numpy(W.synthetic_spect(CHUNK_FRAMES, seed=5))[None]
-                best = None
+                best, probe = None, {}
                 for nt in (8, 16, 32, 64):  # (one thread per logical core -- torch's default -- is 10x slower on a 2 x 64-core host)
                     if nt > (os.cpu_count() or 1):
                         continue
@@ -535,22 +561,30 @@ def main():
                     tp = time.perf_counter()
                     O.model_forward(sd, xc)
                     tp = time.perf_counter() - tp
+                    probe[nt] = round(tp * 1e3)
                     if best is None or tp < best[1]:
                         best = (nt, tp)
                 torch.set_num_threads(best[0])
-                # bounded sample: the whole 300 s track if its 11 chunks fit ~40 s of CPU time, else a shorter excerpt
-                sample_s = TRACK_SECONDS if 11 * best[1] < 40.0 else max(30.0, 29.76 * int(40.0 / best[1]))
+                # bounded sample: the whole 300 s track if its 11 chunks fit ~12 s of CPU time (three repeats follow), else a
+                # shorter excerpt
+                sample_s = TRACK_SECONDS if 11 * best[1] < 12.0 else max(30.0, 29.76 * int(12.0 / best[1]))
                 sig = sig[: int(sample_s * TRACK_SR)]
-                log(f"cpu baseline: {best[0]} threads, {best[1] * 1e3:.0f} ms per chunk; Audio2Beats of {sample_s:.0f} s of track 0")
-                t1 = time.perf_counter()
-                ob, od = O.audio2frames(sd, sig, TRACK_SR)
-                obeats, odown = O.postp_minimal(ob, od)
-                tc = time.perf_counter() - t1
+                log(f"cpu baseline: {best[0]} threads, {best[1] * 1e3:.0f} ms per chunk; 3 x Audio2Beats of {sample_s:.0f} s of track 0")
+                tcs = []
+                for _ in range(3):
+                    t1 = time.perf_counter()
+                    ob, od = O.audio2frames(sd, sig, TRACK_SR)
+                    obeats, odown = O.postp_minimal(ob, od)
+                    tcs.append(time.perf_counter() - t1)
+            tc = min(tcs)
             cpu = {"value": round(sample_s / tc, 2), "unit": "audio-seconds/s", "cores": best[0],
+                   "median": round(sample_s / sorted(tcs)[1], 2), "repeats_s": [round(t, 2) for t in tcs],
                    "host_logical_cores": os.cpu_count(), "kind": "port",
-                   "sample": f"1 x Audio2Beats of {sample_s:.0f} s of one {TRACK_SR} Hz track (resample, log-mel, {len(ob) // 1488 + 1} chunks "
-                             f"batch-1 like the reference, SDPA attention, fp32, post-processing), oracle/beat_this_oracle.py, {tc:.1f} s; "
-                             f"thread count = fastest of 8/16/32/64 on one chunk ({best[1] * 1e3:.0f} ms per chunk)"}
+                   "threads_probe_ms_per_chunk": probe,
+                   "sample": f"3 x Audio2Beats of {sample_s:.0f} s of one {TRACK_SR} Hz track (resample, log-mel, {len(ob) // 1488 + 1} chunks "
+                             f"batch-1 like the reference, SDPA attention, fp32, post-processing), oracle/beat_this_oracle.py, value = "
+                             f"the fastest repeat; thread count = fastest of 8/16/32/64 on one chunk (more threads are slower on "
+                             f"this host: threads_probe_ms_per_chunk), the reference's own default would be one per logical core"}
             ptrack = [torch.from_numpy(sig).to(dev)]
 
             def flips(a, b):
@@ -564,60 +598,142 @@ def main():
                         "flips_beat": flips(beats, obeats), "flips_downbeat": flips(downbeats, odown),
                         "n_beats": len(obeats), "n_downbeats": len(odown), "logit_spread": round(float(ob.std()), 3),
                         "against": f"CPU oracle (fp32) on the same {sample_s:.0f} s waveform, {len(ob)} frames"}
-            log(f"cpu baseline done in {tc:.1f} s; parity")
+            log(f"cpu baseline done ({tc:.1f} s fastest); parity")
             parity = parity_of(a2b)
-            if half and not args.no_extras:
-                log("fp32 path leg")
-                # the exact-fp32 path on the SAME workload: the path under north_star's 1e-3 / identical-beats gate
-                a2b.float16 = False
-                for _ in range(2):
+
+            def path_leg(prec, seconds):
+                """the headline workload in another precision: ~`seconds` of pipelined steps, parity, per-launch profile"""
+                set_prec(prec)
+                for _ in range(3):
                     a2b.many(tracks, TRACK_SR)
                 torch.cuda.synchronize(dev)
-                t32 = time.perf_counter()
-                for _ in range(3):
+                est = ms_per_step * {"half": 0.5, "f32": 2.7, "f32x3": 1.0}[prec] / {"half": 0.5, "f32": 2.7, "f32x3": 1.0}[args.prec]
+                n = max(3, int(seconds / max(est * 1e-3, 1e-3)))
+                fb0 = eng.last_fallbacks
+                t_ = time.perf_counter()
+                for _ in range(n):
                     step()
                 drain()
                 torch.cuda.synchronize(dev)
-                t32 = (time.perf_counter() - t32) / 3
-                fp32_path = {"ms_per_step": round(t32 * 1e3, 2), "audio_seconds_per_s": round(units_per_step / t32, 1),
-                             "dtype": "f32 (v_mfma_f32_32x32x2_f32)", "parity": parity_of(a2b)}
-                if not _lib.lib().bt_half_is_bf16():
-                    # ... and with its GEMMs and attention on three fp16 MFMAs per product (BT_PREC_F32X3): same gate
+                t_ = (time.perf_counter() - t_) / n
+                bd = profile_forward(lambda: a2b.many(tracks, TRACK_SR), 2, chunks_per_step)
+                leg = {"ms_per_step": round(t_ * 1e3, 2), "audio_seconds_per_s": round(units_per_step / t_, 1), "steps": n,
+                       "dtype": DTYPE[prec], "parity": parity_of(a2b), "roofline": roofline_of(bd, prec, chunks_per_step),
+                       "breakdown": bd}
+                if prec == "f32x3":
+                    leg["range_fallbacks"] = eng.last_fallbacks - fb0
+                set_prec(args.prec)
+                return leg
+
+            if not args.no_extras:
+                if args.prec != "half":
+                    log("half path leg")
+                    half_path = path_leg("half", 1.0)
+                    try:  # the reference's OWN float16-autocast error against its fp32 forward (generated from the unmodified
+                        # reference on the final0 golden case, oracle/make_golden.py): the yardstick for this path
+                        rep = json.load(open(os.path.join(ROOT, "tests", "golden", "reference_autocast_report.json")))["final0_lively_T1500_f16"]
+                        half_path["reference_fp16_autocast"] = {
+                            "max_abs_logit": round(max(rep["max_abs_beat"], rep["max_abs_downbeat"]), 6),
+                            "flips_beat": rep["flips_beat"], "flips_downbeat": rep["flips_downbeat"], "n_beats": rep["n_beats_fp32"],
+                            "note": "unmodified reference, torch.autocast(float16) vs its own fp32 forward, one 1500-frame chunk of "
+                                    "the same weights (tests/golden/reference_autocast_report.json)"}
+                    except (OSError, KeyError, ValueError):
+                        pass
+                    half_path["note"] = "float16=True: NOT under the 1e-3 / identical-beats gate (see parity); never `value`"
+                if args.prec != "f32":
+                    log("exact fp32 path leg")
+                    fp32_exact_path = path_leg("f32", 0.4)
+                if args.prec != "f32x3" and not _lib.lib().bt_half_is_bf16():
                     log("f32x3 path leg")
-                    a2b.model.fp32_split_gemms = True
-                    for _ in range(3):
-                        a2b.many(tracks, TRACK_SR)
+                    f32x3_path = path_leg("f32x3", 1.0)
+
+                # ---- single-file latency (BASELINE config 1): one call at a time, host waveform in, beat times out ---------
+                log("latency leg")
+                sig30 = W.synthetic_audio(30.0, seed=7, sr=TRACK_SR)
+                sig300 = tracks[0].cpu().numpy()
+                latency = {"workload": "Audio2Beats.__call__ (= File2Beats minus the audio decoder) on ONE track in host memory: mono "
+                                       "float32 44.1 kHz -> H2D, resample, log-mel, 2 / 11 chunks through the model, aggregation, peak "
+                                       "picking, D2H, host post-processing -> beat times; one call at a time, median of 10"}
+                for prec in ("f32x3", "half", "f32"):
+                    set_prec(prec)
+                    row = {}
+                    for tag, sg in (("30s", sig30), ("300s", sig300)):
+                        for _ in range(3):
+                            a2b(sg, TRACK_SR)
+                        ts = []
+                        for _ in range(10):
+                            t_ = time.perf_counter()
+                            a2b(sg, TRACK_SR)
+                            ts.append(time.perf_counter() - t_)
+                        ts.sort()
+                        row[tag] = {"ms_median": round(ts[5] * 1e3, 3), "ms_min": round(ts[0] * 1e3, 3),
+                                    "audio_seconds_per_s": round(len(sg) / TRACK_SR / ts[5], 1)}
+                    latency[prec] = row
+                set_prec(args.prec)
+                with torch.inference_mode():
+                    t_ = time.perf_counter()
+                    b30, d30 = O.audio2frames(sd, sig30, TRACK_SR)
+                    O.postp_minimal(b30, d30)
+                    t30 = time.perf_counter() - t_
+                latency["cpu_oracle"] = {"30s": {"ms": round(t30 * 1e3, 1), "audio_seconds_per_s": round(30.0 / t30, 1)},
+                                         "300s": {"ms": round(tc * 1e3 * TRACK_SECONDS / sample_s, 1), "audio_seconds_per_s": cpu["value"]},
+                                         "threads": best[0]}
+
+                # ---- trained-like stress weights: does the default path stay on its fast route? ---------------------------
+                if not _lib.lib().bt_half_is_bf16():
+                    log("stress-weights leg")
+                    sd_o = W.random_state_dict(hp, seed=1, style="outlier")
+                    m_o = BeatThis(**{k: hp[k] for k in ("spect_dim", "transformer_dim", "ff_mult", "n_layers", "head_dim", "stem_dim")})
+                    m_o.load_state_dict(sd_o)
+                    a2b_o = Audio2Beats(checkpoint_path=None, device=dev, float16=False, dbn=False)
+                    a2b_o.model = m_o.to(dev)
+                    eng_o = a2b_o.model.engine()
+                    for _ in range(2):
+                        a2b_o.many(tracks, TRACK_SR)
                     torch.cuda.synchronize(dev)
-                    n3 = max(10, int(1.0 / max(ms_per_step * 3e-3, 1e-3)))   # ~1 s of steps
-                    t3 = time.perf_counter()
-                    for _ in range(n3):
-                        step()
-                    drain()
+                    fb0, pend_o = eng_o.last_fallbacks, []
+                    n_o = 8
+                    t_ = time.perf_counter()
+                    for _ in range(n_o):
+                        pend_o.append(a2b_o.many_async(tracks, TRACK_SR))
+                        if len(pend_o) > 1:
+                            pend_o.pop(0).result()
+                    while pend_o:
+                        pend_o.pop(0).result()
                     torch.cuda.synchronize(dev)
-                    t3 = (time.perf_counter() - t3) / n3
-                    fb0 = eng.last_fallbacks
-                    bd3 = profile_forward(lambda: a2b.many(tracks, TRACK_SR), 2, chunks_per_step)
-                    f32x3_path = {"ms_per_step": round(t3 * 1e3, 2), "audio_seconds_per_s": round(units_per_step / t3, 1),
-                                  "steps": n3,
-                                  "dtype": "f32 activations; every product: 3 x v_mfma_f32_32x32x16_f16 on hi + lo operands (BT_PREC_F32X3)",
-                                  "parity": parity_of(a2b), "roofline": roofline_of(bd3, "f32x3", chunks_per_step),
-                                  "breakdown": bd3, "range_fallbacks": eng.last_fallbacks - fb0}
-                    a2b.model.fp32_split_gemms = False
-                a2b.float16 = True
+                    t_ = (time.perf_counter() - t_) / n_o
+                    fallbacks = eng_o.last_fallbacks - fb0
+                    sig_o = sig[: int(60.0 * TRACK_SR)]
+                    with torch.inference_mode():
+                        ob_o, od_o = O.audio2frames(sd_o, sig_o, TRACK_SR)
+                    obt, odt = O.postp_minimal(ob_o, od_o)
+                    res = a2b_o.many_async([torch.from_numpy(sig_o).to(dev)], TRACK_SR)
+                    bt_o, dt_o = res.result()[0]
+                    stress = {"weights": "style='outlier' (beat_this_amd/weights.py): residual outlier channels of ~10^3, heavy-tailed "
+                                         "(Student-t) matrices, sharper attention, frontend activations of ~10^2",
+                              "ms_per_step": round(t_ * 1e3, 2), "audio_seconds_per_s": round(units_per_step / t_, 1), "steps": n_o,
+                              "range_fallbacks": fallbacks, "batches": n_o,
+                              "parity": {"max_abs_logit": round(max(float((res.logits[0].cpu() - ob_o).abs().max()),
+                                                                    float((res.logits[1].cpu() - od_o).abs().max())), 6),
+                                         "flips_beat": flips(bt_o, obt), "flips_downbeat": flips(dt_o, odt), "n_beats": len(obt),
+                                         "n_downbeats": len(odt), "logit_spread": round(float(ob_o.std()), 3),
+                                         "against": "CPU oracle (fp32) on the first 60 s of track 0"}}
+                    del a2b_o, m_o
 
         out = {
             "metric": "audio-seconds processed/sec", "value": round(value, 1), "unit": "audio-seconds/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": {"half": half_name, "f32": "f32", "f32x3": "f32 (every product: 3 x f16 MFMA on hi+lo operands)"}[args.prec],
+            "dtype": {"half": half_name, "f32": "f32", "f32x3": "f32 activations, f16x3 products (3 x f16 MFMA on hi+lo operand halves, f32 accumulate)"}[args.prec],
             "data": "synthetic",
             "config": {"workload": workload, "tracks_per_gpu": args.tracks if args.workload == "tracks" else None,
                        "chunks_per_gpu": chunks_per_step, "global_chunks": world * chunks_per_step,
                        "parallelism": f"track-sharded x{world}, framewise logits all-gathered" if args.workload == "tracks"
                        else f"chunk-sharded x{world}, logits all-gathered"},
             "parity": parity, "roofline": roofline, "cpu_baseline": cpu, "frontend": frontend, "forward_only": forward_only,
-            "fp32_path": fp32_path, "f32x3_path": f32x3_path, "host_inclusive": host_inclusive, "configs": configs,
-            "strong_scaling_cfg4": strong, "rccl_ranks": rccl_ranks,
+            "half_path": half_path, "fp32_exact_path": fp32_exact_path, "f32x3_path": f32x3_path, "latency": latency,
+            "stress_weights": stress, "host_inclusive": host_inclusive, "configs": configs,
+            "strong_scaling_cfg4": strong, "rccl_ranks": rccl_ranks, "rccl_note": dist_note,
             "timed_region": {"steps": args.steps, "repeats": repeats, "steps_timed": n_timed, "seconds": round(elapsed, 3)},
             "breakdown": breakdown,
         }

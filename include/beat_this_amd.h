@@ -40,11 +40,14 @@ extern "C" {
                         * where they are NULL or a shape does not fit, the GEMM falls back to the register-staged kernel on
                         * [hi | lo] weights, beat_this_amd/pack.py _mat).  IEEE fp16 builds only.
                         * RANGE: a hi part holds |a| <= 65504 (main layers, like the reference's own fp16 autocast) or
-                        * |a| <= 2047 (register-chained frontend halves, whose operands are pre-scaled by 32).  Beyond that a
-                        * split yields inf.  The first int32 of the workspace is the forward's range flag: bt_forward zeroes it
-                        * and every kernel that splits operands ORs 1 into it when it sees such a value (2: a non-finite
-                        * logit); a caller that finds it non-zero after the forward must repeat the batch in BT_PREC_F32
-                        * (beat_this_amd/pack.py: Engine does). */
+                        * |a| <= 1023 (register-chained frontend halves, whose operands are pre-scaled by 64).  Beyond that a
+                        * split yields inf, and inf / NaN then spreads to every token of the chunk (attention).  The first
+                        * int32 of the workspace is the forward's range flag: bt_forward zeroes it; the gemm3 / attention /
+                        * QKV kernels OR 1 into it when a value beyond 65504 goes through a split, and whatever ends the call
+                        * -- the head (logits), the final norm or the frontend's exit (bt_forward_stages with last < 2) --
+                        * ORs 2 when its output is not finite, which covers the splits that do not test their operands (the
+                        * register-chained frontend halves, the register-staged GEMM).  A caller that finds the word non-zero
+                        * after the forward must repeat the batch in BT_PREC_F32 (beat_this_amd/pack.py: Engine does). */
 
 #define BT_MAX_LAYERS 32
 
@@ -150,6 +153,9 @@ typedef struct {
 } bt_logmel_tables;
 
 const char* bt_last_error(void);
+/* ABI version of this header: bumped whenever an entry point's signature, a struct layout or a BT_PREC_* value changes; a
+ * binding must see exactly the value it was written against (beat_this_amd/_lib.py does) */
+#define BT_ABI_VERSION 400
 int bt_version(void);
 /* operand type of the half-precision path (BT_PREC_HALF slot of the weight arrays) this library was built
  * with: 0 = IEEE fp16 (default), 1 = bfloat16 (-DBT_HALF_BF16) */
@@ -186,7 +192,7 @@ int bt_forward_stages(bt_engine* e, void* stream, int prec, int first, int last,
  *   BT_UNIT_STEM     d_in spect [B,T,128]              -> d_out [B,T,32,32]   (b, t, f, c)
  *   BT_UNIT_PARTIAL  index = block: d_in [B,T,F,C]     -> d_out [B,T,F,C]     PartialFTTransformer (F = 32 >> index, C = 32 << index)
  *   BT_UNIT_CONV     index = block: d_in [B,T,F,C]     -> d_out [B,T,F/2,2C]  conv (2,3) / stride (2,1) + BatchNorm + GELU
- *   BT_UNIT_LINEAR   d_in [B,T,8,128] (= (f c) order)  -> d_out [B,T,D]
+ *   BT_UNIT_LINEAR   d_in [B,T,4,256] (= (f c) order)  -> d_out [B,T,D]
  *   BT_UNIT_ATTN     index = layer: d_in [B,T,D]       -> d_out = x + Attention(x)      (the residual form the layer computes)
  *   BT_UNIT_FF       index = layer: d_in [B,T,D]       -> d_out = x + FeedForward(x)
  *   BT_UNIT_NORM     d_in [B,T,D]                      -> d_out = RMSNorm(x)

@@ -61,3 +61,39 @@ def pcm16_wav(path, seconds, seed, sr=22050, channels=1):
         pcm = np.stack([pcm, (pcm // 2).astype(np.int16)], 1)
     wavfile.write(str(path), sr, pcm)
     return pcm
+
+
+# ---- Postprocessor with a padding mask (postprocessor.py:58-136); generator: oracle/make_golden_padding.py ---------------
+PADDING_MASK_CASES = ["tail_padding", "holes_and_leading", "all_masked_row", "unbatched"]
+
+
+def padding_mask_case(name):
+    """(beat, downbeat, mask) numpy arrays of a named case: seeded logits with peaks on both sides of every mask edge."""
+    import numpy as np
+
+    rng = np.random.default_rng(PADDING_MASK_CASES.index(name) + 31)
+    T = 300
+    B = 1 if name == "unbatched" else 3
+    beat = rng.normal(-1.0, 1.5, (B, T)).astype(np.float32)
+    down = rng.normal(-2.0, 1.5, (B, T)).astype(np.float32)
+    mask = np.ones((B, T), dtype=bool)
+    if name == "tail_padding":          # what the training batches look like: pieces of 300 / 217 / 100 frames
+        mask[1, 217:] = False
+        mask[2, 100:] = False
+        beat[1, 215:220] = [3.0, 1.0, 2.5, 4.0, 1.0]   # a peak right before the edge, a larger one behind it (masked)
+        down[2, 99] = 2.0
+    elif name == "holes_and_leading":   # masked stretches in front of / between valid frames: indices behind them shift
+        mask[0, :17] = False
+        mask[1, 50:61] = False
+        mask[1, 200:203] = False
+        mask[2, ::2] = False            # every other frame masked: neighbours of a peak are -1000
+        beat[1, 48:64] = 2.0            # a plateau cut by the hole
+        down[0, 15:20] = [5.0, 4.0, 1.0, 3.0, 0.5]
+    elif name == "all_masked_row":
+        mask[1, :] = False
+        mask[2, :150] = False
+    elif name == "unbatched":
+        mask[0, 120:130] = False
+        mask[0, 290:] = False
+        return beat[0], down[0], mask[0]
+    return beat, down, mask

@@ -25,12 +25,13 @@ def test_library_exports_every_declared_symbol():
     L = _lib()
     header = open(os.path.join(ROOT, "include", "beat_this_amd.h")).read()
     declared = set(re.findall(r"\b(bt_[a-z_0-9]+)\s*\(", header))
+    assert re.search(r"#define BT_ABI_VERSION 400\b", header)
     assert {"bt_forward", "bt_logmel", "bt_peaks", "bt_aggregate", "bt_split_chunks", "bt_engine_create"} <= declared
     handle = L.lib()
     for name in declared:
         assert hasattr(handle, name), f"{name} declared in the header but not exported"
     assert set(L.EXPORTS) == declared
-    assert handle.bt_version() >= 100
+    assert handle.bt_version() == L.ABI_VERSION == 400   # (BT_ABI_VERSION of include/beat_this_amd.h)
 
 
 def test_argument_errors_map_to_exceptions():
@@ -127,6 +128,32 @@ def test_host_peak_mask_and_cpu_logits_postprocessor():
     mb, md = pp(rb, rd, mask)
     ob, od = O.postp_minimal(rb[:2500].clone().masked_fill(~mask[:2500], -1000.0), rd[:2500])
     assert np.array_equal(mb, ob) and np.array_equal(md, od)
+
+
+def _check_padding_mask_cases(device):
+    """``Postprocessor(beat, downbeat, padding_mask)`` against the UNMODIFIED reference's outputs on the same seeded inputs
+    (tests/golden/postp_padding_mask.json, oracle/make_golden_padding.py): tail padding, masked stretches in front of and
+    between valid frames (the indices behind them shift, postprocessor.py:113-117), a fully masked row, unbatched call."""
+    from beat_this_amd.postprocessor import Postprocessor
+    from oracle.cases import PADDING_MASK_CASES, padding_mask_case
+
+    gold = json.load(open(os.path.join(GOLDEN, "postp_padding_mask.json")))
+    pp = Postprocessor("minimal", fps=50)
+    for name in PADDING_MASK_CASES:
+        beat, down, mask = padding_mask_case(name)
+        bt, dt = pp(torch.from_numpy(beat).to(device), torch.from_numpy(down).to(device), torch.from_numpy(mask).to(device))
+        if beat.ndim == 1:
+            assert isinstance(bt, np.ndarray) and bt.dtype == np.float64
+            bt, dt = (bt,), (dt,)
+        else:
+            assert isinstance(bt, tuple) and len(bt) == beat.shape[0]
+        for r in range(len(bt)):
+            assert bt[r].tolist() == gold[name]["beats"][r], (name, r)
+            assert dt[r].tolist() == gold[name]["downbeats"][r], (name, r)
+
+
+def test_postprocessor_padding_mask_on_host_logits_matches_reference():
+    _check_padding_mask_cases("cpu")
 
 
 def test_hl32_format_round_trips_and_matches_the_packer():

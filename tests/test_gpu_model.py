@@ -180,6 +180,13 @@ def test_postprocessor_bit_exact():
     assert isinstance(bb, tuple) and len(bb) == 2 and bb[1].tolist() == post["random3000"]["beats"]
 
 
+def test_postprocessor_padding_mask_matches_reference():
+    """The ``padding_mask`` argument (postprocessor.py:85-136) on device logits: bit-exact against the reference's outputs."""
+    from test_cabi import _check_padding_mask_cases
+
+    _check_padding_mask_cases(dev())
+
+
 def test_audio2beats_end_to_end_golden():
     from beat_this_amd import weights as W
     from beat_this_amd.inference import Audio2Beats
@@ -502,10 +509,46 @@ def test_f32x3_range_guard_falls_back_to_exact_fp32(name):
     before = m.engine().last_fallbacks
     got = a2b.many(sigs, 22050)
     assert m.engine().last_fallbacks > before
+    # ... the handle's logits are those of the repeat, not the overflowed ones
+    h = a2b.many_async(sigs, 22050)
+    h.result()
+    assert all(torch.isfinite(t).all() for t in h.logits[:2])
+    # a DBN-type post-processor (madmom is not installed: a stand-in that only looks at what it is given) runs on the host
+    # right away -- it must see the repeated, finite logits, never the overflowed ones
+    seen = []
+
+    class _FakeDBN:
+        type = "dbn"
+
+        def __call__(self, beat, downbeat):
+            seen.append(bool(torch.isfinite(beat).all() and torch.isfinite(downbeat).all()))
+            return np.zeros(0), np.zeros(0)
+    minimal = a2b.frames2beats
+    a2b.frames2beats = _FakeDBN()
+    before = m.engine().last_fallbacks
+    hd = a2b.many_async(sigs, 22050)
+    hd.result()
+    assert m.engine().last_fallbacks > before and seen == [True, True]
+    dbn_logits = hd.logits
+    a2b.frames2beats = minimal
     m.fp32_split_gemms = False
     want = a2b.many(sigs, 22050)
     for (gb, gd), (wb, wd) in zip(got, want):
         assert np.array_equal(gb, wb) and np.array_equal(gd, wd)
+    hw = a2b.many_async(sigs, 22050)
+    hw.result()
+    assert torch.equal(h.logits[0], hw.logits[0]) and torch.equal(dbn_logits[0], hw.logits[0])
+    # stage calls in BT_PREC_F32X3 (bt_forward_stages with last < 2) are guarded as well: frontend / transformer_blocks
+    # called on their own return the exact path's result, not inf / NaN
+    with torch.inference_mode():
+        fe = m.frontend(x)
+        te = m.transformer_blocks(fe)
+        m.fp32_split_gemms = True
+        before = m.engine().last_fallbacks
+        fs = m.frontend(x)
+        ts = m.transformer_blocks(fe)
+    assert m.engine().last_fallbacks == before + 2
+    assert torch.equal(fs, fe) and torch.equal(ts, te) and torch.isfinite(ts).all()
 
 
 @pytest.mark.parametrize("mode", ["fp32", "half", "f32x3"])

@@ -120,6 +120,12 @@ def test_cfg3_small0_128_chunks_f32x3_vs_oracle():
     _check("cfg3_small0_f32x3", "small0", 128, half=False, x3=True, oracle_idx=[0, 63, 127], tol=1e-4, flips_allowed=(0, 0))
 
 
+def test_cfg4_share_final0_64_chunks_f32x3_vs_oracle():
+    # BASELINE config 4's per-GPU share (and the headline's launch shape: 64 / 66 chunks): the gate-carrying path at 1e-4 and
+    # 0 flips against the oracle on four chunks spread over the batch, batch-vs-alone on all 64
+    _check("cfg4_share_f32x3", "final0", 64, half=False, x3=True, oracle_idx=[0, 21, 42, 63], tol=1e-4, flips_allowed=(0, 0))
+
+
 def test_cfg4_share_final0_64_chunks_half_batch_consistency():
     _check("cfg4_share_half", "final0", 64, half=True, x3=False, oracle_idx=[0, 63], tol=0.05, flips_allowed=None)
 
@@ -172,3 +178,77 @@ def test_batched_forward_is_repeatable_bit_for_bit(hp_name, B, half):
               for o in outs[1:])
     report("repeatable", model=hp_name, B=B, half=half, deviating_repeats=bad)
     assert bad == 0
+
+
+# (beat flips, downbeat flips, of 2163 / 1877) of the half path on the benchmark's first track; bench.py's `half_path.parity`
+# reports the same pair.  Update DELIBERATELY, with the reason in the commit, when a kernel change moves it.
+HALF_FLIPS_TRACK0 = (10, 10)
+
+
+def test_half_path_flips_on_the_benchmark_track_are_pinned():
+    """The half path (float16=True) is not under the 1e-3 / identical-beats gate, but what it does to the beats is part of the
+    record: on the benchmark's own first track (final0, "lively" weights, 300 s at 44.1 kHz through resampler and log-mel)
+    its near-threshold peaks flip a FIXED number of beats against the CPU oracle.  Round 3 moved that number (6 / 9 ->
+    10 / 10) with a 1-ulp change of the log-mel kernel and only the bench noticed; this test pins it, and pins the fp32-class
+    default path at zero on the same track."""
+    from beat_this_amd import weights as W
+    from beat_this_amd.inference import Audio2Beats
+    from beat_this_amd.model import BeatThis
+    from oracle import beat_this_oracle as O
+
+    hp = W.resolve_hparams("final0")
+    sd = W.random_state_dict(hp, seed=1, style="lively")
+    sig = W.synthetic_audio(300.0, seed=0, sr=44100)
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    with torch.inference_mode():
+        ob, od = O.audio2frames(sd, sig, 44100)
+    obeats, odown = O.postp_minimal(ob, od)
+    key = lambda a: set(np.round(np.asarray(a) * 100).astype(np.int64))  # noqa: E731
+    got = {}
+    for mode in (True, False):
+        a2b = Audio2Beats(checkpoint_path=None, device=dev(), float16=mode, dbn=False)
+        m = BeatThis(**{k: hp[k] for k in KEYS})
+        m.load_state_dict(sd)
+        a2b.model = m.to(dev())
+        h = a2b.many_async([torch.from_numpy(sig).to(dev())], 44100)
+        beats, downs = h.result()[0]
+        err = max(float((h.logits[0].cpu() - ob).abs().max()), float((h.logits[1].cpu() - od).abs().max()))
+        got[mode] = (len(key(beats) ^ key(obeats)), len(key(downs) ^ key(odown)), err)
+    report("pinned_flips", half=got[True][:2], half_err=got[True][2], default=got[False][:2], default_err=got[False][2],
+           n_beats=len(obeats), n_downbeats=len(odown))
+    assert got[False][:2] == (0, 0) and got[False][2] < 1e-4
+    assert got[True][:2] == HALF_FLIPS_TRACK0, f"half-path flips moved: {got[True][:2]} (pinned {HALF_FLIPS_TRACK0})"
+
+
+@pytest.mark.parametrize("hp_name,B", [("small0", 4), ("final0", 3)])
+def test_outlier_weights_in_three_precisions(hp_name, B):
+    """Trained-like stress weights (weights.random_state_dict style="outlier": residual-stream outlier channels of ~10^3,
+    heavy-tailed matrices, sharp attention, frontend activations of ~10^2) -- what a real checkpoint is expected to look like
+    to the fp16 range and to the hi + lo representation of BT_PREC_F32X3: the exact path and the default (f32x3) path stay
+    inside the 1e-3 gate with identical beats, the default path WITHOUT falling back to the exact one, and the half path is
+    reported."""
+    from beat_this_amd.postprocessor import Postprocessor
+
+    sd, m, x = _setup(hp_name, B, seed=1, style="outlier")
+    xd = x.to(dev())
+    ref = _oracle(sd, x, range(B))
+    pp = Postprocessor("minimal")
+    res = {}
+    for mode in ("f32", "f32x3", "half"):
+        m.fp32_split_gemms = mode == "f32x3"
+        before = m.engine().last_fallbacks
+        with torch.inference_mode(), torch.autocast("cuda", enabled=mode == "half"):
+            r = m(xd)
+        err, fb, fd, nb = 0.0, 0, 0, 0
+        for i, (ob, od) in ref.items():
+            gb, gd = r["beat"][i].float().cpu(), r["downbeat"][i].float().cpu()
+            err = max(err, float((gb - ob).abs().max()), float((gd - od).abs().max()))
+            f = _flips(pp, gb, gd, ob, od)
+            fb, fd, nb = fb + f[0], fd + f[1], nb + f[2]
+        res[mode] = (err, fb, fd, m.engine().last_fallbacks - before)
+        report("outlier_weights", model=hp_name, mode=mode, max_abs_logit=err, flips_beat=fb, flips_downbeat=fd, n_beats=nb,
+               range_fallbacks=res[mode][3], logit_spread=float(torch.stack([v[0] for v in ref.values()]).std()))
+    assert res["f32"][0] < 1e-3 and res["f32"][1:3] == (0, 0)
+    assert res["f32x3"][3] == 0, "BT_PREC_F32X3 fell back to the exact path on outlier channels of ~10^3"
+    assert res["f32x3"][0] < 1e-3 and res["f32x3"][1:3] == (0, 0)
+    assert np.isfinite(res["half"][0])

@@ -41,12 +41,9 @@ LOAD = re.compile(r"^\s*(scratch_load|global_load|buffer_load|flat_load)\w*\s+(v
 WAIT = re.compile(r"vmcnt\((\d+)\)")
 
 
-def asm_of(src):
+def asm_of(src, defines=()):
     out = tempfile.NamedTemporaryFile(suffix=".s", delete=False).name
-    flags = _lib.FLAGS_BY_SOURCE.get(os.path.basename(src), _lib.HIPCC_FLAGS)
-    cmd = [os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), "--offload-arch=gfx950", "-O3", "-std=c++17", *flags, "-S", "--cuda-device-only",
-           f"-I{os.path.join(ROOT, 'include')}", f"-I{os.path.dirname(src)}", src, "-o", out]
-    subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    subprocess.run(_lib.device_asm_command(src, out, defines), check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     text = open(out).read()
     os.unlink(out)
     return text
