@@ -897,6 +897,217 @@ __global__ __launch_bounds__(256, MINW) void attn_frag_x3_kernel(const AttnFragP
   if (OUT == 0 && p.status && __any(!(amax <= 65504.f)) && lane == 0) atomicOr(p.status, 1);
 }
 
+
+// =====================================================================================================================
+// BT_PREC_F32X3, round 4: the same product on a HAND-SCHEDULED key loop (tools/gen/attn_x3_loop.py -> attn_x3_loop.inc).
+// One wave = TWO 32-query blocks (every K / V fragment read from LDS feeds twice the matrix work), 256 queries per
+// workgroup, two workgroups per CU (<= 256 registers per lane); K / V in a ring of four 64-key tiles (16 KB each: [K 8 KB |
+// V 8 KB]) filled by LDS-DMA three tiles ahead.  The loop over the full tiles is ONE asm statement: the two query blocks run
+// half a step apart, so that the 12 MFMAs of one block (its P.V products of the previous step and its scores of the next
+// one) always sit beside the 56 VALU instructions of the other block's softmax step -- five hand-placed single-issue
+// instructions per 32-cycle MFMA gap, which is what one wave can issue beside a saturated matrix pipe
+// (MI355X_MICROARCH.md).  hipcc's own schedule of the same work (attn_frag_x3_kernel above) clusters the split blocks and
+// leaves runs of four back-to-back MFMAs next to runs of twenty VALU instructions: 45 - 50 % matrix-pipe busy.
+// Prologue (Q fragments, reference maximum), the ragged / masked last tile, the overflow fallback (SAFE pass) and the output
+// stores are the C++ of the kernel above, instantiated for two query blocks per wave.
+#include "attn_x3_loop.inc"
+
+template <int OUT>
+__global__ __launch_bounds__(256, 2) void attn_frag_x3q2_kernel(const AttnFragP p, int nqt, int sh_total) {
+  constexpr int QB = 2, KBX = ATTN_X3Q2_KBX, NBUF = ATTN_X3Q2_NBUF;
+  constexpr int TILEX_BYTES = KBX * BLKX_BYTES, BUF_BYTES = 2 * TILEX_BYTES;
+  static_assert(KBX == 2 && NBUF == 4 && BUF_BYTES == 16384, "the generated loop is written for four 16 KB ring buffers");
+  __shared__ __attribute__((aligned(16))) char smem[NBUF * BUF_BYTES + 16];
+  const int bid = blockIdx.x;
+  const int idx = bid >> 3;
+  const int sh = (idx / nqt) * 8 + (bid & 7);
+  const int qt = idx % nqt;
+  if (sh >= sh_total) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 5, lr = lane & 31;
+  const int L = p.L;
+  const int nblk = (L + 31) >> 5;
+  const long seq_off = (long)sh * p.nbp * BLKX_BYTES;
+  const char* kseq = reinterpret_cast<const char*>(p.k) + seq_off;
+  const char* vseq = reinterpret_cast<const char*>(p.v) + seq_off;
+  int* flag = reinterpret_cast<int*>(smem + NBUF * BUF_BYTES);
+  if (tid == 0) *flag = 0;
+
+  QStateX st[QB];
+  const int qb0 = (qt * 4 + wave) * QB;  // this wave's first query block
+  // (the Q fragments are loaded twice: the asm statement below takes 140 of the 256 registers for itself, and what is
+  // only needed again behind it -- Q for the last, ragged tile -- is cheaper fetched again than kept)
+  auto load_q = [&]() {
+    const int ln = lane_id_fresh(), gg = ln >> 5, ll = ln & 31;
+#pragma unroll
+    for (int j = 0; j < QB; ++j) {
+      const int qbc = min(qb0 + j, nblk - 1);
+      const char* qblk = reinterpret_cast<const char*>(p.q) + seq_off + (long)qbc * BLKX_BYTES;
+      st[j].q0 = *reinterpret_cast<const hfx8*>(qblk + ((2 * gg) * 32 + ll) * 16);
+      st[j].q1 = *reinterpret_cast<const hfx8*>(qblk + ((2 * gg + 1) * 32 + ll) * 16);
+      st[j].q0l = *reinterpret_cast<const hfx8*>(qblk + BLK_BYTES + ((2 * gg) * 32 + ll) * 16);
+      st[j].q1l = *reinterpret_cast<const hfx8*>(qblk + BLK_BYTES + ((2 * gg + 1) * 32 + ll) * 16);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (VGPR-returning loads and LDS-DMA do not retire in one order)
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  load_q();
+  const unsigned seq_bytes = (unsigned)p.nbp * BLKX_BYTES;   // (tiles beyond it read as zeros: the ring is always refilled)
+  const rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(kseq), 0, seq_bytes, 0x00020000);
+  const rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(vseq), 0, seq_bytes, 0x00020000);
+  const int ntiles = (nblk + KBX - 1) / KBX;
+  const bool partial = (L & 31) != 0;
+  int nfull = nblk / KBX;  // tiles of KBX unmasked blocks
+  if (partial && nfull * KBX == nblk) --nfull;
+  nfull = __builtin_amdgcn_readfirstlane(nfull);
+  // ring: tile t lives in buffer t & 3 = [K tile | V tile]; tiles 0, 1, 2 now, tile t + 3 from inside tile t's second block
+  auto stage_ring = [&](int tile) {
+    char* kd = smem + (tile & (NBUF - 1)) * BUF_BYTES + wave * 1024;
+    const int so = tile * TILEX_BYTES;
+#pragma unroll
+    for (int i = 0; i < KBX; ++i) __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, (lptr_t)(kd + i * 4096), 16, tid * 16, so + i * 4096, 0, 0);
+#pragma unroll
+    for (int i = 0; i < KBX; ++i) __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (lptr_t)(kd + TILEX_BYTES + i * 4096), 16, tid * 16, so + i * 4096, 0, 0);
+  };
+  stage_ring(0);
+  stage_ring(1);
+  stage_ring(2);
+#pragma unroll
+  for (int j = 0; j < QB; ++j) {
+    zero16(st[j].acc);
+    st[j].l = 0.f;
+    st[j].m = -1e30f;
+  }
+  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // tile 0 (this wave's four pieces of it) has landed
+  __syncthreads();
+  {  // reference maximum of every query: its scores against key block 0
+    const KFragX kf = ld_kx(smem, g, lr);
+    f32x16 s0[QB];
+    score_x<false, QB>(kf, st, s0);
+#pragma unroll
+    for (int j = 0; j < QB; ++j) {
+      float bm = -1e30f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) bm = fmaxf(bm, (crow(r, g) < L) ? s0[j][r] : -1e30f);
+      bm = fmaxf(bm, __shfl_xor(bm, 32));
+#pragma unroll
+      for (int r = 0; r < 16; ++r) st[j].negm[r] = -bm - P_SHIFT;
+    }
+  }
+  if (nfull > 0) {
+    // operand words of the two buffer descriptors as plain SGPR quads (an asm operand cannot be a __amdgpu_buffer_rsrc_t)
+    const unsigned long long ka = (unsigned long long)kseq, va = (unsigned long long)vseq;
+    const u32x4 dk = {(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)ka), (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((ka >> 32) & 0xffffu)),
+                      (unsigned)__builtin_amdgcn_readfirstlane((int)seq_bytes), 0x00020000u};
+    const u32x4 dv = {(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)va), (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((va >> 32) & 0xffffu)),
+                      (unsigned)__builtin_amdgcn_readfirstlane((int)seq_bytes), 0x00020000u};
+    const unsigned lds0 = (unsigned)(unsigned long long)(lptr_t)smem;   // LDS byte address of the ring
+    const unsigned klane = lds0 + ((2 * g) * 32 + lr) * 16, vlane = lds0 + lane * 16, dmaoff = tid * 16;
+    const unsigned m0base = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + wave * 1024));
+    const float m1 = -1.0f;
+    int t = 0, soff = 3 * TILEX_BYTES;
+    asm volatile(ATTN_X3Q2_ASM
+                 : "+v"(st[0].acc), "+v"(st[1].acc), "+v"(st[0].l), "+v"(st[1].l), "+s"(t), "+s"(soff)
+                 : "v"(st[0].q0), "v"(st[0].q1), "v"(st[0].q0l), "v"(st[0].q1l), "v"(st[1].q0), "v"(st[1].q1), "v"(st[1].q0l), "v"(st[1].q1l),
+                   "v"(st[0].negm), "v"(st[1].negm), "v"(klane), "v"(vlane), "v"(dmaoff), "s"(dk), "s"(dv), "s"(m0base), "s"(m1), "s"(nfull)
+                 : ATTN_X3Q2_CLOBBERS);
+  }
+  const float nm0 = st[0].negm[0], nm1 = st[1].negm[0];   // (what the plain code below uses of the splats)
+  // every piece of the ring this wave asked for has landed, and so has everybody else's: the last tile (fewer than KBX
+  // blocks and / or a masked last block) is read from its ring buffer by the plain code
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (nfull < ntiles) {
+    load_q();
+    st[0].negm[0] = nm0;
+    st[1].negm[0] = nm1;
+    const int lane2 = lane_id_fresh(), g2 = lane2 >> 5, lr2 = lane2 & 31;
+    const char* kb = smem + (nfull & (NBUF - 1)) * BUF_BYTES;
+    const char* vb = kb + TILEX_BYTES;
+    const int nb = nblk - nfull * KBX;
+    for (int c = 0; c < nb; ++c) {
+      const int blk = nfull * KBX + c;
+      const KFragX kf = ld_kx(kb + c * BLKX_BYTES, g2, lr2);
+      const VFragX vf = ld_vx(vb + c * BLKX_BYTES, lane2);
+      f32x16 sc[QB];
+      score_x<false, QB>(kf, st, sc);
+      if (partial && blk == nblk - 1) finish_x<false, true, QB>(sc, vf, g2, st, blk * 32, L);
+      else finish_x<false, false, QB>(sc, vf, g2, st, blk * 32, L);
+    }
+    __syncthreads();
+  }
+  // (lane-derived values again, from an operand hipcc cannot see through: nothing but the softmax state stays live across
+  // the asm statement -- a value kept was a spill, and the ISA lint allows no scratch next to LDS-DMA)
+  const int laneE = lane_id_fresh(), gE = laneE >> 5, lrE = laneE & 31, tidE = wave * 64 + laneE;
+  float l_tot[QB];
+  bool bad = false;
+#pragma unroll
+  for (int j = 0; j < QB; ++j) {
+    l_tot[j] = st[j].l + __shfl_xor(st[j].l, 32);
+    const bool valid = qb0 + j < nblk && (qb0 + j) * 32 + lrE < L;
+    bad = bad || (valid && !(l_tot[j] < 65504.f));   // (see attn_frag_x3_kernel)
+  }
+  if (__any(bad) && laneE == 0) *flag = 1;
+  __syncthreads();
+  if (*flag) {  // workgroup-uniform: classic running-maximum pass on the double-buffered plain code
+    __syncthreads();
+    load_q();
+#pragma unroll
+    for (int j = 0; j < QB; ++j) {
+      zero16(st[j].acc);
+      st[j].l = 0.f;
+      st[j].m = -1e30f;
+    }
+    stage_tile_x<KBX>(rk, rv, 0, smem, 0, tidE, wave);
+    __syncthreads();
+    attn_tiles_x<true, QB, KBX>(rk, rv, smem, tidE, wave, laneE, gE, lrE, st, L, nblk, 0, false);
+#pragma unroll
+    for (int j = 0; j < QB; ++j) l_tot[j] = st[j].l + __shfl_xor(st[j].l, 32);
+  }
+
+  const int seq = sh / p.heads, head = sh - seq * p.heads;
+  float amax = 0.f;
+#pragma unroll
+  for (int j = 0; j < QB; ++j) {
+    const int qi = (qb0 + j) * 32 + lrE;
+    const bool okq = qb0 + j < nblk && qi < L;
+    const float gatev = okq ? p.gates[(long)sh * p.nbp * 32 + qi] : 0.f;
+    const long orow = okq ? (long)(seq / p.o_div) * p.o_outer + (long)(seq % p.o_div) * p.o_inner + (long)qi * p.o_tok : 0;
+    const float scale = okq ? gatev / l_tot[j] : 0.f;
+    if constexpr (OUT == 1) {
+      float* op = reinterpret_cast<float*>(p.out) + orow * p.inner + head * 32 + 4 * gE;
+      if (okq) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+          *reinterpret_cast<f32x4*>(op + 8 * a) = f32x4{st[j].acc[4 * a] * scale, st[j].acc[4 * a + 1] * scale,
+                                                         st[j].acc[4 * a + 2] * scale, st[j].acc[4 * a + 3] * scale};
+      }
+    } else {
+      hf* op = reinterpret_cast<hf*>(p.out) + orow * 2 * p.inner + head * 64 + 8 * gE;   // (hl32 row: see attn_frag_x3_kernel)
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        unsigned xh[2], xl[2], yh[2], yl[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const float a0 = st[j].acc[8 * k + 2 * i] * scale, a1 = st[j].acc[8 * k + 2 * i + 1] * scale;
+          const float b0 = st[j].acc[8 * k + 4 + 2 * i] * scale, b1 = st[j].acc[8 * k + 4 + 2 * i + 1] * scale;
+          split_hl4(a0, a1, b0, b1, xh[i], xl[i], yh[i], yl[i]);
+          amax = fmaxf(amax, fmaxf(fmaxf(fabsf(a0), fabsf(a1)), fmaxf(fabsf(b0), fabsf(b1))));
+        }
+        auto h0 = __builtin_amdgcn_permlane32_swap(xh[0], yh[0], false, false);
+        auto h1 = __builtin_amdgcn_permlane32_swap(xh[1], yh[1], false, false);
+        auto l0 = __builtin_amdgcn_permlane32_swap(xl[0], yl[0], false, false);
+        auto l1 = __builtin_amdgcn_permlane32_swap(xl[1], yl[1], false, false);
+        if (okq) {
+          *reinterpret_cast<u32x4*>(op + 16 * k) = u32x4{h0[0], h1[0], h0[1], h1[1]};
+          *reinterpret_cast<u32x4*>(op + 32 + 16 * k) = u32x4{l0[0], l1[0], l0[1], l1[1]};
+        }
+      }
+    }
+  }
+  if (OUT == 0 && p.status && __any(!(amax <= 65504.f)) && laneE == 0) atomicOr(p.status, 1);
+}
+
 }  // namespace
 
 int attn_frag_blocks(int L) { return ((L + 31) / 32 + KB - 1) / KB * KB; }
@@ -919,6 +1130,15 @@ static void launch_x3(const AttnFragP& p, hipStream_t s) {
   hipLaunchKernelGGL((attn_frag_x3_kernel<QB, OUT, KBX, MINW>), dim3((unsigned)grid), dim3(256), 0, s, p, nqt, (int)sh);
 }
 
+template <int OUT>
+static void launch_x3q2(const AttnFragP& p, hipStream_t s) {
+  const int nblk = (p.L + 31) / 32;
+  const int nqt = (nblk + 7) / 8;   // 256 queries (8 blocks) per workgroup
+  const long sh = (long)p.n_seq * p.heads;
+  const long grid = (sh + 7) / 8 * 8 * nqt;
+  hipLaunchKernelGGL((attn_frag_x3q2_kernel<OUT>), dim3((unsigned)grid), dim3(256), 0, s, p, nqt, (int)sh);
+}
+
 int launch_attn_frag(const AttnFragP& p, hipStream_t s) {
   if (p.L <= 0 || p.n_seq <= 0 || p.heads <= 0 || p.inner != p.heads * 32 || p.nbp < attn_frag_blocks(p.L)) return -2;
   if ((long)p.n_seq * p.heads * ((p.L + 127) / 128) > 0x3fffffffL) return -3;
@@ -933,7 +1153,9 @@ int launch_attn_frag(const AttnFragP& p, hipStream_t s) {
     // (register cap of THREE workgroups per CU: capped for four, the kernel spilled two registers around the key loop and
     // their reloads raced the LDS-DMA in flight -- different results on every run of a 16-chunk forward; the ISA lint's
     // fourth rule now rejects any scratch access in a kernel with LDS-DMA)
-    if (p.x3 == 2) { if (p.out_f32) launch_x3<1, 1, 2, 3>(p, s); else launch_x3<1, 0, 2, 3>(p, s); }
+    //   4 = round 4: two query blocks per wave on the hand-scheduled key loop (attn_frag_x3q2_kernel).
+    if (p.x3 == 4) { if (p.out_f32) launch_x3q2<1>(p, s); else launch_x3q2<0>(p, s); }
+    else if (p.x3 == 2) { if (p.out_f32) launch_x3<1, 1, 2, 3>(p, s); else launch_x3<1, 0, 2, 3>(p, s); }
     else { if (p.out_f32) launch_x3<1, 1, 4, 2>(p, s); else launch_x3<1, 0, 4, 2>(p, s); }
     return (int)hipGetLastError();
   }

@@ -14,6 +14,12 @@
 #include "common.h"
 #include "kernels.h"
 
+// BT_PREC_F32X3 attention kernel of the forward (bt_attn_frag_args.x3): 4 = two query blocks per wave on the hand-scheduled
+// key loop (round 4), 2 = the compiler-scheduled 64-key-tile kernel of round 3 (kept for A/B builds: -DBT_X3_ATTN=2)
+#ifndef BT_X3_ATTN
+#define BT_X3_ATTN 4
+#endif
+
 static thread_local std::string g_err;
 static int bt_set_error(int code, const std::string& msg) {
   g_err = msg;
@@ -170,7 +176,7 @@ int run_layer_x3(prof::State* pf, const bt_pair_weights& pw, const float* rope, 
   memset(&a, 0, sizeof a);
   a.q = ws.qf; a.k = ws.kf; a.v = ws.vf; a.gates = ws.gates_h; a.out = ws.ao; a.n_seq = B; a.L = T; a.heads = H;
   a.inner = D; a.nbp = ws.nbp; a.o_div = 1; a.o_outer = T; a.o_inner = 0; a.o_tok = 1;
-  a.x3 = 2; a.out_f32 = 0; a.status = ws.status;   // (x3 = 2: the 64-key LDS tiles, four workgroups per CU -- attn2.hip)
+  a.x3 = BT_X3_ATTN; a.out_f32 = 0; a.status = ws.status;   // (which x3 attention kernel: attn2.hip launch_attn_frag)
   LAUNCH_CAT(CAT_ATTN_FLASH, s, launch_attn_frag(a, s), "attention (hi + lo)");
   memset(&g, 0, sizeof g);
   g.A = ws.ao; g.lda = D; g.M = M; g.K = D; g.W = pw.w_out_x3; g.N = D; g.epi = G3_RESID; g.x3 = 1; g.status = ws.status;
@@ -245,7 +251,7 @@ int run_pair(prof::State* pf, const bt_pair_weights& pw, const float* rope, floa
     memset(&a, 0, sizeof a);
     a.q = ws.qf; a.k = ws.kf; a.v = ws.vf; a.gates = ws.gates_h; a.out = ws.ao; a.n_seq = B * F; a.L = T; a.heads = H;
     a.inner = C; a.nbp = ws.nbp; a.o_div = F; a.o_outer = (long)T * F; a.o_inner = 1; a.o_tok = F;
-    a.x3 = t2x3 ? 2 : 0; a.out_f32 = 1; a.status = ws.status;   // (x3 = 2: the 64-key LDS tiles, attn2.hip)
+    a.x3 = t2x3 ? BT_X3_ATTN : 0; a.out_f32 = 1; a.status = ws.status;
     LAUNCH_CAT(CAT_ATTN_FLASH, s, launch_attn_frag(a, s), "time attention");
     if (fused2_ok) return outff();
     memset(&g, 0, sizeof g);

@@ -102,9 +102,11 @@ def random_state_dict(hp=None, seed: int = 0, style: str = "lively") -> "Ordered
                     residual stream carrying activations of 10^2 .. 10^3 (rows of
                     frontend.linear / to_out / net.4 scaled up, the RMSNorm gammas of those
                     channels scaled down, as trained models do), heavy-tailed (Student-t, 4
-                    degrees of freedom) matrix entries, sharper attention (q / k rows x 2), and
+                    degrees of freedom) matrix entries, sharper attention (q / k rows x 1.25), and
                     frontend BatchNorm scales that push some channels to |a| ~ 10^2.  Exercises
-                    the fp16 range and the hi + lo representation of BT_PREC_F32X3.
+                    the fp16 range and the hi + lo representation of BT_PREC_F32X3.  Kept WELL
+                    CONDITIONED (fp32 and fp64 CPU forwards agree to 2e-6 at the logits), so
+                    that an error against the oracle is the kernels', not the network's.
     """
     hp = resolve_hparams(hp)
     if style == "outlier":
@@ -152,7 +154,7 @@ def random_state_dict(hp=None, seed: int = 0, style: str = "lively") -> "Ordered
     return sd
 
 
-OUTLIER_GAIN = 400.0   # residual-stream magnitude of the outlier channels of style="outlier" (ordinary channels: O(1 .. 10))
+OUTLIER_GAIN = 1000.0   # residual-stream magnitude of the outlier channels of style="outlier" (ordinary channels: O(1 .. 10))
 
 
 def _outlier_state_dict(hp: dict, seed: int) -> "OrderedDict[str, torch.Tensor]":
@@ -160,16 +162,17 @@ def _outlier_state_dict(hp: dict, seed: int) -> "OrderedDict[str, torch.Tensor]"
     sd = random_state_dict(hp, seed=seed, style="lively")
     rng = np.random.default_rng(seed + 7919)
     D, L = hp["transformer_dim"], hp["n_layers"]
-    # heavy-tailed matrix entries: every 2-D weight of the transformer parts times |t_4| / E|t_4| element by element (mean 1,
-    # occasional x5 .. x10)
+    # heavy-tailed matrix entries: every 2-D weight of the transformer parts times |t_4| / sqrt(E t_4^2) element by element
+    # (same RMS -- a larger overall gain makes the network chaotic: fp32 and fp64 CPU forwards then differ by 0.1 at the
+    # logits and no 1e-3 gate means anything -- with occasional entries x4 .. x8)
     for key, v in sd.items():
         if v.dim() == 2 and "task_heads" not in key:
             t = np.abs(rng.standard_t(4, size=tuple(v.shape))).astype(np.float32)
-            sd[key] = v * torch.from_numpy(t / 0.75)
-    # sharper attention: q and k rows of every to_qkv x 1.5 (scores x 2.25)
+            sd[key] = v * torch.from_numpy(t / np.float32(np.sqrt(2.0)))
+    # sharper attention: q and k rows of every to_qkv x 1.25 (scores x 1.56)
     for key, v in sd.items():
         if key.endswith("to_qkv.weight"):
-            v[: 2 * v.shape[1]] *= 1.5
+            v[: 2 * v.shape[1]] *= 1.25
     # outlier channels of the main residual stream: a large, nearly token-independent component (what "massive activations"
     # of trained transformers look like) that the layers keep feeding, and RMSNorm gammas that undo what it does to the norm
     n_out = max(2, D // 128)
@@ -187,7 +190,6 @@ def _outlier_state_dict(hp: dict, seed: int) -> "OrderedDict[str, torch.Tensor]"
     for g in gammas:
         sd[g] *= comp
         sd[g][out_ch] *= 1.0 / (comp * gain / 8)
-    sd["task_heads.beat_downbeat_lin.weight"] *= 0.15   # (logits back to a spread of ~2: peaks on both sides of 0)
     # frontend: two BatchNorm channels per block with a large scale (activations of ~10^2 inside the partial transformers)
     for i in range(3):
         w = sd[f"frontend.blocks.{i}.norm.weight"]

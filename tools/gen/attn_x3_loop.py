@@ -1,0 +1,214 @@
+#!/usr/bin/env python
+"""Generator of the hand-scheduled key loop of attn_frag_x3q2_kernel (csrc/attn2.hip): writes csrc/attn_x3_loop.inc.
+
+    python tools/gen/attn_x3_loop.py            (the .inc is committed; re-run after editing the schedule)
+
+The loop is ONE inline-assembly statement: hipcc allocates the operands that are used as whole vectors (Q fragments, the
+reference-maximum splats, the output accumulators), everything that is touched element by element lives in physical
+registers v116 .. v255 that the statement lists as clobbers.  What the schedule is and why: DESIGN.md section 5
+("hand-scheduled key loop"); the kernel side of the contract (operand order, LDS layout, ring of four 64-key tiles) is in
+csrc/attn2.hip next to the statement.
+
+One wave = two 32-query blocks A and B, one 32-key block per step.  The two blocks run half a step apart:
+    phase X(c):  VALU  softmax of A on key block c        | MFMA  scores of B for block c,     P.V of B for block c - 1
+    phase Y(c):  VALU  softmax of B on key block c        | MFMA  scores of A for block c + 1, P.V of A for block c
+so every phase pairs 12 big MFMAs of one query block (32 cycles each on the SIMD's matrix pipe) with the 56 VALU
+instructions of the other one (16 exponentials, the 24-instruction hi + lo split, 16 row-sum adds) and 4 fragment reads:
+five single-issue instructions per MFMA gap, placed by hand (MI355X_MICROARCH.md: <= 5 fillers fit a gap).
+"""
+import os
+
+KBX = 2                      # 32-key blocks per LDS tile
+BLK = 4096                   # bytes of one [hi 2 KB | lo 2 KB] block
+TILE = KBX * BLK             # K (or V) part of a ring buffer
+BUF = 2 * TILE               # one ring buffer: [K tile | V tile]
+NBUF = 4
+
+# ---- operands (order = the asm statement's operand list in attn2.hip) -------------------------------------------------
+OPS = ["accA", "accB", "lA", "lB", "t", "soff",               # "+v" x4, "+s" x2 (tile index; global byte offset of tile t + 3)
+       "qA0", "qA1", "qA0l", "qA1l", "qB0", "qB1", "qB0l", "qB1l", "negmA", "negmB",   # "v"
+       "klane", "vlane", "dmaoff",                            # "v": LDS byte address of this lane's K / V fragment in buffer 0; tid * 16
+       "rk", "rv", "m0base", "m1", "nfull"]                   # "s": descriptors, LDS address of smem + wave * 1024, -1.0f, loop end
+IDX = {n: i for i, n in enumerate(OPS)}
+
+
+def o(name):
+    return "%" + str(IDX[name])
+
+
+# ---- physical registers -----------------------------------------------------------------------------------------------
+def vr(lo, n=1):
+    return f"v{lo}" if n == 1 else f"v[{lo}:{lo + n - 1}]"
+
+
+S = {"A": 240, "B": 224}          # scores / probabilities, 16 each
+H = {"A": 216, "B": 200}          # packed hi halves of the probabilities, 8 each
+L = {"A": 208, "B": 192}          # packed lo halves
+KB_ = [176, 160]                  # K fragment buffers (k0, k1, k0l, k1l: 4 registers each)
+VB_ = [144, 128]                  # V fragment buffers (v0, v1, v0l, v1l)
+T = 116                           # temporaries: T+0..4 row-sum tree, T+5 kcur, T+6 knext, T+7 vcur, T+8 vnext
+CLOBBER_V = list(range(116, 256))
+ST = 88                           # SGPR temporaries s88 .. s95
+CLOBBER_S = list(range(88, 96))
+
+K_OFF = [0, 512, 2048, 2560]      # k0, k1, k0l, k1l inside a block (lane part in the address register)
+V_OFF = [0, 1024, 2048, 3072]     # v0, v1, v0l, v1l
+
+
+def mfma(d, a, b, c):
+    return f"v_mfma_f32_32x32x16_f16 {d}, {a}, {b}, {c}"
+
+
+def score_mfmas(q, kbuf):
+    """S_q = negm_q + K . Q_q^T: small terms first (k0l q0, k1l q1, k0 q0l, k1 q1l, k0 q0, k1 q1)"""
+    s = vr(S[q], 16)
+    k = [vr(KB_[kbuf] + 4 * i, 4) for i in range(4)]
+    qq = [o(f"q{q}0"), o(f"q{q}1"), o(f"q{q}0l"), o(f"q{q}1l")]
+    seq = [(k[2], qq[0]), (k[3], qq[1]), (k[0], qq[2]), (k[1], qq[3]), (k[0], qq[0]), (k[1], qq[1])]
+    out = []
+    for i, (a, b) in enumerate(seq):
+        out.append(mfma(s, a, b, o(f"negm{q}") if i == 0 else s))
+    return out
+
+
+def pv_mfmas(q, vbuf):
+    """O_q^T += V^T . P_q^T: (v0l h0, v1l h1, v0 l0, v1 l1, v0 h0, v1 h1)"""
+    acc = o(f"acc{q}")
+    v = [vr(VB_[vbuf] + 4 * i, 4) for i in range(4)]
+    h0, h1, l0, l1 = vr(H[q], 4), vr(H[q] + 4, 4), vr(L[q], 4), vr(L[q] + 4, 4)
+    seq = [(v[2], h0), (v[3], h1), (v[0], l0), (v[1], l1), (v[0], h0), (v[1], h1)]
+    return [mfma(acc, a, b, acc) for a, b in seq]
+
+
+def softmax_fillers(q):
+    """the 56 VALU instructions of one query block's softmax step, grouped per MFMA gap (12 groups)"""
+    s = lambda r: vr(S[q] + r)      # noqa: E731
+    h = lambda j: vr(H[q] + j)      # noqa: E731
+    lo = lambda j: vr(L[q] + j)     # noqa: E731
+    t = lambda i: vr(T + i)         # noqa: E731
+    E = [f"v_exp_f32_e32 {s(r)}, {s(r)}" for r in range(16)]
+    C = [f"v_cvt_pk_f16_f32 {h(j)}, {s(2 * j)}, {s(2 * j + 1)}" for j in range(8)]
+    ML = [f"v_fma_mixlo_f16 {lo(j)}, {h(j)}, {o('m1')}, {s(2 * j)} op_sel:[0,0,0] op_sel_hi:[1,0,0]" for j in range(8)]
+    MH = [f"v_fma_mixhi_f16 {lo(j)}, {h(j)}, {o('m1')}, {s(2 * j + 1)} op_sel:[1,0,0] op_sel_hi:[1,0,0]" for j in range(8)]
+    add = lambda d, a, b: f"v_add_f32_e32 {d}, {a}, {b}"   # noqa: E731
+    a, b, c, d, e = t(0), t(1), t(2), t(3), t(4)
+    lq = o(f"l{q}")
+    return [
+        E[0:4], E[4:8], E[8:12], E[12:16],
+        [C[0], C[1], add(a, s(0), s(1)), add(b, s(2), s(3)), ML[0]],
+        [ML[1], MH[0], MH[1], C[2], C[3]],
+        [add(a, a, b), add(c, s(4), s(5)), add(d, s(6), s(7)), ML[2], ML[3]],
+        [MH[2], MH[3], add(c, c, d), add(a, a, c), C[4]],
+        [C[5], add(e, s(8), s(9)), add(b, s(10), s(11)), ML[4], ML[5]],
+        [MH[4], MH[5], add(e, e, b), C[6], C[7]],
+        [add(c, s(12), s(13)), add(d, s(14), s(15)), ML[6], ML[7], MH[6]],
+        [MH[7], add(c, c, d), add(e, e, c), add(a, a, e), add(lq, lq, a)],
+    ]
+
+
+def frag_reads(kind, buf, addr, blk_off):
+    """four ds_read_b128 of one block's K or V fragments (hi and lo) into fragment buffer `buf`"""
+    base = (KB_ if kind == "K" else VB_)[buf]
+    offs = K_OFF if kind == "K" else V_OFF
+    extra = 0 if kind == "K" else TILE
+    return [f"ds_read_b128 {vr(base + 4 * i, 4)}, {addr} offset:{extra + blk_off + offs[i]}" for i in range(4)]
+
+
+def phase(sm, mm, pv_vbuf, sc_kbuf, reads, head=(), tail_groups=None):
+    """one phase: MFMAs of block `mm` (P.V from V buffer pv_vbuf, then scores from K buffer sc_kbuf, interleaved),
+    softmax of block `sm` in the gaps, `reads` = four fragment reads placed in the first four gaps"""
+    # scores first, then the P.V products: the scores are read by the VALU (exponentials) in the NEXT phase's first gap, and
+    # an MFMA result must not be read by anything but an accumulating MFMA for 12 wait states -- six MFMAs and thirty
+    # fillers lie between; the P.V products read probability words whose last half was written in the previous phase's last
+    # gap (VALU write -> MFMA operand: 2 wait states): they come seventh
+    pv, sc = pv_mfmas(mm, pv_vbuf), score_mfmas(mm, sc_kbuf)
+    mf = sc + pv
+    fill = softmax_fillers(sm)
+    out = list(head)
+    for i in range(12):
+        out.append(mf[i])
+        out += fill[i]
+        if i < 4:
+            out.append(reads[i])
+        if tail_groups and i in tail_groups:
+            out += tail_groups[i]
+    return out
+
+
+def dma_group(piece, s_dst, s_off):
+    """one LDS-DMA instruction of the refill (1 KB per wave): piece 0, 1 = K pieces, 2, 3 = V pieces of the tile"""
+    rs = o("rk") if piece < 2 else o("rv")
+    lds_add = (piece & 1) * 4096 + (TILE if piece >= 2 else 0)
+    glb_add = (piece & 1) * 4096
+    return [f"s_add_u32 m0, {s_dst}, {lds_add}",
+            f"s_add_u32 s{ST + 2}, {s_off}, {glb_add}",
+            f"buffer_load_dwordx4 {o('dmaoff')}, {rs}, s{ST + 2} offen lds"]
+
+
+def build():
+    kcur, knext = vr(T + 5), vr(T + 6)
+    s0, s1 = f"s{ST}", f"s{ST + 1}"
+    A = []
+    # ---- fill: addresses of tile t, K(0) -> K buffer 0, V(0) -> both V buffers (the first P.V of B multiplies zeros), zero
+    # B's probability words, scores of A for block 0
+    A += ["s_nop 4",
+          f"s_and_b32 {s0}, {o('t')}, {NBUF - 1}", f"s_lshl_b32 {s0}, {s0}, {BUF.bit_length() - 1}",
+          f"v_add_u32_e32 {kcur}, {s0}, {o('klane')}"]
+    A += frag_reads("K", 0, kcur, 0)
+    # (V reads take the K lane address minus the K lane part plus the V lane part: separate address register)
+    A += [f"v_add_u32_e32 {knext}, {s0}, {o('vlane')}"]
+    A += frag_reads("V", 0, knext, 0) + frag_reads("V", 1, knext, 0)
+    for j in range(8):
+        A += [f"v_mov_b32_e32 {vr(H['B'] + j)}, 0", f"v_mov_b32_e32 {vr(L['B'] + j)}, 0"]
+    A += ["s_waitcnt lgkmcnt(0)"]
+    A += score_mfmas("A", 0)
+    A += ["s_nop 7", "s_nop 7"]   # (MFMA result -> VALU read: 12 wait states; once per workgroup)
+    A += [f"Lloop%=:"]
+    # ---- per tile: addresses (K reads: kcur / knext, V reads: vcur / vnext kept in T+7 / T+8) -------------------------------
+    vcur, vnext = vr(T + 7), vr(T + 8)
+    A += [f"s_and_b32 {s0}, {o('t')}, {NBUF - 1}", f"s_lshl_b32 {s0}, {s0}, {BUF.bit_length() - 1}",
+          f"s_add_u32 {s1}, {o('t')}, 1", f"s_and_b32 {s1}, {s1}, {NBUF - 1}", f"s_lshl_b32 {s1}, {s1}, {BUF.bit_length() - 1}",
+          f"v_add_u32_e32 {kcur}, {s0}, {o('klane')}", f"v_add_u32_e32 {vcur}, {s0}, {o('vlane')}",
+          f"v_add_u32_e32 {knext}, {s1}, {o('klane')}", f"v_add_u32_e32 {vnext}, {s1}, {o('vlane')}"]
+    # block c = 0 of the tile (global parity even): K(c) in K buffer 0, V(c) in V buffer 0, V(c - 1) in V buffer 1
+    A += phase("A", "B", pv_vbuf=1, sc_kbuf=0, reads=frag_reads("K", 1, kcur, BLK))                       # X(0): reads K(1)
+    A += phase("B", "A", pv_vbuf=0, sc_kbuf=1, reads=frag_reads("V", 1, vcur, BLK), head=["s_waitcnt lgkmcnt(0)"])  # Y(0): reads V(1)
+    # block c = 1: the next tile must have landed before its K(0) is read; the refill of the ring goes into this phase's later gaps
+    s_dst = f"s{ST + 3}"
+    refill_prep = [f"s_add_u32 {s_dst}, {o('t')}, 3", f"s_and_b32 {s_dst}, {s_dst}, {NBUF - 1}",
+                   f"s_lshl_b32 {s_dst}, {s_dst}, {BUF.bit_length() - 1}", f"s_add_u32 {s_dst}, {s_dst}, {o('m0base')}"]
+    tg = {4: refill_prep, 5: dma_group(0, s_dst, o("soff")), 6: dma_group(1, s_dst, o("soff")),
+          7: dma_group(2, s_dst, o("soff")), 8: dma_group(3, s_dst, o("soff"))}
+    A += phase("A", "B", pv_vbuf=0, sc_kbuf=1, reads=frag_reads("K", 0, knext, 0),
+               head=["s_waitcnt vmcnt(4) lgkmcnt(0)", "s_barrier"], tail_groups=tg)                                    # X(1): reads K(0) of tile t + 1
+    A += phase("B", "A", pv_vbuf=1, sc_kbuf=0, reads=frag_reads("V", 0, vnext, 0), head=["s_waitcnt lgkmcnt(0)"])  # Y(1): reads V(0) of tile t + 1
+    A += [f"s_add_u32 {o('soff')}, {o('soff')}, {BUF // 2}",     # (a tile of K is TILE bytes in global memory; so is V)
+          f"s_add_u32 {o('t')}, {o('t')}, 1",
+          f"s_cmp_lt_i32 {o('t')}, {o('nfull')}",
+          f"s_cbranch_scc1 Lloop%="]
+    # ---- drain: P.V of B for the last block (V buffer 1), then the MFMA results may be read by compiler code
+    A += pv_mfmas("B", 1)
+    A += ["s_waitcnt lgkmcnt(0)", "s_nop 7", "s_nop 7"]   # (the fragment reads of the next tile land in registers hipcc may reuse)
+    return A
+
+
+def main():
+    lines = build()
+    here = os.path.dirname(os.path.abspath(__file__))
+    out = os.path.join(here, "..", "..", "beat_this_amd", "csrc", "attn_x3_loop.inc")
+    n_mfma = sum("v_mfma" in x for x in lines)
+    with open(out, "w") as f:
+        f.write("// GENERATED by tools/gen/attn_x3_loop.py -- do not edit; the schedule is described there and in DESIGN.md.\n")
+        f.write(f"// {len(lines)} instructions, {n_mfma} MFMAs; operands: " + ", ".join(f"%{i} {n}" for i, n in enumerate(OPS)) + "\n")
+        f.write("#define ATTN_X3Q2_ASM \\\n")
+        for x in lines:
+            f.write(f'  "{x}\\n\\t" \\\n')
+        f.write('  ""\n')
+        f.write("#define ATTN_X3Q2_CLOBBERS " + ", ".join(f'"v{i}"' for i in CLOBBER_V) + ", " +
+                ", ".join(f'"s{i}"' for i in CLOBBER_S) + ', "scc", "memory"\n')
+        f.write(f"#define ATTN_X3Q2_KBX {KBX}\n#define ATTN_X3Q2_NBUF {NBUF}\n")
+    print(f"wrote {os.path.normpath(out)}: {len(lines)} instructions, {n_mfma} MFMAs")
+
+
+if __name__ == "__main__":
+    main()
