@@ -1154,8 +1154,13 @@ int launch_attn_frag(const AttnFragP& p, hipStream_t s) {
     // their reloads raced the LDS-DMA in flight -- different results on every run of a 16-chunk forward; the ISA lint's
     // fourth rule now rejects any scratch access in a kernel with LDS-DMA)
     //   4 = round 4: two query blocks per wave on the hand-scheduled key loop (attn_frag_x3q2_kernel).
-    if (p.x3 == 4) { if (p.out_f32) launch_x3q2<1>(p, s); else launch_x3q2<0>(p, s); }
-    else if (p.x3 == 2) { if (p.out_f32) launch_x3<1, 1, 2, 3>(p, s); else launch_x3<1, 0, 2, 3>(p, s); }
+    // 4 is taken for launches of at least two full rounds of its 256-query workgroups (two per CU); below that the 64-key
+    // kernel's finer grain (128 queries per workgroup, three per CU) fills the chip better: a 2-chunk single-file forward is
+    // 192 workgroups of the former against 384 of the latter.
+    const long wg4 = (long)p.n_seq * p.heads * (((p.L + 31) / 32 + 7) / 8);
+    if (p.x3 == 4 && wg4 >= 1024) { if (p.out_f32) launch_x3q2<1>(p, s); else launch_x3q2<0>(p, s); }
+    else if (p.x3 == 5) { if (p.out_f32) launch_x3q2<1>(p, s); else launch_x3q2<0>(p, s); }   // (forced: tests, probes)
+    else if (p.x3 == 2 || p.x3 == 4) { if (p.out_f32) launch_x3<1, 1, 2, 3>(p, s); else launch_x3<1, 0, 2, 3>(p, s); }
     else { if (p.out_f32) launch_x3<1, 1, 4, 2>(p, s); else launch_x3<1, 0, 4, 2>(p, s); }
     return (int)hipGetLastError();
   }

@@ -299,8 +299,9 @@ int bt_attention(void* stream, int prec, const bt_attn_args* a);
  * pre-scaled by log2(e)/sqrt(32).  nbp >= bt_attn_frag_blocks(L).  Output as bt_attention (half).
  * x3 != 0 (BT_PREC_F32X3): blocks of 4 KB = [hi block | lo block] of the fp32 values, three MFMAs per product; output
  * fp32 [rows, inner] (out_f32 != 0) or hl32 half [rows, 2 inner]; status (may be NULL) = range flag of the hl32 output;
- * x3 = 1: 128-key LDS tiles, x3 = 2: 64-key tiles (the same arithmetic, bit-identical results); x3 = 4: two query blocks per
- * wave on a hand-scheduled key loop (the forward's choice since round 4; same products, row sums added in another order). */
+ * x3 = 1: 128-key LDS tiles, x3 = 2: 64-key tiles (the same arithmetic, bit-identical results); x3 = 5: two query blocks per
+ * wave on a hand-scheduled key loop (same products, row sums added in another order); x3 = 4 (the forward's choice since
+ * round 4): 5 for launches of at least 1024 of its workgroups, 2 below. */
 typedef struct {
   const void* q; const void* k; const void* v; const float* gates; void* out;
   int32_t n_seq, L, heads, inner, nbp, o_div; int64_t o_outer, o_inner, o_tok;

@@ -205,7 +205,7 @@ def _run_attn(q, k, v, gates, n_seq, L, heads, out_f32, variant=1, **omap):
     return out.double().cpu() if out_f32 else from_hl32(out.cpu())
 
 
-@pytest.mark.parametrize("variant", [1, 2, 4])   # bt_attn_frag_args.x3: keys per LDS tile / 4 = the hand-scheduled two-query-block kernel (attn2.hip)
+@pytest.mark.parametrize("variant", [1, 2, 5])   # bt_attn_frag_args.x3: keys per LDS tile / 5 = the hand-scheduled two-query-block kernel, forced (4 = by launch size; attn2.hip)
 @pytest.mark.parametrize("out_f32", [False, True])
 @pytest.mark.parametrize("n_seq,L,heads", [(3, 1500, 2), (2, 77, 1), (1, 128, 4), (5, 1012, 1), (2, 1, 1), (2, 33, 2),
                                            (1, 1499, 1), (2, 129, 1), (9, 96, 1), (2, 257, 1), (2, 250, 1), (1, 64, 1)])
@@ -232,14 +232,14 @@ def test_attention_frag_x3_time_direction_rowmap():
     SH = B * F
     q, k, v = (_mk((SH, T, 32), 40 + i).float().double() for i in range(3))
     gates = torch.sigmoid(_mk((SH, T), 44)).float().double()
-    out = _run_attn(q, k, v, gates, SH, T, heads, True, 4, o_div=F, o_outer=T * F, o_inner=1, o_tok=F)
+    out = _run_attn(q, k, v, gates, SH, T, heads, True, 5, o_div=F, o_outer=T * F, o_inner=1, o_tok=F)
     ref = _attn_ref(q, k, v, gates).view(B, F, T, 32).permute(0, 2, 1, 3).reshape(B * T * F, 32)
     err = _rel(out, ref)
     report("attn_frag_x3_rowmap", rel=err)
     assert err < 4e-6
 
 
-@pytest.mark.parametrize("variant", [1, 2, 4])
+@pytest.mark.parametrize("variant", [1, 2, 5])
 @pytest.mark.parametrize("L", [300, 1500])
 def test_attention_frag_x3_overflow_fallback(L, variant):
     """Scores that exceed the first key block's maximum by more than the fp16 probabilities can hold force the SAFE
@@ -262,7 +262,7 @@ def test_attention_frag_x3_overflow_fallback(L, variant):
     assert err < 6e-6
 
 
-@pytest.mark.parametrize("variant", [1, 2, 4])
+@pytest.mark.parametrize("variant", [1, 2, 4, 5])
 def test_attention_frag_x3_at_scale_is_repeatable(variant):
     """The main-layer launch shape of a 16-chunk batch (256 sequence-heads x 1500 tokens) four times: bit-identical.
     (Round 3: the 64-key variant, capped to 128 registers, spilled two of them around the key loop; the reloads raced the

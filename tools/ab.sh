@@ -7,7 +7,7 @@ export BT_DEV=1
 for i in 1 2 3; do
   for l in "$@" ""; do
     if [ -n "$l" ]; then export BT_LIB_PATH=$R/$l; else unset BT_LIB_PATH; fi
-    python bench.py --no-cpu-baseline --steps 30 $AB_ARGS 2>/dev/null | python -c "
+    python bench.py --no-cpu-baseline --no-extras --steps 30 $AB_ARGS 2>/dev/null | python -c "
 import sys, json
 d = json.loads(sys.stdin.read())
 b = d['breakdown']

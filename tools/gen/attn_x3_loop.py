@@ -117,20 +117,26 @@ def frag_reads(kind, buf, addr, blk_off):
 def phase(sm, mm, pv_vbuf, sc_kbuf, reads, head=(), tail_groups=None):
     """one phase: MFMAs of block `mm` (P.V from V buffer pv_vbuf, then scores from K buffer sc_kbuf, interleaved),
     softmax of block `sm` in the gaps, `reads` = four fragment reads placed in the first four gaps"""
-    # scores first, then the P.V products: the scores are read by the VALU (exponentials) in the NEXT phase's first gap, and
-    # an MFMA result must not be read by anything but an accumulating MFMA for 12 wait states -- six MFMAs and thirty
-    # fillers lie between; the P.V products read probability words whose last half was written in the previous phase's last
-    # gap (VALU write -> MFMA operand: 2 wait states): they come seventh
+    # The two chains of the phase alternate (score, P.V, score, P.V ...): two MFMAs on the SAME accumulator with other
+    # instructions issued in between lose the back-to-back accumulator forwarding (+43 cycles each, MI355X_MICROARCH.md);
+    # alternated, the next MFMA of a chain issues 64 cycles after its predecessor, whose result is long written.  Hazards:
+    # the scores are read by the VALU (exponentials) in the NEXT phase's first gap -- the last score MFMA is the eleventh,
+    # 12 instructions ahead of them (an MFMA result may not be read by anything but an accumulating MFMA for 12 wait
+    # states); the first P.V MFMA reads probability words whose last half was written six instructions earlier.
     pv, sc = pv_mfmas(mm, pv_vbuf), score_mfmas(mm, sc_kbuf)
-    mf = sc + pv
+    mf = [x for pair in zip(sc, pv) for x in pair]
     fill = softmax_fillers(sm)
     out = list(head)
+    if ABL & 4:
+        out = [h for h in out if "barrier" not in h]
     for i in range(12):
-        out.append(mf[i])
-        out += fill[i]
-        if i < 4:
+        if not ((ABL & 16) and i % 2 == 0) and not ((ABL & 8) and i % 2 == 1):
+            out.append(mf[i])
+        if not (ABL & 1):
+            out += fill[i]
+        if i < 4 and not (ABL & 2):
             out.append(reads[i])
-        if tail_groups and i in tail_groups:
+        if tail_groups and i in tail_groups and not (ABL & 4):
             out += tail_groups[i]
     return out
 
@@ -143,6 +149,10 @@ def dma_group(piece, s_dst, s_off):
     return [f"s_add_u32 m0, {s_dst}, {lds_add}",
             f"s_add_u32 s{ST + 2}, {s_off}, {glb_add}",
             f"buffer_load_dwordx4 {o('dmaoff')}, {rs}, s{ST + 2} offen lds"]
+
+
+ABL = 0   # development ablations (results are garbage): 1 no softmax VALU, 2 no fragment reads in the loop, 4 no refill / barrier,
+          # 8 no P.V MFMAs, 16 no score MFMAs
 
 
 def build():
@@ -193,17 +203,23 @@ def build():
 
 
 def main():
-    lines = build()
+    global ABL
     here = os.path.dirname(os.path.abspath(__file__))
     out = os.path.join(here, "..", "..", "beat_this_amd", "csrc", "attn_x3_loop.inc")
+    lines = build()
     n_mfma = sum("v_mfma" in x for x in lines)
     with open(out, "w") as f:
         f.write("// GENERATED by tools/gen/attn_x3_loop.py -- do not edit; the schedule is described there and in DESIGN.md.\n")
         f.write(f"// {len(lines)} instructions, {n_mfma} MFMAs; operands: " + ", ".join(f"%{i} {n}" for i, n in enumerate(OPS)) + "\n")
-        f.write("#define ATTN_X3Q2_ASM \\\n")
-        for x in lines:
-            f.write(f'  "{x}\\n\\t" \\\n')
-        f.write('  ""\n')
+        f.write("// (-DBT_X3Q2_ABL=n, development builds: ablated forms of the loop whose results are garbage -- what the loop spends where)\n")
+        f.write("#ifndef BT_X3Q2_ABL\n#define BT_X3Q2_ABL 0\n#endif\n")
+        for abl in (0, 1, 2, 3, 4, 7, 8, 16, 9, 17):
+            ABL = abl
+            f.write(f"#if BT_X3Q2_ABL == {abl}\n#define ATTN_X3Q2_ASM \\\n")
+            for x in build():
+                f.write(f'  "{x}\\n\\t" \\\n')
+            f.write('  ""\n#endif\n')
+        ABL = 0
         f.write("#define ATTN_X3Q2_CLOBBERS " + ", ".join(f'"v{i}"' for i in CLOBBER_V) + ", " +
                 ", ".join(f'"s{i}"' for i in CLOBBER_S) + ', "scc", "memory"\n')
         f.write(f"#define ATTN_X3Q2_KBX {KBX}\n#define ATTN_X3Q2_NBUF {NBUF}\n")

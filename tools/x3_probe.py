@@ -46,7 +46,7 @@ def attention(n_seq, heads, Lq, label):
     qd, kd, vd = q.to(dev), k.to(dev), v.to(dev)
     gates = torch.rand((SH, nbp * 32), generator=g).to(dev)
     outs = {}
-    for variant in (1, 2, 4):
+    for variant in (1, 2, 5):
         out = torch.zeros((n_seq * Lq, 2 * heads * 32), dtype=torch.float16, device=dev)
         a = L.AttnFragArgs()
         a.q, a.k, a.v, a.gates, a.out = qd.data_ptr(), kd.data_ptr(), vd.data_ptr(), gates.data_ptr(), out.data_ptr()
