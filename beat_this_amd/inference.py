@@ -31,6 +31,7 @@ import torch
 
 from . import _lib
 from .model import BeatThis
+from .pack import Engine
 from .postprocessor import Postprocessor
 from .preprocessing import LogMelSpect, load_audio
 from .utils import replace_state_dict_key, save_beat_tsv
@@ -149,6 +150,38 @@ def _gather_chunks(spect: torch.Tensor, starts: np.ndarray, T: int):
     return chunks, d_starts
 
 
+USE_GRAPHS = True   # single-file path: the forward of up to Engine.GRAPH_MAX_CHUNKS chunks is replayed as one hipGraph
+
+
+def _graphed_forward(model, spect: torch.Tensor, starts: np.ndarray, T: int):
+    """The chunks of one piece through a captured forward (pack.Engine.graph_forward): the chunk gather writes straight into
+    the graph's input buffer and the aggregation reads the graph's logits -- no launches from the host but three, no copies.
+    -> (beat, downbeat, device starts), or None when the model is not a BeatThis on its fused path, the piece is too long,
+    graphs are off, or the range guard of BT_PREC_F32X3 fired (the caller then takes the ordinary path, fallback included)."""
+    if not USE_GRAPHS or not isinstance(model, BeatThis) or len(starts) > Engine.GRAPH_MAX_CHUNKS or _model_hooked(model):
+        return None
+    eng = model.engine()
+    prec = model._precision()
+    entry = eng.graph_forward(len(starts), T, prec)
+    if entry is None:
+        return None
+    dev = spect.device
+    with torch.cuda.device(dev):
+        d_starts = _lib.upload(np.asarray(starts, dtype=np.int32), dev)
+        _lib.check(_lib.lib().bt_split_chunks(_lib.stream_ptr(dev), spect.data_ptr(), spect.shape[0], d_starts.data_ptr(), len(starts), T,
+                                              entry.x.data_ptr()))
+        entry.replay()
+        if prec == _lib.PREC_F32X3 and int(entry.flag.item()) != 0:
+            return None   # (operands beyond the fp16 range: the ordinary path repeats the piece and counts the fallback)
+    return entry.beat, entry.down, d_starts
+
+
+def _model_hooked(model) -> bool:
+    from .model import _hooked_below
+
+    return _hooked_below(model) or bool(model._forward_hooks or model._forward_pre_hooks)
+
+
 def _run_batched(model, chunks: torch.Tensor):
     """model over (B,T,128) in equal slices of at most MAX_CHUNKS_PER_LAUNCH -> beat, downbeat (B,T)."""
     B = chunks.shape[0]
@@ -173,9 +206,13 @@ def split_predict_aggregate(spect: torch.Tensor, chunk_size: int, border_size: i
         return {"beat": empty, "downbeat": empty.clone()}
     starts = chunk_starts(n, chunk_size, border_size)
     T = chunk_length(n, chunk_size, border_size)
-    chunks, d_starts = _gather_chunks(spect, starts, T)
-    cb, cd = _run_batched(model, chunks)
-    cb, cd = cb.float().contiguous(), cd.float().contiguous()
+    fast = _graphed_forward(model, spect, starts, T) if overlap_mode == "keep_first" else None
+    if fast is not None:
+        cb, cd, d_starts = fast
+    else:
+        chunks, d_starts = _gather_chunks(spect, starts, T)
+        cb, cd = _run_batched(model, chunks)
+        cb, cd = cb.float().contiguous(), cd.float().contiguous()
     if overlap_mode != "keep_first":  # "keep_last": reference-compatible torch glue
         preds = [{"beat": cb[i], "downbeat": cd[i]} for i in range(len(starts))]
         beat, down = aggregate_prediction(preds, starts, n, chunk_size, border_size, overlap_mode, spect.device)
@@ -482,8 +519,8 @@ def batch_predict_aggregate(spect: torch.Tensor, frame_off, chunk_size: int, bor
     dev = spect.device
     frame_off = np.asarray(frame_off, dtype=np.int64)
     total = int(frame_off[-1])
-    beat = torch.empty((total,), dtype=torch.float32, device=dev)
-    down = torch.empty((total,), dtype=torch.float32, device=dev)
+    both = torch.empty((2, total), dtype=torch.float32, device=dev)   # (one buffer: the peak picker takes it without a concatenation)
+    beat, down = both[0], both[1]
     rows, pieces = [], []
     for k in range(len(frame_off) - 1):
         lo, hi = int(frame_off[k]), int(frame_off[k + 1])
@@ -529,8 +566,11 @@ def batch_predict_aggregate(spect: torch.Tensor, frame_off, chunk_size: int, bor
                 chunks = torch.empty((nb, chunk_size, 128), dtype=torch.float32, device=dev)
                 _lib.check(lib.bt_split_chunks_batch(_lib.stream_ptr(dev), spect.data_ptr(), d_rows[4 * i:].data_ptr(), nb,
                                                      chunk_size, chunks.data_ptr()))
-                r = model(chunks)
-                cb[i: i + nb], cd[i: i + nb] = r["beat"], r["downbeat"]
+                if isinstance(model, BeatThis) and not _model_hooked(model):
+                    model._run(chunks, 0, 2, out=(cb[i: i + nb], cd[i: i + nb]))   # logits straight into their rows
+                else:
+                    r = model(chunks)
+                    cb[i: i + nb], cd[i: i + nb] = r["beat"], r["downbeat"]
         for st_ in side:
             if st_ is not main:
                 main.wait_stream(st_)

@@ -210,8 +210,16 @@ class BeatThis(nn.Module):
         beat, down = self._run(x, 0, 2)
         return {"beat": beat, "downbeat": down}
 
-    def _run(self, x: torch.Tensor, first: int, last: int):
-        """Stages first..last in the engine; precision follows autocast like the whole forward."""
+    def _precision(self) -> int:
+        """BT_PREC_* of a forward issued now: half under autocast, else hi + lo (fp32_split_gemms) or exact fp32."""
+        half = torch.is_autocast_enabled("cuda") if hasattr(torch, "is_autocast_enabled") else False
+        if half:
+            return _lib.PREC_HALF
+        return _lib.PREC_F32X3 if self.fp32_split_gemms else _lib.PREC_F32
+
+    def _run(self, x: torch.Tensor, first: int, last: int, out=None):
+        """Stages first..last in the engine; precision follows autocast like the whole forward.  ``out``: see
+        Engine.forward_stages."""
         if x.dim() != 3:
             raise ValueError(f"expected a (batch, time, features) input, got {tuple(x.shape)}")
         _lib.require_gpu(x, "stage input")
@@ -219,12 +227,7 @@ class BeatThis(nn.Module):
             D = self.hparams["transformer_dim"]
             empty = torch.empty((x.shape[0], x.shape[1]), dtype=torch.float32, device=x.device)
             return (empty, empty.clone()) if last == 2 else torch.empty((x.shape[0], x.shape[1], D), dtype=torch.float32, device=x.device)
-        half = torch.is_autocast_enabled("cuda") if hasattr(torch, "is_autocast_enabled") else False
-        if half:
-            prec = _lib.PREC_HALF
-        else:
-            prec = _lib.PREC_F32X3 if self.fp32_split_gemms else _lib.PREC_F32
-        return self.engine().forward_stages(x, prec, first, last)
+        return self.engine().forward_stages(x, self._precision(), first, last, out=out)
 
     def _run_unit(self, x: torch.Tensor, kind: str, index: int):
         """A sub-module call (see _Node): reference layouts in and out, fp32 results; precision follows autocast (the hi + lo

@@ -349,6 +349,7 @@ class Engine:
         except Exception:   # the old handle (and its table) stay valid
             self.packed.desc.rope, self.packed.desc.rope_len, self.packed._rope_t = old_rope, old_len, old_t
             raise
+        self.__dict__.pop("_graphs", None)   # (captured forwards hold the old table's address)
         old_h, self._h = self._h, h       # swap first, then release: self._h never dangles
         _lib.lib().bt_engine_destroy(old_h)   # (its profiling records, if a bench leg had some open, go with it)
 
@@ -377,9 +378,10 @@ class Engine:
         """spect: (B, T, 128) fp32 on the engine's device -> (beat, downbeat) fp32 (B, T)."""
         return self.forward_stages(spect, prec, 0, 2)
 
-    def forward_stages(self, spect: torch.Tensor, prec: int, first: int, last: int):
+    def forward_stages(self, spect: torch.Tensor, prec: int, first: int, last: int, out=None):
         """Stages first..last of BeatThis.forward (0 frontend, 1 transformer_blocks, 2 task_heads; bt_forward_stages):
-        (B, T, 128) or (B, T, D) fp32 in -> (B, T, D) fp32, or (beat, downbeat) when the head is included."""
+        (B, T, 128) or (B, T, D) fp32 in -> (B, T, D) fp32, or (beat, downbeat) when the head is included.
+        ``out`` = (beat, downbeat): contiguous fp32 (B, T) tensors the logits are written into (last == 2 only)."""
         _lib.require_gpu(spect, "stage input")
         B, T, M = spect.shape
         D = self.packed.desc.transformer_dim
@@ -392,7 +394,12 @@ class Engine:
             raise ValueError("empty batch")
         ws = self._workspace(need)
         beat = down = out = None
-        if last == 2:
+        if last == 2 and out is not None:
+            beat, down = out
+            for t in (beat, down):
+                if t.dtype != torch.float32 or tuple(t.shape) != (B, T) or not t.is_contiguous() or t.device != x.device:
+                    raise ValueError("out: two contiguous fp32 (batch, time) tensors on the input's device")
+        elif last == 2:
             beat = torch.empty((B, T), dtype=torch.float32, device=self.device)
             down = torch.empty((B, T), dtype=torch.float32, device=self.device)
         else:
@@ -414,7 +421,7 @@ class Engine:
                     self._deferred.append((host, ev))
                 elif int(flag.item()) != 0:
                     self.last_fallbacks += 1
-                    return self.forward_stages(spect, _lib.PREC_F32, first, last)
+                    return self.forward_stages(spect, _lib.PREC_F32, first, last, out=out)
         return (beat, down) if last == 2 else out
 
     def forward_unit(self, x: torch.Tensor, prec: int, unit: int, index: int, out_shape) -> torch.Tensor:
@@ -434,6 +441,36 @@ class Engine:
             _lib.check(_lib.lib().bt_forward_unit(self._h, _lib.stream_ptr(self.device), prec, unit, index, x.data_ptr(),
                                                   out.data_ptr(), B, T, ws.data_ptr(), ws.numel()))
         return out
+
+    # -- small batches as hipGraphs -----------------------------------------------------------------------------------------
+    GRAPH_MAX_CHUNKS = 11    # a 5-minute track; beyond that the launches of a forward are a negligible share of it
+    GRAPH_MAX_ENTRIES = 6    # graphs kept per engine (least recently used goes first); each owns its workspace (~80 MB / chunk)
+
+    def graph_forward(self, B: int, T: int, prec: int):
+        """The whole forward of a (B, T, 128) batch as ONE hipGraph with buffers of its own, for the single-file path (a 30 s
+        file is 2 chunks = ~55 launches whose host side is a sixth of the call): -> entry with ``.x`` (B, T, 128) to fill,
+        ``.replay()`` and ``.beat`` / ``.down`` (B, T) holding the logits afterwards (valid until the next replay of the same
+        entry), or None where graphs are off / not applicable.  Entries are per (stream, B, T, precision); a capture that
+        fails switches graphs off for this engine and the caller falls back to plain launches."""
+        if not getattr(self, "_graphs_ok", True) or B > self.GRAPH_MAX_CHUNKS or self._deferred is not None or self._h_prof_on():
+            return None
+        cache = self.__dict__.setdefault("_graphs", collections.OrderedDict())
+        key = (torch.cuda.current_stream(self.device), B, T, prec, self.packed.desc.rope_len)
+        e = cache.pop(key, None)
+        if e is None:
+            try:
+                e = _GraphEntry(self, B, T, prec)
+            except Exception as err:  # noqa: BLE001  (capture not available: plain launches from now on)
+                self._graphs_ok = False
+                self._graph_error = repr(err)
+                return None
+        cache[key] = e
+        while len(cache) > self.GRAPH_MAX_ENTRIES:
+            cache.popitem(last=False)
+        return e
+
+    def _h_prof_on(self) -> bool:
+        return bool(getattr(self, "profiling", False))
 
     # -- BT_PREC_F32X3 range guard, deferred form ------------------------------------------------------------------------
     def deferred_range_checks(self):
@@ -463,3 +500,32 @@ class Engine:
         if bad:
             self.last_fallbacks += 1
         return bad
+
+
+class _GraphEntry:
+    """One captured forward (Engine.graph_forward)."""
+
+    def __init__(self, eng: Engine, B: int, T: int, prec: int):
+        dev = eng.device
+        eng.ensure_positions(T)
+        self.eng, self.B, self.T, self.prec = eng, B, T, prec
+        self.x = torch.zeros((B, T, 128), dtype=torch.float32, device=dev)
+        self.beat = torch.empty((B, T), dtype=torch.float32, device=dev)
+        self.down = torch.empty((B, T), dtype=torch.float32, device=dev)
+        need = _lib.lib().bt_workspace_bytes(eng._h, B, T, prec)
+        self.ws = torch.empty(need, dtype=torch.uint8, device=dev)
+        self.flag = self.ws[:4].view(torch.int32)
+        self._launch()                       # once eagerly (lazy module loading, allocator warm-up) ...
+        torch.cuda.synchronize(dev)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):   # ... then recorded on torch's capture stream
+            self._launch()
+
+    def _launch(self):
+        with torch.cuda.device(self.eng.device):
+            _lib.check(_lib.lib().bt_forward_stages(self.eng._h, _lib.stream_ptr(self.eng.device), self.prec, 0, 2, self.x.data_ptr(),
+                                                    self.B, self.T, self.ws.data_ptr(), self.ws.numel(), 0, self.beat.data_ptr(),
+                                                    self.down.data_ptr()))
+
+    def replay(self):
+        self.graph.replay()

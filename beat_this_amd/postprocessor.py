@@ -132,7 +132,13 @@ class Postprocessor:
         if n == 0 or total == 0:
             return PendingBeats(None, None, frame_off, 0, self.fps)
         dev = beat.device
-        logits = torch.cat([beat.reshape(-1).float(), downbeat.reshape(-1).float()])   # [2 * total]
+        b1, d1 = beat.reshape(-1), downbeat.reshape(-1)
+        if (b1.dtype == d1.dtype == torch.float32 and b1.is_contiguous() and d1.is_contiguous() and b1.numel() == total
+                and b1.untyped_storage().data_ptr() == d1.untyped_storage().data_ptr()
+                and d1.data_ptr() == b1.data_ptr() + 4 * total):
+            logits = b1   # (the batched forward writes both rows into one buffer: bt_peaks_batch addresses them by offset)
+        else:
+            logits = torch.cat([b1.float(), d1.float()])   # [2 * total]
         lens = (frame_off[1:] - frame_off[:-1]).astype(np.int32)
         spans = np.empty((2 * n, 2), dtype=np.int32)     # array 2 k = beat of track k, 2 k + 1 = its downbeat
         spans[0::2, 0], spans[1::2, 0] = frame_off[:-1], total + frame_off[:-1]

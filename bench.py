@@ -368,6 +368,7 @@ def main():
             # would stretch each other's event intervals)
             saved, _inf.CONCURRENT_STREAMS = _inf.CONCURRENT_STREAMS, 1
             run()
+            eng.profiling = True   # (no graph captures while events are recorded)
             lib.bt_profile_begin(eng._h)
             for _ in range(n_prof):
                 run()
@@ -376,6 +377,7 @@ def main():
             ms = (C.c_double * ncat)()
             cnt = (C.c_int32 * ncat)()
             _lib.check(lib.bt_profile_end(eng._h, ms, cnt, ncat))
+            eng.profiling = False
             bd = {}
             for i, name in enumerate(_lib.PROFILE_CATEGORIES):
                 if cnt[i]:

@@ -608,3 +608,31 @@ def test_ff_mult_other_than_four_loads_and_matches_oracle():
     errh = float((rh["beat"].cpu() - ob).abs().max())
     report("ff_mult2", err_f32=err, err_half=errh)
     assert err < LOGIT_TOL_F32 and errh < 0.1
+
+
+@pytest.mark.parametrize("mode", [False, True, "exact"])
+def test_single_file_path_on_a_captured_forward_matches_plain_launches(mode):
+    """Pieces of up to 11 chunks run their forward as one hipGraph (pack.Engine.graph_forward: chunk gather into the graph's
+    input, replay, aggregation from its outputs).  Same kernels, same arguments: the logits must equal the plain launches'
+    bit for bit, on the first call (capture) and on replays, for several piece lengths sharing / not sharing an entry, and
+    the result must not be disturbed by a later call of another length (entries own their buffers)."""
+    from beat_this_amd import inference as inf
+    from beat_this_amd import weights as W
+    from beat_this_amd.inference import Spect2Frames
+
+    s2f = Spect2Frames(checkpoint_path=None, device=dev(), float16=mode)
+    s2f.model = _model("small0", 1, "lively")
+    pieces = [torch.from_numpy(W.synthetic_spect(n, seed=70 + i)).to(dev()) for i, n in enumerate((3100, 1501, 2000, 16000, 700))]
+    assert inf.USE_GRAPHS
+    got = [s2f(p) for p in pieces]            # captures (3 chunks, 2, 2 again = replay of the same entry, 11, short piece: no graph)
+    again = [s2f(p) for p in pieces]          # replays
+    eng = s2f.model.engine()
+    assert getattr(eng, "_graphs_ok", True), getattr(eng, "_graph_error", "")
+    assert len(eng.__dict__.get("_graphs", {})) == 3
+    inf.USE_GRAPHS = False
+    try:
+        plain = [s2f(p) for p in pieces]
+    finally:
+        inf.USE_GRAPHS = True
+    for (b1, d1), (b2, d2), (b0, d0) in zip(got, again, plain):
+        assert torch.equal(b1, b0) and torch.equal(d1, d0) and torch.equal(b2, b0) and torch.equal(d2, d0)
