@@ -620,7 +620,8 @@ DEVI void score_x(const KFragX& kf, const QStateX (&st)[QB], f32x16 (&sc)[QB]) {
 // with VALU adds -- the attention output's 1.1e-5 relative error at L = 1500 on the outlier-key test did not move, nor did
 // it when the scores stopped riding on the reference maximum: it is the 22-bit operand representation, 2^-22 |q| |k|
 // per score, amplified by scores of magnitude 60, not the accumulation.)
-template <bool SAFE, bool MASK, int QB>
+// (PRESUB: the scores already carry the reference maximum -- it rode on the first score MFMA's accumulator input)
+template <bool SAFE, bool MASK, int QB, bool PRESUB = (QB == 1)>
 DEVI void finish_x(f32x16 (&sc)[QB], const VFragX& vf, int g, QStateX (&st)[QB], int key0, int L) {
 #pragma unroll
   for (int j = 0; j < QB; ++j) {
@@ -644,7 +645,7 @@ DEVI void finish_x(f32x16 (&sc)[QB], const VFragX& vf, int g, QStateX (&st)[QB],
       for (int r = 0; r < 16; ++r) sc[j][r] = __builtin_amdgcn_exp2f(sc[j][r] - m_new);
     } else {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) sc[j][r] = __builtin_amdgcn_exp2f(QB == 1 ? sc[j][r] : sc[j][r] + st[j].negm[0]);
+      for (int r = 0; r < 16; ++r) sc[j][r] = __builtin_amdgcn_exp2f(PRESUB ? sc[j][r] : sc[j][r] + st[j].negm[0]);
       if constexpr (MASK) {
 #pragma unroll
         for (int r = 0; r < 16; ++r)
@@ -1019,8 +1020,13 @@ __global__ __launch_bounds__(256, 2) void attn_frag_x3q2_kernel(const AttnFragP 
   __syncthreads();
   if (nfull < ntiles) {
     load_q();
-    st[0].negm[0] = nm0;
-    st[1].negm[0] = nm1;
+    // (the same arithmetic as the key loop and as attn_frag_x3_kernel, bit for bit: the reference maximum rides on the first
+    // score MFMA's accumulator input -- results must not depend on which kernel a launch size selects)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      st[0].negm[r] = nm0;
+      st[1].negm[r] = nm1;
+    }
     const int lane2 = lane_id_fresh(), g2 = lane2 >> 5, lr2 = lane2 & 31;
     const char* kb = smem + (nfull & (NBUF - 1)) * BUF_BYTES;
     const char* vb = kb + TILEX_BYTES;
@@ -1030,9 +1036,9 @@ __global__ __launch_bounds__(256, 2) void attn_frag_x3q2_kernel(const AttnFragP 
       const KFragX kf = ld_kx(kb + c * BLKX_BYTES, g2, lr2);
       const VFragX vf = ld_vx(vb + c * BLKX_BYTES, lane2);
       f32x16 sc[QB];
-      score_x<false, QB>(kf, st, sc);
-      if (partial && blk == nblk - 1) finish_x<false, true, QB>(sc, vf, g2, st, blk * 32, L);
-      else finish_x<false, false, QB>(sc, vf, g2, st, blk * 32, L);
+      score_x<true, QB>(kf, st, sc);
+      if (partial && blk == nblk - 1) finish_x<false, true, QB, true>(sc, vf, g2, st, blk * 32, L);
+      else finish_x<false, false, QB, true>(sc, vf, g2, st, blk * 32, L);
     }
     __syncthreads();
   }

@@ -227,7 +227,7 @@ class BeatThis(nn.Module):
             D = self.hparams["transformer_dim"]
             empty = torch.empty((x.shape[0], x.shape[1]), dtype=torch.float32, device=x.device)
             return (empty, empty.clone()) if last == 2 else torch.empty((x.shape[0], x.shape[1], D), dtype=torch.float32, device=x.device)
-        return self.engine().forward_stages(x, self._precision(), first, last, out=out)
+        return self.engine().forward_stages(x, self._precision(), first, last, logits_out=out)
 
     def _run_unit(self, x: torch.Tensor, kind: str, index: int):
         """A sub-module call (see _Node): reference layouts in and out, fp32 results; precision follows autocast (the hi + lo

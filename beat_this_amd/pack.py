@@ -378,10 +378,10 @@ class Engine:
         """spect: (B, T, 128) fp32 on the engine's device -> (beat, downbeat) fp32 (B, T)."""
         return self.forward_stages(spect, prec, 0, 2)
 
-    def forward_stages(self, spect: torch.Tensor, prec: int, first: int, last: int, out=None):
+    def forward_stages(self, spect: torch.Tensor, prec: int, first: int, last: int, logits_out=None):
         """Stages first..last of BeatThis.forward (0 frontend, 1 transformer_blocks, 2 task_heads; bt_forward_stages):
         (B, T, 128) or (B, T, D) fp32 in -> (B, T, D) fp32, or (beat, downbeat) when the head is included.
-        ``out`` = (beat, downbeat): contiguous fp32 (B, T) tensors the logits are written into (last == 2 only)."""
+        ``logits_out`` = (beat, downbeat): contiguous fp32 (B, T) tensors the logits are written into (last == 2 only)."""
         _lib.require_gpu(spect, "stage input")
         B, T, M = spect.shape
         D = self.packed.desc.transformer_dim
@@ -394,11 +394,11 @@ class Engine:
             raise ValueError("empty batch")
         ws = self._workspace(need)
         beat = down = out = None
-        if last == 2 and out is not None:
-            beat, down = out
+        if last == 2 and logits_out is not None:
+            beat, down = logits_out
             for t in (beat, down):
                 if t.dtype != torch.float32 or tuple(t.shape) != (B, T) or not t.is_contiguous() or t.device != x.device:
-                    raise ValueError("out: two contiguous fp32 (batch, time) tensors on the input's device")
+                    raise ValueError("logits_out: two contiguous fp32 (batch, time) tensors on the input's device")
         elif last == 2:
             beat = torch.empty((B, T), dtype=torch.float32, device=self.device)
             down = torch.empty((B, T), dtype=torch.float32, device=self.device)
@@ -421,7 +421,7 @@ class Engine:
                     self._deferred.append((host, ev))
                 elif int(flag.item()) != 0:
                     self.last_fallbacks += 1
-                    return self.forward_stages(spect, _lib.PREC_F32, first, last, out=out)
+                    return self.forward_stages(spect, _lib.PREC_F32, first, last, logits_out=logits_out)
         return (beat, down) if last == 2 else out
 
     def forward_unit(self, x: torch.Tensor, prec: int, unit: int, index: int, out_shape) -> torch.Tensor:

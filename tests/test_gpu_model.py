@@ -624,11 +624,11 @@ def test_single_file_path_on_a_captured_forward_matches_plain_launches(mode):
     s2f.model = _model("small0", 1, "lively")
     pieces = [torch.from_numpy(W.synthetic_spect(n, seed=70 + i)).to(dev()) for i, n in enumerate((3100, 1501, 2000, 16000, 700))]
     assert inf.USE_GRAPHS
-    got = [s2f(p) for p in pieces]            # captures (3 chunks, 2, 2 again = replay of the same entry, 11, short piece: no graph)
+    got = [s2f(p) for p in pieces]            # captures (3 chunks, 2, 2 again = replay of the same entry, 11, one odd-length chunk)
     again = [s2f(p) for p in pieces]          # replays
     eng = s2f.model.engine()
     assert getattr(eng, "_graphs_ok", True), getattr(eng, "_graph_error", "")
-    assert len(eng.__dict__.get("_graphs", {})) == 3
+    assert len(eng.__dict__.get("_graphs", {})) == 4
     inf.USE_GRAPHS = False
     try:
         plain = [s2f(p) for p in pieces]

@@ -227,6 +227,22 @@ def test_attention_frag_x3(n_seq, L, heads, out_f32, variant):
     assert err < (6e-6 if L <= 300 else 2e-5)
 
 
+@pytest.mark.parametrize("out_f32", [False, True])
+@pytest.mark.parametrize("n_seq,L,heads", [(3, 1500, 2), (2, 257, 1), (1, 64, 1), (2, 77, 1), (1, 1499, 1), (2, 128, 2)])
+def test_attention_frag_x3_variants_agree_bit_for_bit(n_seq, L, heads, out_f32):
+    """The forward picks the x3 attention kernel by launch size (64-key tiles for small launches, the hand-scheduled
+    two-query-block kernel for large ones): every kernel must produce the SAME bits -- same products in the same order, same
+    row-sum tree, the reference maximum on the accumulator input everywhere -- or a piece's logits (and, through an exact
+    x == maxpool(x) comparison, its beats) would depend on what else was in the batch."""
+    SH = n_seq * heads
+    q = _mk((SH, L, 32), 30, 0.6).float().double()
+    k = _mk((SH, L, 32), 31).float().double()
+    v = _mk((SH, L, 32), 32).float().double()
+    gates = torch.sigmoid(_mk((SH, L), 33)).float().double()
+    outs = [_run_attn(q, k, v, gates, n_seq, L, heads, out_f32, variant) for variant in (1, 2, 5)]
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[1], outs[2])
+
+
 def test_attention_frag_x3_time_direction_rowmap():
     B, T, F, heads = 2, 150, 4, 1
     SH = B * F
