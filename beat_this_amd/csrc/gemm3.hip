@@ -49,6 +49,11 @@ struct G3CfgT { static constexpr int BM = 192, BN = 256, BK = 64, WGM = 2, WGN =
 struct G3CfgSX { static constexpr int BM = 128, BN = 128, BK = 64, WGM = 2, WGN = 2, NST = 2, OCC = 2; };
 struct G3CfgBX { static constexpr int BM = 256, BN = 256, BK = 64, WGM = 2, WGN = 4, NST = 2, OCC = 1; };
 struct G3CfgTX { static constexpr int BM = 192, BN = 256, BK = 64, WGM = 2, WGN = 4, NST = 2, OCC = 1; };
+// MX (round 4): 256 x 128 tiles on k-steps of 16 (half an hl32 group per LDS row: 64 B = [16 hi | 16 lo]), 4 waves of 128 x 64,
+// 24 KB per stage, 3 stages -> still TWO workgroups per CU (147 KB), i.e. the second workgroup keeps hiding the epilogue,
+// with 3/4 of the L2 -> LDS operand bytes per flop of the 128 x 128 tiles (the stream every 128 x 128 GEMM here is bound by,
+// DESIGN.md section 5) and 3/4 of the fragment reads per MFMA (a 128 x 64 wave tile: 12 reads per 24 MFMAs).
+struct G3CfgMX { static constexpr int BM = 256, BN = 128, BK = 32, WGM = 2, WGN = 2, NST = 3, OCC = 2; };
 
 // BT_PREC_F32X3: XCD groups a large weight matrix is split over (1 = off; launch_cfg).  tools/x3_probe.py, M = 24000:
 // FF1 (W = 4 MB of hl32) 206 / 189 / 202 us with 1 / 2 / 4 groups, FF2 175 / 165 / 164, frontend.linear and the
@@ -125,7 +130,8 @@ void gemm3_kernel(const Gemm3P p, int n_tiles, int total_tiles, int per_xcd, int
   constexpr int TB = BM / CFG::WGM / 32;       // 32-token blocks per wave
   constexpr int FB = BN / CFG::WGN / 32;       // 32-feature blocks per wave
   constexpr int ROWB = BK * 2;                 // bytes per LDS row (BK half elements)
-  constexpr int KR = X3 ? BK / 2 : BK;         // k values per k-step (X3: a row is 32 hi + 32 lo halves)
+  constexpr int KR = X3 ? BK / 2 : BK;         // k values per k-step (X3: a row is BK / 2 hi + BK / 2 lo halves)
+  constexpr bool HL16 = X3 && BK == 32;        // X3 on 64-byte rows: a k-step is HALF an hl32 group (16 hi + 16 lo halves)
   constexpr int EB = X3 ? 4 : 2;               // operand bytes per k value
   constexpr int CPR = ROWB / 16;               // 16-byte chunks per row (4 or 8)
   constexpr int RPI = 64 / CPR;                // rows covered by one wave-instruction (1 KB)
@@ -133,7 +139,7 @@ void gemm3_kernel(const Gemm3P p, int n_tiles, int total_tiles, int per_xcd, int
   constexpr int APC = A_BYTES / (NT * 16), WPC = W_BYTES / (NT * 16);  // LDS-DMA pieces per thread and k-step
   static_assert(EPI != G3_QKV || TB == FB, "the V columns swap the operand roles: square wave tile needed");
   static_assert(BN / CFG::WGN == 64, "ssq partials are per 64 columns = one wave");
-  static_assert(!X3 || ROWB == 128, "hl32: one k-step of 32 = 64 hi + 64 lo bytes per row");
+  static_assert(!X3 || ROWB == 128 || ROWB == 64, "hl32: a k-step is a whole group (128 B per row) or half of one (64 B)");
   static_assert(NST * ST_BYTES >= NW * 8192, "the epilogues stage 8 KB per wave in the ring's LDS");
   __shared__ __attribute__((aligned(16))) char smem[NST * ST_BYTES];
   // XCD-aware tile order (block b -> XCD b % 8).  nsplit = 1: the n-tiles sharing one A panel run on the same XCD, an XCD
@@ -189,7 +195,8 @@ void gemm3_kernel(const Gemm3P p, int n_tiles, int total_tiles, int per_xcd, int
       ok = seq < p.n_seq && t < p.L;
       row = (long)seq * p.L + t;
     }
-    voffA[i] = ok ? (unsigned)(row * p.lda * EB + c * 16) : OOB;
+    // (HL16: LDS chunks 0, 1 = the hi halves of the step's 16 k values, 2, 3 = their lo halves, 64 B further in the group)
+    voffA[i] = ok ? (unsigned)(row * p.lda * EB + (HL16 ? (c >> 1) * 64 + (c & 1) * 16 : c * 16)) : OOB;
     if constexpr (EPI == G3_RESID) {  // conv: which of the three time taps exist for this row
       const int t = p.conv_C2 > 0 ? (int)((row / p.conv_F) % p.conv_T) : 1;
       tapmask[i] = ok ? ((t >= 1 ? 1 : 0) | 2 | (t + 1 < p.conv_T ? 4 : 0)) : 0;
@@ -199,7 +206,7 @@ void gemm3_kernel(const Gemm3P p, int n_tiles, int total_tiles, int per_xcd, int
   for (int i = 0; i < WPC; ++i) {
     const int r = (i * NW + wave) * RPI + lane / CPR;
     const int c = (lane % CPR) ^ swz(r);
-    voffW[i] = (unsigned)((long)(n0 + r) * p.K * EB + c * 16);
+    voffW[i] = (unsigned)((long)(n0 + r) * p.K * EB + (HL16 ? (c >> 1) * 64 + (c & 1) * 16 : c * 16));
   }
   // LDS-DMA of one k-step: APC pieces of the A tile, WPC of the W tile (1 KB per wave-instruction; the pieces of a
   // thread are NW KB apart).  The instruction's immediate offset would also move the LDS address, so it stays 0 and
@@ -214,10 +221,11 @@ void gemm3_kernel(const Gemm3P p, int n_tiles, int total_tiles, int per_xcd, int
 #define G3_ISSUE(kt, stage)                                                                                          \
   do {                                                                                                                \
     char* st_ = smem + (stage) * ST_BYTES + wave * 1024;                                                              \
-    const int so_ = (kt) * ROWB;                                                                                      \
+    const int so_ = HL16 ? ((kt) >> 1) * 128 + ((kt) & 1) * 32 : (kt) * ROWB;                                         \
     if (conv) {                                                                                                       \
       const int tap_ = ((kt) * KR) >> c2_shift;                                                                       \
-      const int soa_ = tap_ * (int)tap_bytes + (((kt) * KR) & (p.conv_C2 - 1)) * EB;                                  \
+      const int kin_ = ((kt) * KR) & (p.conv_C2 - 1);                                                                 \
+      const int soa_ = tap_ * (int)tap_bytes + (HL16 ? (kin_ >> 5) * 128 + ((kin_ >> 4) & 1) * 32 : kin_ * EB);      \
       _Pragma("unroll") for (int i_ = 0; i_ < APC; ++i_)                                                              \
           __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lptr_t)(st_ + i_ * NW * 1024), 16,                            \
                                                    ((tapmask[i_] >> tap_) & 1) ? voffA[i_] : OOB, soa_, 0, 0);        \
@@ -665,6 +673,10 @@ bool gemm3_supported(const Gemm3P& p) {
 #ifndef X3_BIG_FF1
 #define X3_BIG_FF1 0
 #endif
+// BT_PREC_F32X3: the 256 x 128 k16 configuration (G3CfgMX) for FF1 / out-projection / convolutions / frontend.linear
+#ifndef X3_MX
+#define X3_MX 1
+#endif
 
 int launch_gemm3(const Gemm3P& p, hipStream_t s) {
   if (!gemm3_supported(p)) return -2;
@@ -687,6 +699,9 @@ int launch_gemm3(const Gemm3P& p, hipStream_t s) {
   // 256 or 192 token rows per tile: fewer (rounds over the 256 CUs) x (rows per tile) wins
   auto cost = [&](int bm) { const long t = ((long)p.M + bm - 1) / bm * (p.N / 256); return (t + 255) / 256 * bm; };
   const bool rows192 = big && p.epi == G3_RESID && force != 1 && cost(192) < cost(256);
+  // BT_PREC_F32X3: everything but QKV (square wave tiles) and the long-K residual GEMM (256-column tiles) on the 256 x 128
+  // k16 configuration; x3 & 15 = 4 forces it, 3 forces the 128 x 128 tiles (tools/x3_probe.py, tests)
+  const bool mx = p.x3 && p.epi != G3_QKV && !big && !rows192 && force != 0 && ((p.x3 & 15) == 4 || (X3_MX && p.M >= 1024));
   if (p.x3) {
 #ifdef BT_DEV
     // development: ablations of the x3 kernel (results are garbage): BT_G3_ABL = 1 no LDS-DMA after the prologue, 4 no MFMAs
@@ -703,10 +718,12 @@ int launch_gemm3(const Gemm3P& p, hipStream_t s) {
 #endif
     switch (p.epi) {
       case G3_FF1:
-        if (big) launch_cfg<G3_FF1, G3CfgBX, true>(p, s); else launch_cfg<G3_FF1, G3CfgSX, true>(p, s);
+        if (mx) launch_cfg<G3_FF1, G3CfgMX, true>(p, s);
+        else if (big) launch_cfg<G3_FF1, G3CfgBX, true>(p, s); else launch_cfg<G3_FF1, G3CfgSX, true>(p, s);
         break;
       case G3_RESID:
-        if (rows192) launch_cfg<G3_RESID, G3CfgTX, true>(p, s);
+        if (mx) launch_cfg<G3_RESID, G3CfgMX, true>(p, s);
+        else if (rows192) launch_cfg<G3_RESID, G3CfgTX, true>(p, s);
         else if (big) launch_cfg<G3_RESID, G3CfgBX, true>(p, s);
         else launch_cfg<G3_RESID, G3CfgSX, true>(p, s);
         break;

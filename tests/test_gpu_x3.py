@@ -28,13 +28,15 @@ def _ssq_parts(x32):
     return (x32.double() ** 2).view(M, D // 64, 64).sum(-1).T.contiguous().float()
 
 
-def _call(nsplit=0, **kw):
+def _call(nsplit=0, cfg=1, **kw):
     from beat_this_amd import _lib as L
 
     a = L.Gemm3Args()
     for k, v in kw.items():
         setattr(a, k, v.data_ptr() if isinstance(v, torch.Tensor) else v)
-    a.x3 = 1 | (nsplit << 4)   # (bits 4.. force the number of XCD groups the weight matrix is split over: gemm3.hip launch_cfg)
+    # x3 & 15: 1 = the launcher's choice, 3 = 128 x 128 tiles, 4 = the 256 x 128 k16 configuration (gemm3.hip: G3CfgMX);
+    # bits 4.. force the number of XCD groups the weight matrix is split over (launch_cfg)
+    a.x3 = cfg | (nsplit << 4)
     L.check(L.lib().bt_gemm3(L.stream_ptr(dev()), C.byref(a)))
     torch.cuda.synchronize()
 
@@ -43,20 +45,23 @@ def _status():
     return torch.zeros(1, dtype=torch.int32, device=dev())
 
 
+@pytest.mark.parametrize("cfg", [1, 3, 4])
 @pytest.mark.parametrize("M,K,N,nsplit", [(1500, 512, 2048, 0), (333, 128, 512, 0), (24000, 512, 2048, 0), (49500, 512, 2048, 0),
                                           (24000, 512, 2048, 2), (24000, 512, 2048, 4), (777, 512, 2048, 8), (1500, 128, 512, 2)])
-def test_gemm3_x3_ff1(M, K, N, nsplit):
+def test_gemm3_x3_ff1(M, K, N, nsplit, cfg):
+    if cfg != 1 and (nsplit or M == 49500):
+        pytest.skip("forced tile configurations: one pass over the shapes without the XCD-split variants")
     """out = gelu_erf(rms(A) W^T + b) as hl32 planes; operands are fp32 values (exactly representable as hi + lo)."""
     x = _mk((M, K), 1, 2.0).float()
     W, b = _mk((N, K), 2, 1 / math.sqrt(K)).float(), _mk((N,), 3)
     out = torch.zeros((M, 2 * N), dtype=torch.float16, device=dev())
     st = _status()
-    _call(nsplit, A=to_hl32(x).to(dev()), lda=K, M=M, K=K, W=to_hl32(pad_rows(W, 256)).to(dev()), N=N, epi=0, bias=b.float().to(dev()),
+    _call(nsplit, cfg, A=to_hl32(x).to(dev()), lda=K, M=M, K=K, W=to_hl32(pad_rows(W, 256)).to(dev()), N=N, epi=0, bias=b.float().to(dev()),
           ssq_in=_ssq_parts(x).to(dev()), ssq_parts=K // 64, out=out, ldo=N, status=st)
     rs = math.sqrt(K) / x.double().norm(dim=-1, keepdim=True).clamp_min(1e-12)
     ref = torch.nn.functional.gelu(from_hl32(to_hl32(x)) @ from_hl32(to_hl32(W)).T * rs + b)
     err = _rel(from_hl32(out.cpu()), ref)
-    report("gemm3_x3_ff1", M=M, K=K, N=N, nsplit=nsplit, rel=err)
+    report("gemm3_x3_ff1", M=M, K=K, N=N, nsplit=nsplit, cfg=cfg, rel=err)
     assert err < 3e-6 and int(st.item()) == 0
 
 
@@ -64,7 +69,10 @@ def test_gemm3_x3_ff1(M, K, N, nsplit):
 @pytest.mark.parametrize("M,K,N,bias,nsplit", [(1500, 2048, 512, True, 0), (777, 512, 512, False, 0), (130, 128, 128, True, 0),
                                                (24000, 2048, 512, True, 0), (32768, 1024, 512, False, 0), (49500, 512, 512, True, 0),
                                                (24000, 2048, 512, True, 2), (32768, 1024, 512, False, 2), (777, 512, 512, False, 4)])
-def test_gemm3_x3_resid(M, K, N, bias, nsplit):
+@pytest.mark.parametrize("cfg", [1, 3, 4])
+def test_gemm3_x3_resid(M, K, N, bias, nsplit, cfg):
+    if cfg != 1 and (nsplit or M == 32768):
+        pytest.skip("forced tile configurations: one pass over the shapes without the XCD-split variants")
     A = _mk((M, K), 4).float()
     W = _mk((N, K), 5, 0.5 / math.sqrt(K)).float()
     b = _mk((N,), 6)
@@ -73,15 +81,35 @@ def test_gemm3_x3_resid(M, K, N, bias, nsplit):
     xb = torch.full((M, 2 * N), float("nan"), dtype=torch.float16, device=dev())
     ssq = torch.full((N // 64, M), -1.0, dtype=torch.float32, device=dev())
     st = _status()
-    _call(nsplit, A=to_hl32(A).to(dev()), lda=K, M=M, K=K, W=to_hl32(pad_rows(W, 256)).to(dev()), N=N, epi=1,
+    _call(nsplit, cfg, A=to_hl32(A).to(dev()), lda=K, M=M, K=K, W=to_hl32(pad_rows(W, 256)).to(dev()), N=N, epi=1,
           bias=b.float().to(dev()) if bias else 0, x=x, ldx=N, xb=xb, ssq_out=ssq, status=st)
     ref = x0.double() + from_hl32(to_hl32(A)) @ from_hl32(to_hl32(W)).T + (b if bias else 0)
     err = _rel(x, ref)
     xc = x.double().cpu()
     errb = float((from_hl32(xb.cpu()) - xc).abs().max() / xc.abs().max())   # the shadow IS the new x, to 2^-22
     errs = _rel(ssq, (ref ** 2).view(M, N // 64, 64).sum(-1).T)
-    report("gemm3_x3_resid", M=M, K=K, N=N, nsplit=nsplit, rel=err, shadow=errb, ssq=errs)
+    report("gemm3_x3_resid", M=M, K=K, N=N, nsplit=nsplit, cfg=cfg, rel=err, shadow=errb, ssq=errs)
     assert err < 2e-6 and errb < 1e-6 and errs < 1e-5 and int(st.item()) == 0
+
+
+def test_gemm3_x3_tile_configurations_agree_bit_for_bit():
+    """128 x 128 tiles on k-steps of 32 and 256 x 128 tiles on k-steps of 16 issue the same MFMAs on the same operand pieces
+    in the same order per output element: identical bits (a piece's result must not depend on the batch it ran in)."""
+    M, K, N = 3000, 512, 1024
+    x = _mk((M, K), 1, 2.0).float()
+    W, b = _mk((N, K), 2, 1 / math.sqrt(K)).float(), _mk((N,), 3)
+    outs = []
+    for cfg in (3, 4):
+        out = torch.zeros((M, 2 * N), dtype=torch.float16, device=dev())
+        _call(0, cfg, A=to_hl32(x).to(dev()), lda=K, M=M, K=K, W=to_hl32(pad_rows(W, 256)).to(dev()), N=N, epi=0, bias=b.float().to(dev()),
+              ssq_in=_ssq_parts(x).to(dev()), ssq_parts=K // 64, out=out, ldo=N, status=_status())
+        xr = _mk((M, N), 7).float().to(dev())
+        xb = torch.zeros((M, 2 * N), dtype=torch.float16, device=dev())
+        _call(0, cfg, A=to_hl32(x).to(dev()), lda=K, M=M, K=K, W=to_hl32(pad_rows(W, 256)).to(dev()), N=N, epi=1, bias=b.float().to(dev()),
+              x=xr, ldx=N, xb=xb, ssq_out=torch.zeros((N // 64, M), device=dev()), status=_status())
+        outs.append((out, xr, xb))
+    for a, c in zip(outs[0], outs[1]):
+        assert torch.equal(a, c)
 
 
 @pytest.mark.parametrize("n_seq,L,heads", [(2, 1500, 4), (3, 77, 4), (1, 1, 4), (5, 130, 8), (16, 1500, 16)])

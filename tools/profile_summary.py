@@ -16,10 +16,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "prof_r03")
 RND = sys.argv[2] if len(sys.argv) > 2 else "r03"
 out_dir = os.path.join(ROOT, "profiles")
-B = "python bench.py --no-cpu-baseline --no-extras --min-seconds 0"
-CMD = {"head": f"{B} --steps 5 --warmup 1", "head1s": f"{B} --steps 5 --warmup 1 --streams 1   (the launch configuration of "
-       "bench.py's roofline leg: whole 66-chunk launches on one stream)",
-       "fwd": f"{B} --workload forward --chunks 16 --steps 10 --warmup 2",
+B = "python bench.py --no-cpu-baseline --no-extras --no-dist --min-seconds 0"
+CMD = {"head": f"{B} --steps 5 --warmup 1 --prec half", "head1s": f"{B} --steps 5 --warmup 1 --prec half --streams 1   (the launch "
+       "configuration of bench.py's roofline legs: whole 66-chunk launches on one stream)",
+       "fwd": f"{B} --workload forward --chunks 16 --prec half --steps 10 --warmup 2",
+       "head_x3_2s": f"{B} --steps 5 --warmup 1 --prec f32x3   (the headline's own launch configuration: 33-chunk slices on two streams)",
        "fwd_x3": f"{B} --workload forward --chunks 16 --prec f32x3 --steps 8 --warmup 2",
        "head_x3": f"{B} --steps 5 --warmup 1 --prec f32x3 --streams 1   (the f32x3 path's roofline launch shape)",
        "cfg3": f"{B} --workload forward --model small0 --prec f32 --chunks 128 --steps 2 --warmup 1"}
@@ -58,7 +59,7 @@ def write(name, lines):
     print(f"-> profiles/{name}\n")
 
 
-for tag in ("head", "head1s", "fwd", "fwd_x3", "head_x3"):
+for tag in ("head", "head1s", "fwd", "fwd_x3", "head_x3", "head_x3_2s"):
     tr = read_trace("trace_" + tag)
     if not tr:
         continue
@@ -99,11 +100,11 @@ for suffix, wl in (("", "BeatThis.forward, final0, 16 chunks, half operands"), (
                      f"{im[1] / max(im[0], 1):11.0f} {iv[1] / max(iv[0], 1):11.0f}")
     write(f"{RND}_pmc_mfma{suffix}.txt", lines)
 
-CATS = {"attn_flash": ("attn_frag_kernel", "attn_frag_x3_kernel", "attn_flash"), "layer_tail": ("layer_tail_kernel",)}
+CATS = {"attn_flash": ("attn_frag_kernel", "attn_frag_x3_kernel", "attn_frag_x3q2_kernel", "attn_flash"), "layer_tail": ("layer_tail_kernel",)}
 for tag, wl, jname, meta in (("", "BeatThis.forward, final0, 16 chunks, half operands", "pmc_traffic.json", {"model": "final0", "prec": "half", "chunks": 16}),
                              ("_x3", "BeatThis.forward, final0, 16 chunks, BT_PREC_F32X3", "pmc_traffic_f32x3.json", {"model": "final0", "prec": "f32x3", "chunks": 16}),
                              ("_cfg3", "BASELINE config 3: BeatThis.forward, small0, exact fp32, 128 chunks", "pmc_traffic_cfg3.json", {"model": "small0", "prec": "f32", "chunks": 128}),
-                             ("_head", "headline (6 x 300 s tracks through Audio2Beats)", None, None)):
+                             ("_head", "headline (6 x 300 s tracks through Audio2Beats, default precision)", None, None)):
     fetch, wr = read_pmc("pmc_fetch" + tag), read_pmc("pmc_write" + tag)
     if not fetch:
         continue

@@ -92,11 +92,41 @@ def gemm(M, K, N, epi, label, heads=0, n_seq=0, Lq=0, force=1, nsplit=0):
     st = L.stream_ptr(dev)
     us = timeit(lambda: L.check(lib.bt_gemm3(st, C.byref(a))))
     flop = 2.0 * M * K * a.N
-    print(f"gemm3 x3 {label} [{ {1: 'auto', 2: '256-row tiles', 3: '128-row tiles'}[force] }, W over {nsplit or 'auto'} XCD groups] M={M} K={K} N={a.N}: {us:8.1f} us  {flop / us / 1e6:7.1f} TFLOP/s algorithmic "
+    print(f"gemm3 x3 {label} [{ {1: 'auto', 2: '256-row tiles', 3: '128-row tiles', 4: '256 x 128 k16 tiles'}[force] }, W over {nsplit or 'auto'} XCD groups] M={M} K={K} N={a.N}: {us:8.1f} us  {flop / us / 1e6:7.1f} TFLOP/s algorithmic "
           f"({3 * flop / us / 1e6:7.1f} on the matrix pipe)", flush=True)
 
 
 T = 1500
+if len(sys.argv) > 2 and sys.argv[2].startswith("loop"):
+    # python tools/x3_probe.py 16 loop:5 [seconds] -- one attention variant back to back for a few seconds (power / clock sampling
+    # from outside: tools/power_probe.sh)
+    import time
+    want = int(sys.argv[2].split(":")[1])
+    secs = float(sys.argv[3]) if len(sys.argv) > 3 else 4.0
+    g = torch.Generator().manual_seed(1)
+    SH, nbp = B * 32, lib.bt_attn_frag_blocks(T)
+    mk = lambda s: (torch.randn((SH, nbp, 2, 1024), generator=g) * s).to(torch.float16)  # noqa: E731
+    q, k, v = mk(0.6), mk(1.0), mk(1.0)
+    for t in (q, k, v):
+        t[:, :, 1] *= 2.0 ** -11
+    qd, kd, vd = q.to(dev), k.to(dev), v.to(dev)
+    gates = torch.rand((SH, nbp * 32), generator=g).to(dev)
+    out = torch.zeros((SH * T, 64), dtype=torch.float16, device=dev)
+    a = L.AttnFragArgs()
+    a.q, a.k, a.v, a.gates, a.out = qd.data_ptr(), kd.data_ptr(), vd.data_ptr(), gates.data_ptr(), out.data_ptr()
+    a.n_seq, a.L, a.heads, a.inner, a.nbp, a.o_div, a.o_outer, a.o_inner, a.o_tok = SH, T, 1, 32, nbp, 1, T, 0, 1
+    a.x3, a.out_f32, a.status = want, 0, 0
+    st = L.stream_ptr(dev)
+    t0, n = time.time(), 0
+    while time.time() - t0 < secs:
+        for _ in range(20):
+            L.check(lib.bt_attention_frag(st, C.byref(a)))
+        torch.cuda.synchronize()
+        n += 20
+    el = time.time() - t0
+    print(f"attention x3 variant {want}, {SH} sequences: {n} launches in {el:.2f} s = {el / n * 1e6:.1f} us per launch, "
+          f"{3 * 2 * 2 * SH * T * T * 32 / (el / n) / 1e12:.0f} TFLOP/s on the matrix pipe", flush=True)
+    sys.exit(0)
 attention(B, 16, T, f"main layer ({B} chunks x 16 heads)")
 attention(B * 32, 1, T, f"frontend block 0 ({B * 32} sequences x 1 head)")
 attention(B * 8, 4, T, f"frontend block 2 ({B * 8} sequences x 4 heads)")
@@ -104,9 +134,10 @@ if len(sys.argv) > 2 and sys.argv[2] == "attn":
     sys.exit(0)
 M = B * T
 gemm(M, 512, 3 * 512 + 16, 2, "QKV", heads=16, n_seq=B, Lq=T)
-for f in (3, 2):
+for f in (3, 4, 3, 4):
     gemm(M, 512, 512, 1, "out-projection", force=f)
     gemm(M, 512, 2048, 0, "FF1", force=f)
+for f in (3, 2):
     gemm(M, 2048, 512, 1, "FF2", force=f)
     gemm(M, 1024, 512, 1, "frontend.linear", force=f)
 gemm(M, 2048, 512, 1, "FF2 (auto)")
