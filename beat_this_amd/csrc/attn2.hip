@@ -717,12 +717,88 @@ DEVI void attn_tiles_x(rsrc_t rk, rsrc_t rv, char* smem, int tid, int wave, int 
   }
 }
 
+// Reference maximum of this wave's queries for the fast pass: their scores against the first TWO key blocks (tile 0 is in LDS
+// buffer 0 whatever the tile size; one block for L <= 32) -> st[j].negm = -(max) - P_SHIFT on every register.  A later key
+// may score up to 16 + P_SHIFT octaves above it before the fast pass overflows; 64 keys instead of 32 make that ~60 times
+// rarer on Gaussian scores at no cost (the blocks are there).  Shared by every x3 kernel: the reference point is part of
+// the arithmetic, and the kernels must agree bit for bit.
+template <int QB>
+DEVI void ref_max_x(const char* smem, int g, int lr, QStateX (&st)[QB], int L, int nblk) {
+  float bm[QB];
+#pragma unroll
+  for (int j = 0; j < QB; ++j) bm[j] = -1e30f;
+  const int nref = min(2, nblk);
+  for (int c = 0; c < nref; ++c) {
+    const KFragX kf = ld_kx(smem + c * BLKX_BYTES, g, lr);
+    f32x16 s0[QB];
+    score_x<false, QB>(kf, st, s0);
+#pragma unroll
+    for (int j = 0; j < QB; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) bm[j] = fmaxf(bm[j], (32 * c + crow(r, g) < L) ? s0[j][r] : -1e30f);
+  }
+#pragma unroll
+  for (int j = 0; j < QB; ++j) {
+    const float m = fmaxf(bm[j], __shfl_xor(bm[j], 32));
+#pragma unroll
+    for (int r = 0; r < 16; ++r) st[j].negm[r] = -m - P_SHIFT;
+  }
+}
+
+// The fallback of a workgroup whose fast pass overflowed (a key scored more than 16 + P_SHIFT octaves above the reference
+// point): the maxima of its queries over ALL keys -- from the hi . hi products alone, two MFMAs per block: a reference point
+// needs no more -- after which the SAME fast pass runs again and cannot overflow (every probability <= 2^-P_SHIFT).  About a
+// quarter of a fast pass on top of the two, against three to four for the classic running-maximum loop this replaces
+// (round 4: 2.7 % of the workgroups of the benchmark's forward take this path, 30 % on the outlier stress weights).
+// Plain double-buffered tiles in LDS buffers 0 / 1 (as attn_tiles_x); every LDS-DMA is drained on return.
+template <int QB, int KBX>
+DEVI void row_max_pass_x(rsrc_t rk, rsrc_t rv, char* smem, int tid, int wave, int g, int lr, QStateX (&st)[QB], int L, int nblk) {
+  constexpr int TILEX_BYTES = KBX * BLKX_BYTES;
+  const int ntiles = (nblk + KBX - 1) / KBX;
+  float bm[QB];
+#pragma unroll
+  for (int j = 0; j < QB; ++j) bm[j] = -1e30f;
+  stage_tile_x<KBX>(rk, rv, 0, smem, 0, tid, wave);
+  __syncthreads();
+  for (int t = 0; t < ntiles; ++t) {
+    if (t + 1 < ntiles) stage_tile_x<KBX>(rk, rv, t + 1, smem, (t + 1) & 1, tid, wave);
+    const char* kb = smem + (t & 1) * 2 * TILEX_BYTES;
+    const int nb = min(KBX, nblk - t * KBX);
+    for (int c = 0; c < nb; ++c) {
+      const char* blk = kb + c * BLKX_BYTES;
+      const hfx8 k0 = *reinterpret_cast<const hfx8*>(blk + ((2 * g) * 32 + lr) * 16);
+      const hfx8 k1 = *reinterpret_cast<const hfx8*>(blk + ((2 * g + 1) * 32 + lr) * 16);
+      const int key0 = (t * KBX + c) * 32;
+#pragma unroll
+      for (int j = 0; j < QB; ++j) {
+        f32x16 sc;
+        zero16(sc);
+        sc = MFMA32_H(k0, st[j].q0, sc);
+        sc = MFMA32_H(k1, st[j].q1, sc);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) bm[j] = fmaxf(bm[j], (key0 + crow(r, g) < L) ? sc[r] : -1e30f);
+      }
+    }
+    __syncthreads();  // tile t + 1 has landed (every wave waited for its own copies), tile t is free
+  }
+  // The reference point of the re-run sits TWO octaves above the row maximum (probabilities <= 4, row sums <= 1500 x 4): the
+  // fast pass's own shift (P_SHIFT octaves BELOW its reference point) buys headroom for keys that have not been seen yet;
+  // here all have been, and every octave not spent on headroom keeps one more octave of small probabilities out of fp16's
+  // subnormal range (absolute 2^-25 per term: with the maximum at 2^-4 the row sums were 1.3e-5 off, tests/test_gpu_x3.py).
+#pragma unroll
+  for (int j = 0; j < QB; ++j) {
+    const float m = fmaxf(bm[j], __shfl_xor(bm[j], 32));
+#pragma unroll
+    for (int r = 0; r < 16; ++r) st[j].negm[r] = 2.0f - m;
+  }
+}
+
 // Fast pass: reference maximum of every query from key block 0, then the key loop software-pipelined by hand over the
 // tiles of KB unmasked blocks: the scores of block c + 1 are issued BEFORE the exponentials of block c (two score
 // buffers alternate: the loop is unrolled over the tile, no register copies), one barrier per tile at its last block.
 template <int QB, int KBX>
 DEVI void attn_fast_x(rsrc_t rk, rsrc_t rv, char* smem, int tid, int wave, int lane, int g, int lr, QStateX (&st)[QB], int L,
-                      int nblk) {
+                      int nblk, bool have_ref = false) {   // have_ref: st[j].negm is set (the re-run behind row_max_pass_x)
   constexpr int TILEX_BYTES = KBX * BLKX_BYTES;
   static_assert(KBX % 2 == 0, "two score buffers alternate over the blocks of a tile");
   const int ntiles = (nblk + KBX - 1) / KBX;
@@ -743,19 +819,11 @@ DEVI void attn_fast_x(rsrc_t rk, rsrc_t rv, char* smem, int tid, int wave, int l
   // fit the register file): there the scores of the next block follow the current block's products.
   constexpr bool PIPE = QB == 1;
   f32x16 s2[PIPE ? 2 : 1][QB];  // scores of the current / the next block (compile-time indices: the tile loop is unrolled)
+  if (!have_ref) ref_max_x<QB>(smem, g, lr, st, L, nblk);   // (workgroup-uniform)
   KFragX kf = ld_kx(smem, g, lr);
-  score_x<false, QB>(kf, st, s2[0]);
-#pragma unroll
-  for (int j = 0; j < QB; ++j) {  // reference max of each query: its scores against key block 0
-    float bm = -1e30f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) bm = fmaxf(bm, (crow(r, g) < L) ? s2[0][j][r] : -1e30f);
-    bm = fmaxf(bm, __shfl_xor(bm, 32));
-#pragma unroll
-    for (int r = 0; r < (QB == 1 ? 16 : 1); ++r) st[j].negm[r] = -bm - P_SHIFT;
-  }
-  // (one query block per wave: the scores of block 0 of tile 0 again, now on the reference maximum)
+  // the scores of block 0 of tile 0 (one query block per wave: on the reference maximum, which rides on the accumulator input)
   if (QB == 1 && nfull > 0) score_x<true, QB>(kf, st, s2[0]);
+  else if (QB != 1) score_x<false, QB>(kf, st, s2[0]);
   for (int t = 0; t < nfull; ++t) {
     const char* kb = smem + (t & 1) * 2 * TILEX_BYTES;
     const char* vb = kb + TILEX_BYTES;
@@ -837,17 +905,13 @@ __global__ __launch_bounds__(256, MINW) void attn_frag_x3_kernel(const AttnFragP
   }
   if (__any(bad) && lane == 0) *flag = 1;
   __syncthreads();
-  if (*flag) {  // workgroup-uniform
+#ifdef BT_DEV
+  if (p.status && tid == 0) { atomicAdd(p.status + 2, 1); if (*flag) atomicAdd(p.status + 1, 1); }
+#endif
+  if (*flag) {  // workgroup-uniform: row maxima over all keys, then the same fast pass on them (row_max_pass_x)
     __syncthreads();
-#pragma unroll
-    for (int j = 0; j < QB; ++j) {
-      zero16(st[j].acc);
-      st[j].l = 0.f;
-      st[j].m = -1e30f;
-    }
-    stage_tile_x<KBX>(rk, rv, 0, smem, 0, tid, wave);
-    __syncthreads();
-    attn_tiles_x<true, QB, KBX>(rk, rv, smem, tid, wave, lane, g, lr, st, L, nblk, 0, false);
+    row_max_pass_x<QB, KBX>(rk, rv, smem, tid, wave, g, lr, st, L, nblk);
+    attn_fast_x<QB, KBX>(rk, rv, smem, tid, wave, lane, g, lr, st, L, nblk, true);
 #pragma unroll
     for (int j = 0; j < QB; ++j) l_tot[j] = st[j].l + __shfl_xor(st[j].l, 32);
   }
@@ -970,78 +1034,70 @@ __global__ __launch_bounds__(256, 2) void attn_frag_x3q2_kernel(const AttnFragP 
 #pragma unroll
     for (int i = 0; i < KBX; ++i) __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (lptr_t)(kd + TILEX_BYTES + i * 4096), 16, tid * 16, so + i * 4096, 0, 0);
   };
+  // One fast pass: the ring holds (or is receiving) tiles 0, 1, 2, st[j].negm the reference points; the full tiles on the asm
+  // loop, the last, ragged tile on the plain code.  On return every LDS-DMA of the workgroup has landed.
+  auto fast_pass = [&]() {
+#pragma unroll
+    for (int j = 0; j < QB; ++j) {
+      zero16(st[j].acc);
+      st[j].l = 0.f;
+    }
+    const float nm0 = st[0].negm[0], nm1 = st[1].negm[0];   // (what the plain code below needs of the splats)
+    if (nfull > 0) {
+      // operand words of the two buffer descriptors as plain SGPR quads (an asm operand cannot be a __amdgpu_buffer_rsrc_t)
+      const unsigned long long ka = (unsigned long long)kseq, va = (unsigned long long)vseq;
+      const u32x4 dk = {(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)ka), (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((ka >> 32) & 0xffffu)),
+                        (unsigned)__builtin_amdgcn_readfirstlane((int)seq_bytes), 0x00020000u};
+      const u32x4 dv = {(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)va), (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((va >> 32) & 0xffffu)),
+                        (unsigned)__builtin_amdgcn_readfirstlane((int)seq_bytes), 0x00020000u};
+      const int ln = lane_id_fresh();
+      const unsigned lds0 = (unsigned)(unsigned long long)(lptr_t)smem;   // LDS byte address of the ring
+      const unsigned klane = lds0 + ((2 * (ln >> 5)) * 32 + (ln & 31)) * 16, vlane = lds0 + ln * 16, dmaoff = (wave * 64 + ln) * 16;
+      const unsigned m0base = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + wave * 1024));
+      const float m1 = -1.0f;
+      int t = 0, soff = 3 * TILEX_BYTES;
+      asm volatile(ATTN_X3Q2_ASM
+                   : "+v"(st[0].acc), "+v"(st[1].acc), "+v"(st[0].l), "+v"(st[1].l), "+s"(t), "+s"(soff)
+                   : "v"(st[0].q0), "v"(st[0].q1), "v"(st[0].q0l), "v"(st[0].q1l), "v"(st[1].q0), "v"(st[1].q1), "v"(st[1].q0l), "v"(st[1].q1l),
+                     "v"(st[0].negm), "v"(st[1].negm), "v"(klane), "v"(vlane), "v"(dmaoff), "s"(dk), "s"(dv), "s"(m0base), "s"(m1), "s"(nfull)
+                   : ATTN_X3Q2_CLOBBERS);
+    }
+    // every piece of the ring this wave asked for has landed, and so has everybody else's: the last tile (fewer than KBX
+    // blocks and / or a masked last block) is read from its ring buffer by the plain code
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (nfull < ntiles) {
+      load_q();
+      // (the same arithmetic as the key loop and as attn_frag_x3_kernel, bit for bit: the reference maximum rides on the first
+      // score MFMA's accumulator input -- results must not depend on which kernel a launch size selects)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        st[0].negm[r] = nm0;
+        st[1].negm[r] = nm1;
+      }
+      const int lane2 = lane_id_fresh(), g2 = lane2 >> 5, lr2 = lane2 & 31;
+      const char* kb = smem + (nfull & (NBUF - 1)) * BUF_BYTES;
+      const char* vb = kb + TILEX_BYTES;
+      const int nb = nblk - nfull * KBX;
+      for (int c = 0; c < nb; ++c) {
+        const int blk = nfull * KBX + c;
+        const KFragX kf = ld_kx(kb + c * BLKX_BYTES, g2, lr2);
+        const VFragX vf = ld_vx(vb + c * BLKX_BYTES, lane2);
+        f32x16 sc[QB];
+        score_x<true, QB>(kf, st, sc);
+        if (partial && blk == nblk - 1) finish_x<false, true, QB, true>(sc, vf, g2, st, blk * 32, L);
+        else finish_x<false, false, QB, true>(sc, vf, g2, st, blk * 32, L);
+      }
+      __syncthreads();
+    }
+  };
   stage_ring(0);
   stage_ring(1);
   stage_ring(2);
-#pragma unroll
-  for (int j = 0; j < QB; ++j) {
-    zero16(st[j].acc);
-    st[j].l = 0.f;
-    st[j].m = -1e30f;
-  }
   asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // tile 0 (this wave's four pieces of it) has landed
   __syncthreads();
-  {  // reference maximum of every query: its scores against key block 0
-    const KFragX kf = ld_kx(smem, g, lr);
-    f32x16 s0[QB];
-    score_x<false, QB>(kf, st, s0);
-#pragma unroll
-    for (int j = 0; j < QB; ++j) {
-      float bm = -1e30f;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) bm = fmaxf(bm, (crow(r, g) < L) ? s0[j][r] : -1e30f);
-      bm = fmaxf(bm, __shfl_xor(bm, 32));
-#pragma unroll
-      for (int r = 0; r < 16; ++r) st[j].negm[r] = -bm - P_SHIFT;
-    }
-  }
-  if (nfull > 0) {
-    // operand words of the two buffer descriptors as plain SGPR quads (an asm operand cannot be a __amdgpu_buffer_rsrc_t)
-    const unsigned long long ka = (unsigned long long)kseq, va = (unsigned long long)vseq;
-    const u32x4 dk = {(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)ka), (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((ka >> 32) & 0xffffu)),
-                      (unsigned)__builtin_amdgcn_readfirstlane((int)seq_bytes), 0x00020000u};
-    const u32x4 dv = {(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)va), (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((va >> 32) & 0xffffu)),
-                      (unsigned)__builtin_amdgcn_readfirstlane((int)seq_bytes), 0x00020000u};
-    const unsigned lds0 = (unsigned)(unsigned long long)(lptr_t)smem;   // LDS byte address of the ring
-    const unsigned klane = lds0 + ((2 * g) * 32 + lr) * 16, vlane = lds0 + lane * 16, dmaoff = tid * 16;
-    const unsigned m0base = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + wave * 1024));
-    const float m1 = -1.0f;
-    int t = 0, soff = 3 * TILEX_BYTES;
-    asm volatile(ATTN_X3Q2_ASM
-                 : "+v"(st[0].acc), "+v"(st[1].acc), "+v"(st[0].l), "+v"(st[1].l), "+s"(t), "+s"(soff)
-                 : "v"(st[0].q0), "v"(st[0].q1), "v"(st[0].q0l), "v"(st[0].q1l), "v"(st[1].q0), "v"(st[1].q1), "v"(st[1].q0l), "v"(st[1].q1l),
-                   "v"(st[0].negm), "v"(st[1].negm), "v"(klane), "v"(vlane), "v"(dmaoff), "s"(dk), "s"(dv), "s"(m0base), "s"(m1), "s"(nfull)
-                 : ATTN_X3Q2_CLOBBERS);
-  }
-  const float nm0 = st[0].negm[0], nm1 = st[1].negm[0];   // (what the plain code below uses of the splats)
-  // every piece of the ring this wave asked for has landed, and so has everybody else's: the last tile (fewer than KBX
-  // blocks and / or a masked last block) is read from its ring buffer by the plain code
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (nfull < ntiles) {
-    load_q();
-    // (the same arithmetic as the key loop and as attn_frag_x3_kernel, bit for bit: the reference maximum rides on the first
-    // score MFMA's accumulator input -- results must not depend on which kernel a launch size selects)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      st[0].negm[r] = nm0;
-      st[1].negm[r] = nm1;
-    }
-    const int lane2 = lane_id_fresh(), g2 = lane2 >> 5, lr2 = lane2 & 31;
-    const char* kb = smem + (nfull & (NBUF - 1)) * BUF_BYTES;
-    const char* vb = kb + TILEX_BYTES;
-    const int nb = nblk - nfull * KBX;
-    for (int c = 0; c < nb; ++c) {
-      const int blk = nfull * KBX + c;
-      const KFragX kf = ld_kx(kb + c * BLKX_BYTES, g2, lr2);
-      const VFragX vf = ld_vx(vb + c * BLKX_BYTES, lane2);
-      f32x16 sc[QB];
-      score_x<true, QB>(kf, st, sc);
-      if (partial && blk == nblk - 1) finish_x<false, true, QB, true>(sc, vf, g2, st, blk * 32, L);
-      else finish_x<false, false, QB, true>(sc, vf, g2, st, blk * 32, L);
-    }
-    __syncthreads();
-  }
+  ref_max_x<QB>(smem, g, lr, st, L, nblk);
+  fast_pass();
   // (lane-derived values again, from an operand hipcc cannot see through: nothing but the softmax state stays live across
   // the asm statement -- a value kept was a spill, and the ISA lint allows no scratch next to LDS-DMA)
   const int laneE = lane_id_fresh(), gE = laneE >> 5, lrE = laneE & 31, tidE = wave * 64 + laneE;
@@ -1055,18 +1111,19 @@ __global__ __launch_bounds__(256, 2) void attn_frag_x3q2_kernel(const AttnFragP 
   }
   if (__any(bad) && laneE == 0) *flag = 1;
   __syncthreads();
-  if (*flag) {  // workgroup-uniform: classic running-maximum pass on the double-buffered plain code
+#ifdef BT_DEV   // development: how many workgroups re-run on the running-maximum pass (words 1, 2 of the status block)
+  if (p.status && tid == 0) { atomicAdd(p.status + 2, 1); if (*flag) atomicAdd(p.status + 1, 1); }
+#endif
+  if (*flag) {  // workgroup-uniform: row maxima over all keys, then the same fast pass on them (row_max_pass_x)
     __syncthreads();
     load_q();
-#pragma unroll
-    for (int j = 0; j < QB; ++j) {
-      zero16(st[j].acc);
-      st[j].l = 0.f;
-      st[j].m = -1e30f;
-    }
-    stage_tile_x<KBX>(rk, rv, 0, smem, 0, tidE, wave);
+    row_max_pass_x<QB, KBX>(rk, rv, smem, tidE, wave, gE, lrE, st, L, nblk);
+    stage_ring(0);
+    stage_ring(1);
+    stage_ring(2);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     __syncthreads();
-    attn_tiles_x<true, QB, KBX>(rk, rv, smem, tidE, wave, laneE, gE, lrE, st, L, nblk, 0, false);
+    fast_pass();
 #pragma unroll
     for (int j = 0; j < QB; ++j) l_tot[j] = st[j].l + __shfl_xor(st[j].l, 32);
   }
