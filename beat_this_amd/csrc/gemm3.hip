@@ -701,7 +701,10 @@ int launch_gemm3(const Gemm3P& p, hipStream_t s) {
   const bool rows192 = big && p.epi == G3_RESID && force != 1 && cost(192) < cost(256);
   // BT_PREC_F32X3: everything but QKV (square wave tiles) and the long-K residual GEMM (256-column tiles) on the 256 x 128
   // k16 configuration; x3 & 15 = 4 forces it, 3 forces the 128 x 128 tiles (tools/x3_probe.py, tests)
-  const bool mx = p.x3 && p.epi != G3_QKV && !big && !rows192 && force != 0 && ((p.x3 & 15) == 4 || (X3_MX && p.M >= 1024));
+  // (taken when its 256-row tiles still give every CU its two workgroups: a 2-chunk single-file forward stays on the
+  // 128 x 128 tiles, whose grid is twice as large)
+  const long mx_tiles = ((long)p.M + 255) / 256 * ((p.N + 127) / 128);
+  const bool mx = p.x3 && p.epi != G3_QKV && !big && !rows192 && force != 0 && ((p.x3 & 15) == 4 || (X3_MX && mx_tiles >= 512));
   if (p.x3) {
 #ifdef BT_DEV
     // development: ablations of the x3 kernel (results are garbage): BT_G3_ABL = 1 no LDS-DMA after the prologue, 4 no MFMAs
