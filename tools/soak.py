@@ -21,7 +21,7 @@ mode = sys.argv[2] if len(sys.argv) > 2 else "pinned"
 prec = sys.argv[3] if len(sys.argv) > 3 else "half"
 dev = torch.device("cuda:0")
 hp = W.resolve_hparams("final0")
-a2b = Audio2Beats(checkpoint_path=None, device=dev, float16={"half": True, "f32": False, "f32x3": "f32x3"}[prec])
+a2b = Audio2Beats(checkpoint_path=None, device=dev, float16={"half": True, "f32": "exact", "f32x3": False}[prec])
 m = BeatThis(**hp)
 m.load_state_dict(W.random_state_dict(hp, seed=1, style="lively"))
 a2b.model = m.to(dev).eval()

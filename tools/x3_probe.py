@@ -133,6 +133,23 @@ attention(B * 8, 4, T, f"frontend block 2 ({B * 8} sequences x 4 heads)")
 if len(sys.argv) > 2 and sys.argv[2] == "attn":
     sys.exit(0)
 M = B * T
+if len(sys.argv) > 2 and sys.argv[2].startswith("gloop"):
+    # python tools/x3_probe.py 16 gloop:ff1|ff2|qkv|out [seconds] -- one GEMM back to back (power / clock sampling from outside)
+    import time
+    which = sys.argv[2].split(":")[1]
+    secs = float(sys.argv[3]) if len(sys.argv) > 3 else 4.0
+    shape = {"ff1": (M, 512, 2048, 0, {}), "ff2": (M, 2048, 512, 1, {}), "out": (M, 512, 512, 1, {}),
+             "qkv": (M, 512, 3 * 512 + 16, 2, dict(heads=16, n_seq=B, Lq=T))}[which]
+    def timeit(fn, n=20):   # noqa: F811  (the set-up of gemm() once, then launches for `secs` seconds)
+        t0, k = time.time(), 0
+        while time.time() - t0 < secs:
+            for _ in range(20):
+                fn()
+            torch.cuda.synchronize()
+            k += 20
+        return (time.time() - t0) / k * 1e6
+    gemm(shape[0], shape[1], shape[2], shape[3], which, **shape[4])
+    sys.exit(0)
 gemm(M, 512, 3 * 512 + 16, 2, "QKV", heads=16, n_seq=B, Lq=T)
 for f in (3, 4, 3, 4):
     gemm(M, 512, 512, 1, "out-projection", force=f)
