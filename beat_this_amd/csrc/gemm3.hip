@@ -131,9 +131,6 @@ void gemm3_kernel(const Gemm3P p, int n_tiles, int total_tiles, int per_xcd, int
   constexpr int FB = BN / CFG::WGN / 32;       // 32-feature blocks per wave
   constexpr int ROWB = BK * 2;                 // bytes per LDS row (BK half elements)
   constexpr int KR = X3 ? BK / 2 : BK;         // k values per k-step (X3: a row is BK / 2 hi + BK / 2 lo halves)
-#ifndef X3_MX_ROLL
-#define X3_MX_ROLL 1   // 0: the one-set k-loop for the 256 x 128 configuration too (A/B builds)
-#endif
   constexpr bool HL16 = X3 && BK == 32;        // X3 on 64-byte rows: a k-step is HALF an hl32 group (16 hi + 16 lo halves)
   constexpr int EB = X3 ? 4 : 2;               // operand bytes per k value
   constexpr int CPR = ROWB / 16;               // 16-byte chunks per row (4 or 8)
@@ -290,11 +287,8 @@ void gemm3_kernel(const Gemm3P p, int n_tiles, int total_tiles, int per_xcd, int
   }
   // FF1: this lane's bias values (MFMA layout: 4-feature runs 8 q + 4 g of each 32-feature block), requested here for the
   // same reason -- in the epilogue each block's four loads were a memory round trip in front of its GELU
-  // (not in the HL16 configuration: its k-loop keeps two sets of operand fragments in registers, the 32 bias registers do
-  // not fit next to them; the bias is fetched in the epilogue there)
-  constexpr bool ROLL = HL16 && X3_MX_ROLL != 0;
-  f32x4 bqv[EPI == G3_FF1 && !ROLL ? FB : 1][4];
-  if constexpr (EPI == G3_FF1 && !ROLL) {
+  f32x4 bqv[EPI == G3_FF1 ? FB : 1][4];
+  if constexpr (EPI == G3_FF1) {
 #pragma unroll
     for (int a = 0; a < FB; ++a)
 #pragma unroll
@@ -333,95 +327,6 @@ void gemm3_kernel(const Gemm3P p, int n_tiles, int total_tiles, int per_xcd, int
   int stage = 0, stage2 = NST - 1;
   long long t_wait = 0, t_bar = 0, t_loop0 = 0;
   if constexpr ((ABL & 8) != 0) t_loop0 = clock64();
-  if constexpr (ROLL) {
-    // ---- k-steps of 16 with the operand fragments double-buffered in REGISTERS (round 4) ---------------------------------
-    // The fragments of step kt + 1 are read from LDS while step kt is multiplied, so no MFMA waits for a fragment read (the
-    // one-set loop below exposes four LDS round trips per step).  Every wave holds step kt's fragments in registers when
-    // it passes step kt's barrier, so that barrier frees the LDS stage of tile kt as well: the three-stage ring runs THREE
-    // tiles ahead (kt + 1 landed, kt + 2 and kt + 3 in flight) instead of two.
-    static_assert(NST == 3 && MS == 2, "HL16: three stages, one k16 piece (hi chunk pair 0, lo chunk pair 1) per row");
-    // (waits as BUILTINS, not inline assembly: hipcc's wait-count pass then knows that the fragment set read one step ago is
-    // complete at the barrier and puts no lgkmcnt(0) of its own in front of the MFMAs -- which would also wait for the set
-    // just requested; encoding of s_waitcnt on gfx9: vmcnt[3:0] | expcnt << 4 | lgkmcnt << 8 | vmcnt[5:4] << 14)
-#define G3_WAITCNT(vm) __builtin_amdgcn_s_waitcnt(((vm) & 15) | (7 << 4) | (0 << 8) | (((vm) >> 4) << 14))
-    if (2 < nk) G3_ISSUE(2, 2);
-    if (nk > 2) G3_WAITCNT(2 * LPS);
-    else if (nk > 1) G3_WAITCNT(LPS);
-    else G3_WAITCNT(0);
-    __builtin_amdgcn_s_barrier();   // tile 0 is readable by every wave
-    // Fragment registers: the wave's NP row blocks are multiplied one after the other (6 MFMAs each); the fragments of
-    // blocks 0 .. NP - 2 are re-read for the next tile right after their block's MFMAs were issued (ONE register set), the
-    // last block and the two column blocks are needed until the step ends and have two sets: 72 registers instead of 96.
-    hfx8 ph[NP - 1], pl[NP - 1], rh[2], rl[2], qh[2][NQ], ql[2][NQ];
-#define G3_RD(dst, stg, ofs, m) dst = *reinterpret_cast<const hfx8*>(smem + (stg) * ST_BYTES + (ofs) + kc[m])
-#define G3_READ_LATE(set, stg)   /* what the whole step needs: column blocks and the last row block */                  \
-    do {                                                                                                                \
-      _Pragma("unroll") for (int b = 0; b < NQ; ++b) {                                                                  \
-        G3_RD(qh[set][b], stg, qofs + b * 32 * ROWB, 0);                                                                \
-        G3_RD(ql[set][b], stg, qofs + b * 32 * ROWB, 1);                                                                \
-      }                                                                                                                 \
-      G3_RD(rh[set], stg, pofs + (NP - 1) * 32 * ROWB, 0);                                                              \
-      G3_RD(rl[set], stg, pofs + (NP - 1) * 32 * ROWB, 1);                                                              \
-    } while (0)
-#define G3_BLOCK(fh, fl, a, cur)   /* small terms first, the same order as every other configuration */                \
-    do {                                                                                                                \
-      _Pragma("unroll") for (int b = 0; b < NQ; ++b) acc[a][b] = MFMA32_H(fl, qh[cur][b], acc[a][b]);                   \
-      _Pragma("unroll") for (int b = 0; b < NQ; ++b) acc[a][b] = MFMA32_H(fh, ql[cur][b], acc[a][b]);                   \
-      _Pragma("unroll") for (int b = 0; b < NQ; ++b) acc[a][b] = MFMA32_H(fh, qh[cur][b], acc[a][b]);                   \
-    } while (0)
-#define G3_MMA(cur, NEXT, stg)                                                                                         \
-    do {                                                                                                                \
-      _Pragma("unroll") for (int a = 0; a < NP - 1; ++a) {                                                              \
-        G3_BLOCK(ph[a], pl[a], a, cur);                                                                                 \
-        __builtin_amdgcn_sched_barrier(0);                                                                              \
-        if (NEXT) {                                                                                                     \
-          G3_RD(ph[a], stg, pofs + a * 32 * ROWB, 0);                                                                   \
-          G3_RD(pl[a], stg, pofs + a * 32 * ROWB, 1);                                                                   \
-          __builtin_amdgcn_sched_barrier(0);                                                                            \
-        }                                                                                                               \
-      }                                                                                                                 \
-      G3_BLOCK(rh[cur], rl[cur], NP - 1, cur);                                                                          \
-    } while (0)
-    // a step that has a successor: make tile k + 1 readable, refill the stage of tile k, multiply while the next fragments
-    // arrive (the last of them is requested one row block = 6 MFMAs before the step ends)
-#define G3_STEP(k, cur)                                                                                                \
-    do {                                                                                                                \
-      if ((k) + 2 < nk) G3_WAITCNT(LPS); else G3_WAITCNT(0);   /* tile k + 1 landed; reads of tile k returned */        \
-      __builtin_amdgcn_s_barrier();                                                                                     \
-      if ((k) + 3 < nk) G3_ISSUE((k) + 3, sk);             /* into the stage of tile k: everybody holds its fragments */ \
-      G3_READ_LATE((cur) ^ 1, sk1);                                                                                     \
-      __builtin_amdgcn_sched_barrier(0);                                                                                \
-      G3_MMA(cur, 1, sk1);                                                                                              \
-      sk = sk1; sk1 = sk1 == 2 ? 0 : sk1 + 1;                                                                           \
-    } while (0)
-    G3_READ_LATE(0, 0);
-#pragma unroll
-    for (int a = 0; a < NP - 1; ++a) {
-      G3_RD(ph[a], 0, pofs + a * 32 * ROWB, 0);
-      G3_RD(pl[a], 0, pofs + a * 32 * ROWB, 1);
-    }
-    int sk = 0, sk1 = 1;   // stage of tile k, of tile k + 1
-    int kt = 0;
-    for (; kt + 2 < nk; kt += 2) {
-      G3_STEP(kt, 0);
-      G3_STEP(kt + 1, 1);
-    }
-    if (kt + 1 < nk) {   // two steps left: the last one's late fragments are in set 1
-      G3_STEP(kt, 0);
-      G3_WAITCNT(0);
-      rh[0] = rh[1]; rl[0] = rl[1];
-#pragma unroll
-      for (int b = 0; b < NQ; ++b) { qh[0][b] = qh[1][b]; ql[0][b] = ql[1][b]; }
-    }
-    G3_WAITCNT(0);
-    G3_MMA(0, 0, 0);
-#undef G3_BLOCK
-#undef G3_READ_LATE
-#undef G3_RD
-#undef G3_MMA
-#undef G3_WAITCNT
-#undef G3_STEP
-  } else
   for (int kt = 0; kt < nk; ++kt) {
     long long tq0 = 0, tq1 = 0;
     if constexpr ((ABL & 8) != 0) tq0 = clock64();
@@ -504,17 +409,8 @@ void gemm3_kernel(const Gemm3P p, int n_tiles, int total_tiles, int per_xcd, int
 #pragma unroll
       for (int a = 0; a < FB; ++a) {
         float v[16];
-        if constexpr (ROLL) {
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const f32x4 bb = *reinterpret_cast<const f32x4*>(p.bias + nb0 + a * 32 + 8 * q + 4 * g);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) v[4 * q + i] = gelu_erf(fmaf(acc[a][b][4 * q + i], rs[b], bb[i]));
-          }
-        } else {
-#pragma unroll
-          for (int r = 0; r < 16; ++r) v[r] = gelu_erf(fmaf(acc[a][b][r], rs[b], bqv[a][r >> 2][r & 3]));
-        }
+        for (int r = 0; r < 16; ++r) v[r] = gelu_erf(fmaf(acc[a][b][r], rs[b], bqv[a][r >> 2][r & 3]));
         u32x4 hi[2], lo[2];
         pack_row_hl(v, hi, lo, amax);
 #pragma unroll
