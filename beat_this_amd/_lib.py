@@ -19,13 +19,13 @@ if os.environ.get("BT_DEV") == "1" and os.environ.get("BT_LIB_PATH"):  # develop
     LIB_PATH = os.environ["BT_LIB_PATH"]
 SOURCES = ["gemm.hip", "gemm2.hip", "gemm3.hip", "attn.hip", "attn2.hip", "fused.hip", "fused2.hip", "qkv_front.hip", "frontend.hip", "logmel.hip",
            "tail.hip", "engine.hip"]
-HEADERS = ["common.h", "chain.h", "kernels.h", os.path.join("..", "..", "include", "beat_this_amd.h")]
+HEADERS = ["common.h", "chain.h", "kernels.h", "attn_x3_loop.inc", os.path.join("..", "..", "include", "beat_this_amd.h")]
 
 BT_OK, BT_ERR_ARG, BT_ERR_HIP, BT_ERR_WORKSPACE = 0, -1, -2, -3
-ABI_VERSION = 400   # BT_ABI_VERSION of include/beat_this_amd.h this binding was written against
+ABI_VERSION = 500   # BT_ABI_VERSION of include/beat_this_amd.h this binding was written against
 PREC_F32, PREC_HALF, PREC_F32X3 = 0, 1, 3   # (2 was the withdrawn e4m3 experiment)
 MAX_LAYERS = 32
-PROFILE_CATEGORIES = ["stem", "qkv_gemm", "attn_freq", "attn_flash", "out_gemm", "ff1_gemm", "ff2_gemm", "conv_gemm",
+PROFILE_CATEGORIES = ["stem", "qkv_gemm", "attn_flash", "out_gemm", "ff1_gemm", "ff2_gemm", "conv_gemm",
                       "linear_gemm", "head", "ff_fused", "attn_freq_fused", "layer_tail"]
 
 GEMM_EPI_STORE, GEMM_EPI_RESID, GEMM_EPI_QKV = 0, 1, 2
@@ -35,7 +35,7 @@ GEMM_F_RMS, GEMM_F_BIAS, GEMM_F_GELU, GEMM_F_OUT_F32, GEMM_F_A_F32, GEMM_F_CONV,
 class PairWeights(C.Structure):
     _fields_ = [("dim", C.c_int32), ("heads", C.c_int32), ("w_qkvg", C.c_void_p * 2), ("b_gates", C.c_void_p),
                 ("w_out", C.c_void_p * 2), ("w_ff1", C.c_void_p * 2), ("b_ff1", C.c_void_p),
-                ("w_ff2", C.c_void_p * 2), ("b_ff2", C.c_void_p), ("w_outp", C.c_void_p * 2),
+                ("w_ff2", C.c_void_p * 2), ("b_ff2", C.c_void_p),
                 ("w_ff_frag", C.c_void_p * 2), ("w_qkv_frag", C.c_void_p),
                 ("w_outff_frag", C.c_void_p * 2), ("w_attnff_frag", C.c_void_p * 2),
                 ("w_tail_frag", C.c_void_p),
@@ -105,6 +105,8 @@ EXPORTS = {
     "bt_struct_sizes": (None, [C.POINTER(C.c_int32)]),
     "bt_engine_create": (C.c_int, [C.POINTER(ModelDesc), C.POINTER(C.c_void_p)]),
     "bt_engine_destroy": (None, [C.c_void_p]),
+    "bt_engine_set_option": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "bt_engine_get_option": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int)]),
     "bt_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "bt_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t,
                              C.c_void_p, C.c_void_p]),

@@ -562,6 +562,7 @@ struct QStateX {
   hfx8 q0, q1, q0l, q1l;  // Q^T operand (hi, lo): dims [16g, 16g+8) and [16g+8, 16g+16) of this lane's query
   f32x16 acc;             // O^T accumulator
   float l;                // row sum of this lane's 16 keys per block (the two halves are added at the end)
+  f32x4 l4;               // P16: the same sum taken from the ROUNDED probabilities on 4x4x4 MFMAs (four equal registers)
   float m;                // running max (SAFE pass)
   f32x16 negm;            // fast pass, one query block per wave: -(reference max) - P_SHIFT splat = accumulator input of
                           // the first score MFMA;  two query blocks per wave (no registers for a splat): only negm[0] is
@@ -621,7 +622,19 @@ DEVI void score_x(const KFragX& kf, const QStateX (&st)[QB], f32x16 (&sc)[QB]) {
 // it when the scores stopped riding on the reference maximum: it is the 22-bit operand representation, 2^-22 |q| |k|
 // per score, amplified by scores of magnitude 60, not the accumulation.)
 // (PRESUB: the scores already carry the reference maximum -- it rode on the first score MFMA's accumulator input)
-template <bool SAFE, bool MASK, int QB, bool PRESUB = (QB == 1)>
+//
+// P16 (round 5, the default since the flip-rate soak of profiles/r05_flip_frontier.txt): the probabilities enter the product
+// as their fp16 hi parts only -- O^T += V_hi^T . P_hi^T + V_lo^T . P_hi^T, four MFMAs instead of six, no lo split -- and the
+// row sums are taken from the SAME rounded values (v_mfma_f32_4x4x4_16b_f16 with an all-ones A operand, like the half
+// kernel): numerator and denominator of the softmax see identical probabilities, fp16 subnormals included, so what the
+// rounding leaves in O / l is sum_j p_j d_j (v_j - o) / sum_j p_j with |d_j| <= 2^-12 -- the spread of V around the output, not V
+// itself.  An fp16 overflow of a probability is inf in the row sum (-> the re-run on the row maxima, as before).
+DEVI unsigned cvt_pk_rn(float a, float b) {   // (the instruction the hand-scheduled loop uses; leading wait state: a and b may
+  unsigned w;                                  // be v_exp results, which a non-transcendental VALU may not read right away)
+  asm("s_nop 0\n\tv_cvt_pk_f16_f32 %0, %1, %2" : "=v"(w) : "v"(a), "v"(b));
+  return w;
+}
+template <bool SAFE, bool MASK, int QB, bool PRESUB = (QB == 1), bool P16 = false>
 DEVI void finish_x(f32x16 (&sc)[QB], const VFragX& vf, int g, QStateX (&st)[QB], int key0, int L) {
 #pragma unroll
   for (int j = 0; j < QB; ++j) {
@@ -639,6 +652,7 @@ DEVI void finish_x(f32x16 (&sc)[QB], const VFragX& vf, int g, QStateX (&st)[QB],
       const float alpha = __builtin_amdgcn_exp2f(st[j].m - m_new);
       st[j].m = m_new;
       st[j].l *= alpha;
+      if constexpr (P16) st[j].l4 *= alpha;
 #pragma unroll
       for (int r = 0; r < 16; ++r) st[j].acc[r] *= alpha;
 #pragma unroll
@@ -652,9 +666,33 @@ DEVI void finish_x(f32x16 (&sc)[QB], const VFragX& vf, int g, QStateX (&st)[QB],
           if (key0 + crow(r, g) >= L) sc[j][r] = 0.f;
       }
     }
-    const float a = (sc[j][0] + sc[j][1]) + (sc[j][2] + sc[j][3]), b = (sc[j][4] + sc[j][5]) + (sc[j][6] + sc[j][7]);
-    const float c = (sc[j][8] + sc[j][9]) + (sc[j][10] + sc[j][11]), d = (sc[j][12] + sc[j][13]) + (sc[j][14] + sc[j][15]);
-    st[j].l += (a + b) + (c + d);
+    if constexpr (!P16) {
+      const float a = (sc[j][0] + sc[j][1]) + (sc[j][2] + sc[j][3]), b = (sc[j][4] + sc[j][5]) + (sc[j][6] + sc[j][7]);
+      const float c = (sc[j][8] + sc[j][9]) + (sc[j][10] + sc[j][11]), d = (sc[j][12] + sc[j][13]) + (sc[j][14] + sc[j][15]);
+      st[j].l += (a + b) + (c + d);
+    }
+  }
+  if constexpr (P16) {
+    u32x4 w0[QB], w1[QB];
+#pragma unroll
+    for (int j = 0; j < QB; ++j) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        w0[j][i] = cvt_pk_rn(sc[j][2 * i], sc[j][2 * i + 1]);
+        w1[j][i] = cvt_pk_rn(sc[j][8 + 2 * i], sc[j][8 + 2 * i + 1]);
+      }
+      rowsum8(st[j].l4, w0[j]);
+      rowsum8(st[j].l4, w1[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < QB; ++j) st[j].acc = MFMA32_H(vf.v0l, __builtin_bit_cast(hfx8, w0[j]), st[j].acc);
+#pragma unroll
+    for (int j = 0; j < QB; ++j) st[j].acc = MFMA32_H(vf.v1l, __builtin_bit_cast(hfx8, w1[j]), st[j].acc);
+#pragma unroll
+    for (int j = 0; j < QB; ++j) st[j].acc = MFMA32_H(vf.v0, __builtin_bit_cast(hfx8, w0[j]), st[j].acc);
+#pragma unroll
+    for (int j = 0; j < QB; ++j) st[j].acc = MFMA32_H(vf.v1, __builtin_bit_cast(hfx8, w1[j]), st[j].acc);
+    return;
   }
   u32x4 h0[QB], l0[QB], h1[QB], l1[QB];
 #pragma unroll
@@ -693,7 +731,7 @@ DEVI void stage_tile_x(rsrc_t rk, rsrc_t rv, int tile, char* smem, int buf, int 
 // Plain pass, one key block at a time (SAFE: classic online softmax over all tiles; fast: only the tiles from `t0` on --
 // the ragged / masked last tile): tile t + 1 is staged while tile t is consumed, one barrier per tile.
 // On entry tile t0 must be readable in buffer t0 & 1 (and tile t0 + 1, if `next_staged`, on its way into the other one).
-template <bool SAFE, int QB, int KBX>
+template <bool SAFE, int QB, int KBX, bool P16 = false>
 DEVI void attn_tiles_x(rsrc_t rk, rsrc_t rv, char* smem, int tid, int wave, int lane, int g, int lr, QStateX (&st)[QB], int L,
                        int nblk, int t0, bool next_staged) {
   constexpr int TILEX_BYTES = KBX * BLKX_BYTES;
@@ -710,8 +748,8 @@ DEVI void attn_tiles_x(rsrc_t rk, rsrc_t rv, char* smem, int tid, int wave, int 
       const VFragX vf = ld_vx(vb + c * BLKX_BYTES, lane);
       f32x16 sc[QB];
       score_x<!SAFE && QB == 1, QB>(kf, st, sc);
-      if (partial && blk == nblk - 1) finish_x<SAFE, true, QB>(sc, vf, g, st, blk * 32, L);
-      else finish_x<SAFE, false, QB>(sc, vf, g, st, blk * 32, L);
+      if (partial && blk == nblk - 1) finish_x<SAFE, true, QB, (QB == 1), P16>(sc, vf, g, st, blk * 32, L);
+      else finish_x<SAFE, false, QB, (QB == 1), P16>(sc, vf, g, st, blk * 32, L);
     }
     __syncthreads();  // tile t + 1 has landed (every wave waited for its own copies), tile t is free
   }
@@ -722,6 +760,11 @@ DEVI void attn_tiles_x(rsrc_t rk, rsrc_t rv, char* smem, int tid, int wave, int 
 // may score up to 16 + P_SHIFT octaves above it before the fast pass overflows; 64 keys instead of 32 make that ~60 times
 // rarer on Gaussian scores at no cost (the blocks are there).  Shared by every x3 kernel: the reference point is part of
 // the arithmetic, and the kernels must agree bit for bit.
+// Round 5: the reference point is rounded UP to a whole octave.  Probabilities relative to two reference points that differ
+// by whole octaves differ by a power of two, and both the hi + lo split and the fp16 rounding of P16 commute with that
+// (outside fp16's subnormal range): a workgroup that re-runs on its row maxima (row_max_pass_x) then reproduces what the
+// fast pass would have given without the overflow, so a query's result does not depend on which other queries share its
+// workgroup -- 128 or 256 of them, by the kernel a launch size selects -- beyond the subnormal tail.
 template <int QB>
 DEVI void ref_max_x(const char* smem, int g, int lr, QStateX (&st)[QB], int L, int nblk) {
   float bm[QB];
@@ -739,7 +782,7 @@ DEVI void ref_max_x(const char* smem, int g, int lr, QStateX (&st)[QB], int L, i
   }
 #pragma unroll
   for (int j = 0; j < QB; ++j) {
-    const float m = fmaxf(bm[j], __shfl_xor(bm[j], 32));
+    const float m = ceilf(fmaxf(bm[j], __shfl_xor(bm[j], 32)));
 #pragma unroll
     for (int r = 0; r < 16; ++r) st[j].negm[r] = -m - P_SHIFT;
   }
@@ -787,7 +830,7 @@ DEVI void row_max_pass_x(rsrc_t rk, rsrc_t rv, char* smem, int tid, int wave, in
   // subnormal range (absolute 2^-25 per term: with the maximum at 2^-4 the row sums were 1.3e-5 off, tests/test_gpu_x3.py).
 #pragma unroll
   for (int j = 0; j < QB; ++j) {
-    const float m = fmaxf(bm[j], __shfl_xor(bm[j], 32));
+    const float m = ceilf(fmaxf(bm[j], __shfl_xor(bm[j], 32)));   // (whole octaves: see ref_max_x)
 #pragma unroll
     for (int r = 0; r < 16; ++r) st[j].negm[r] = 2.0f - m;
   }
@@ -796,7 +839,7 @@ DEVI void row_max_pass_x(rsrc_t rk, rsrc_t rv, char* smem, int tid, int wave, in
 // Fast pass: reference maximum of every query from key block 0, then the key loop software-pipelined by hand over the
 // tiles of KB unmasked blocks: the scores of block c + 1 are issued BEFORE the exponentials of block c (two score
 // buffers alternate: the loop is unrolled over the tile, no register copies), one barrier per tile at its last block.
-template <int QB, int KBX>
+template <int QB, int KBX, bool P16 = false>
 DEVI void attn_fast_x(rsrc_t rk, rsrc_t rv, char* smem, int tid, int wave, int lane, int g, int lr, QStateX (&st)[QB], int L,
                       int nblk, bool have_ref = false) {   // have_ref: st[j].negm is set (the re-run behind row_max_pass_x)
   constexpr int TILEX_BYTES = KBX * BLKX_BYTES;
@@ -812,6 +855,7 @@ DEVI void attn_fast_x(rsrc_t rk, rsrc_t rv, char* smem, int tid, int wave, int l
   for (int j = 0; j < QB; ++j) {
     zero16(st[j].acc);
     st[j].l = 0.f;
+    st[j].l4 = f32x4{0.f, 0.f, 0.f, 0.f};
     st[j].m = -1e30f;
   }
   // PIPE (one query block per wave): the scores of block c + 1 are issued before the exponentials of block c, two score
@@ -843,18 +887,18 @@ DEVI void attn_fast_x(rsrc_t rk, rsrc_t rv, char* smem, int tid, int wave, int l
         if (have_next) kf = ld_kx(kb_next, g, lr);
       }
       if (PIPE && have_next) score_x<true, QB>(kf, st, s2[nxt]);
-      finish_x<false, false, QB>(s2[cur], vf, g, st, 0, L);
+      finish_x<false, false, QB, (QB == 1), P16>(s2[cur], vf, g, st, 0, L);
       if (!PIPE && have_next) score_x<false, QB>(kf, st, s2[0]);
     }
   }
   if (nfull < ntiles)  // last tile: fewer than KBX blocks and / or a masked last block (staged by the loop / the prologue)
-    attn_tiles_x<false, QB, KBX>(rk, rv, smem, tid, wave, lane, g, lr, st, L, nblk, nfull, true);
+    attn_tiles_x<false, QB, KBX, P16>(rk, rv, smem, tid, wave, lane, g, lr, st, L, nblk, nfull, true);
   else
     __syncthreads();
 }
 
 // OUT: 0 = hl32 planes [rows, 2 inner] (main layers), 1 = fp32 [rows, inner] (frontend)
-template <int QB, int OUT, int KBX, int MINW>
+template <int QB, int OUT, int KBX, int MINW, bool P16>
 __global__ __launch_bounds__(256, MINW) void attn_frag_x3_kernel(const AttnFragP p, int nqt, int sh_total) {
   constexpr int TILEX_BYTES = KBX * BLKX_BYTES;
   __shared__ __attribute__((aligned(16))) char smem[2 * 2 * TILEX_BYTES + 16];
@@ -891,16 +935,17 @@ __global__ __launch_bounds__(256, MINW) void attn_frag_x3_kernel(const AttnFragP
   const unsigned seq_bytes = (unsigned)p.nbp * BLKX_BYTES;
   const rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(kseq), 0, seq_bytes, 0x00020000);
   const rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(vseq), 0, seq_bytes, 0x00020000);
-  attn_fast_x<QB, KBX>(rk, rv, smem, tid, wave, lane, g, lr, st, L, nblk);
+  attn_fast_x<QB, KBX, P16>(rk, rv, smem, tid, wave, lane, g, lr, st, L, nblk);
+  auto lane_sum = [&](int j) { return P16 ? st[j].l4[0] : st[j].l; };
   float l_tot[QB];
   bool bad = false;
 #pragma unroll
   for (int j = 0; j < QB; ++j) {
-    l_tot[j] = st[j].l + __shfl_xor(st[j].l, 32);
+    l_tot[j] = lane_sum(j) + __shfl_xor(lane_sum(j), 32);
     const bool valid = qb0 + j < nblk && (qb0 + j) * 32 + lr < L;
     // the row sum is taken from the UNSPLIT fp32 probabilities, so an fp16 overflow of a hi part (p > 65504) does not turn
     // it into inf: but such a p makes the sum exceed 65504 as well -> this query needs the running-max pass (a sum that
-    // large without any single overflow only costs the re-run)
+    // large without any single overflow only costs the re-run).  (P16: the sum is taken from the rounded values -- inf then)
     bad = bad || (valid && !(l_tot[j] < 65504.f));
   }
   if (__any(bad) && lane == 0) *flag = 1;
@@ -911,9 +956,9 @@ __global__ __launch_bounds__(256, MINW) void attn_frag_x3_kernel(const AttnFragP
   if (*flag) {  // workgroup-uniform: row maxima over all keys, then the same fast pass on them (row_max_pass_x)
     __syncthreads();
     row_max_pass_x<QB, KBX>(rk, rv, smem, tid, wave, g, lr, st, L, nblk);
-    attn_fast_x<QB, KBX>(rk, rv, smem, tid, wave, lane, g, lr, st, L, nblk, true);
+    attn_fast_x<QB, KBX, P16>(rk, rv, smem, tid, wave, lane, g, lr, st, L, nblk, true);
 #pragma unroll
-    for (int j = 0; j < QB; ++j) l_tot[j] = st[j].l + __shfl_xor(st[j].l, 32);
+    for (int j = 0; j < QB; ++j) l_tot[j] = lane_sum(j) + __shfl_xor(lane_sum(j), 32);
   }
 
   const int seq = sh / p.heads, head = sh - seq * p.heads;
@@ -977,7 +1022,7 @@ __global__ __launch_bounds__(256, MINW) void attn_frag_x3_kernel(const AttnFragP
 // stores are the C++ of the kernel above, instantiated for two query blocks per wave.
 #include "attn_x3_loop.inc"
 
-template <int OUT>
+template <int OUT, bool P16>
 __global__ __launch_bounds__(256, 2) void attn_frag_x3q2_kernel(const AttnFragP p, int nqt, int sh_total) {
   constexpr int QB = 2, KBX = ATTN_X3Q2_KBX, NBUF = ATTN_X3Q2_NBUF;
   constexpr int TILEX_BYTES = KBX * BLKX_BYTES, BUF_BYTES = 2 * TILEX_BYTES;
@@ -1041,6 +1086,7 @@ __global__ __launch_bounds__(256, 2) void attn_frag_x3q2_kernel(const AttnFragP 
     for (int j = 0; j < QB; ++j) {
       zero16(st[j].acc);
       st[j].l = 0.f;
+      st[j].l4 = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     const float nm0 = st[0].negm[0], nm1 = st[1].negm[0];   // (what the plain code below needs of the splats)
     if (nfull > 0) {
@@ -1056,11 +1102,18 @@ __global__ __launch_bounds__(256, 2) void attn_frag_x3q2_kernel(const AttnFragP 
       const unsigned m0base = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + wave * 1024));
       const float m1 = -1.0f;
       int t = 0, soff = 3 * TILEX_BYTES;
-      asm volatile(ATTN_X3Q2_ASM
-                   : "+v"(st[0].acc), "+v"(st[1].acc), "+v"(st[0].l), "+v"(st[1].l), "+s"(t), "+s"(soff)
-                   : "v"(st[0].q0), "v"(st[0].q1), "v"(st[0].q0l), "v"(st[0].q1l), "v"(st[1].q0), "v"(st[1].q1), "v"(st[1].q0l), "v"(st[1].q1l),
-                     "v"(st[0].negm), "v"(st[1].negm), "v"(klane), "v"(vlane), "v"(dmaoff), "s"(dk), "s"(dv), "s"(m0base), "s"(m1), "s"(nfull)
-                   : ATTN_X3Q2_CLOBBERS);
+      if constexpr (P16)
+        asm volatile(ATTN_X3Q2P_ASM
+                     : "+v"(st[0].acc), "+v"(st[1].acc), "+v"(st[0].l4), "+v"(st[1].l4), "+s"(t), "+s"(soff)
+                     : "v"(st[0].q0), "v"(st[0].q1), "v"(st[0].q0l), "v"(st[0].q1l), "v"(st[1].q0), "v"(st[1].q1), "v"(st[1].q0l), "v"(st[1].q1l),
+                       "v"(st[0].negm), "v"(st[1].negm), "v"(klane), "v"(vlane), "v"(dmaoff), "s"(dk), "s"(dv), "s"(m0base), "s"(m1), "s"(nfull)
+                     : ATTN_X3Q2P_CLOBBERS);
+      else
+        asm volatile(ATTN_X3Q2_ASM
+                     : "+v"(st[0].acc), "+v"(st[1].acc), "+v"(st[0].l), "+v"(st[1].l), "+s"(t), "+s"(soff)
+                     : "v"(st[0].q0), "v"(st[0].q1), "v"(st[0].q0l), "v"(st[0].q1l), "v"(st[1].q0), "v"(st[1].q1), "v"(st[1].q0l), "v"(st[1].q1l),
+                       "v"(st[0].negm), "v"(st[1].negm), "v"(klane), "v"(vlane), "v"(dmaoff), "s"(dk), "s"(dv), "s"(m0base), "s"(m1), "s"(nfull)
+                     : ATTN_X3Q2_CLOBBERS);
     }
     // every piece of the ring this wave asked for has landed, and so has everybody else's: the last tile (fewer than KBX
     // blocks and / or a masked last block) is read from its ring buffer by the plain code
@@ -1085,8 +1138,8 @@ __global__ __launch_bounds__(256, 2) void attn_frag_x3q2_kernel(const AttnFragP 
         const VFragX vf = ld_vx(vb + c * BLKX_BYTES, lane2);
         f32x16 sc[QB];
         score_x<true, QB>(kf, st, sc);
-        if (partial && blk == nblk - 1) finish_x<false, true, QB, true>(sc, vf, g2, st, blk * 32, L);
-        else finish_x<false, false, QB, true>(sc, vf, g2, st, blk * 32, L);
+        if (partial && blk == nblk - 1) finish_x<false, true, QB, true, P16>(sc, vf, g2, st, blk * 32, L);
+        else finish_x<false, false, QB, true, P16>(sc, vf, g2, st, blk * 32, L);
       }
       __syncthreads();
     }
@@ -1101,11 +1154,12 @@ __global__ __launch_bounds__(256, 2) void attn_frag_x3q2_kernel(const AttnFragP 
   // (lane-derived values again, from an operand hipcc cannot see through: nothing but the softmax state stays live across
   // the asm statement -- a value kept was a spill, and the ISA lint allows no scratch next to LDS-DMA)
   const int laneE = lane_id_fresh(), gE = laneE >> 5, lrE = laneE & 31, tidE = wave * 64 + laneE;
+  auto lane_sum = [&](int j) { return P16 ? st[j].l4[0] : st[j].l; };
   float l_tot[QB];
   bool bad = false;
 #pragma unroll
   for (int j = 0; j < QB; ++j) {
-    l_tot[j] = st[j].l + __shfl_xor(st[j].l, 32);
+    l_tot[j] = lane_sum(j) + __shfl_xor(lane_sum(j), 32);
     const bool valid = qb0 + j < nblk && (qb0 + j) * 32 + lrE < L;
     bad = bad || (valid && !(l_tot[j] < 65504.f));   // (see attn_frag_x3_kernel)
   }
@@ -1125,7 +1179,7 @@ __global__ __launch_bounds__(256, 2) void attn_frag_x3q2_kernel(const AttnFragP 
     __syncthreads();
     fast_pass();
 #pragma unroll
-    for (int j = 0; j < QB; ++j) l_tot[j] = st[j].l + __shfl_xor(st[j].l, 32);
+    for (int j = 0; j < QB; ++j) l_tot[j] = lane_sum(j) + __shfl_xor(lane_sum(j), 32);
   }
 
   const int seq = sh / p.heads, head = sh - seq * p.heads;
@@ -1184,22 +1238,22 @@ static void launch_v(const AttnFragP& p, hipStream_t s) {
   hipLaunchKernelGGL((attn_frag_kernel<ABL, QB>), dim3((unsigned)grid), dim3(256), 0, s, p, nqt, (int)sh);
 }
 
-template <int QB, int OUT, int KBX, int MINW>
+template <int QB, int OUT, int KBX, int MINW, bool P16>
 static void launch_x3(const AttnFragP& p, hipStream_t s) {
   const int nblk = (p.L + 31) / 32;
   const int nqt = (nblk + 4 * QB - 1) / (4 * QB);
   const long sh = (long)p.n_seq * p.heads;
   const long grid = (sh + 7) / 8 * 8 * nqt;
-  hipLaunchKernelGGL((attn_frag_x3_kernel<QB, OUT, KBX, MINW>), dim3((unsigned)grid), dim3(256), 0, s, p, nqt, (int)sh);
+  hipLaunchKernelGGL((attn_frag_x3_kernel<QB, OUT, KBX, MINW, P16>), dim3((unsigned)grid), dim3(256), 0, s, p, nqt, (int)sh);
 }
 
-template <int OUT>
+template <int OUT, bool P16>
 static void launch_x3q2(const AttnFragP& p, hipStream_t s) {
   const int nblk = (p.L + 31) / 32;
   const int nqt = (nblk + 7) / 8;   // 256 queries (8 blocks) per workgroup
   const long sh = (long)p.n_seq * p.heads;
   const long grid = (sh + 7) / 8 * 8 * nqt;
-  hipLaunchKernelGGL((attn_frag_x3q2_kernel<OUT>), dim3((unsigned)grid), dim3(256), 0, s, p, nqt, (int)sh);
+  hipLaunchKernelGGL((attn_frag_x3q2_kernel<OUT, P16>), dim3((unsigned)grid), dim3(256), 0, s, p, nqt, (int)sh);
 }
 
 int launch_attn_frag(const AttnFragP& p, hipStream_t s) {
@@ -1220,11 +1274,24 @@ int launch_attn_frag(const AttnFragP& p, hipStream_t s) {
     // 4 is taken for launches of at least two full rounds of its 256-query workgroups (two per CU); below that the 64-key
     // kernel's finer grain (128 queries per workgroup, three per CU) fills the chip better: a 2-chunk single-file forward is
     // 192 workgroups of the former against 384 of the latter.
+    // + BT_X3_P16 (8): the P16 arithmetic (finish_x) on the same kernel selection; all kernels of one arithmetic agree bit for bit
     const long wg4 = (long)p.n_seq * p.heads * (((p.L + 31) / 32 + 7) / 8);
-    if (p.x3 == 4 && wg4 >= 1024) { if (p.out_f32) launch_x3q2<1>(p, s); else launch_x3q2<0>(p, s); }
-    else if (p.x3 == 5) { if (p.out_f32) launch_x3q2<1>(p, s); else launch_x3q2<0>(p, s); }   // (forced: tests, probes)
-    else if (p.x3 == 2 || p.x3 == 4) { if (p.out_f32) launch_x3<1, 1, 2, 3>(p, s); else launch_x3<1, 0, 2, 3>(p, s); }
-    else { if (p.out_f32) launch_x3<1, 1, 4, 2>(p, s); else launch_x3<1, 0, 4, 2>(p, s); }
+    const int kern = p.x3 & 7;
+    const int form = (kern == 4 && wg4 >= 1024) || kern == 5 ? 0 : (kern == 2 || kern == 4) ? 1 : 2;   // (5 = forced: tests, probes)
+    switch (form * 4 + (p.out_f32 ? 2 : 0) + ((p.x3 & 8) ? 1 : 0)) {
+      case 0: launch_x3q2<0, false>(p, s); break;
+      case 1: launch_x3q2<0, true>(p, s); break;
+      case 2: launch_x3q2<1, false>(p, s); break;
+      case 3: launch_x3q2<1, true>(p, s); break;
+      case 4: launch_x3<1, 0, 2, 3, false>(p, s); break;
+      case 5: launch_x3<1, 0, 2, 3, true>(p, s); break;
+      case 6: launch_x3<1, 1, 2, 3, false>(p, s); break;
+      case 7: launch_x3<1, 1, 2, 3, true>(p, s); break;
+      case 8: launch_x3<1, 0, 4, 2, false>(p, s); break;
+      case 9: launch_x3<1, 0, 4, 2, true>(p, s); break;
+      case 10: launch_x3<1, 1, 4, 2, false>(p, s); break;
+      default: launch_x3<1, 1, 4, 2, true>(p, s); break;
+    }
     return (int)hipGetLastError();
   }
   // (Two query blocks per wave -- QB = 2, half the fragment reads per MFMA at half the occupancy -- measured equal.)

@@ -246,8 +246,10 @@ class Spect2Frames:
         self.device = _gpu_device(device)
         mode = _precision_mode(float16)
         self.float16 = mode == "half"
-        # what ``float16=False`` means for a BeatThis model assigned to ``.model``: hi + lo fp16 operands (BT_PREC_F32X3, the
-        # default) or exact fp32 MFMAs ("exact"); ``self.model.fp32_split_gemms`` remains the switch afterwards
+        # what ``float16=False`` means here: hi + lo fp16 operands (BT_PREC_F32X3, the default of BeatThis itself) or exact fp32
+        # MFMAs ("exact").  ``model.fp32_split_gemms`` is the switch; a model assigned to ``.model`` keeps the value its owner
+        # gave it (a model shared by two objects is not flipped by the second one) -- except that an object created with
+        # float16="exact" turns it off on the models it is given, since that is what it was asked for.
         self.fp32_mode = "exact" if mode == "exact" or _lib.lib().bt_half_is_bf16() else "f32x3"
         self.model = load_model(checkpoint_path, self.device)
 
@@ -257,8 +259,8 @@ class Spect2Frames:
 
     @model.setter
     def model(self, m):
-        if isinstance(m, BeatThis):
-            m.fp32_split_gemms = self.fp32_mode == "f32x3"
+        if isinstance(m, BeatThis) and self.fp32_mode == "exact":
+            m.fp32_split_gemms = False
         self._model = m
 
     def spect2frames(self, spect):
@@ -424,7 +426,7 @@ class Audio2Beats(Audio2Frames):
                 def result(s): return s.out
             return _Done([self.frames2beats(beat[frame_off[k]: frame_off[k + 1]], down[frame_off[k]: frame_off[k + 1]])
                           for k in range(len(signals))])
-        checks = [] if getattr(self.model, "fp32_split_gemms", False) and not self.float16 else None
+        checks = [] if isinstance(self.model, BeatThis) and self.model.fp32_split_gemms and not self.float16 else None
         beat, down = self.spect2frames_batch(spect, frame_off, checks=checks)
         pending = self.frames2beats.ragged_async(beat, down, frame_off)
         pending.logits = (beat, down, frame_off)   # framewise logits of the batch (concatenated), for callers that want them
@@ -495,9 +497,10 @@ def batch_predict_aggregate(spect: torch.Tensor, frame_off, chunk_size: int, bor
     (``Engine.deferred_range_checks``): with ``checks=None`` the flags are looked at before returning and the batch is
     repeated on the exact fp32 path if one fired; a caller that passes a list gets ``(engine, flags)`` appended instead and
     evaluates them itself (``Audio2Beats.many_async``)."""
-    guard = isinstance(model, BeatThis) and model.fp32_split_gemms and not torch.is_autocast_enabled("cuda")
+    guard = isinstance(model, BeatThis) and model._precision() == _lib.PREC_F32X3
     if guard:
         eng = model.engine()
+        eng.ensure_positions(chunk_size)   # (the rotary table cannot grow while range checks are pending: grow it first)
         with eng.deferred_range_checks() as flags:
             out = batch_predict_aggregate(spect, frame_off, chunk_size, border_size, _Unguarded(model))
         if checks is not None:

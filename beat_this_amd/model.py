@@ -135,9 +135,10 @@ class BeatThis(nn.Module):
         # outside autocast: True = every product of the forward on three half MFMAs over hi + lo operand halves
         # (BT_PREC_F32X3: fp32-class results -- 1e-5 at the logits, identical beats -- at 16/3 of the fp32 matrix rate; operands
         # beyond the fp16 range of a hi half are detected and the batch is repeated on the exact path, Engine.forward_stages);
-        # False = exact fp32 MFMAs.  A bare module starts on the exact path; the inference classes (Spect2Frames ...,
-        # ``float16=False``) switch the model they are given to the hi + lo path, which is the API's default precision.
-        self.fp32_split_gemms = False
+        # False = exact fp32 MFMAs.  True is the default of the module itself since round 5: load_model()
+        # -- what hubconf.py exports as ``beat_this`` and what pl_module.py hands to split_predict_aggregate -- returns a
+        # model on the same precision the inference classes run (a bfloat16 build has no hi + lo path: exact there).
+        self.fp32_split_gemms = True
         self.eval()
 
     def __getstate__(self):
@@ -215,7 +216,7 @@ class BeatThis(nn.Module):
         half = torch.is_autocast_enabled("cuda") if hasattr(torch, "is_autocast_enabled") else False
         if half:
             return _lib.PREC_HALF
-        return _lib.PREC_F32X3 if self.fp32_split_gemms else _lib.PREC_F32
+        return _lib.PREC_F32X3 if self.fp32_split_gemms and not _lib.lib().bt_half_is_bf16() else _lib.PREC_F32
 
     def _run(self, x: torch.Tensor, first: int, last: int, out=None):
         """Stages first..last in the engine; precision follows autocast like the whole forward.  ``out``: see

@@ -332,6 +332,21 @@ class Engine:
 
     MAX_WORKSPACES = 4
     SHRINK_AFTER = 8   # consecutive requests of < 1/4 of a stream's workspace before it is given back
+    OPTIONS = {"x3_attn_p16": 1}   # name -> BT_OPT_* of include/beat_this_amd.h
+
+    def set_options(self, opts: dict) -> None:
+        """Arithmetic variants of the engine (bt_engine_set_option), e.g. ``{"x3_attn_p16": 0}`` for the three-term P.V of
+        rounds 3 - 4.  Captured forwards are dropped: a graph replays the kernels it was recorded with."""
+        for name, value in opts.items():
+            if name not in self.OPTIONS:
+                raise ValueError(f"unknown engine option {name!r} (known: {sorted(self.OPTIONS)})")
+            _lib.check(_lib.lib().bt_engine_set_option(self._h, self.OPTIONS[name], int(value)))
+        self.__dict__.pop("_graphs", None)
+
+    def get_option(self, name: str) -> int:
+        v = C.c_int(0)
+        _lib.check(_lib.lib().bt_engine_get_option(self._h, self.OPTIONS[name], C.byref(v)))
+        return int(v.value)
 
     def ensure_positions(self, T: int) -> None:
         """Sequences longer than the rotary table (1536 rows by default: the reference's chunks are 1500 frames, but its module
@@ -350,6 +365,8 @@ class Engine:
             self.packed.desc.rope, self.packed.desc.rope_len, self.packed._rope_t = old_rope, old_len, old_t
             raise
         self.__dict__.pop("_graphs", None)   # (captured forwards hold the old table's address)
+        for name in self.OPTIONS:            # the new handle inherits the old one's options
+            _lib.check(_lib.lib().bt_engine_set_option(h, self.OPTIONS[name], self.get_option(name)))
         old_h, self._h = self._h, h       # swap first, then release: self._h never dangles
         _lib.lib().bt_engine_destroy(old_h)   # (its profiling records, if a bench leg had some open, go with it)
 
@@ -444,30 +461,45 @@ class Engine:
 
     # -- small batches as hipGraphs -----------------------------------------------------------------------------------------
     GRAPH_MAX_CHUNKS = 11    # a 5-minute track; beyond that the launches of a forward are a negligible share of it
-    GRAPH_MAX_ENTRIES = 6    # graphs kept per engine (least recently used goes first); each owns its workspace (~80 MB / chunk)
+    GRAPH_T = 1500           # only full-length chunks are captured: B is then the only variable (pieces of <= 1488 frames
+                             # have T = frames + 12 -- one capture per clip length would cost more than it ever saves)
+    GRAPH_MAX_ENTRIES = 12   # graphs kept per engine (least recently used goes first); entries of a stream share a workspace
 
     def graph_forward(self, B: int, T: int, prec: int):
-        """The whole forward of a (B, T, 128) batch as ONE hipGraph with buffers of its own, for the single-file path (a 30 s
-        file is 2 chunks = ~55 launches whose host side is a sixth of the call): -> entry with ``.x`` (B, T, 128) to fill,
-        ``.replay()`` and ``.beat`` / ``.down`` (B, T) holding the logits afterwards (valid until the next replay of the same
-        entry), or None where graphs are off / not applicable.  Entries are per (stream, B, T, precision); a capture that
-        fails switches graphs off for this engine and the caller falls back to plain launches."""
-        if not getattr(self, "_graphs_ok", True) or B > self.GRAPH_MAX_CHUNKS or self._deferred is not None or self._h_prof_on():
+        """The whole forward of a (B, T, 128) batch as ONE hipGraph, for the single-file path (a 30 s file is 2 chunks = ~55
+        launches whose host side is a sixth of the call): -> entry with ``.x`` (B, T, 128) to fill, ``.replay()`` and
+        ``.beat`` / ``.down`` (B, T) holding the logits afterwards (valid until the next replay on the same stream), or None
+        where graphs are off / not applicable (T != GRAPH_T, too many chunks, pending range checks, profiling).  Entries are
+        per (stream, B, precision); a capture that fails -- or whose replay does not reproduce the plain launches -- switches
+        graphs off for this engine and the caller falls back to plain launches."""
+        if not getattr(self, "_graphs_ok", True) or T != self.GRAPH_T or B > self.GRAPH_MAX_CHUNKS or self._deferred is not None \
+                or self._h_prof_on():
             return None
-        cache = self.__dict__.setdefault("_graphs", collections.OrderedDict())
-        key = (torch.cuda.current_stream(self.device), B, T, prec, self.packed.desc.rope_len)
-        e = cache.pop(key, None)
+        stream = torch.cuda.current_stream(self.device)
+        key = (stream, B, T, prec)
+        e = self.__dict__.setdefault("_graphs", collections.OrderedDict()).pop(key, None)
         if e is None:
             try:
-                e = _GraphEntry(self, B, T, prec)
+                e = _GraphEntry(self, B, T, prec, stream)
             except Exception as err:  # noqa: BLE001  (capture not available: plain launches from now on)
                 self._graphs_ok = False
                 self._graph_error = repr(err)
                 return None
+        # (the dictionary again: constructing an entry may have grown the rotary table, which drops the captured forwards)
+        cache = self.__dict__.setdefault("_graphs", collections.OrderedDict())
         cache[key] = e
         while len(cache) > self.GRAPH_MAX_ENTRIES:
             cache.popitem(last=False)
         return e
+
+    def _graph_workspace(self, stream, need: int) -> torch.Tensor:
+        """One workspace per stream for all captured forwards replayed on it (replays of one stream run in order, so they can
+        share it); an entry that needs more gets a larger one, which later entries share (older graphs keep theirs alive)."""
+        pool = self.__dict__.setdefault("_graph_ws", {})
+        ws = pool.get(stream)
+        if ws is None or ws.numel() < need:
+            ws = pool[stream] = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return ws
 
     def _h_prof_on(self) -> bool:
         return bool(getattr(self, "profiling", False))
@@ -505,21 +537,35 @@ class Engine:
 class _GraphEntry:
     """One captured forward (Engine.graph_forward)."""
 
-    def __init__(self, eng: Engine, B: int, T: int, prec: int):
+    def __init__(self, eng: Engine, B: int, T: int, prec: int, stream):
         dev = eng.device
         eng.ensure_positions(T)
         self.eng, self.B, self.T, self.prec = eng, B, T, prec
-        self.x = torch.zeros((B, T, 128), dtype=torch.float32, device=dev)
-        self.beat = torch.empty((B, T), dtype=torch.float32, device=dev)
-        self.down = torch.empty((B, T), dtype=torch.float32, device=dev)
-        need = _lib.lib().bt_workspace_bytes(eng._h, B, T, prec)
-        self.ws = torch.empty(need, dtype=torch.uint8, device=dev)
-        self.flag = self.ws[:4].view(torch.int32)
-        self._launch()                       # once eagerly (lazy module loading, allocator warm-up) ...
-        torch.cuda.synchronize(dev)
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):   # ... then recorded on torch's capture stream
-            self._launch()
+        # Everything below happens with the ENGINE's device current and on streams of that device: torch.cuda.graph's default
+        # capture stream belongs to whatever device was current when it was first made, and kernels launched on another
+        # stream than the capturing one run eagerly and leave the graph empty (ADVICE r4: a model on cuda:1 while cuda:0 is
+        # current replayed nothing and returned the logits of the warm-up run).
+        with torch.cuda.device(dev):
+            self.x = torch.zeros((B, T, 128), dtype=torch.float32, device=dev)
+            self.beat = torch.empty((B, T), dtype=torch.float32, device=dev)
+            self.down = torch.empty((B, T), dtype=torch.float32, device=dev)
+            self.ws = eng._graph_workspace(stream, _lib.lib().bt_workspace_bytes(eng._h, B, T, prec))
+            self.flag = self.ws[:4].view(torch.int32)
+            self._launch()                       # once eagerly (lazy module loading, allocator warm-up) ...
+            torch.cuda.synchronize(dev)
+            want = (self.beat.clone(), self.down.clone())
+            capture = torch.cuda.Stream(device=dev)
+            capture.wait_stream(torch.cuda.current_stream(dev))
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph, stream=capture):   # ... then recorded on a stream of the engine's device
+                self._launch()
+            # a capture is only trusted once a replay has reproduced the plain launches bit for bit (same kernels, same input)
+            self.beat.fill_(float("nan"))
+            self.down.fill_(float("nan"))
+            self.graph.replay()
+            torch.cuda.synchronize(dev)
+            if not (torch.equal(self.beat, want[0]) and torch.equal(self.down, want[1])):
+                raise RuntimeError("captured forward does not reproduce the plain launches (empty capture?)")
 
     def _launch(self):
         with torch.cuda.device(self.eng.device):

@@ -75,7 +75,7 @@ def flops_per_chunk(D: int, T: int = CHUNK_FRAMES, ff_mult: int = 4):
       qkv_gemm        = gemm3 QKV (main layers) + qkv_front_kernel (time-direction QKV of the frontend)
       attn_flash      = attn_frag_kernel      time-direction + main attention
       out_gemm / ff1_gemm / ff2_gemm = gemm3  main layers only"""
-    cat = dict(stem=2 * T * 32 * 32 * 12, qkv_gemm=0, attn_freq=0, attn_flash=0, out_gemm=0, ff1_gemm=0, ff2_gemm=0,
+    cat = dict(stem=2 * T * 32 * 32 * 12, qkv_gemm=0, attn_flash=0, out_gemm=0, ff1_gemm=0, ff2_gemm=0,
                conv_gemm=0, linear_gemm=2 * T * 1024 * D, head=2 * T * D * 2, ff_fused=0, attn_freq_fused=0, layer_tail=0)
     for blk in range(3):
         Cc, F = 32 << blk, 32 >> blk
@@ -137,6 +137,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the side legs (other precisions, latency, configs, frontend)")
     ap.add_argument("--no-dist", action="store_true", help="N = 1 without bringing up the RCCL process group")
+    ap.add_argument("--x3-p16", type=int, default=1, choices=[0, 1],
+                    help="BT_OPT_X3_ATTN_P16 of the default precision: 1 = probabilities enter P.V as fp16 hi parts (default), "
+                         "0 = three-term P.V of rounds 3 - 4 (A/B runs)")
     ap.add_argument("--min-seconds", type=float, default=2.0,
                     help="the K timed steps are repeated until the timed region is at least this long (0: exactly K steps)")
     ap.add_argument("--watchdog", type=int, default=900, help="seconds after which a stuck run dumps its stacks and exits")
@@ -212,6 +215,7 @@ def main():
     model.load_state_dict(sd)
     a2b = Audio2Beats(checkpoint_path=None, device=dev, float16={"half": True, "f32": "exact", "f32x3": False}[args.prec], dbn=False)
     a2b.model = model.to(dev)
+    a2b.model.engine().set_options({"x3_attn_p16": args.x3_p16})
     half_name = _lib.half_dtype_name()
     DTYPE = {"half": half_name, "f32": "f32 (v_mfma_f32_32x32x2_f32)",
              "f32x3": "f32 activations; every product: 3 x v_mfma_f32_32x32x16_f16 on hi + lo operands (BT_PREC_F32X3)"}
@@ -305,13 +309,32 @@ def main():
             dist.all_reduce(est, op=dist.ReduceOp.MIN)
         repeats = max(1, int(-(-args.min_seconds // max(float(est.item()), 1e-6))))
     log(f"timed region: {args.steps} steps x {repeats}")
+    # package energy over the timed region from the SMU's accumulator (tools/smi.py: rsmi_dev_energy_count_get), read right
+    # before the first and right after the last step's fence -- joules are what this path is bound by
+    from tools.smi import EnergyMeter
+
+    meter = EnergyMeter(dev)
+    meter.start()
     t0 = time.perf_counter()
     for _ in range(args.steps * repeats):
         step()
     last = drain()
     fence()
     elapsed = time.perf_counter() - t0
+    joules = meter.stop()
     n_timed = args.steps * repeats
+    energy = {"available": False, "reason": meter.why}
+    if joules is not None:
+        jt = torch.tensor([joules[0]], dtype=torch.float64, device=dev)
+        if use_dist:
+            dist.all_reduce(jt)   # whole job: the sum over the ranks' packages
+        energy = {"available": True, "joules_per_step": round(float(jt.item()) / n_timed, 3),
+                  "audio_seconds_per_joule": round(units_per_step * n_timed / max(float(jt.item()), 1e-9), 2),
+                  "avg_package_power_W": round(joules[0] / max(joules[1], 1e-9), 1), "packages": world,
+                  "counter_resolution_uJ": round(meter.smi.resolution_uj, 3), "power_cap_W": meter.smi.cap_w(),
+                  "region_seconds_by_counter": round(joules[1], 3),
+                  "source": "rsmi_dev_energy_count_get before / after the timed region (idle power of the package included)"}
+        log(f"energy: {energy['joules_per_step']} J / step, {energy['avg_package_power_W']} W average")
     log(f"timed region done: {1e3 * elapsed / n_timed:.3f} ms / step over {elapsed:.2f} s")
     if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -397,6 +420,9 @@ def main():
             dom = max(bd, key=lambda k: bd[k]["ms_per_step"])
             d = bd[dom]
             peak = PEAK_TFLOPS[prec]
+            p16 = prec == "f32x3" and dom == "attn_flash" and bool(args.x3_p16)
+            if p16:   # scores on three MFMAs per product, P.V on two (BT_OPT_X3_ATTN_P16): 2.5 pipe flops per algorithmic flop
+                peak = PEAK_TFLOPS["half"] / 2.5
             traffic, traffic_src = None, None
             try:  # HBM bytes per launch of the dominant category: PMC counters of separate rocprofv3 passes, committed
                 name = "pmc_traffic.json" if prec == "half" else f"pmc_traffic_{prec}.json"
@@ -414,8 +440,11 @@ def main():
                     "flop_per_launch": fl[dom] * chunks / d["launches_per_step"],
                     "forward_ms_per_step": round(tot, 3),
                     "whole_forward_tflops": round(FLOP_PER_CHUNK * chunks / (tot * 1e-3) / 1e12, 2),
-                    "whole_forward_frac": round(FLOP_PER_CHUNK * chunks / (tot * 1e-3) / 1e12 / peak, 4),
-                    "peak_note": {"half": "dense fp16 MFMA peak", "f32": "fp32 MFMA peak",
+                    "whole_forward_frac": round(FLOP_PER_CHUNK * chunks / (tot * 1e-3) / 1e12 / PEAK_TFLOPS[prec], 4),
+                    "frac_of_dense_fp16_peak": round(d["tflops"] / PEAK_TFLOPS["half"], 4) if prec != "f32" else None,
+                    "peak_note": "dense fp16 MFMA peak / 2.5: the attention's scores run three fp16 MFMAs per product, its P.V two "
+                                 "(whole_forward_frac is against a third of the dense peak: the GEMMs run three)" if p16 else
+                                 {"half": "dense fp16 MFMA peak", "f32": "fp32 MFMA peak",
                                   "f32x3": "a third of the dense fp16 MFMA peak: every product is three fp16 MFMAs"}[prec]}
 
         roofline = roofline_of(breakdown, args.prec, chunks_per_step)
@@ -726,19 +755,21 @@ def main():
             "metric": "audio-seconds processed/sec", "value": round(value, 1), "unit": "audio-seconds/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": {"half": half_name, "f32": "f32", "f32x3": "f32 activations, f16x3 products (3 x f16 MFMA on hi+lo operand halves, f32 accumulate)"}[args.prec],
+            "dtype": {"half": half_name, "f32": "f32", "f32x3": "f32 activations, f16x3 products (3 x f16 MFMA on hi+lo operand halves, f32 accumulate; attention P.V: 2 x, probabilities as fp16 hi parts)" if args.x3_p16 else "f32 activations, f16x3 products (3 x f16 MFMA on hi+lo operand halves, f32 accumulate)"}[args.prec],
             "data": "synthetic",
             "config": {"workload": workload, "tracks_per_gpu": args.tracks if args.workload == "tracks" else None,
                        "chunks_per_gpu": chunks_per_step, "global_chunks": world * chunks_per_step,
                        "parallelism": f"track-sharded x{world}, framewise logits all-gathered" if args.workload == "tracks"
                        else f"chunk-sharded x{world}, logits all-gathered"},
-            "parity": parity, "roofline": roofline, "cpu_baseline": cpu, "frontend": frontend, "forward_only": forward_only,
-            "half_path": half_path, "fp32_exact_path": fp32_exact_path, "f32x3_path": f32x3_path, "latency": latency,
+            "parity": parity, "roofline": roofline, "cpu_baseline": cpu, "energy": energy, "frontend": frontend, "forward_only": forward_only,
+            "half_path": half_path, "fp32_exact_path": fp32_exact_path, "latency": latency,
             "stress_weights": stress, "host_inclusive": host_inclusive, "configs": configs,
             "strong_scaling_cfg4": strong, "rccl_ranks": rccl_ranks, "rccl_note": dist_note,
             "timed_region": {"steps": args.steps, "repeats": repeats, "steps_timed": n_timed, "seconds": round(elapsed, 3)},
             "breakdown": breakdown,
         }
+        if f32x3_path is not None:   # (only when the headline is another precision: --prec half / f32)
+            out["f32x3_path"] = f32x3_path
         if last is not None and args.workload == "tracks":
             out["config"]["beats_in_last_track"] = int(len(last[-1][0]))
         sys.stdout.flush()

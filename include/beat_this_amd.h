@@ -68,11 +68,9 @@ typedef struct {
   const float* b_ff1;
   const void* w_ff2[2];
   const float* b_ff2;
-  /* PERM32 copies (columns reordered inside every block of 32: new[16 g + r] = old[(r & 3) +
-   * 8 (r >> 2) + 4 g], g in {0,1}, r in [0,16)) consumed by the register-chained fused kernels of
-   * csrc/fused.hip; only used for dim <= 128 (frontend), may be NULL otherwise. */
-  const void* w_outp[2];   /* (unused since round 2: was to_out.0.weight with PERM32 columns for the retired attn_freq_fused_kernel) */
-  /* FF weights for ff_fused_kernel, fragment-major: for each hidden block hb (32 hidden units):
+  /* ("PERM32" below: columns reordered inside every block of 32, new[16 g + r] = old[(r & 3) + 8 (r >> 2) + 4 g],
+   * g in {0,1}, r in [0,16) -- the order in which an MFMA accumulator holds them.)
+   * FF weights for ff_fused_kernel, fragment-major: for each hidden block hb (32 hidden units):
    * dim/32 tiles of W1 (rows hb*32.., k-tile kt) then dim/32 tiles of PERM32'd W2 (rows mt*32..,
    * cols hb*32..); a tile is [half h][lane 0..63][8] (bf16) or [quarter][lane][4] (fp32) with
    * element (lane, i) = W[tile_row0 + (lane & 31)][tile_col0 + 16 (lane >> 5) + i], i in [0,16). */
@@ -155,7 +153,7 @@ typedef struct {
 const char* bt_last_error(void);
 /* ABI version of this header: bumped whenever an entry point's signature, a struct layout or a BT_PREC_* value changes; a
  * binding must see exactly the value it was written against (beat_this_amd/_lib.py does) */
-#define BT_ABI_VERSION 400
+#define BT_ABI_VERSION 500
 int bt_version(void);
 /* operand type of the half-precision path (BT_PREC_HALF slot of the weight arrays) this library was built
  * with: 0 = IEEE fp16 (default), 1 = bfloat16 (-DBT_HALF_BF16) */
@@ -168,6 +166,15 @@ void bt_struct_sizes(int32_t* out);
 /* BeatThis(**hparams) + load_state_dict (inference.py:56-87): keeps a copy of `desc`. */
 int bt_engine_create(const bt_model_desc* desc, bt_engine** out);
 void bt_engine_destroy(bt_engine* e);
+/* Options of an engine (arithmetic variants of BT_PREC_F32X3 that stay inside north_star's 1e-3 / identical-beats gate but
+ * are not bit-identical to each other; both are kept so that the choice can be measured: tools/flip_soak.py,
+ * profiles/r05_flip_frontier.txt).  bt_engine_set_option returns BT_ERR_ARG for an unknown option / value.
+ *   BT_OPT_X3_ATTN_P16  1 (default): the attention probabilities of the time-direction and main-layer attention enter P.V as
+ *                       their fp16 hi parts (two MFMAs per fragment pair instead of three), row sums from the same rounded
+ *                       values;  0: three-term P.V with the probabilities split hi + lo (rounds 3 - 4). */
+#define BT_OPT_X3_ATTN_P16 1
+int bt_engine_set_option(bt_engine* e, int option, int value);
+int bt_engine_get_option(const bt_engine* e, int option, int* value);
 /* bytes of scratch bt_forward needs for a [B,T,128] batch (its first int32 is the BT_PREC_F32X3 range flag) */
 size_t bt_workspace_bytes(const bt_engine* e, int B, int T, int prec);
 
@@ -263,18 +270,17 @@ int bt_postprocess_host(const int32_t* beat_idx, int n_beat_idx, const int32_t* 
  * milliseconds and launch counts per category (index = BT_CAT_*). */
 #define BT_CAT_STEM 0
 #define BT_CAT_QKV_GEMM 1
-#define BT_CAT_ATTN_FREQ 2   /* (unused since round 2: the frequency-direction attention runs inside BT_CAT_ATTN_FREQ_FUSED) */
-#define BT_CAT_ATTN_FLASH 3  /* attn_flash_kernel: time-direction + main attention */
-#define BT_CAT_OUT_GEMM 4
-#define BT_CAT_FF1_GEMM 5
-#define BT_CAT_FF2_GEMM 6
-#define BT_CAT_CONV_GEMM 7
-#define BT_CAT_LINEAR_GEMM 8
-#define BT_CAT_HEAD 9
-#define BT_CAT_FF_FUSED 10        /* ff_fused_kernel (frontend FF blocks) */
-#define BT_CAT_ATTN_FREQ_FUSED 11 /* attnff_fused_kernel: frequency-direction half (QKV + attention + out-proj + FF) */
-#define BT_CAT_LAYER_TAIL 12      /* layer_tail_kernel (main layers: out-projection + FF1 + FF2 in one launch) */
-#define BT_PROFILE_CATEGORIES 13
+#define BT_CAT_ATTN_FLASH 2  /* time-direction + main attention */
+#define BT_CAT_OUT_GEMM 3
+#define BT_CAT_FF1_GEMM 4
+#define BT_CAT_FF2_GEMM 5
+#define BT_CAT_CONV_GEMM 6
+#define BT_CAT_LINEAR_GEMM 7
+#define BT_CAT_HEAD 8
+#define BT_CAT_FF_FUSED 9         /* ff_fused_kernel (frontend FF blocks) */
+#define BT_CAT_ATTN_FREQ_FUSED 10 /* attnff_fused_kernel: frequency-direction half (QKV + attention + out-proj + FF) */
+#define BT_CAT_LAYER_TAIL 11      /* layer_tail_kernel (main layers: out-projection + FF1 + FF2 in one launch) */
+#define BT_PROFILE_CATEGORIES 12
 void bt_profile_begin(bt_engine* e);
 int bt_profile_end(bt_engine* e, double* ms_by_category, int32_t* launches_by_category, int n_categories);
 
@@ -299,9 +305,10 @@ int bt_attention(void* stream, int prec, const bt_attn_args* a);
  * pre-scaled by log2(e)/sqrt(32).  nbp >= bt_attn_frag_blocks(L).  Output as bt_attention (half).
  * x3 != 0 (BT_PREC_F32X3): blocks of 4 KB = [hi block | lo block] of the fp32 values, three MFMAs per product; output
  * fp32 [rows, inner] (out_f32 != 0) or hl32 half [rows, 2 inner]; status (may be NULL) = range flag of the hl32 output;
- * x3 = 1: 128-key LDS tiles, x3 = 2: 64-key tiles (the same arithmetic, bit-identical results); x3 = 5: two query blocks per
- * wave on a hand-scheduled key loop (same products, row sums added in another order); x3 = 4 (the forward's choice since
- * round 4): 5 for launches of at least 1024 of its workgroups, 2 below. */
+ * x3 = 1: 128-key LDS tiles, x3 = 2: 64-key tiles, x3 = 5: two query blocks per wave on a hand-scheduled key loop -- the same
+ * arithmetic in all three, bit-identical results; x3 = 4 (the forward's choice since round 4): 5 for launches of at least
+ * 1024 of its workgroups, 2 below.  + 8 (BT_X3_P16): the P16 arithmetic (BT_OPT_X3_ATTN_P16) on the same kernel choice. */
+#define BT_X3_P16 8
 typedef struct {
   const void* q; const void* k; const void* v; const float* gates; void* out;
   int32_t n_seq, L, heads, inner, nbp, o_div; int64_t o_outer, o_inner, o_tok;

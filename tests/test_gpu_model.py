@@ -13,6 +13,8 @@ from gpu_util import dev, report
 pytestmark = pytest.mark.gpu
 
 LOGIT_TOL_F32 = 1e-3   # BASELINE.json north_star: framewise logits within 1e-3 (fp32 path)
+X3_TOL = 3e-4          # what the tests hold the default precision (BT_PREC_F32X3 with the P16 attention) to: the admission bound of
+                       # the flip-rate soak (profiles/r05_flip_frontier.txt), a third of the gate
 
 
 def _model(hp, seed, style):
@@ -297,7 +299,7 @@ def test_ablation_variants_against_oracle(variant, prec_half):
     eb = float((r["beat"].cpu() - ob).abs().max())
     ed = float((r["downbeat"].cpu() - od).abs().max())
     report("ablation", variant=variant, half=prec_half, err_beat=eb, err_downbeat=ed, spread=float(ob.std()))
-    tol = 2.5e-2 if prec_half is True else 1e-4 if prec_half == "f32x3" else 1e-3   # (half: the reference's fp16-autocast scale)
+    tol = 2.5e-2 if prec_half is True else X3_TOL if prec_half == "f32x3" else 1e-3   # (half: the reference's fp16-autocast scale)
     assert eb < tol and ed < tol
     if prec_half == "f32x3":
         assert m.engine().last_fallbacks == 0
@@ -439,12 +441,19 @@ def test_fp32_split_gemms_stay_within_the_fp32_gate(name):
     sd = W.random_state_dict(hp, seed=6, style="lively")
     m = _model(name, 6, "lively")
     x = torch.from_numpy(np.stack([W.synthetic_spect(1500, seed=75 + i) for i in range(2)]))
+    assert m.fp32_split_gemms          # (the module's own default since round 5)
     with torch.inference_mode():
         ob, od = O.model_forward(sd, x)
+        m.fp32_split_gemms = False
         exact = m(x.to(dev()))
         m.fp32_split_gemms = True
         split = m(x.to(dev()))
+        m.engine().set_options({"x3_attn_p16": 0})     # three-term P.V (rounds 3 - 4): the tighter variant of the same path
+        split3 = m(x.to(dev()))
+        m.engine().set_options({"x3_attn_p16": 1})
         m.fp32_split_gemms = False
+    e3 = max(float((split3["beat"].cpu() - ob).abs().max()), float((split3["downbeat"].cpu() - od).abs().max()))
+    assert e3 < 1e-4 and not torch.equal(split3["beat"], split["beat"])
     e_oracle = max(float((split["beat"].cpu() - ob).abs().max()), float((split["downbeat"].cpu() - od).abs().max()))
     e_exact = max(float((split[k] - exact[k]).abs().max()) for k in ("beat", "downbeat"))
     post = Postprocessor()
@@ -454,8 +463,8 @@ def test_fp32_split_gemms_stay_within_the_fp32_gate(name):
         b1, d1 = post(split["beat"][i], split["downbeat"][i])
         flips += len(set(np.round(b0 * 100).astype(int)) ^ set(np.round(b1 * 100).astype(int)))
         flips += len(set(np.round(d0 * 100).astype(int)) ^ set(np.round(d1 * 100).astype(int)))
-    report("f32x3", model=name, err_vs_oracle=e_oracle, err_vs_exact_fp32=e_exact, flips_vs_exact=flips)
-    assert e_oracle < LOGIT_TOL_F32 and flips == 0
+    report("f32x3", model=name, err_vs_oracle=e_oracle, err_vs_exact_fp32=e_exact, flips_vs_exact=flips, err_three_term_vs_oracle=e3)
+    assert e_oracle < X3_TOL and flips == 0
     # the user-facing switch: float16="f32x3" selects it without autocast
     from beat_this_amd.inference import Spect2Frames
 
@@ -465,7 +474,7 @@ def test_fp32_split_gemms_stay_within_the_fp32_gate(name):
     b2, d2 = s2f.spect2frames(x[0].to(dev()))
     s2f.model.fp32_split_gemms = False
     b3, d3 = s2f.spect2frames(x[0].to(dev()))   # the exact fp32 path through the same chunking
-    assert float((b2 - b3).abs().max()) < 1e-4 and float((d2 - d3).abs().max()) < 1e-4 and not torch.equal(b2, b3)
+    assert float((b2 - b3).abs().max()) < X3_TOL and float((d2 - d3).abs().max()) < X3_TOL and not torch.equal(b2, b3)
 
 
 @pytest.mark.parametrize("name", ["small0", "final0"])
@@ -487,6 +496,7 @@ def test_f32x3_range_guard_falls_back_to_exact_fp32(name):
     m = m.to(dev())
     x = torch.from_numpy(np.stack([W.synthetic_spect(900, seed=80 + i) for i in range(2)])).to(dev())
     with torch.inference_mode():
+        m.fp32_split_gemms = False
         exact = m(x)
         assert torch.isfinite(exact["beat"]).all()
         m.fp32_split_gemms = True
@@ -497,11 +507,12 @@ def test_f32x3_range_guard_falls_back_to_exact_fp32(name):
     # ordinary weights: the flag stays down and the result is NOT the exact path's bit pattern (the split path really ran)
     m2 = _model(name, 6, "lively")
     with torch.inference_mode():
+        m2.fp32_split_gemms = False
         e2 = m2(x)
         m2.fp32_split_gemms = True
         s2 = m2(x)
     assert m2.engine().last_fallbacks == 0 and not torch.equal(s2["beat"], e2["beat"])
-    assert float((s2["beat"] - e2["beat"]).abs().max()) < 1e-4
+    assert float((s2["beat"] - e2["beat"]).abs().max()) < X3_TOL
     # batched track API (deferred flags): same beats as the exact path
     a2b = Audio2Beats(checkpoint_path=None, device=dev(), float16="f32x3")
     a2b.model = m
@@ -571,7 +582,7 @@ def test_forward_takes_sequences_longer_than_a_chunk(mode):
     err = max(float((r["beat"].cpu() - ob).abs().max()), float((r["downbeat"].float().cpu() - od).abs().max()))
     report("long_sequence", mode=mode, T=2100, max_abs_logit=err)
     assert r["beat"].shape == (1, 2100) and r1500["beat"].shape == (1, 1500)
-    assert err < (2e-2 if mode == "half" else LOGIT_TOL_F32 if mode == "fp32" else 1e-4)
+    assert err < (2e-2 if mode == "half" else LOGIT_TOL_F32 if mode == "fp32" else X3_TOL)
 
 
 def test_empty_inputs_and_cpu_device():
@@ -610,6 +621,40 @@ def test_ff_mult_other_than_four_loads_and_matches_oracle():
     assert err < LOGIT_TOL_F32 and errh < 0.1
 
 
+def test_bare_load_model_runs_the_default_precision_with_its_range_guard():
+    """what hubconf.py exports (``load_model``) and what pl_module.py:264 does with it
+    (``split_predict_aggregate(spect, 1500, 6, "keep_first", model)``) run BT_PREC_F32X3 -- not the three times slower exact
+    path -- and keep its guard: a residual stream of 1e6 is repeated on the exact path (inference.py:56-87, 188-230)."""
+    from beat_this_amd import _lib
+    from beat_this_amd import weights as W
+    from beat_this_amd.inference import load_model, split_predict_aggregate
+
+    hp = W.resolve_hparams("small0")
+    sd = W.random_state_dict(hp, seed=6, style="lively")
+
+    def ckpt(state):
+        return {"hyper_parameters": dict(hp), "state_dict": {"model." + k: v for k, v in state.items()}}
+    m = load_model(ckpt(sd), dev())
+    assert m.fp32_split_gemms and (m._precision() == _lib.PREC_F32X3 or _lib.lib().bt_half_is_bf16())
+    spect = torch.from_numpy(W.synthetic_spect(3100, seed=9)).to(dev())
+    with torch.inference_mode():
+        r = split_predict_aggregate(spect, 1500, 6, "keep_first", m)
+        m.fp32_split_gemms = False
+        e = split_predict_aggregate(spect, 1500, 6, "keep_first", m)
+        m.fp32_split_gemms = True
+    assert m.engine().last_fallbacks == 0
+    assert not torch.equal(r["beat"], e["beat"]) and float((r["beat"] - e["beat"]).abs().max()) < X3_TOL
+    sd2 = dict(sd)
+    sd2["frontend.linear.bias"] = sd["frontend.linear.bias"] * 3.0e5
+    m2 = load_model(ckpt(sd2), dev())
+    with torch.inference_mode():
+        r2 = split_predict_aggregate(spect, 1500, 6, "keep_first", m2)
+        assert m2.engine().last_fallbacks >= 1
+        m2.fp32_split_gemms = False
+        e2 = split_predict_aggregate(spect, 1500, 6, "keep_first", m2)
+    assert torch.isfinite(r2["beat"]).all() and torch.equal(r2["beat"], e2["beat"]) and torch.equal(r2["downbeat"], e2["downbeat"])
+
+
 @pytest.mark.parametrize("mode", [False, True, "exact"])
 def test_single_file_path_on_a_captured_forward_matches_plain_launches(mode):
     """Pieces of up to 11 chunks run their forward as one hipGraph (pack.Engine.graph_forward: chunk gather into the graph's
@@ -624,11 +669,12 @@ def test_single_file_path_on_a_captured_forward_matches_plain_launches(mode):
     s2f.model = _model("small0", 1, "lively")
     pieces = [torch.from_numpy(W.synthetic_spect(n, seed=70 + i)).to(dev()) for i, n in enumerate((3100, 1501, 2000, 16000, 700))]
     assert inf.USE_GRAPHS
-    got = [s2f(p) for p in pieces]            # captures (3 chunks, 2, 2 again = replay of the same entry, 11, one odd-length chunk)
+    got = [s2f(p) for p in pieces]            # captures (3 chunks, 2, 2 again = replay of the same entry, 11; the odd-length chunk runs plain)
     again = [s2f(p) for p in pieces]          # replays
     eng = s2f.model.engine()
     assert getattr(eng, "_graphs_ok", True), getattr(eng, "_graph_error", "")
-    assert len(eng.__dict__.get("_graphs", {})) == 4
+    assert len(eng.__dict__.get("_graphs", {})) == 3     # (only full-length chunks are captured: Engine.GRAPH_T)
+    assert len({id(e.ws) for e in eng.__dict__["_graphs"].values()}) <= 2   # entries of a stream share a workspace (a larger need replaces it)
     inf.USE_GRAPHS = False
     try:
         plain = [s2f(p) for p in pieces]

@@ -271,6 +271,81 @@ def test_attention_frag_x3_variants_agree_bit_for_bit(n_seq, L, heads, out_f32):
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[1], outs[2])
 
 
+# ---- P16 (round 5, the forward's default; bt_attn_frag_args.x3 + 8): probabilities enter P.V as fp16 hi parts ---------------------
+def _attn_ref_p16(q, k, v, gates, fallback=False):
+    """float64 restatement of the P16 arithmetic: probabilities relative to the reference point of the fast pass (the maximum
+    over the first two key blocks, four octaves of headroom) -- or of the re-run (two octaves above the row maximum) --
+    rounded to fp16, the SAME rounded values in numerator and denominator."""
+    s = q @ k.transpose(-1, -2)                      # base-2 exponents: q carries log2(e) / sqrt(d)
+    m = torch.ceil(s.max(-1).values) - 2.0 if fallback else torch.ceil(s[..., : min(64, s.shape[-1])].max(-1).values) + 4.0
+    h = torch.exp2(s - m[..., None]).float().to(torch.float16).double()
+    return h @ v / h.sum(-1, keepdim=True) * gates[..., None]
+
+
+@pytest.mark.parametrize("variant", [9, 10, 13])
+@pytest.mark.parametrize("out_f32", [False, True])
+@pytest.mark.parametrize("n_seq,L,heads", [(3, 1500, 2), (2, 77, 1), (1, 128, 4), (5, 1012, 1), (2, 1, 1), (2, 33, 2),
+                                           (1, 1499, 1), (2, 129, 1), (9, 96, 1), (2, 257, 1), (2, 250, 1), (1, 64, 1)])
+def test_attention_frag_x3_p16(n_seq, L, heads, out_f32, variant):
+    SH = n_seq * heads
+    q = _mk((SH, L, 32), 30, 0.6).float().double()
+    k = _mk((SH, L, 32), 31).float().double()
+    v = _mk((SH, L, 32), 32).float().double()
+    k[0, 7 % L] *= 6.0  # one outlier key
+    k = k.float().double()
+    gates = torch.sigmoid(_mk((SH, L), 33)).float().double()
+    out = _run_attn(q, k, v, gates, n_seq, L, heads, out_f32, variant)
+
+    def rows(t):
+        return t.view(n_seq, heads, L, 32).permute(0, 2, 1, 3).reshape(n_seq * L, heads * 32)
+    err_sim = _rel(out, rows(_attn_ref_p16(q, k, v, gates)))
+    err = _rel(out, rows(_attn_ref(q, k, v, gates)))
+    report("attn_frag_x3_p16", n_seq=n_seq, L=L, heads=heads, out_f32=out_f32, variant=variant, rel=err, rel_vs_p16_restatement=err_sim)
+    # against the restatement of its own arithmetic the kernel is as exact as the three-term one (what remains: the 22-bit
+    # scores, and a probability here and there that rounds the other way because the reference point differs in its last
+    # bit); against the exact softmax it carries the fp16 rounding of the probabilities, damped by the common denominator
+    assert err_sim < (1.2e-5 if L <= 300 else 4e-5) and err < 3e-4
+
+
+@pytest.mark.parametrize("out_f32", [False, True])
+@pytest.mark.parametrize("n_seq,L,heads", [(3, 1500, 2), (2, 257, 1), (1, 64, 1), (2, 77, 1), (1, 1499, 1), (2, 128, 2)])
+def test_attention_frag_x3_p16_variants_agree_bit_for_bit(n_seq, L, heads, out_f32):
+    """as test_attention_frag_x3_variants_agree_bit_for_bit, for the P16 arithmetic: 128-key tiles, 64-key tiles and the
+    hand-scheduled statement ATTN_X3Q2P_ASM (row sums on 4x4x4 MFMAs in the same order everywhere)"""
+    SH = n_seq * heads
+    q = _mk((SH, L, 32), 30, 0.6).float().double()
+    k = _mk((SH, L, 32), 31).float().double()
+    v = _mk((SH, L, 32), 32).float().double()
+    gates = torch.sigmoid(_mk((SH, L), 33)).float().double()
+    outs = [_run_attn(q, k, v, gates, n_seq, L, heads, out_f32, variant) for variant in (9, 10, 13)]
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[1], outs[2])
+    three_term = _run_attn(q, k, v, gates, n_seq, L, heads, out_f32, 2)
+    assert not torch.equal(outs[0], three_term) or L == 1   # (the option does select another arithmetic)
+
+
+@pytest.mark.parametrize("variant", [9, 10, 13])
+@pytest.mark.parametrize("L", [300, 1500])
+def test_attention_frag_x3_p16_overflow_fallback(L, variant):
+    """the re-run on the row maxima (a key 16 + 4 octaves above the reference point of the fast pass) in the P16 arithmetic:
+    an fp16 overflow of a probability is inf in the row sum taken from the rounded values"""
+    SH = 3
+    q = _mk((SH, L, 32), 50, 0.5)
+    k = _mk((SH, L, 32), 51)
+    v = _mk((SH, L, 32), 52)
+    q[1, 5] = 0.0
+    q[1, 5, 0] = 25.0
+    k[1, L - 40] = 0.0
+    k[1, L - 40, 0] = 24.0
+    q, k, v = (t.float().double() for t in (q, k, v))
+    gates = torch.ones((SH, L), dtype=torch.float64)
+    out = _run_attn(q, k, v, gates, SH, L, 1, True, variant)
+    ref = _attn_ref(q, k, v, gates).reshape(SH * L, 32)
+    assert torch.isfinite(out).all()
+    err = _rel(out, ref)
+    report("attn_frag_x3_p16_overflow", L=L, variant=variant, rel=err)
+    assert err < 3e-4
+
+
 def test_attention_frag_x3_time_direction_rowmap():
     B, T, F, heads = 2, 150, 4, 1
     SH = B * F
@@ -306,7 +381,7 @@ def test_attention_frag_x3_overflow_fallback(L, variant):
     assert err < 6e-6
 
 
-@pytest.mark.parametrize("variant", [1, 2, 4, 5])
+@pytest.mark.parametrize("variant", [1, 2, 4, 5, 12, 13])
 def test_attention_frag_x3_at_scale_is_repeatable(variant):
     """The main-layer launch shape of a 16-chunk batch (256 sequence-heads x 1500 tokens) four times: bit-identical.
     (Round 3: the 64-key variant, capped to 128 registers, spilled two of them around the key loop; the reloads raced the
@@ -338,7 +413,7 @@ def test_attention_frag_x3_at_scale_is_repeatable(variant):
         ref = _attn_ref(q[sh].double(), k[sh].double(), v[sh].double(), gates[sh].double())
         s_, h_ = divmod(sh, heads)
         got = from_hl32(outs[0].cpu()[s_ * L:(s_ + 1) * L])[:, h_ * 32:(h_ + 1) * 32]
-        assert _rel(got, ref) < 1e-5
+        assert _rel(got, ref) < (1e-5 if variant < 8 else 3e-4)
 
 
 # ---- frontend: time-direction QKV projection and the shadow of the fused out-projection + FF kernel -------------------------

@@ -15,6 +15,12 @@ One wave = two 32-query blocks A and B, one 32-key block per step.  The two bloc
 so every phase pairs 12 big MFMAs of one query block (32 cycles each on the SIMD's matrix pipe) with the 56 VALU
 instructions of the other one (16 exponentials, the 24-instruction hi + lo split, 16 row-sum adds) and 4 fragment reads:
 five single-issue instructions per MFMA gap, placed by hand (MI355X_MICROARCH.md: <= 5 fillers fit a gap).
+
+Round 5: a second statement, ATTN_X3Q2P_ASM -- the "P16" arithmetic (profiles/r05_flip_frontier.txt): the
+probabilities enter P.V as their fp16 hi parts only (P_hi . V_hi + P_hi . V_lo: four MFMAs instead of six, no lo split), and
+the row sums are taken from the SAME rounded values on v_mfma_f32_4x4x4_16b_f16 with an all-ones A operand (numerator and
+denominator of the softmax see identical probabilities, fp16 subnormals included, so the rounding largely cancels in O / l).
+Per step and query block: 10 big + 4 small MFMAs and 24 VALU instructions (16 exponentials, 8 conversions) against 12 and 56.
 """
 import os
 
@@ -104,6 +110,101 @@ def softmax_fillers(q):
         [add(c, s(12), s(13)), add(d, s(14), s(15)), ML[6], ML[7], MH[6]],
         [MH[7], add(c, c, d), add(e, e, c), add(a, a, e), add(lq, lq, a)],
     ]
+
+
+ONES = 126                        # v[126:127]: packed fp16 (1, 1, 1, 1) -- the A operand of the row-sum MFMAs (P16)
+
+
+def pv_mfmas_p(q, vbuf):
+    """P16: O_q^T += V^T . P_hi^T: (v0l h0, v1l h1, v0 h0, v1 h1)"""
+    acc = o(f"acc{q}")
+    v = [vr(VB_[vbuf] + 4 * i, 4) for i in range(4)]
+    h0, h1 = vr(H[q], 4), vr(H[q] + 4, 4)
+    return [mfma(acc, a, b, acc) for a, b in [(v[2], h0), (v[3], h1), (v[0], h0), (v[1], h1)]]
+
+
+def rowsum_mfmas(q):
+    """P16: l_q (four registers, all equal) += the lane's 16 rounded probabilities, four at a time: D = ones(4x4) . B"""
+    lq = o(f"l{q}")
+    return [f"v_mfma_f32_4x4x4_16b_f16 {lq}, {vr(ONES, 2)}, {vr(H[q] + 2 * i, 2)}, {lq}" for i in range(4)]
+
+
+def phase_p(sm, mm, pv_vbuf, sc_kbuf, reads, head=(), dma=None):
+    """P16 phase: MFMAs of block `mm` -- P.V (4) and row sums (4 small) of its previous key block, scores (6) of its next one --
+    beside the 24 VALU instructions of block `sm`'s softmax step.  Order: pv0 | R0 | sc0 sc1 | pv1 | R1 | sc2 sc3 | pv2 | R2 |
+    sc4 sc5 | pv3 | R3.  Same-accumulator big MFMAs are either issued back to back (the score pairs: exact-overlap forwarding,
+    as in the prologue) or have another big MFMA in between (>= 16 quad cycles); a small MFMA always follows a filler group, so
+    that the wave issues its VALU work in the preceding big MFMA's shadow before it queues for the pipe; the last score MFMA
+    is followed by pv3, R3 and the next phase's pv0 before the first exponential reads the scores (>= 18 quad cycles by pipe
+    occupancy alone; 12 are required)."""
+    pv, sc, rs = pv_mfmas_p(mm, pv_vbuf), score_mfmas(mm, sc_kbuf), rowsum_mfmas(mm)
+    s = lambda r: vr(S[sm] + r)      # noqa: E731
+    E = [f"v_exp_f32_e32 {s(r)}, {s(r)}" for r in range(16)]
+    C = [f"v_cvt_pk_f16_f32 {vr(H[sm] + j)}, {s(2 * j)}, {s(2 * j + 1)}" for j in range(8)]
+    g = [E[0:4] + [reads[0]],
+         E[4:8] + [reads[1]] + E[8:12] + [reads[2]],
+         E[12:16] + [reads[3]],
+         C[0:4],
+         C[4:6],
+         C[6:8],
+         []]
+    if dma:   # refill of the ring (X(1) only): address arithmetic first, then one LDS-DMA instruction per filler group
+        g[2] = g[2] + dma[0]
+        for i in range(4):
+            g[3 + i] = g[3 + i] + dma[1 + i]
+    out = list(head)
+    out += [pv[0]] + g[0] + [rs[0]]
+    out += [sc[0], sc[1]] + g[1]
+    out += [pv[1]] + g[2] + [rs[1]]
+    out += [sc[2], sc[3]] + g[3]
+    out += [pv[2]] + g[4] + [rs[2]]
+    out += [sc[4], sc[5]] + g[5]
+    out += [pv[3]] + g[6] + [rs[3]]
+    return out
+
+
+def build_p():
+    """the P16 statement: same ring, same phases, same fragment buffers as build()"""
+    kcur, knext = vr(T + 5), vr(T + 6)
+    vcur, vnext = vr(T + 7), vr(T + 8)
+    s0, s1 = f"s{ST}", f"s{ST + 1}"
+    A = []
+    A += ["s_nop 4",
+          f"v_mov_b32_e32 {vr(ONES)}, 0x3c003c00", f"v_mov_b32_e32 {vr(ONES + 1)}, 0x3c003c00",
+          f"s_and_b32 {s0}, {o('t')}, {NBUF - 1}", f"s_lshl_b32 {s0}, {s0}, {BUF.bit_length() - 1}",
+          f"v_add_u32_e32 {kcur}, {s0}, {o('klane')}"]
+    A += frag_reads("K", 0, kcur, 0)
+    A += [f"v_add_u32_e32 {knext}, {s0}, {o('vlane')}"]
+    A += frag_reads("V", 0, knext, 0) + frag_reads("V", 1, knext, 0)
+    for j in range(8):
+        A += [f"v_mov_b32_e32 {vr(H['B'] + j)}, 0"]
+    A += ["s_waitcnt lgkmcnt(0)"]
+    A += score_mfmas("A", 0)
+    A += ["s_nop 7", "s_nop 7"]
+    A += ["Lloop%=:"]
+    A += [f"s_and_b32 {s0}, {o('t')}, {NBUF - 1}", f"s_lshl_b32 {s0}, {s0}, {BUF.bit_length() - 1}",
+          f"s_add_u32 {s1}, {o('t')}, 1", f"s_and_b32 {s1}, {s1}, {NBUF - 1}", f"s_lshl_b32 {s1}, {s1}, {BUF.bit_length() - 1}",
+          f"v_add_u32_e32 {kcur}, {s0}, {o('klane')}", f"v_add_u32_e32 {vcur}, {s0}, {o('vlane')}",
+          f"v_add_u32_e32 {knext}, {s1}, {o('klane')}", f"v_add_u32_e32 {vnext}, {s1}, {o('vlane')}"]
+    A += phase_p("A", "B", pv_vbuf=1, sc_kbuf=0, reads=frag_reads("K", 1, kcur, BLK))
+    A += phase_p("B", "A", pv_vbuf=0, sc_kbuf=1, reads=frag_reads("V", 1, vcur, BLK), head=["s_waitcnt lgkmcnt(0)"])
+    s_dst = f"s{ST + 3}"
+    refill_prep = [f"s_add_u32 {s_dst}, {o('t')}, 3", f"s_and_b32 {s_dst}, {s_dst}, {NBUF - 1}",
+                   f"s_lshl_b32 {s_dst}, {s_dst}, {BUF.bit_length() - 1}", f"s_add_u32 {s_dst}, {s_dst}, {o('m0base')}"]
+    dma = [refill_prep] + [dma_group(i, s_dst, o("soff")) for i in range(4)]
+    A += phase_p("A", "B", pv_vbuf=0, sc_kbuf=1, reads=frag_reads("K", 0, knext, 0),
+                 head=["s_waitcnt vmcnt(4) lgkmcnt(0)", "s_barrier"], dma=dma)
+    A += phase_p("B", "A", pv_vbuf=1, sc_kbuf=0, reads=frag_reads("V", 0, vnext, 0), head=["s_waitcnt lgkmcnt(0)"])
+    A += [f"s_add_u32 {o('soff')}, {o('soff')}, {BUF // 2}",
+          f"s_add_u32 {o('t')}, {o('t')}, 1",
+          f"s_cmp_lt_i32 {o('t')}, {o('nfull')}",
+          "s_cbranch_scc1 Lloop%="]
+    # drain: P.V and row sums of B for the last block (V buffer 1); dependent MFMAs kept apart by explicit wait states
+    pv, rs = pv_mfmas_p("B", 1), rowsum_mfmas("B")
+    for i in range(4):
+        A += [pv[i], rs[i], "s_nop 7", "s_nop 3"]
+    A += ["s_waitcnt lgkmcnt(0)", "s_nop 7", "s_nop 7"]
+    return A
 
 
 def frag_reads(kind, buf, addr, blk_off):
@@ -220,7 +321,20 @@ def main():
                 f.write(f'  "{x}\\n\\t" \\\n')
             f.write('  ""\n#endif\n')
         ABL = 0
+        lp = build_p()
+        f.write(f"// P16 statement: {len(lp)} instructions, {sum('v_mfma_f32_32x32' in x for x in lp)} big + "
+                f"{sum('v_mfma_f32_4x4x4' in x for x in lp)} small MFMAs; operands as above with lA / lB four registers each\n")
+        f.write("#define ATTN_X3Q2P_ASM \\\n")
+        for x in lp:
+            f.write(f'  "{x}\\n\\t" \\\n')
+        f.write('  ""\n')
         f.write("#define ATTN_X3Q2_CLOBBERS " + ", ".join(f'"v{i}"' for i in CLOBBER_V) + ", " +
+                ", ".join(f'"s{i}"' for i in CLOBBER_S) + ', "scc", "memory"\n')
+        # (P16 leaves the lo words, the row-sum tree's temporaries and v125 to the compiler: its row sums are four registers)
+        used_p = sorted(set(range(S["A"], S["A"] + 16)) | set(range(S["B"], S["B"] + 16)) | set(range(H["A"], H["A"] + 8)) |
+                        set(range(H["B"], H["B"] + 8)) | set(range(KB_[1], KB_[0] + 16)) | set(range(VB_[1], VB_[0] + 16)) |
+                        set(range(T + 5, T + 9)) | {ONES, ONES + 1})
+        f.write("#define ATTN_X3Q2P_CLOBBERS " + ", ".join(f'"v{i}"' for i in used_p) + ", " +
                 ", ".join(f'"s{i}"' for i in CLOBBER_S) + ', "scc", "memory"\n')
         f.write(f"#define ATTN_X3Q2_KBX {KBX}\n#define ATTN_X3Q2_NBUF {NBUF}\n")
     print(f"wrote {os.path.normpath(out)}: {len(lines)} instructions, {n_mfma} MFMAs")
