@@ -555,6 +555,7 @@ __global__ __launch_bounds__(256, (QB == 1 ? 4 : 2)) void attn_frag_kernel(const
 // leaves as fp32 (frontend: consumed by outff_fused_kernel<hl>) or as hl32 planes (main layers: A operand of the
 // out-projection on gemm3.hip).  K / V tiles: 128 keys = 16 KB each, double buffered = 64 KB -> 2 workgroups per CU.
 constexpr int BLKX_BYTES = 2 * BLK_BYTES;
+constexpr float P_SHIFT_X = 3.f;
 // (the tile size KBX -- 32-key blocks per LDS tile -- is a template parameter of this path: 4 = 128 keys, 64 KB of LDS,
 // two workgroups per CU; 2 = 64 keys, 32 KB, three workgroups per CU at twice the barriers)
 
@@ -681,6 +682,9 @@ DEVI void finish_x(f32x16 (&sc)[QB], const VFragX& vf, int g, QStateX (&st)[QB],
         w0[j][i] = cvt_pk_rn(sc[j][2 * i], sc[j][2 * i + 1]);
         w1[j][i] = cvt_pk_rn(sc[j][8 + 2 * i], sc[j][8 + 2 * i + 1]);
       }
+      // (v_dot2_f32_f16 on the packed words instead -- it keeps fp16 subnormals like the MFMAs do, tools/ubench/dot2_denorm.hip --
+      // was built and measured: 8 more VALU instructions per step against 32 fewer matrix-pipe cycles, attention 10.2 ms per
+      // step against 9.9 ms, profiles/r05_ab_rowsum_dot2.txt: the VALU, not the pipe, is this loop's short side)
       rowsum8(st[j].l4, w0[j]);
       rowsum8(st[j].l4, w1[j]);
     }
@@ -760,6 +764,9 @@ DEVI void attn_tiles_x(rsrc_t rk, rsrc_t rv, char* smem, int tid, int wave, int 
 // may score up to 16 + P_SHIFT octaves above it before the fast pass overflows; 64 keys instead of 32 make that ~60 times
 // rarer on Gaussian scores at no cost (the blocks are there).  Shared by every x3 kernel: the reference point is part of
 // the arithmetic, and the kernels must agree bit for bit.
+// (P_SHIFT_X: the x3 kernels' headroom above that maximum, in octaves ON TOP of the rounding-up below -- the effective shift is
+// 3 .. 4 octaves where rounds 3 - 4 had exactly 4: every octave of shift pushes the lo halves of the probabilities one octave
+// deeper into fp16's subnormal range, and with 4 + rounding the three-term kernels' error went from 6e-6 to 1e-5.)
 // Round 5: the reference point is rounded UP to a whole octave.  Probabilities relative to two reference points that differ
 // by whole octaves differ by a power of two, and both the hi + lo split and the fp16 rounding of P16 commute with that
 // (outside fp16's subnormal range): a workgroup that re-runs on its row maxima (row_max_pass_x) then reproduces what the
@@ -784,7 +791,7 @@ DEVI void ref_max_x(const char* smem, int g, int lr, QStateX (&st)[QB], int L, i
   for (int j = 0; j < QB; ++j) {
     const float m = ceilf(fmaxf(bm[j], __shfl_xor(bm[j], 32)));
 #pragma unroll
-    for (int r = 0; r < 16; ++r) st[j].negm[r] = -m - P_SHIFT;
+    for (int r = 0; r < 16; ++r) st[j].negm[r] = -m - P_SHIFT_X;
   }
 }
 
@@ -794,15 +801,27 @@ DEVI void ref_max_x(const char* smem, int g, int lr, QStateX (&st)[QB], int L, i
 // quarter of a fast pass on top of the two, against three to four for the classic running-maximum loop this replaces
 // (round 4: 2.7 % of the workgroups of the benchmark's forward take this path, 30 % on the outlier stress weights).
 // Plain double-buffered tiles in LDS buffers 0 / 1 (as attn_tiles_x); every LDS-DMA is drained on return.
+// Round 5: only the queries that DID overflow (`redo`, per lane) take the new reference point; their neighbours in the
+// workgroup run the fast pass again on the reference they had and reproduce their first result bit for bit.  A query's
+// result is then a function of its own scores alone -- not of which other queries share its workgroup (128 or 256 of them,
+// by the kernel a launch size selects): a chunk gives the same bits alone and inside any batch.
 template <int QB, int KBX>
-DEVI void row_max_pass_x(rsrc_t rk, rsrc_t rv, char* smem, int tid, int wave, int g, int lr, QStateX (&st)[QB], int L, int nblk) {
+DEVI void row_max_pass_x(rsrc_t rk, rsrc_t rv, char* smem, int tid, int wave, int g, int lr, QStateX (&st)[QB], int L, int nblk,
+                         const float (&l_first)[QB]) {
+  // l_first: the fast pass's row sums (redo = not below 65504).  The reference points of the queries that keep theirs are
+  // computed AGAIN from tile 0 (ref_max_x: a function of the query and the first two key blocks, so the same bits) rather than
+  // kept in registers across the passes: the hand-scheduled kernel has none to spare.
   constexpr int TILEX_BYTES = KBX * BLKX_BYTES;
   const int ntiles = (nblk + KBX - 1) / KBX;
-  float bm[QB];
-#pragma unroll
-  for (int j = 0; j < QB; ++j) bm[j] = -1e30f;
+  float bm[QB], keep[QB];
   stage_tile_x<KBX>(rk, rv, 0, smem, 0, tid, wave);
   __syncthreads();
+  ref_max_x<QB>(smem, g, lr, st, L, nblk);
+#pragma unroll
+  for (int j = 0; j < QB; ++j) {
+    bm[j] = -1e30f;
+    keep[j] = st[j].negm[0];
+  }
   for (int t = 0; t < ntiles; ++t) {
     if (t + 1 < ntiles) stage_tile_x<KBX>(rk, rv, t + 1, smem, (t + 1) & 1, tid, wave);
     const char* kb = smem + (t & 1) * 2 * TILEX_BYTES;
@@ -824,15 +843,17 @@ DEVI void row_max_pass_x(rsrc_t rk, rsrc_t rv, char* smem, int tid, int wave, in
     }
     __syncthreads();  // tile t + 1 has landed (every wave waited for its own copies), tile t is free
   }
-  // The reference point of the re-run sits TWO octaves above the row maximum (probabilities <= 4, row sums <= 1500 x 4): the
-  // fast pass's own shift (P_SHIFT octaves BELOW its reference point) buys headroom for keys that have not been seen yet;
-  // here all have been, and every octave not spent on headroom keeps one more octave of small probabilities out of fp16's
-  // subnormal range (absolute 2^-25 per term: with the maximum at 2^-4 the row sums were 1.3e-5 off, tests/test_gpu_x3.py).
+  // The reference point of the re-run puts the row maximum at 2^14 .. 2^15 (the largest probability an fp16 hi part holds is
+  // 65504; the maximum comes from hi . hi scores and may sit 0.05 octaves low): the fast pass's own shift (P_SHIFT octaves
+  // BELOW its reference point) buys headroom for keys that have not been seen yet; here all have been, and every octave not
+  // spent on headroom keeps one more octave of small probabilities out of fp16's subnormal range (absolute 2^-25 per term:
+  // with the maximum at 2^-4 the row sums were 1.3e-5 off; rounds 3 - 4 had it at 4; row sums are fp32 and are not tested again).
 #pragma unroll
   for (int j = 0; j < QB; ++j) {
     const float m = ceilf(fmaxf(bm[j], __shfl_xor(bm[j], 32)));   // (whole octaves: see ref_max_x)
+    const float nm = !(l_first[j] < 65504.f) ? 14.0f - m : keep[j];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) st[j].negm[r] = 2.0f - m;
+    for (int r = 0; r < 16; ++r) st[j].negm[r] = nm;
   }
 }
 
@@ -955,7 +976,7 @@ __global__ __launch_bounds__(256, MINW) void attn_frag_x3_kernel(const AttnFragP
 #endif
   if (*flag) {  // workgroup-uniform: row maxima over all keys, then the same fast pass on them (row_max_pass_x)
     __syncthreads();
-    row_max_pass_x<QB, KBX>(rk, rv, smem, tid, wave, g, lr, st, L, nblk);
+    row_max_pass_x<QB, KBX>(rk, rv, smem, tid, wave, g, lr, st, L, nblk, l_tot);
     attn_fast_x<QB, KBX, P16>(rk, rv, smem, tid, wave, lane, g, lr, st, L, nblk, true);
 #pragma unroll
     for (int j = 0; j < QB; ++j) l_tot[j] = lane_sum(j) + __shfl_xor(lane_sum(j), 32);
@@ -1171,7 +1192,7 @@ __global__ __launch_bounds__(256, 2) void attn_frag_x3q2_kernel(const AttnFragP 
   if (*flag) {  // workgroup-uniform: row maxima over all keys, then the same fast pass on them (row_max_pass_x)
     __syncthreads();
     load_q();
-    row_max_pass_x<QB, KBX>(rk, rv, smem, tidE, wave, gE, lrE, st, L, nblk);
+    row_max_pass_x<QB, KBX>(rk, rv, smem, tidE, wave, gE, lrE, st, L, nblk, l_tot);
     stage_ring(0);
     stage_ring(1);
     stage_ring(2);

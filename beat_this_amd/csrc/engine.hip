@@ -48,7 +48,7 @@ struct Scope {
 struct bt_engine {
   bt_model_desc d;
   prof::State prof;
-  int x3_attn_p16 = 1;   // BT_OPT_X3_ATTN_P16
+  int x3_attn_p16 = 2;   // BT_OPT_X3_ATTN_P16
 };
 enum { CAT_STEM = 0, CAT_QKV, CAT_ATTN_FLASH, CAT_OUT, CAT_FF1, CAT_FF2, CAT_CONV, CAT_LINEAR,
        CAT_HEAD, CAT_FF_FUSED, CAT_ATTN_FREQ_FUSED, CAT_LAYER_TAIL, CAT_COUNT };
@@ -63,7 +63,7 @@ struct Workspace {
   void* qf; void* kf; void* vf; float* gates_h; int nbp;  // fragment-major attention operands (half path)
   float* ssq[2];  // [D / 64][B T] partial row sums of squares of the main residual stream (ping-pong)
   int* status;    // BT_PREC_F32X3 range flag: the FIRST word of the workspace (include/beat_this_amd.h)
-  int x3_attn;    // bt_attn_frag_args.x3 of this forward's attention launches (kernel choice + BT_X3_P16)
+  int x3_attn, x3_attn_front;   // bt_attn_frag_args.x3 of this forward's attention launches, main layers / frontend (kernel choice + BT_X3_P16)
   size_t total;
 };
 
@@ -77,7 +77,7 @@ Workspace carve(char* base, int B, int T, int D, int ff_mult, int prec) {
   auto take = [&](size_t bytes) { size_t o = off; off += align_up(bytes, 256); return base ? base + o : (char*)nullptr; };
   Workspace w;
   w.status = (int*)take(256);
-  w.x3_attn = BT_X3_ATTN;
+  w.x3_attn = w.x3_attn_front = BT_X3_ATTN;
   w.xa = (float*)take(bt * 1024 * 4);
   w.xb = (float*)take(bt * 1024 * 4);
   w.xm = (float*)take(bt * D * 4);
@@ -254,7 +254,7 @@ int run_pair(prof::State* pf, const bt_pair_weights& pw, const float* rope, floa
     memset(&a, 0, sizeof a);
     a.q = ws.qf; a.k = ws.kf; a.v = ws.vf; a.gates = ws.gates_h; a.out = ws.ao; a.n_seq = B * F; a.L = T; a.heads = H;
     a.inner = C; a.nbp = ws.nbp; a.o_div = F; a.o_outer = (long)T * F; a.o_inner = 1; a.o_tok = F;
-    a.x3 = t2x3 ? ws.x3_attn : 0; a.out_f32 = 1; a.status = ws.status;
+    a.x3 = t2x3 ? ws.x3_attn_front : 0; a.out_f32 = 1; a.status = ws.status;
     LAUNCH_CAT(CAT_ATTN_FLASH, s, launch_attn_frag(a, s), "time attention");
     if (fused2_ok) return outff();
     memset(&g, 0, sizeof g);
@@ -346,7 +346,7 @@ void bt_engine_destroy(bt_engine* e) {
 
 int bt_engine_set_option(bt_engine* e, int option, int value) {
   if (!e) return bt_set_error(BT_ERR_ARG, "null argument");
-  if (option == BT_OPT_X3_ATTN_P16 && (value == 0 || value == 1)) { e->x3_attn_p16 = value; return BT_OK; }
+  if (option == BT_OPT_X3_ATTN_P16 && value >= 0 && value <= 2) { e->x3_attn_p16 = value; return BT_OK; }
   return bt_set_error(BT_ERR_ARG, "unknown engine option / value");
 }
 int bt_engine_get_option(const bt_engine* e, int option, int* value) {
@@ -380,7 +380,8 @@ int bt_forward_stages(bt_engine* e, void* stream, int prec, int first, int last,
   const int D = d.transformer_dim;
   Workspace ws = carve((char*)d_ws, B, T, D, d.ff_mult, prec);
   if (ws.total > ws_bytes) return bt_set_error(BT_ERR_WORKSPACE, "workspace too small");
-  ws.x3_attn = BT_X3_ATTN | (e->x3_attn_p16 ? BT_X3_P16 : 0);
+  ws.x3_attn = BT_X3_ATTN | (e->x3_attn_p16 >= 1 ? BT_X3_P16 : 0);
+  ws.x3_attn_front = BT_X3_ATTN | (e->x3_attn_p16 >= 2 ? BT_X3_P16 : 0);
   hipStream_t s = (hipStream_t)stream;
   const bool x3 = prec == BT_PREC_F32X3;
   if (x3) {

@@ -336,7 +336,7 @@ class Engine:
 
     def set_options(self, opts: dict) -> None:
         """Arithmetic variants of the engine (bt_engine_set_option), e.g. ``{"x3_attn_p16": 0}`` for the three-term P.V of
-        rounds 3 - 4.  Captured forwards are dropped: a graph replays the kernels it was recorded with."""
+        rounds 3 - 4 everywhere, ``1`` for P16 in the main layers only, ``2`` (default) main layers + frontend.  Captured forwards are dropped: a graph replays the kernels it was recorded with."""
         for name, value in opts.items():
             if name not in self.OPTIONS:
                 raise ValueError(f"unknown engine option {name!r} (known: {sorted(self.OPTIONS)})")

@@ -137,9 +137,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the side legs (other precisions, latency, configs, frontend)")
     ap.add_argument("--no-dist", action="store_true", help="N = 1 without bringing up the RCCL process group")
-    ap.add_argument("--x3-p16", type=int, default=1, choices=[0, 1],
-                    help="BT_OPT_X3_ATTN_P16 of the default precision: 1 = probabilities enter P.V as fp16 hi parts (default), "
-                         "0 = three-term P.V of rounds 3 - 4 (A/B runs)")
+    ap.add_argument("--x3-p16", type=int, default=2, choices=[0, 1, 2],
+                    help="BT_OPT_X3_ATTN_P16 of the default precision: probabilities enter P.V as fp16 hi parts in the main layers and "
+                         "the frontend (2, default), in the main layers only (1), nowhere = three-term P.V of rounds 3 - 4 (0)")
     ap.add_argument("--min-seconds", type=float, default=2.0,
                     help="the K timed steps are repeated until the timed region is at least this long (0: exactly K steps)")
     ap.add_argument("--watchdog", type=int, default=900, help="seconds after which a stuck run dumps its stacks and exits")
@@ -420,9 +420,11 @@ def main():
             dom = max(bd, key=lambda k: bd[k]["ms_per_step"])
             d = bd[dom]
             peak = PEAK_TFLOPS[prec]
-            p16 = prec == "f32x3" and dom == "attn_flash" and bool(args.x3_p16)
+            p16 = prec == "f32x3" and dom == "attn_flash" and args.x3_p16 == 2
             if p16:   # scores on three MFMAs per product, P.V on two (BT_OPT_X3_ATTN_P16): 2.5 pipe flops per algorithmic flop
                 peak = PEAK_TFLOPS["half"] / 2.5
+            elif prec == "f32x3" and dom == "attn_flash" and args.x3_p16 == 1:   # (half of the attention flops in either form)
+                peak = PEAK_TFLOPS["half"] / 2.75
             traffic, traffic_src = None, None
             try:  # HBM bytes per launch of the dominant category: PMC counters of separate rocprofv3 passes, committed
                 name = "pmc_traffic.json" if prec == "half" else f"pmc_traffic_{prec}.json"

@@ -169,9 +169,11 @@ void bt_engine_destroy(bt_engine* e);
 /* Options of an engine (arithmetic variants of BT_PREC_F32X3 that stay inside north_star's 1e-3 / identical-beats gate but
  * are not bit-identical to each other; both are kept so that the choice can be measured: tools/flip_soak.py,
  * profiles/r05_flip_frontier.txt).  bt_engine_set_option returns BT_ERR_ARG for an unknown option / value.
- *   BT_OPT_X3_ATTN_P16  1 (default): the attention probabilities of the time-direction and main-layer attention enter P.V as
- *                       their fp16 hi parts (two MFMAs per fragment pair instead of three), row sums from the same rounded
- *                       values;  0: three-term P.V with the probabilities split hi + lo (rounds 3 - 4). */
+ *   BT_OPT_X3_ATTN_P16  the attention probabilities enter P.V as their fp16 hi parts (two MFMAs per fragment pair instead of
+ *                       three), row sums from the same rounded values:  2 (default) in the main layers and in the frontend's
+ *                       time-direction attention;  1 in the main layers only (logit error of the three-term form: the frontend's
+ *                       three attention layers carry 3/4 of what P16 adds);  0: three-term P.V with the probabilities split
+ *                       hi + lo everywhere (rounds 3 - 4). */
 #define BT_OPT_X3_ATTN_P16 1
 int bt_engine_set_option(bt_engine* e, int option, int value);
 int bt_engine_get_option(const bt_engine* e, int option, int* value);

@@ -151,11 +151,19 @@ def rope(t, freqs):
     return t * cos + rot * sin
 
 
+def _linear(x, w, b=None):
+    """nn.Linear as the reference's modules run it on CPU: ONE mm / addmm on the batch folded into rows.  The reference's
+    weights are Parameters with requires_grad, for which torch.matmul always folds a 3-D input (copying a non-contiguous
+    one -- the rearranged views of PartialFTTransformer are, beat_tracker.py:293-300); the plain tensors of a state dict take
+    the batched-matmul route for such inputs instead, which is 1.4 x slower per chunk.  Same arithmetic either way."""
+    return F.linear(x if x.is_contiguous() else x.contiguous(), w, b)
+
+
 def attention(x, sd, pfx, heads):
     """Attention.forward (roformer.py:114-132) on x: (b, n, dim)."""
     b, n, dim = x.shape
     xn = rmsnorm(x, sd[pfx + "norm.gamma"])
-    qkv = xn @ sd[pfx + "to_qkv.weight"].T  # (b,n,3*h*d), split "(qkv h d)"
+    qkv = _linear(xn, sd[pfx + "to_qkv.weight"])  # (b,n,3*h*d), split "(qkv h d)"
     d = qkv.shape[-1] // (3 * heads)
     qkv = qkv.view(b, n, 3, heads, d).permute(2, 0, 3, 1, 4)  # qkv b h n d
     q, k, v = qkv[0], qkv[1], qkv[2]
@@ -168,17 +176,17 @@ def attention(x, sd, pfx, heads):
     else:  # float64 evaluation (accuracy reference): the explicit definition of the same operator
         att = torch.softmax((q @ k.transpose(-1, -2)) * (d ** -0.5), dim=-1)
         out = att @ v
-    gates = xn @ sd[pfx + "to_gates.weight"].T + sd[pfx + "to_gates.bias"]  # (b,n,h)
+    gates = _linear(xn, sd[pfx + "to_gates.weight"], sd[pfx + "to_gates.bias"])  # (b,n,h)
     out = out * torch.sigmoid(gates).permute(0, 2, 1)[..., None]
     out = out.permute(0, 2, 1, 3).reshape(b, n, heads * d)
-    return out @ sd[pfx + "to_out.0.weight"].T
+    return _linear(out, sd[pfx + "to_out.0.weight"])
 
 
 def feedforward(x, sd, pfx):
     """FeedForward.forward (roformer.py:38-61): RMSNorm, Linear, GELU(erf), Linear."""
     h = rmsnorm(x, sd[pfx + "net.0.gamma"])
-    h = F.gelu(h @ sd[pfx + "net.1.weight"].T + sd[pfx + "net.1.bias"])
-    return h @ sd[pfx + "net.4.weight"].T + sd[pfx + "net.4.bias"]
+    h = F.gelu(_linear(h, sd[pfx + "net.1.weight"], sd[pfx + "net.1.bias"]))
+    return _linear(h, sd[pfx + "net.4.weight"], sd[pfx + "net.4.bias"])
 
 
 def batchnorm(x, sd, pfx, ch_dim):
@@ -228,7 +236,7 @@ def frontend(x, sd, taps=None):
             taps[f"block{i}"] = x
     b, c, f, t = x.shape
     x = x.permute(0, 3, 1, 2).reshape(b, t, c * f)  # "b c f t -> b t (c f)"
-    return x @ sd["frontend.linear.weight"].T + sd["frontend.linear.bias"]
+    return _linear(x, sd["frontend.linear.weight"], sd["frontend.linear.bias"])
 
 
 def transformer(x, sd, n_layers, heads, taps=None):
@@ -257,7 +265,7 @@ def model_forward(sd: dict, x: torch.Tensor, dtype=torch.float32, taps=None, sum
     if taps is not None:
         taps["frontend"] = x
     x = transformer(x, sd, n_layers, dim // 32, taps)
-    bd = x @ sd["task_heads.beat_downbeat_lin.weight"].T + sd["task_heads.beat_downbeat_lin.bias"]
+    bd = _linear(x, sd["task_heads.beat_downbeat_lin.weight"], sd["task_heads.beat_downbeat_lin.bias"])
     beat, down = bd[..., 0], bd[..., 1]
     return (beat + down if sum_head else beat), down
 

@@ -299,10 +299,19 @@ def test_ablation_variants_against_oracle(variant, prec_half):
     eb = float((r["beat"].cpu() - ob).abs().max())
     ed = float((r["downbeat"].cpu() - od).abs().max())
     report("ablation", variant=variant, half=prec_half, err_beat=eb, err_downbeat=ed, spread=float(ob.std()))
-    tol = 2.5e-2 if prec_half is True else X3_TOL if prec_half == "f32x3" else 1e-3   # (half: the reference's fp16-autocast scale)
+    # (half: the reference's fp16-autocast scale.  f32x3 = the default precision with the P16 attention in the frontend as well:
+    # these small / narrow variants amplify the frontend's share more than final0 / small0 do -- 3e-4 .. 6e-4 measured, held to
+    # the gate itself here and to 1.5e-4 with P16 in the main layers only, BT_OPT_X3_ATTN_P16 = 1)
+    tol = 2.5e-2 if prec_half is True else 1e-3
     assert eb < tol and ed < tol
     if prec_half == "f32x3":
         assert m.engine().last_fallbacks == 0
+        m.engine().set_options({"x3_attn_p16": 1})
+        with torch.inference_mode():
+            r1 = m(x.to(dev()))
+        e1 = max(float((r1["beat"].cpu() - ob).abs().max()), float((r1["downbeat"].cpu() - od).abs().max()))
+        report("ablation_p16_main_only", variant=variant, err=e1)
+        assert e1 < 1.5e-4
 
 
 @pytest.mark.parametrize("B,T", [(1, 37), (2, 1), (5, 333), (33, 64)])
@@ -450,7 +459,7 @@ def test_fp32_split_gemms_stay_within_the_fp32_gate(name):
         split = m(x.to(dev()))
         m.engine().set_options({"x3_attn_p16": 0})     # three-term P.V (rounds 3 - 4): the tighter variant of the same path
         split3 = m(x.to(dev()))
-        m.engine().set_options({"x3_attn_p16": 1})
+        m.engine().set_options({"x3_attn_p16": 2})
         m.fp32_split_gemms = False
     e3 = max(float((split3["beat"].cpu() - ob).abs().max()), float((split3["downbeat"].cpu() - od).abs().max()))
     assert e3 < 1e-4 and not torch.equal(split3["beat"], split["beat"])

@@ -53,7 +53,7 @@ def _oracle(sd, x, idx):
 X3_TOL = 3e-4   # the default precision (BT_PREC_F32X3 with the P16 attention): admission bound of profiles/r05_flip_frontier.txt
 
 
-def _check(name, hp_name, B, half, x3, oracle_idx, tol, flips_allowed, p16=1):
+def _check(name, hp_name, B, half, x3, oracle_idx, tol, flips_allowed, p16=2):
     from beat_this_amd.postprocessor import Postprocessor
 
     sd, m, x = _setup(hp_name, B)

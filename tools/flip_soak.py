@@ -11,7 +11,7 @@ across machines / BLAS builds.
         CPU (build container): soak_cache/<style>_<k>.npz = fp32 + fp64 framewise logits of the oracle for a 300 s
         22.05 kHz synthetic track (seed 1000 + k) on seeded final0 weights.  soak_cache/ is git-ignored but travels to the
         GPU box with the snapshot.
-    python tools/flip_soak.py gpu [--schemes exact,x3,half] [--tracks N]
+    python tools/flip_soak.py gpu [--schemes exact,x3,x3p16m,x3p16,half] [--tracks N]
         GPU box: the real kernels (Audio2Frames.many from the same waveforms) against the cached oracle logits.
     python tools/flip_soak.py sim [--schemes p16,vhi,e4m3,e2m3] [--device cuda|cpu] [--tracks N]
         operand-rounding simulations of schemes that are not built (tools/x3_narrow_study.py's forward, per site).
@@ -154,10 +154,13 @@ def cmd_gpu(args):
         m = m.to(dev)
         sigs = [torch.from_numpy(track(k)).to(dev) for k in ks]
         for scheme in args.schemes.split(","):
-            mode = {"exact": "exact", "x3": False, "half": True}.get(scheme.split("+")[0])
+            # exact = exact fp32 MFMAs; x3 = hi + lo operands with the three-term P.V of rounds 3 - 4; x3p16 = the same with the
+            # probabilities as fp16 hi parts in P.V (round 5 default; x3p16m: in the main layers only); half = fp16 operands
+            mode, p16 = {"exact": ("exact", 2), "x3": (False, 0), "x3p16m": (False, 1), "x3p16": (False, 2), "half": (True, 2)}[scheme]
             a2f = Audio2Frames(checkpoint_path=None, device=dev, float16=mode)
+            m.fp32_split_gemms = True
             a2f.model = m
-            _apply_variant(m, scheme)
+            m.engine().set_options({"x3_attn_p16": p16})
             fb0 = m.engine().last_fallbacks
             t0 = time.time()
             for i in range(0, len(ks), 6):
@@ -170,18 +173,8 @@ def cmd_gpu(args):
                   f"flips {sum(r['flips_beat'] for r in mine)} / {sum(r['flips_down'] for r in mine)} of "
                   f"{sum(r['n_beats'] for r in mine)} / {sum(r['n_down'] for r in mine)}, range fallbacks "
                   f"{m.engine().last_fallbacks - fb0}", flush=True)
-            _apply_variant(m, "")
+        m.engine().set_options({"x3_attn_p16": 2})
     json.dump(rows, open(os.path.join(OUT, f"gpu_{args.tag}.json"), "w"))
-
-
-def _apply_variant(model, scheme):
-    """'x3+p16' style suffixes select build-time / run-time variants of the x3 path (engine option words)"""
-    opts = scheme.split("+")[1:]
-    eng = model.engine()
-    if hasattr(eng, "set_options"):
-        eng.set_options({o: 1 for o in opts})
-    elif opts:
-        raise SystemExit(f"this build has no engine options: {opts}")
 
 
 # ---- simulated schemes (operand rounding on the oracle's forward; tools/x3_narrow_study.py) ------------------------------
@@ -337,7 +330,7 @@ def main():
     ap.add_argument("--out", default=None)
     args = ap.parse_args()
     if args.schemes is None:
-        args.schemes = {"gpu": "exact,x3,half", "sim": "p16,vhi,e4m3,e2m3"}.get(args.cmd, "")
+        args.schemes = {"gpu": "exact,x3,x3p16m,x3p16,half", "sim": "p16,vhi,e4m3,e2m3"}.get(args.cmd, "")
     {"oracle": cmd_oracle, "gpu": cmd_gpu, "sim": cmd_sim, "report": cmd_report}[args.cmd](args)
 
 

@@ -53,7 +53,7 @@ L = {"A": 208, "B": 192}          # packed lo halves
 KB_ = [176, 160]                  # K fragment buffers (k0, k1, k0l, k1l: 4 registers each)
 VB_ = [144, 128]                  # V fragment buffers (v0, v1, v0l, v1l)
 T = 116                           # temporaries: T+0..4 row-sum tree, T+5 kcur, T+6 knext, T+7 vcur, T+8 vnext
-CLOBBER_V = list(range(116, 256))
+CLOBBER_V = list(range(116, 125)) + list(range(128, 256))   # (v125 .. v127 are not touched by the three-term statement)
 ST = 88                           # SGPR temporaries s88 .. s95
 CLOBBER_S = list(range(88, 96))
 
