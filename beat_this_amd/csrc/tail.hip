@@ -67,24 +67,14 @@ DEVI void agpr_fence(f32x16& acc) { asm volatile("" : "+a"(acc)); }
 
 // DS reads and LDS-DMA issues are pinned where they are written (ALU / MFMA may move across): the scheduler otherwise
 // hoists all 32 fragment reads of a step in front of its MFMAs -- 128 VGPRs of landing space that do not exist here --
-// and bunches the LDS-DMA issues (see issue_piece).
+// and bunches the LDS-DMA issues.
 #define TAIL_PIN_DS() __builtin_amdgcn_sched_barrier(0x1 | 0x2 | 0x4 | 0x8 | 0x400)
 
-// Development ablations (-DBT_TAIL_ABL=bits, results are garbage; tools/tail_time.py): 1 no LDS-DMA, 2 no fragment reads,
-// 4 no activation.  M = 24000 (188 workgroups) / 32768 (256): whole kernel 161 / 186 us; without the LDS-DMA 119 / 120;
-// without the fragment reads 157 / 161; without the activation 147 / 160; MFMAs + prologue + epilogue only 108 / 109.
-#ifndef BT_TAIL_ABL
-#define BT_TAIL_ABL 0
-#endif
+// (What the kernel spends where was measured in round 2 with ablated builds of it -- M = 24000 (188 workgroups) / 32768 (256):
+// whole kernel 161 / 186 us; without the LDS-DMA 119 / 120; without the fragment reads 157 / 161; without the activation 147 /
+// 160; MFMAs + prologue + epilogue only 108 / 109 -- DESIGN.md section 5; the switches are gone from the source.)
 DEVI Frag<hf> tail_frag(const char* p, int lane) {
-#if BT_TAIL_ABL & 2
-  Frag<hf> f;
-  f.v[0] = f.v[1] = __builtin_bit_cast(hfx8, u32x4{(unsigned)lane, 1u, 2u, 3u});
-  asm volatile("" : "+v"(f.v[0]), "+v"(f.v[1]));
-  return f;
-#else
   return lds_frag<hf>(p, lane);
-#endif
 }
 
 template <int C>
@@ -103,41 +93,17 @@ struct TRing {
   char* lds;
   int tid, wave, total;
   DEVI void issue(int s) {
-#if BT_TAIL_ABL & 1
-    return;
-#endif
     if (s >= total) return;
     char* dst = lds + (s % NST) * STEP_B + wave * 1024;
 #pragma unroll
     for (int i = 0; i < CH; ++i)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)(dst + i * 4096), 16, tid * 16, s * STEP_B + i * 4096, 0, 0);
   }
-  // Piece i (4 KB of the workgroup, 1 KB of this wave) of step s: lets a step's CH = KT pieces be issued one per tile
-  // iteration of the step being multiplied instead of all at once behind the barrier.  BT_TAIL_ISSUE selects the placement
-  // (A/B on one box, 16 chunks, layer tail per forward): 2 = burst behind the barrier 1.048 ms (ships); 6 = one piece per
-  // iteration between full sched_barrier(0)s 1.028 ms; 5 = one piece per iteration after its MFMAs 1.036 ms; 1 = burst at
-  // the first iteration.  0 / 3 / 4 (one piece per iteration in front of the masked sched_barrier, free to move) produce
-  // GARBAGE -- hipcc's placement of the DMA around the masked barrier, not the hardware: the pinned forms 5 and 6 are
-  // correct (tools/tail_debug.py).  The placement hardly matters because an LDS-DMA instruction blocks the issuing wave
-  // until the load path takes it (75 GB/s per CU at best: 64 us for the layer's 4.7 MB) and with one wave per SIMD no
-  // other wave issues MFMAs meanwhile: stream (64 us) and MFMAs (63 us) serialise to ~150 us (tools/ubench/tail_stream.hip).
-#ifndef BT_TAIL_ISSUE
-#define BT_TAIL_ISSUE 2
-#endif
-  DEVI void issue_piece(int s, int i) {
-#if BT_TAIL_ISSUE == 2
-    return;
-#elif BT_TAIL_ISSUE == 1
-    if (i == 0) issue(s);
-    return;
-#endif
-#if BT_TAIL_ABL & 1
-    return;
-#endif
-    if (s >= total) return;
-    char* dst = lds + (s % NST) * STEP_B + wave * 1024;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)(dst + i * 4096), 16, tid * 16, s * STEP_B + i * 4096, 0, 0);
-  }
+  // (Issuing a step's CH pieces one per tile iteration instead of as one burst behind the barrier was measured in round 2:
+  // 1.028 - 1.036 ms per forward against 1.048 for the burst when pinned between full scheduling barriers, GARBAGE when left
+  // free to move around the masked one -- hipcc's placement, not the hardware.  The placement hardly matters: an LDS-DMA
+  // instruction blocks the issuing wave until the load path takes it, and with one wave per SIMD nobody else issues MFMAs
+  // meanwhile.  The burst ships; the variants are gone from the source.)
   DEVI void prologue() {
 #pragma unroll
     for (int s = 0; s < NST - 1; ++s) issue(s);
@@ -148,7 +114,6 @@ struct TRing {
     // vmcnt(0): step s -- the only one in flight in a two-stage ring -- has landed)
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-#if BT_TAIL_ISSUE == 2
     // hipcc reloads spilled registers (scratch_load -> VGPR) wherever it likes and waits for them with COUNTED vmcnt
     // values that assume LDS-DMA and VGPR returns retire in one order -- they do not (fused2.hip): a reload placed between
     // this barrier and the burst and used behind it (the build of round 2 had one, an LDS address) would be "waited for"
@@ -159,7 +124,6 @@ struct TRing {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     issue(s + NST - 1);
     __builtin_amdgcn_sched_barrier(0);
-#endif
     return lds + (s % NST) * STEP_B;   // (the caller issues step s + NST - 1 piece by piece while it multiplies step s)
   }
 };
@@ -185,33 +149,13 @@ DEVI void ff_step(RING& ws, int step, int lane, const Frag<hf> (&xf)[KT], f32x16
       if (HAS_A) na = tail_frag(wb + (t + 1) * TILE_B, lane);
       if (HAS_B) nb = tail_frag(wb + (KT + t + 1) * TILE_B, lane);
     }
-#if BT_TAIL_ISSUE == 0 || BT_TAIL_ISSUE == 3
-    ws.issue_piece(step + RING::NST - 1, t);
-#elif BT_TAIL_ISSUE == 6
-    __builtin_amdgcn_sched_barrier(0);
-    ws.issue_piece(step + RING::NST - 1, t);
-    __builtin_amdgcn_sched_barrier(0);
-#elif BT_TAIL_ISSUE == 4
-    if (t == 0) ws.issue(step + RING::NST - 1);
-#endif
     TAIL_PIN_DS();
-#ifndef BT_TAIL_ALTERNATE
     // the two MFMAs (k-halves) of a product back to back
     if (HAS_A) {
       if (t == 0) mma32_vgpr_first(ne, fa, xf[0]);
       else mma32_vgpr(ne, fa, xf[t]);
     }
-#else
-    // EXPERIMENT (-DBT_TAIL_ALTERNATE): the k-halves of the A product and of the B product alternate, so that no MFMA takes
-    // the accumulator its predecessor is still writing.  A/B: 1.07 vs 1.047 ms per forward -- not faster: dependent
-    // back-to-back accumulation is not what this kernel waits for (its weight stream is).
-    if (HAS_A) {
-      if (t == 0) asm volatile(TAIL_MFMA " %0, %1, %2, 0" : "=&v"(ne) : "v"(fa.v[0]), "v"(xf[0].v[0]));
-      else asm volatile(TAIL_MFMA " %0, %1, %2, %0" : "+v"(ne) : "v"(fa.v[0]), "v"(xf[t].v[0]));
-    }
-    if (HAS_B) asm volatile(TAIL_MFMA " %0, %1, %2, %0" : "+a"(acc2[t]) : "v"(fb.v[0]), "v"(hprev.v[0]));
-#endif
-    if (HAS_G && !(BT_TAIL_ABL & 4) && (t * 8) % KT == 0) {
+    if (HAS_G && (t * 8) % KT == 0) {
 #pragma unroll
       for (int q = 0; q < (KT >= 8 ? 1 : 8 / KT); ++q) {  // elements r, r + 1 -> one packed dword of the next B operand
         const int r = 2 * (t * 8 / KT + q);
@@ -219,20 +163,9 @@ DEVI void ff_step(RING& ws, int step, int lane, const Frag<hf> (&xf)[KT], f32x16
         hw[r >> 1] = pk2(gelu_tanh(fmaf(ce[r], scale, b[0])), gelu_tanh(fmaf(ce[r + 1], scale, b[1])));
       }
     }
-#ifndef BT_TAIL_ALTERNATE
     if (HAS_B) mma32_agpr(acc2[t], fb, hprev);
-#else
-    if (HAS_A) asm volatile(TAIL_MFMA " %0, %1, %2, %0" : "+v"(ne) : "v"(fa.v[1]), "v"(xf[t].v[1]));
-    if (HAS_B) asm volatile(TAIL_MFMA " %0, %1, %2, %0" : "+a"(acc2[t]) : "v"(fb.v[1]), "v"(hprev.v[1]));
-#endif
-#if BT_TAIL_ISSUE == 5
-    ws.issue_piece(step + RING::NST - 1, t);
-#endif
     if (t + 1 < KT) { fa = na; fb = nb; }
   }
-#if BT_TAIL_ABL & 4
-  for (int i = 0; i < 8; ++i) hw[i] = 0x3c003c00u;
-#endif
   if (HAS_G) {
     hcur.v[0] = __builtin_bit_cast(hfx8, u32x4{hw[0], hw[1], hw[2], hw[3]});
     hcur.v[1] = __builtin_bit_cast(hfx8, u32x4{hw[4], hw[5], hw[6], hw[7]});
@@ -301,24 +234,12 @@ __global__ __launch_bounds__(256, 1) void layer_tail_kernel(const LayerTailP p) 
         n0 = tail_frag(wb + (kt + 1) * TILE_B, lane);
         n1 = tail_frag(wb + (KT + kt + 1) * TILE_B, lane);
       }
-#if BT_TAIL_ISSUE == 0 || BT_TAIL_ISSUE == 4
-      ws.issue_piece(st + NST - 1, kt);
-#elif BT_TAIL_ISSUE == 6
-      __builtin_amdgcn_sched_barrier(0);
-      ws.issue_piece(st + NST - 1, kt);
-      __builtin_amdgcn_sched_barrier(0);
-#elif BT_TAIL_ISSUE == 3
-      if (kt == 0) ws.issue(st + NST - 1);
-#endif
       TAIL_PIN_DS();
       // straight into the residual row's accumulator tiles (AGPRs): x += Wout . ao costs no VALU and no extra registers
       asm volatile(TAIL_MFMA " %0, %1, %2, %0" : "+a"(acc2[2 * st]) : "v"(f0.v[0]), "v"(af[kt].v[0]));
       asm volatile(TAIL_MFMA " %0, %1, %2, %0" : "+a"(acc2[2 * st + 1]) : "v"(f1.v[0]), "v"(af[kt].v[0]));
       asm volatile(TAIL_MFMA " %0, %1, %2, %0" : "+a"(acc2[2 * st]) : "v"(f0.v[1]), "v"(af[kt].v[1]));
       asm volatile(TAIL_MFMA " %0, %1, %2, %0" : "+a"(acc2[2 * st + 1]) : "v"(f1.v[1]), "v"(af[kt].v[1]));
-#if BT_TAIL_ISSUE == 5
-      ws.issue_piece(st + NST - 1, kt);
-#endif
       if (kt + 1 < KT) { f0 = n0; f1 = n1; }
     }
   }
