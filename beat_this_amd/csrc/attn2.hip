@@ -772,11 +772,40 @@ DEVI void attn_tiles_x(rsrc_t rk, rsrc_t rv, char* smem, int tid, int wave, int 
 // (outside fp16's subnormal range): a workgroup that re-runs on its row maxima (row_max_pass_x) then reproduces what the
 // fast pass would have given without the overflow, so a query's result does not depend on which other queries share its
 // workgroup -- 128 or 256 of them, by the kernel a launch size selects -- beyond the subnormal tail.
+// Round 5, second change: the query's OWN key block joins the two leading ones (`kdiag[j]`: the K fragments of key block
+// qblk[j], fetched from global memory with the Q fragments).  With rotary positions the largest scores of a query sit near
+// its own position far more often than among the first 64 frames of the piece: the re-run rate of the benchmark's forward
+// fell from 1.1 % of the attention workgroups to the figure in DESIGN.md section 5 (21 % on the outlier stress weights before).
+// (diag_max_x: that block's part, computed right behind the loads -- before any LDS-DMA is issued -- so that its fragments are
+// dead when the passes start; dmax[j] = this lane's maximum over its 16 keys of the block.)
 template <int QB>
-DEVI void ref_max_x(const char* smem, int g, int lr, QStateX (&st)[QB], int L, int nblk) {
+DEVI void diag_max_x(const char* kseq, const int (&qblk)[QB], int g, int lr, const QStateX (&st)[QB], int L, float (&dmax)[QB]) {
+  KFragX kd[QB];
+#pragma unroll
+  for (int j = 0; j < QB; ++j) kd[j] = ld_kx(kseq + (long)qblk[j] * BLKX_BYTES, g, lr);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (VGPR-returning loads: landed before the first LDS-DMA is issued)
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int j = 0; j < QB; ++j) {
+    f32x16 sd;
+    zero16(sd);
+    sd = MFMA32_H(kd[j].k0l, st[j].q0, sd);
+    sd = MFMA32_H(kd[j].k1l, st[j].q1, sd);
+    sd = MFMA32_H(kd[j].k0, st[j].q0l, sd);
+    sd = MFMA32_H(kd[j].k1, st[j].q1l, sd);
+    sd = MFMA32_H(kd[j].k0, st[j].q0, sd);
+    sd = MFMA32_H(kd[j].k1, st[j].q1, sd);
+    float m = -1e30f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) m = fmaxf(m, (32 * qblk[j] + crow(r, g) < L) ? sd[r] : -1e30f);
+    dmax[j] = m;
+  }
+}
+template <int QB>
+DEVI void ref_max_x(const char* smem, int g, int lr, QStateX (&st)[QB], int L, int nblk, const float (&dmax)[QB]) {
   float bm[QB];
 #pragma unroll
-  for (int j = 0; j < QB; ++j) bm[j] = -1e30f;
+  for (int j = 0; j < QB; ++j) bm[j] = dmax[j];
   const int nref = min(2, nblk);
   for (int c = 0; c < nref; ++c) {
     const KFragX kf = ld_kx(smem + c * BLKX_BYTES, g, lr);
@@ -807,16 +836,17 @@ DEVI void ref_max_x(const char* smem, int g, int lr, QStateX (&st)[QB], int L, i
 // by the kernel a launch size selects): a chunk gives the same bits alone and inside any batch.
 template <int QB, int KBX>
 DEVI void row_max_pass_x(rsrc_t rk, rsrc_t rv, char* smem, int tid, int wave, int g, int lr, QStateX (&st)[QB], int L, int nblk,
-                         const float (&l_first)[QB]) {
+                         const float (&l_first)[QB], const char* kseq, const int (&qblk)[QB]) {
   // l_first: the fast pass's row sums (redo = not below 65504).  The reference points of the queries that keep theirs are
   // computed AGAIN from tile 0 (ref_max_x: a function of the query and the first two key blocks, so the same bits) rather than
   // kept in registers across the passes: the hand-scheduled kernel has none to spare.
   constexpr int TILEX_BYTES = KBX * BLKX_BYTES;
   const int ntiles = (nblk + KBX - 1) / KBX;
-  float bm[QB], keep[QB];
+  float bm[QB], keep[QB], dmax[QB];
+  diag_max_x<QB>(kseq, qblk, g, lr, st, L, dmax);
   stage_tile_x<KBX>(rk, rv, 0, smem, 0, tid, wave);
   __syncthreads();
-  ref_max_x<QB>(smem, g, lr, st, L, nblk);
+  ref_max_x<QB>(smem, g, lr, st, L, nblk, dmax);
 #pragma unroll
   for (int j = 0; j < QB; ++j) {
     bm[j] = -1e30f;
@@ -862,7 +892,8 @@ DEVI void row_max_pass_x(rsrc_t rk, rsrc_t rv, char* smem, int tid, int wave, in
 // buffers alternate: the loop is unrolled over the tile, no register copies), one barrier per tile at its last block.
 template <int QB, int KBX, bool P16 = false>
 DEVI void attn_fast_x(rsrc_t rk, rsrc_t rv, char* smem, int tid, int wave, int lane, int g, int lr, QStateX (&st)[QB], int L,
-                      int nblk, bool have_ref = false) {   // have_ref: st[j].negm is set (the re-run behind row_max_pass_x)
+                      int nblk, const float (&dmax)[QB],
+                      bool have_ref = false) {   // have_ref: st[j].negm is set (the re-run behind row_max_pass_x; dmax unused)
   constexpr int TILEX_BYTES = KBX * BLKX_BYTES;
   static_assert(KBX % 2 == 0, "two score buffers alternate over the blocks of a tile");
   const int ntiles = (nblk + KBX - 1) / KBX;
@@ -884,7 +915,7 @@ DEVI void attn_fast_x(rsrc_t rk, rsrc_t rv, char* smem, int tid, int wave, int l
   // fit the register file): there the scores of the next block follow the current block's products.
   constexpr bool PIPE = QB == 1;
   f32x16 s2[PIPE ? 2 : 1][QB];  // scores of the current / the next block (compile-time indices: the tile loop is unrolled)
-  if (!have_ref) ref_max_x<QB>(smem, g, lr, st, L, nblk);   // (workgroup-uniform)
+  if (!have_ref) ref_max_x<QB>(smem, g, lr, st, L, nblk, dmax);   // (workgroup-uniform)
   KFragX kf = ld_kx(smem, g, lr);
   // the scores of block 0 of tile 0 (one query block per wave: on the reference maximum, which rides on the accumulator input)
   if (QB == 1 && nfull > 0) score_x<true, QB>(kf, st, s2[0]);
@@ -939,10 +970,12 @@ __global__ __launch_bounds__(256, MINW) void attn_frag_x3_kernel(const AttnFragP
   if (tid == 0) *flag = 0;
 
   QStateX st[QB];
+  int qbi[QB];
   const int qb0 = (qt * 4 + wave) * QB;  // this wave's first query block
 #pragma unroll
   for (int j = 0; j < QB; ++j) {
     const int qbc = min(qb0 + j, nblk - 1);
+    qbi[j] = qbc;
     const char* qblk = reinterpret_cast<const char*>(p.q) + seq_off + (long)qbc * BLKX_BYTES;
     st[j].q0 = *reinterpret_cast<const hfx8*>(qblk + ((2 * g) * 32 + lr) * 16);
     st[j].q1 = *reinterpret_cast<const hfx8*>(qblk + ((2 * g + 1) * 32 + lr) * 16);
@@ -956,7 +989,9 @@ __global__ __launch_bounds__(256, MINW) void attn_frag_x3_kernel(const AttnFragP
   const unsigned seq_bytes = (unsigned)p.nbp * BLKX_BYTES;
   const rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(kseq), 0, seq_bytes, 0x00020000);
   const rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(vseq), 0, seq_bytes, 0x00020000);
-  attn_fast_x<QB, KBX, P16>(rk, rv, smem, tid, wave, lane, g, lr, st, L, nblk);
+  float dmax[QB];   // the queries' own key block in the reference maximum (diag_max_x: its loads land with the Q fragments')
+  diag_max_x<QB>(kseq, qbi, g, lr, st, L, dmax);
+  attn_fast_x<QB, KBX, P16>(rk, rv, smem, tid, wave, lane, g, lr, st, L, nblk, dmax);
   auto lane_sum = [&](int j) { return P16 ? st[j].l4[0] : st[j].l; };
   float l_tot[QB];
   bool bad = false;
@@ -976,8 +1011,8 @@ __global__ __launch_bounds__(256, MINW) void attn_frag_x3_kernel(const AttnFragP
 #endif
   if (*flag) {  // workgroup-uniform: row maxima over all keys, then the same fast pass on them (row_max_pass_x)
     __syncthreads();
-    row_max_pass_x<QB, KBX>(rk, rv, smem, tid, wave, g, lr, st, L, nblk, l_tot);
-    attn_fast_x<QB, KBX, P16>(rk, rv, smem, tid, wave, lane, g, lr, st, L, nblk, true);
+    row_max_pass_x<QB, KBX>(rk, rv, smem, tid, wave, g, lr, st, L, nblk, l_tot, kseq, qbi);
+    attn_fast_x<QB, KBX, P16>(rk, rv, smem, tid, wave, lane, g, lr, st, L, nblk, dmax, true);
 #pragma unroll
     for (int j = 0; j < QB; ++j) l_tot[j] = lane_sum(j) + __shfl_xor(lane_sum(j), 32);
   }
@@ -1083,6 +1118,11 @@ __global__ __launch_bounds__(256, 2) void attn_frag_x3q2_kernel(const AttnFragP 
     __builtin_amdgcn_sched_barrier(0);
   };
   load_q();
+  float dmax[QB];   // the queries' own key block in the reference maximum: before any LDS-DMA is in flight (diag_max_x)
+  {
+    const int qbi[QB] = {min(qb0, nblk - 1), min(qb0 + 1, nblk - 1)};
+    diag_max_x<QB>(kseq, qbi, g, lr, st, L, dmax);
+  }
   const unsigned seq_bytes = (unsigned)p.nbp * BLKX_BYTES;   // (tiles beyond it read as zeros: the ring is always refilled)
   const rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(kseq), 0, seq_bytes, 0x00020000);
   const rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(vseq), 0, seq_bytes, 0x00020000);
@@ -1111,30 +1151,30 @@ __global__ __launch_bounds__(256, 2) void attn_frag_x3q2_kernel(const AttnFragP 
     }
     const float nm0 = st[0].negm[0], nm1 = st[1].negm[0];   // (what the plain code below needs of the splats)
     if (nfull > 0) {
-      // operand words of the two buffer descriptors as plain SGPR quads (an asm operand cannot be a __amdgpu_buffer_rsrc_t)
-      const unsigned long long ka = (unsigned long long)kseq, va = (unsigned long long)vseq;
-      const u32x4 dk = {(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)ka), (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((ka >> 32) & 0xffffu)),
-                        (unsigned)__builtin_amdgcn_readfirstlane((int)seq_bytes), 0x00020000u};
-      const u32x4 dv = {(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)va), (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((va >> 32) & 0xffffu)),
-                        (unsigned)__builtin_amdgcn_readfirstlane((int)seq_bytes), 0x00020000u};
-      const int ln = lane_id_fresh();
-      const unsigned lds0 = (unsigned)(unsigned long long)(lptr_t)smem;   // LDS byte address of the ring
-      const unsigned klane = lds0 + ((2 * (ln >> 5)) * 32 + (ln & 31)) * 16, vlane = lds0 + ln * 16, dmaoff = (wave * 64 + ln) * 16;
-      const unsigned m0base = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + wave * 1024));
-      const float m1 = -1.0f;
-      int t = 0, soff = 3 * TILEX_BYTES;
-      if constexpr (P16)
-        asm volatile(ATTN_X3Q2P_ASM
-                     : "+v"(st[0].acc), "+v"(st[1].acc), "+v"(st[0].l4), "+v"(st[1].l4), "+s"(t), "+s"(soff)
-                     : "v"(st[0].q0), "v"(st[0].q1), "v"(st[0].q0l), "v"(st[0].q1l), "v"(st[1].q0), "v"(st[1].q1), "v"(st[1].q0l), "v"(st[1].q1l),
-                       "v"(st[0].negm), "v"(st[1].negm), "v"(klane), "v"(vlane), "v"(dmaoff), "s"(dk), "s"(dv), "s"(m0base), "s"(m1), "s"(nfull)
-                     : ATTN_X3Q2P_CLOBBERS);
-      else
-        asm volatile(ATTN_X3Q2_ASM
-                     : "+v"(st[0].acc), "+v"(st[1].acc), "+v"(st[0].l), "+v"(st[1].l), "+s"(t), "+s"(soff)
-                     : "v"(st[0].q0), "v"(st[0].q1), "v"(st[0].q0l), "v"(st[0].q1l), "v"(st[1].q0), "v"(st[1].q1), "v"(st[1].q0l), "v"(st[1].q1l),
-                       "v"(st[0].negm), "v"(st[1].negm), "v"(klane), "v"(vlane), "v"(dmaoff), "s"(dk), "s"(dv), "s"(m0base), "s"(m1), "s"(nfull)
-                     : ATTN_X3Q2_CLOBBERS);
+    // operand words of the two buffer descriptors as plain SGPR quads (an asm operand cannot be a __amdgpu_buffer_rsrc_t)
+    const unsigned long long ka = (unsigned long long)kseq, va = (unsigned long long)vseq;
+    const u32x4 dk = {(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)ka), (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((ka >> 32) & 0xffffu)),
+                      (unsigned)__builtin_amdgcn_readfirstlane((int)seq_bytes), 0x00020000u};
+    const u32x4 dv = {(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)va), (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((va >> 32) & 0xffffu)),
+                      (unsigned)__builtin_amdgcn_readfirstlane((int)seq_bytes), 0x00020000u};
+    const int ln = lane_id_fresh();
+    const unsigned lds0 = (unsigned)(unsigned long long)(lptr_t)smem;   // LDS byte address of the ring
+    const unsigned klane = lds0 + ((2 * (ln >> 5)) * 32 + (ln & 31)) * 16, vlane = lds0 + ln * 16, dmaoff = (wave * 64 + ln) * 16;
+    const unsigned m0base = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + wave * 1024));
+    const float m1 = -1.0f;
+    int t = 0, soff = 3 * TILEX_BYTES;
+    if constexpr (P16)
+      asm volatile(ATTN_X3Q2P_ASM
+                   : "+v"(st[0].acc), "+v"(st[1].acc), "+v"(st[0].l4), "+v"(st[1].l4), "+s"(t), "+s"(soff)
+                   : "v"(st[0].q0), "v"(st[0].q1), "v"(st[0].q0l), "v"(st[0].q1l), "v"(st[1].q0), "v"(st[1].q1), "v"(st[1].q0l), "v"(st[1].q1l),
+                     "v"(st[0].negm), "v"(st[1].negm), "v"(klane), "v"(vlane), "v"(dmaoff), "s"(dk), "s"(dv), "s"(m0base), "s"(m1), "s"(nfull)
+                   : ATTN_X3Q2P_CLOBBERS);
+    else
+      asm volatile(ATTN_X3Q2_ASM
+                   : "+v"(st[0].acc), "+v"(st[1].acc), "+v"(st[0].l), "+v"(st[1].l), "+s"(t), "+s"(soff)
+                   : "v"(st[0].q0), "v"(st[0].q1), "v"(st[0].q0l), "v"(st[0].q1l), "v"(st[1].q0), "v"(st[1].q1), "v"(st[1].q0l), "v"(st[1].q1l),
+                     "v"(st[0].negm), "v"(st[1].negm), "v"(klane), "v"(vlane), "v"(dmaoff), "s"(dk), "s"(dv), "s"(m0base), "s"(m1), "s"(nfull)
+                   : ATTN_X3Q2_CLOBBERS);
     }
     // every piece of the ring this wave asked for has landed, and so has everybody else's: the last tile (fewer than KBX
     // blocks and / or a masked last block) is read from its ring buffer by the plain code
@@ -1170,38 +1210,49 @@ __global__ __launch_bounds__(256, 2) void attn_frag_x3q2_kernel(const AttnFragP 
   stage_ring(2);
   asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // tile 0 (this wave's four pieces of it) has landed
   __syncthreads();
-  ref_max_x<QB>(smem, g, lr, st, L, nblk);
+  ref_max_x<QB>(smem, g, lr, st, L, nblk, dmax);
   fast_pass();
-  // (lane-derived values again, from an operand hipcc cannot see through: nothing but the softmax state stays live across
-  // the asm statement -- a value kept was a spill, and the ISA lint allows no scratch next to LDS-DMA)
-  const int laneE = lane_id_fresh(), gE = laneE >> 5, lrE = laneE & 31, tidE = wave * 64 + laneE;
+  // (Lane-derived values are taken again from an operand hipcc cannot see through wherever they are needed: nothing but the
+  // softmax state may stay live across an asm statement -- the three-term one leaves 18 registers -- and a value kept was a
+  // spill, which the ISA lint does not allow next to LDS-DMA.  That includes the second statement on the re-run path: the
+  // row sums and lane ids of the epilogue are formed behind it, not carried around it.)
   auto lane_sum = [&](int j) { return P16 ? st[j].l4[0] : st[j].l; };
-  float l_tot[QB];
-  bool bad = false;
+  {
+    const int ln = lane_id_fresh();
+    bool bad = false;
 #pragma unroll
-  for (int j = 0; j < QB; ++j) {
-    l_tot[j] = lane_sum(j) + __shfl_xor(lane_sum(j), 32);
-    const bool valid = qb0 + j < nblk && (qb0 + j) * 32 + lrE < L;
-    bad = bad || (valid && !(l_tot[j] < 65504.f));   // (see attn_frag_x3_kernel)
+    for (int j = 0; j < QB; ++j) {
+      const float lt = lane_sum(j) + __shfl_xor(lane_sum(j), 32);
+      const bool valid = qb0 + j < nblk && (qb0 + j) * 32 + (ln & 31) < L;
+      bad = bad || (valid && !(lt < 65504.f));   // (see attn_frag_x3_kernel)
+    }
+    if (__any(bad) && ln == 0) *flag = 1;
   }
-  if (__any(bad) && laneE == 0) *flag = 1;
   __syncthreads();
-#ifdef BT_DEV   // development: how many workgroups re-run on the running-maximum pass (words 1, 2 of the status block)
+#ifdef BT_DEV   // development: how many workgroups re-run on their row maxima (words 1, 2 of the status block)
   if (p.status && tid == 0) { atomicAdd(p.status + 2, 1); if (*flag) atomicAdd(p.status + 1, 1); }
 #endif
-  if (*flag) {  // workgroup-uniform: row maxima over all keys, then the same fast pass on them (row_max_pass_x)
+  if (*flag) {  // workgroup-uniform: row maxima over all keys for the queries that overflowed (row_max_pass_x), then the same pass again
     __syncthreads();
     load_q();
-    row_max_pass_x<QB, KBX>(rk, rv, smem, tidE, wave, gE, lrE, st, L, nblk, l_tot);
+    const int ln = lane_id_fresh();
+    const int qb0r = __builtin_amdgcn_readfirstlane((qt * 4 + wave) * QB);
+    const int qbi[QB] = {min(qb0r, nblk - 1), min(qb0r + 1, nblk - 1)};
+    float l_first[QB];
+#pragma unroll
+    for (int j = 0; j < QB; ++j) l_first[j] = lane_sum(j) + __shfl_xor(lane_sum(j), 32);
+    row_max_pass_x<QB, KBX>(rk, rv, smem, wave * 64 + ln, wave, ln >> 5, ln & 31, st, L, nblk, l_first, kseq, qbi);
     stage_ring(0);
     stage_ring(1);
     stage_ring(2);
     asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     __syncthreads();
     fast_pass();
-#pragma unroll
-    for (int j = 0; j < QB; ++j) l_tot[j] = lane_sum(j) + __shfl_xor(lane_sum(j), 32);
   }
+  const int laneE = lane_id_fresh(), gE = laneE >> 5, lrE = laneE & 31;
+  float l_tot[QB];
+#pragma unroll
+  for (int j = 0; j < QB; ++j) l_tot[j] = lane_sum(j) + __shfl_xor(lane_sum(j), 32);
 
   const int seq = sh / p.heads, head = sh - seq * p.heads;
   float amax = 0.f;

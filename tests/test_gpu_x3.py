@@ -274,11 +274,14 @@ def test_attention_frag_x3_variants_agree_bit_for_bit(n_seq, L, heads, out_f32):
 # ---- P16 (round 5, the forward's default; bt_attn_frag_args.x3 + 8): probabilities enter P.V as fp16 hi parts ---------------------
 def _attn_ref_p16(q, k, v, gates):
     """float64 restatement of the P16 arithmetic: probabilities relative to the reference point of the fast pass (the maximum
-    over the first two key blocks rounded up to a whole octave, four octaves of headroom) -- or, for the queries whose fast
-    pass overflows fp16, of the re-run (row maximum at 2^14 .. 2^15) -- rounded to fp16, the SAME rounded values in numerator
-    and denominator."""
+    over the first two key blocks and the query's own key block, rounded up to a whole octave, plus three octaves of headroom)
+    -- or, for the queries whose fast pass overflows fp16, of the re-run (row maximum at 2^14 .. 2^15) -- rounded to fp16, the
+    SAME rounded values in numerator and denominator."""
     s = q @ k.transpose(-1, -2)                      # base-2 exponents: q carries log2(e) / sqrt(d)
-    m = torch.ceil(s[..., : min(64, s.shape[-1])].max(-1).values) + 3.0
+    L = s.shape[-1]
+    own = torch.arange(L)[:, None] // 32 == torch.arange(L)[None, :] // 32          # [query, key]: same 32-token block
+    lead = (torch.arange(L) < 64)[None, :].expand(L, L)
+    m = torch.ceil(s.masked_fill(~(own | lead), -1e30).max(-1).values) + 3.0
     over = (s.max(-1).values - m) >= 15.99
     m = torch.where(over, torch.ceil(s.max(-1).values) - 14.0, m)
     h = torch.exp2(s - m[..., None]).float().to(torch.float16).double()
