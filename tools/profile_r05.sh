@@ -1,11 +1,11 @@
 #!/bin/bash
-# Round-4 profile collection on one GPU box (outputs under gpurun_out/prof_r04, summarised by tools/profile_summary.py):
+# Round-5 profile collection on one GPU box (outputs under gpurun_out/prof_r05, summarised by tools/profile_summary.py):
 #   kernel traces of the bench command (headline, single-stream headline, 16-chunk forward) for the half AND the f32x3
 #   path, SQ / GRBM counters (MFMA-busy cycles, wave cycles, GUI active) of both forwards, HBM traffic counters in SEPARATE
 #   passes (MI355X_MICROARCH.md, HBM section) for the half forward, the f32x3 forward, BASELINE config 3 (small0 fp32, 128
 #   chunks) and the headline, and rocm-smi power / clock samples while the forwards loop.
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-O=$R/gpurun_out/prof_r04
+O=$R/gpurun_out/prof_r05
 rm -rf $O; mkdir -p $O
 export TMPDIR=/tmp
 cd /tmp
@@ -47,5 +47,5 @@ done
 rocm-smi --showmaxpower 2>&1 | grep -iE "power" >> $O/smi_idle.txt
 find $O -name "*.csv" | wc -l
 du -sh $O
-# (the csv files travel back with gpurun_out/; tools/profile_summary.py turns them into profiles/r04_* in the build container)
+# (the csv files travel back with gpurun_out/; tools/profile_summary.py turns them into profiles/r05_* in the build container)
 find $O -name "*.db" -delete 2>/dev/null
