@@ -618,6 +618,14 @@ def main():
                              f"batch-1 like the reference, SDPA attention, fp32, post-processing), oracle/beat_this_oracle.py, value = "
                              f"the fastest repeat; thread count = fastest of 8/16/32/64 on one chunk (more threads are slower on "
                              f"this host: threads_probe_ms_per_chunk), the reference's own default would be one per logical core"}
+            try:   # how the port compares with the code it stands in for (measured in the build container, where the reference
+                # exists: tools/port_speed.py -- alternating runs of one chunk, fastest of each)
+                pv = json.load(open(os.path.join(ROOT, "profiles", "r05_port_vs_reference.json")))
+                cpu["port_vs_reference"] = {k: pv[k] for k in ("port_vs_reference", "port_ms_per_chunk", "reference_ms_per_chunk",
+                                                               "threads", "host_cores", "model")}
+                cpu["port_vs_reference"]["note"] = "oracle.model_forward / the unmodified reference's BeatThis.forward, build container (tools/port_speed.py)"
+            except (OSError, KeyError, ValueError):
+                pass
             ptrack = [torch.from_numpy(sig).to(dev)]
 
             def flips(a, b):
