@@ -54,6 +54,11 @@ struct G3CfgTX { static constexpr int BM = 192, BN = 256, BK = 64, WGM = 2, WGN 
 // with 3/4 of the L2 -> LDS operand bytes per flop of the 128 x 128 tiles (the stream every 128 x 128 GEMM here is bound by,
 // DESIGN.md section 5) and 3/4 of the fragment reads per MFMA (a 128 x 64 wave tile: 12 reads per 24 MFMAs).
 struct G3CfgMX { static constexpr int BM = 256, BN = 128, BK = 32, WGM = 2, WGN = 2, NST = 3, OCC = 2; };
+// HX (round 5): 64 x 128 tiles (waves of 32 x 64), 24 KB per stage, 2 stages -> three workgroups per CU: the residual GEMMs of a
+// single-file forward (M = 3000 rows: out-projection and FF2 are 24 x 4 = 96 tiles of 128 x 128 on 256 CUs) get twice the
+// workgroups at half the work each.  Same MFMAs on the same operand pieces in the same k order per output element:
+// bit-identical to the other configurations (tested).
+struct G3CfgHX { static constexpr int BM = 64, BN = 128, BK = 64, WGM = 2, WGN = 2, NST = 2, OCC = 3; };
 
 // BT_PREC_F32X3: XCD groups a large weight matrix is split over (1 = off; launch_cfg).  tools/x3_probe.py, M = 24000:
 // FF1 (W = 4 MB of hl32) 206 / 189 / 202 us with 1 / 2 / 4 groups, FF2 175 / 165 / 164, frontend.linear and the
@@ -705,6 +710,9 @@ int launch_gemm3(const Gemm3P& p, hipStream_t s) {
   // 128 x 128 tiles, whose grid is twice as large)
   const long mx_tiles = ((long)p.M + 255) / 256 * ((p.N + 127) / 128);
   const bool mx = p.x3 && p.epi != G3_QKV && !big && !rows192 && force != 0 && ((p.x3 & 15) == 4 || (X3_MX && mx_tiles >= 512));
+  // the 64-row tiles for residual GEMMs whose 128 x 128 grid leaves CUs idle (a single-file forward); x3 & 15 = 5 forces them
+  const long sx_tiles = ((long)p.M + 127) / 128 * ((p.N + 127) / 128);
+  const bool hx = p.x3 && p.epi == G3_RESID && !big && !rows192 && !mx && ((p.x3 & 15) == 5 || ((p.x3 & 15) <= 1 && force_big < 0 && sx_tiles < 256));
   if (p.x3) {
 #ifdef BT_DEV
     // development: ablations of the x3 kernel (results are garbage): BT_G3_ABL = 1 no LDS-DMA after the prologue, 4 no MFMAs
@@ -726,6 +734,7 @@ int launch_gemm3(const Gemm3P& p, hipStream_t s) {
         break;
       case G3_RESID:
         if (mx) launch_cfg<G3_RESID, G3CfgMX, true>(p, s);
+        else if (hx) launch_cfg<G3_RESID, G3CfgHX, true>(p, s);
         else if (rows192) launch_cfg<G3_RESID, G3CfgTX, true>(p, s);
         else if (big) launch_cfg<G3_RESID, G3CfgBX, true>(p, s);
         else launch_cfg<G3_RESID, G3CfgSX, true>(p, s);

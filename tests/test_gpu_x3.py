@@ -34,7 +34,8 @@ def _call(nsplit=0, cfg=1, **kw):
     a = L.Gemm3Args()
     for k, v in kw.items():
         setattr(a, k, v.data_ptr() if isinstance(v, torch.Tensor) else v)
-    # x3 & 15: 1 = the launcher's choice, 3 = 128 x 128 tiles, 4 = the 256 x 128 k16 configuration (gemm3.hip: G3CfgMX);
+    # x3 & 15: 1 = the launcher's choice, 3 = 128 x 128 tiles, 4 = the 256 x 128 k16 configuration (gemm3.hip: G3CfgMX), 5 = the
+    # 64 x 128 tiles (G3CfgHX, residual epilogue only);
     # bits 4.. force the number of XCD groups the weight matrix is split over (launch_cfg)
     a.x3 = cfg | (nsplit << 4)
     L.check(L.lib().bt_gemm3(L.stream_ptr(dev()), C.byref(a)))
@@ -69,7 +70,7 @@ def test_gemm3_x3_ff1(M, K, N, nsplit, cfg):
 @pytest.mark.parametrize("M,K,N,bias,nsplit", [(1500, 2048, 512, True, 0), (777, 512, 512, False, 0), (130, 128, 128, True, 0),
                                                (24000, 2048, 512, True, 0), (32768, 1024, 512, False, 0), (49500, 512, 512, True, 0),
                                                (24000, 2048, 512, True, 2), (32768, 1024, 512, False, 2), (777, 512, 512, False, 4)])
-@pytest.mark.parametrize("cfg", [1, 3, 4])
+@pytest.mark.parametrize("cfg", [1, 3, 4, 5])   # (5 = the 64 x 128 tiles of a single-file forward's residual GEMMs, round 5)
 def test_gemm3_x3_resid(M, K, N, bias, nsplit, cfg):
     if cfg != 1 and (nsplit or M == 32768):
         pytest.skip("forced tile configurations: one pass over the shapes without the XCD-split variants")
@@ -99,7 +100,7 @@ def test_gemm3_x3_tile_configurations_agree_bit_for_bit():
     x = _mk((M, K), 1, 2.0).float()
     W, b = _mk((N, K), 2, 1 / math.sqrt(K)).float(), _mk((N,), 3)
     outs = []
-    for cfg in (3, 4):
+    for cfg in (3, 4, 5):
         out = torch.zeros((M, 2 * N), dtype=torch.float16, device=dev())
         _call(0, cfg, A=to_hl32(x).to(dev()), lda=K, M=M, K=K, W=to_hl32(pad_rows(W, 256)).to(dev()), N=N, epi=0, bias=b.float().to(dev()),
               ssq_in=_ssq_parts(x).to(dev()), ssq_parts=K // 64, out=out, ldo=N, status=_status())
@@ -108,8 +109,9 @@ def test_gemm3_x3_tile_configurations_agree_bit_for_bit():
         _call(0, cfg, A=to_hl32(x).to(dev()), lda=K, M=M, K=K, W=to_hl32(pad_rows(W, 256)).to(dev()), N=N, epi=1, bias=b.float().to(dev()),
               x=xr, ldx=N, xb=xb, ssq_out=torch.zeros((N // 64, M), device=dev()), status=_status())
         outs.append((out, xr, xb))
-    for a, c in zip(outs[0], outs[1]):
-        assert torch.equal(a, c)
+    for other in outs[1:]:
+        for a, c in zip(outs[0], other):
+            assert torch.equal(a, c)
 
 
 @pytest.mark.parametrize("n_seq,L,heads", [(2, 1500, 4), (3, 77, 4), (1, 1, 4), (5, 130, 8), (16, 1500, 16)])
