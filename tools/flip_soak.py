@@ -61,7 +61,7 @@ def margin_stats(x):
     """How close is each peak decision of logit vector x (fp32 oracle)?  A frame t is a peak iff x[t] == max(x[t-3..t+3]) and
     x[t] > 0.  The decision margin of a peak is min(x[t] - second largest in its window, x[t] - 0); of a non-peak with
     x[t] > 0 that is the runner-up of its window: (window max - x[t]).  A perturbation smaller than half the margin cannot
-    flip that decision.  Returns the sorted smallest margins (the frontier's x axis)."""
+    flip that decision.  Returns the sorted margins (the frontier's x axis)."""
     x = np.asarray(x, dtype=np.float64)
     n = len(x)
     pad = np.concatenate([np.full(3, -np.inf), x, np.full(3, -np.inf)])
@@ -73,7 +73,7 @@ def margin_stats(x):
     cand = (~is_peak) & (x > 0)
     m_cand = (omax - x)[cand]                                           # a positive non-peak becomes one
     m_zero = np.abs(x[(x >= omax)])                                     # window maxima near 0 (sign decision)
-    return np.sort(np.concatenate([m_peak, m_cand, m_zero]))[:64]
+    return np.sort(np.concatenate([m_peak, m_cand, m_zero]))
 
 
 def cmd_oracle(args):
