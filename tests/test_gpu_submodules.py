@@ -18,6 +18,9 @@ def _model(style="lively", **hp):
     sd = W.random_state_dict(h, seed=5, style=style)
     m = BeatThis(**h)
     m.load_state_dict(sd)
+    # (sub-module calls run the exact fp32 kernels; the module's own default for whole stages and forwards is the hi + lo path
+    # since round 5 -- these tests compare like with like, the last one also checks the default against the hooked chain)
+    m.fp32_split_gemms = False
     return m.to(dev()).eval(), {k: v.double() if v.is_floating_point() else v for k, v in sd.items()}, h
 
 
@@ -143,4 +146,7 @@ def test_hooks_on_deep_submodules_fire_in_the_whole_forward():
     assert float((hooked["beat"] - plain["beat"]).abs().max()) < 1e-5 and float((hooked["downbeat"] - plain["downbeat"]).abs().max()) < 1e-5
     with torch.inference_mode():
         again = m(x)   # hooks removed: the fast path again
+        m.fp32_split_gemms = True
+        default = m(x)   # the module's default precision against the chain of exact sub-modules: fp32-class agreement
     assert torch.equal(again["beat"], plain["beat"])
+    assert 0 < float((default["beat"] - hooked["beat"]).abs().max()) < 3e-4
