@@ -22,7 +22,7 @@ SOURCES = ["gemm.hip", "gemm2.hip", "gemm3.hip", "attn.hip", "attn2.hip", "fused
 HEADERS = ["common.h", "chain.h", "kernels.h", "attn_x3_loop.inc", os.path.join("..", "..", "include", "beat_this_amd.h")]
 
 BT_OK, BT_ERR_ARG, BT_ERR_HIP, BT_ERR_WORKSPACE = 0, -1, -2, -3
-ABI_VERSION = 500   # BT_ABI_VERSION of include/beat_this_amd.h this binding was written against
+ABI_VERSION = 510   # BT_ABI_VERSION of include/beat_this_amd.h this binding was written against
 PREC_F32, PREC_HALF, PREC_F32X3 = 0, 1, 3   # (2 was the withdrawn e4m3 experiment)
 MAX_LAYERS = 32
 PROFILE_CATEGORIES = ["stem", "qkv_gemm", "attn_flash", "out_gemm", "ff1_gemm", "ff2_gemm", "conv_gemm",
@@ -41,7 +41,8 @@ class PairWeights(C.Structure):
                 ("w_tail_frag", C.c_void_p),
                 ("w_outff_frag_x3", C.c_void_p), ("w_attnff_frag_x3", C.c_void_p),
                 ("w_qkvg_x3", C.c_void_p), ("w_out_x3", C.c_void_p), ("w_ff1_x3", C.c_void_p), ("w_ff2_x3", C.c_void_p),
-                ("w_qkv_frag_x3", C.c_void_p)]
+                ("w_qkv_frag_x3", C.c_void_p),
+                ("w_qkvg_f8", C.c_void_p), ("w_out_f8", C.c_void_p), ("w_ff1_f8", C.c_void_p), ("w_ff2_f8", C.c_void_p)]
 
 
 class ModelDesc(C.Structure):

@@ -1051,11 +1051,26 @@ __global__ __launch_bounds__(256, MINW) void attn_frag_x3_kernel(const AttnFragP
         }
         auto h0 = __builtin_amdgcn_permlane32_swap(xh[0], yh[0], false, false);
         auto h1 = __builtin_amdgcn_permlane32_swap(xh[1], yh[1], false, false);
+        if (p.out_f32 == 2) {
+          // hl8 row (BT_OPT_X3_GEMM_FP8 = 2: the out-projection runs the fp8 cross terms): the group is [32 hi halves | 32 hi bytes |
+          // 32 lo bytes]; this lane's 8 features 16 k + 8 g .. + 7 are 8 bytes in each byte section
+          const float s0 = st[j].acc[8 * k] * scale, s1 = st[j].acc[8 * k + 1] * scale, s2 = st[j].acc[8 * k + 2] * scale, s3 = st[j].acc[8 * k + 3] * scale;
+          const float t0 = st[j].acc[8 * k + 4] * scale, t1 = st[j].acc[8 * k + 5] * scale, t2 = st[j].acc[8 * k + 6] * scale, t3 = st[j].acc[8 * k + 7] * scale;
+          auto b8 = __builtin_amdgcn_permlane32_swap(pk4_f8(s0, s1, s2, s3), pk4_f8(t0, t1, t2, t3), false, false);
+          auto c8 = __builtin_amdgcn_permlane32_swap(lo4_f8(s0, s1, s2, s3, xh[0], xh[1]), lo4_f8(t0, t1, t2, t3, yh[0], yh[1]), false, false);
+          if (okq) {
+            *reinterpret_cast<u32x4*>(op + 16 * k) = u32x4{h0[0], h1[0], h0[1], h1[1]};
+            char* gb = reinterpret_cast<char*>(op) - 16 * g;   // the group's first byte
+            *reinterpret_cast<u32x2*>(gb + 64 + 16 * k + 8 * g) = u32x2{b8[0], b8[1]};
+            *reinterpret_cast<u32x2*>(gb + 96 + 16 * k + 8 * g) = u32x2{c8[0], c8[1]};
+          }
+        } else {
         auto l0 = __builtin_amdgcn_permlane32_swap(xl[0], yl[0], false, false);
         auto l1 = __builtin_amdgcn_permlane32_swap(xl[1], yl[1], false, false);
         if (okq) {
           *reinterpret_cast<u32x4*>(op + 16 * k) = u32x4{h0[0], h1[0], h0[1], h1[1]};
           *reinterpret_cast<u32x4*>(op + 32 + 16 * k) = u32x4{l0[0], l1[0], l0[1], l1[1]};
+        }
         }
       }
     }
@@ -1285,11 +1300,26 @@ __global__ __launch_bounds__(256, 2) void attn_frag_x3q2_kernel(const AttnFragP 
         }
         auto h0 = __builtin_amdgcn_permlane32_swap(xh[0], yh[0], false, false);
         auto h1 = __builtin_amdgcn_permlane32_swap(xh[1], yh[1], false, false);
+        if (p.out_f32 == 2) {
+          // hl8 row (BT_OPT_X3_GEMM_FP8 = 2: the out-projection runs the fp8 cross terms): the group is [32 hi halves | 32 hi bytes |
+          // 32 lo bytes]; this lane's 8 features 16 k + 8 g .. + 7 are 8 bytes in each byte section
+          const float s0 = st[j].acc[8 * k] * scale, s1 = st[j].acc[8 * k + 1] * scale, s2 = st[j].acc[8 * k + 2] * scale, s3 = st[j].acc[8 * k + 3] * scale;
+          const float t0 = st[j].acc[8 * k + 4] * scale, t1 = st[j].acc[8 * k + 5] * scale, t2 = st[j].acc[8 * k + 6] * scale, t3 = st[j].acc[8 * k + 7] * scale;
+          auto b8 = __builtin_amdgcn_permlane32_swap(pk4_f8(s0, s1, s2, s3), pk4_f8(t0, t1, t2, t3), false, false);
+          auto c8 = __builtin_amdgcn_permlane32_swap(lo4_f8(s0, s1, s2, s3, xh[0], xh[1]), lo4_f8(t0, t1, t2, t3, yh[0], yh[1]), false, false);
+          if (okq) {
+            *reinterpret_cast<u32x4*>(op + 16 * k) = u32x4{h0[0], h1[0], h0[1], h1[1]};
+            char* gb = reinterpret_cast<char*>(op) - 16 * gE;   // the group's first byte
+            *reinterpret_cast<u32x2*>(gb + 64 + 16 * k + 8 * gE) = u32x2{b8[0], b8[1]};
+            *reinterpret_cast<u32x2*>(gb + 96 + 16 * k + 8 * gE) = u32x2{c8[0], c8[1]};
+          }
+        } else {
         auto l0 = __builtin_amdgcn_permlane32_swap(xl[0], yl[0], false, false);
         auto l1 = __builtin_amdgcn_permlane32_swap(xl[1], yl[1], false, false);
         if (okq) {
           *reinterpret_cast<u32x4*>(op + 16 * k) = u32x4{h0[0], h1[0], h0[1], h1[1]};
           *reinterpret_cast<u32x4*>(op + 32 + 16 * k) = u32x4{l0[0], l1[0], l0[1], l1[1]};
+        }
         }
       }
     }
@@ -1350,7 +1380,7 @@ int launch_attn_frag(const AttnFragP& p, hipStream_t s) {
     const long wg4 = (long)p.n_seq * p.heads * (((p.L + 31) / 32 + 7) / 8);
     const int kern = p.x3 & 7;
     const int form = (kern == 4 && wg4 >= 1024) || kern == 5 ? 0 : (kern == 2 || kern == 4) ? 1 : 2;   // (5 = forced: tests, probes)
-    switch (form * 4 + (p.out_f32 ? 2 : 0) + ((p.x3 & 8) ? 1 : 0)) {
+    switch (form * 4 + (p.out_f32 == 1 ? 2 : 0) + ((p.x3 & 8) ? 1 : 0)) {   // (out_f32 = 2: hl8 rows, a run-time branch of the hl32 epilogue)
       case 0: launch_x3q2<0, false>(p, s); break;
       case 1: launch_x3q2<0, true>(p, s); break;
       case 2: launch_x3q2<1, false>(p, s); break;

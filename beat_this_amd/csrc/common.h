@@ -169,6 +169,19 @@ DEVI void split_hl(float a, float b, unsigned& whi, unsigned& wlo) {
       : "v"(a), "v"(b), "s"(m1));
 }
 
+// "hl8" operands (BT_OPT_X3_GEMM_FP8, gemm3.hip X3 = 2): four fp32 values -> their four e4m3 bytes (v_cvt_pk_fp8_f32: OCP e4m3 on
+// gfx950, saturating at 448) ...
+DEVI unsigned pk4_f8(float a, float b, float c, float d) {
+  int w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
+  w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
+  return (unsigned)w;
+}
+// ... and, given their packed hi halves, the lo bytes e4m3(2^11 (v - hi)) (difference and scaling are exact in fp32)
+DEVI unsigned lo4_f8(float a, float b, float c, float d, unsigned h01, unsigned h23) {
+  const hfx2 p = __builtin_bit_cast(hfx2, h01), q = __builtin_bit_cast(hfx2, h23);
+  return pk4_f8((a - (float)p[0]) * 2048.f, (b - (float)p[1]) * 2048.f, (c - (float)q[0]) * 2048.f, (d - (float)q[1]) * 2048.f);
+}
+
 DEVI void st16(float* dst, const float* v) {  // 16 floats, 64 B aligned enough for 16 B stores
   f32x4* d = reinterpret_cast<f32x4*>(dst);
 #pragma unroll

@@ -49,6 +49,7 @@ struct bt_engine {
   bt_model_desc d;
   prof::State prof;
   int x3_attn_p16 = 2;   // BT_OPT_X3_ATTN_P16
+  int x3_gemm_fp8 = 0;   // BT_OPT_X3_GEMM_FP8
 };
 enum { CAT_STEM = 0, CAT_QKV, CAT_ATTN_FLASH, CAT_OUT, CAT_FF1, CAT_FF2, CAT_CONV, CAT_LINEAR,
        CAT_HEAD, CAT_FF_FUSED, CAT_ATTN_FREQ_FUSED, CAT_LAYER_TAIL, CAT_COUNT };
@@ -63,6 +64,7 @@ struct Workspace {
   void* qf; void* kf; void* vf; float* gates_h; int nbp;  // fragment-major attention operands (half path)
   float* ssq[2];  // [D / 64][B T] partial row sums of squares of the main residual stream (ping-pong)
   int* status;    // BT_PREC_F32X3 range flag: the FIRST word of the workspace (include/beat_this_amd.h)
+  int x3_gemm_fp8;              // BT_OPT_X3_GEMM_FP8 of this forward
   int x3_attn, x3_attn_front;   // bt_attn_frag_args.x3 of this forward's attention launches, main layers / frontend (kernel choice + BT_X3_P16)
   size_t total;
 };
@@ -78,6 +80,7 @@ Workspace carve(char* base, int B, int T, int D, int ff_mult, int prec) {
   Workspace w;
   w.status = (int*)take(256);
   w.x3_attn = w.x3_attn_front = BT_X3_ATTN;
+  w.x3_gemm_fp8 = 0;
   w.xa = (float*)take(bt * 1024 * 4);
   w.xb = (float*)take(bt * 1024 * 4);
   w.xm = (float*)take(bt * D * 4);
@@ -163,15 +166,17 @@ int run_layer_half(prof::State* pf, const bt_pair_weights& pw, const float* rope
 // Main transformer layer in BT_PREC_F32X3 on the same kernels with hi + lo operands (gemm3.hip X3, attn2.hip
 // attn_frag_x3_kernel): the fp32 residual stream ws.xm is shadowed by hl32 planes (ws.xmb), the attention output and
 // the hidden activation travel as hl32 planes, q / k / v as 4 KB [hi | lo] fragment blocks; statistics as in the half layer.
+// xmb_f8: the shadow of the residual stream this layer finds is hl8 (BT_OPT_X3_GEMM_FP8 = 2: written by the previous layer's FF2 or
+// by frontend.linear); next_f8: this layer's FF2 leaves it in that form for the next one
 int run_layer_x3(prof::State* pf, const bt_pair_weights& pw, const float* rope, const Workspace& ws, int B, int T,
-                 int ff_mult, hipStream_t s) {
+                 int ff_mult, hipStream_t s, bool xmb_f8 = false, bool next_f8 = false) {
   const int D = pw.dim, H = pw.heads, HID = ff_mult * D;
   const int M = B * T;
   const int parts = D / 64;
   Gemm3P g;
   memset(&g, 0, sizeof g);
-  g.A = ws.xmb; g.lda = D; g.M = M; g.K = D; g.W = pw.w_qkvg_x3; g.N = 3 * D + H; g.epi = G3_QKV;
-  g.ssq_in = ws.ssq[0]; g.ssq_parts = parts; g.x3 = 1; g.status = ws.status;
+  g.A = ws.xmb; g.lda = D; g.M = M; g.K = D; g.W = xmb_f8 ? pw.w_qkvg_f8 : pw.w_qkvg_x3; g.N = 3 * D + H; g.epi = G3_QKV;
+  g.ssq_in = ws.ssq[0]; g.ssq_parts = parts; g.x3 = 1 | (xmb_f8 ? G3_X3_F8 : 0); g.status = ws.status;
   g.n_seq = B; g.L = T; g.nblk = (T + 31) / 32; g.nbp = ws.nbp; g.heads = H; g.inner = D; g.rope = rope;
   g.qf = ws.qf; g.kf = ws.kf; g.vf = ws.vf; g.gates = ws.gates_h; g.b_gates = pw.b_gates;
   LAUNCH_CAT(CAT_QKV, s, launch_gemm3(g, s), "qkv gemm (hi + lo)");
@@ -179,18 +184,26 @@ int run_layer_x3(prof::State* pf, const bt_pair_weights& pw, const float* rope, 
   memset(&a, 0, sizeof a);
   a.q = ws.qf; a.k = ws.kf; a.v = ws.vf; a.gates = ws.gates_h; a.out = ws.ao; a.n_seq = B; a.L = T; a.heads = H;
   a.inner = D; a.nbp = ws.nbp; a.o_div = 1; a.o_outer = T; a.o_inner = 0; a.o_tok = 1;
-  a.x3 = ws.x3_attn; a.out_f32 = 0; a.status = ws.status;   // (which x3 attention kernel / arithmetic: attn2.hip launch_attn_frag)
+  // BT_OPT_X3_GEMM_FP8 = 2: out-projection (and QKV) on hl8 operands as well -- the attention writes its rows in that form
+  const bool out8 = ws.x3_gemm_fp8 >= 2 && pw.w_out_f8;
+  a.x3 = ws.x3_attn; a.out_f32 = out8 ? 2 : 0; a.status = ws.status;   // (which x3 attention kernel / arithmetic: attn2.hip launch_attn_frag)
   LAUNCH_CAT(CAT_ATTN_FLASH, s, launch_attn_frag(a, s), "attention (hi + lo)");
+  // BT_OPT_X3_GEMM_FP8 >= 1: the feed-forward GEMMs on hl8 operands (fp8 cross terms): the out-projection leaves its shadow of
+  // the residual stream in that form, FF1 its hidden activation; FF2's shadow feeds the next layer's QKV and stays hl32
+  const bool ff8 = ws.x3_gemm_fp8 >= 1 && pw.w_ff1_f8 && pw.w_ff2_f8;
   memset(&g, 0, sizeof g);
-  g.A = ws.ao; g.lda = D; g.M = M; g.K = D; g.W = pw.w_out_x3; g.N = D; g.epi = G3_RESID; g.x3 = 1; g.status = ws.status;
+  g.A = ws.ao; g.lda = D; g.M = M; g.K = D; g.W = out8 ? pw.w_out_f8 : pw.w_out_x3; g.N = D; g.epi = G3_RESID; g.status = ws.status;
+  g.x3 = 1 | (out8 ? G3_X3_F8 : 0) | (ff8 ? G3_X3_OUT_F8 : 0);
   g.x = ws.xm; g.ldx = D; g.xb = ws.xmb; g.ssq_out = ws.ssq[1];
   LAUNCH_CAT(CAT_OUT, s, launch_gemm3(g, s), "out-proj gemm (hi + lo)");
   memset(&g, 0, sizeof g);
-  g.A = ws.xmb; g.lda = D; g.M = M; g.K = D; g.W = pw.w_ff1_x3; g.N = HID; g.epi = G3_FF1; g.x3 = 1; g.status = ws.status;
+  g.A = ws.xmb; g.lda = D; g.M = M; g.K = D; g.W = ff8 ? pw.w_ff1_f8 : pw.w_ff1_x3; g.N = HID; g.epi = G3_FF1; g.status = ws.status;
+  g.x3 = 1 | (ff8 ? G3_X3_F8 | G3_X3_OUT_F8 : 0);
   g.bias = pw.b_ff1; g.ssq_in = ws.ssq[1]; g.ssq_parts = parts; g.out = ws.hid; g.ldo = HID;
   LAUNCH_CAT(CAT_FF1, s, launch_gemm3(g, s), "ff1 gemm (hi + lo)");
   memset(&g, 0, sizeof g);
-  g.A = ws.hid; g.lda = HID; g.M = M; g.K = HID; g.W = pw.w_ff2_x3; g.N = D; g.epi = G3_RESID; g.x3 = 1; g.status = ws.status;
+  g.A = ws.hid; g.lda = HID; g.M = M; g.K = HID; g.W = ff8 ? pw.w_ff2_f8 : pw.w_ff2_x3; g.N = D; g.epi = G3_RESID; g.status = ws.status;
+  g.x3 = 1 | (ff8 ? G3_X3_F8 : 0) | (next_f8 ? G3_X3_OUT_F8 : 0);
   g.bias = pw.b_ff2; g.x = ws.xm; g.ldx = D; g.xb = ws.xmb; g.ssq_out = ws.ssq[0];
   LAUNCH_CAT(CAT_FF2, s, launch_gemm3(g, s), "ff2 gemm (hi + lo)");
   return BT_OK;
@@ -347,11 +360,13 @@ void bt_engine_destroy(bt_engine* e) {
 int bt_engine_set_option(bt_engine* e, int option, int value) {
   if (!e) return bt_set_error(BT_ERR_ARG, "null argument");
   if (option == BT_OPT_X3_ATTN_P16 && value >= 0 && value <= 2) { e->x3_attn_p16 = value; return BT_OK; }
+  if (option == BT_OPT_X3_GEMM_FP8 && value >= 0 && value <= 2) { e->x3_gemm_fp8 = value; return BT_OK; }
   return bt_set_error(BT_ERR_ARG, "unknown engine option / value");
 }
 int bt_engine_get_option(const bt_engine* e, int option, int* value) {
   if (!e || !value) return bt_set_error(BT_ERR_ARG, "null argument");
   if (option == BT_OPT_X3_ATTN_P16) { *value = e->x3_attn_p16; return BT_OK; }
+  if (option == BT_OPT_X3_GEMM_FP8) { *value = e->x3_gemm_fp8; return BT_OK; }
   return bt_set_error(BT_ERR_ARG, "unknown engine option");
 }
 
@@ -382,6 +397,7 @@ int bt_forward_stages(bt_engine* e, void* stream, int prec, int first, int last,
   if (ws.total > ws_bytes) return bt_set_error(BT_ERR_WORKSPACE, "workspace too small");
   ws.x3_attn = BT_X3_ATTN | (e->x3_attn_p16 >= 1 ? BT_X3_P16 : 0);
   ws.x3_attn_front = BT_X3_ATTN | (e->x3_attn_p16 >= 2 ? BT_X3_P16 : 0);
+  ws.x3_gemm_fp8 = e->x3_gemm_fp8;
   hipStream_t s = (hipStream_t)stream;
   const bool x3 = prec == BT_PREC_F32X3;
   if (x3) {
@@ -413,6 +429,7 @@ int bt_forward_stages(bt_engine* e, void* stream, int prec, int first, int last,
   }
 
   const size_t xm_bytes = (size_t)B * T * D * 4;
+  bool xmb_f8 = false;   // the shadow of the main residual stream is hl8 (BT_OPT_X3_GEMM_FP8 = 2) when the first layer starts
   if (first == 2) {  // task_heads on a normalised [B,T,D] input
     if (!d.head_w_raw) return bt_set_error(BT_ERR_ARG, "stage entry at task_heads needs head_w_raw");
     HeadP hp;
@@ -484,7 +501,8 @@ int bt_forward_stages(bt_engine* e, void* stream, int prec, int first, int last,
     memset(&g, 0, sizeof g);
     g.A = x; g.lda = 1024; g.M = B * T; g.K = 1024; g.W = fast_x3 ? d.lin_w_x3 : d.lin_w[BT_PREC_HALF]; g.N = D; g.epi = G3_RESID;
     g.no_resid = 1; g.bias = d.lin_b; g.x = ws.xm; g.ldx = D; g.xb = ws.xmb; g.ssq_out = ws.ssq[0];
-    g.x3 = fast_x3; g.status = ws.status;
+    xmb_f8 = fast_x3 && ws.x3_gemm_fp8 >= 2 && d.n_layers > 0 && d.layers[0].w_qkvg_f8;   // (layer 0's QKV reads it in that form)
+    g.x3 = fast_x3 ? 1 | (xmb_f8 ? G3_X3_OUT_F8 : 0) : 0; g.status = ws.status;
     LAUNCH_CAT(CAT_LINEAR, s, launch_gemm3(g, s), "frontend linear gemm");
   } else {
     GemmP g;
@@ -506,11 +524,14 @@ int bt_forward_stages(bt_engine* e, void* stream, int prec, int first, int last,
     return BT_OK;
   }
   for (int l = 0; l < d.n_layers; ++l) {
-    int rc = fast_x3 ? run_layer_x3(pf, d.layers[l], d.rope, ws, B, T, d.ff_mult, s)
+    // (hl8 shadow for the next layer's QKV: only when that layer has the weights for it)
+    const bool next_f8 = fast_x3 && ws.x3_gemm_fp8 >= 2 && l + 1 < d.n_layers && d.layers[l + 1].w_qkvg_f8 && d.layers[l].w_ff2_f8;
+    int rc = fast_x3 ? run_layer_x3(pf, d.layers[l], d.rope, ws, B, T, d.ff_mult, s, xmb_f8, next_f8)
              : fast_layers ? run_layer_half(pf, d.layers[l], d.rope, ws, B, T, d.ff_mult, s)
                          : run_pair(pf, d.layers[l], d.rope, ws.xm, use_shadow ? ws.xmb : nullptr, ws, B, T, 1, 0, prec, s, nullptr,
                                     d.ff_mult, x3);
     if (rc) return rc;
+    xmb_f8 = next_f8;
   }
   if (last == 1) {
     if (!d.norm_out_g) return bt_set_error(BT_ERR_ARG, "stage exit after transformer_blocks needs norm_out_g");

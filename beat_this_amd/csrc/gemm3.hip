@@ -120,6 +120,28 @@ DEVI void pack_row_hl(const float (&v)[16], u32x4 (&hi)[2], u32x4 (&lo)[2], floa
     lo[k] = u32x4{l0[0], l1[0], l0[1], l1[1]};
   }
 }
+// pack_row_hl for the hl8 form: hi halves as there; hi bytes / lo bytes of the lane's 8 features 16 k + 8 g .. + 7 after the exchange
+DEVI void pack_row_f8(const float (&v)[16], u32x4 (&hi)[2], u32x2 (&h8)[2], u32x2 (&l8)[2], float& amax) {
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    unsigned xh[2], xl[2], yh[2], yl[2];
+    split2(v[8 * k], v[8 * k + 1], xh[0], xl[0], amax);
+    split2(v[8 * k + 2], v[8 * k + 3], xh[1], xl[1], amax);
+    split2(v[8 * k + 4], v[8 * k + 5], yh[0], yl[0], amax);
+    split2(v[8 * k + 6], v[8 * k + 7], yh[1], yl[1], amax);
+    const unsigned x8 = pk4_f8(v[8 * k], v[8 * k + 1], v[8 * k + 2], v[8 * k + 3]);
+    const unsigned y8 = pk4_f8(v[8 * k + 4], v[8 * k + 5], v[8 * k + 6], v[8 * k + 7]);
+    const unsigned xl8 = lo4_f8(v[8 * k], v[8 * k + 1], v[8 * k + 2], v[8 * k + 3], xh[0], xh[1]);
+    const unsigned yl8 = lo4_f8(v[8 * k + 4], v[8 * k + 5], v[8 * k + 6], v[8 * k + 7], yh[0], yh[1]);
+    auto h0 = __builtin_amdgcn_permlane32_swap(xh[0], yh[0], false, false);
+    auto h1 = __builtin_amdgcn_permlane32_swap(xh[1], yh[1], false, false);
+    auto b8 = __builtin_amdgcn_permlane32_swap(x8, y8, false, false);
+    auto c8 = __builtin_amdgcn_permlane32_swap(xl8, yl8, false, false);
+    hi[k] = u32x4{h0[0], h1[0], h0[1], h1[1]};
+    h8[k] = u32x2{b8[0], b8[1]};
+    l8[k] = u32x2{c8[0], c8[1]};
+  }
+}
 // range guard: one flag word per forward (Gemm3P.status), set when a value beyond the fp16 range went through a split
 DEVI void flag_range(int* status, float amax) {
   if (status && __any(!(amax <= 65504.f)) && (threadIdx.x & 63) == 0) atomicOr(status, 1);
@@ -127,7 +149,15 @@ DEVI void flag_range(int* status, float amax) {
 
 // ABL (development, BT_G3_ABL = 8): per-wave timing dump (k-loop, waits, epilogue) read by tools/gemm3_probe.py;
 // bits 0 - 2 (no LDS-DMA after the prologue / no GELU / no MFMAs) are ablations that can be instantiated by hand
-template <int EPI, typename CFG, bool X3 = false, int ABL = 0>
+// X3: 0 = half operands, 1 = hl32 operands (BT_PREC_F32X3), 2 = "hl8" operands (round 5, BASELINE config 5: the cross terms
+// of the hi + lo product on ONE block-scaled fp8 MFMA per 32-k step).  An hl8 group of 32 columns is 128 B like an hl32 one:
+// [32 hi halves | 32 hi bytes = e4m3(v) | 32 lo bytes = e4m3(2^11 (v - hi))]; per 32-k step and tile pair
+//   acc += 2^-11 [hi bytes(P) | lo bytes(P)] . [lo bytes(Q) | hi bytes(Q)]     v_mfma_scale_f32_32x32x64_f8f6f4, K = 64 = both
+//                                                                               cross terms, the 2^-11 in its E8M0 scale operand
+//   acc += hi(P) . hi(Q)                                                        two v_mfma_f32_32x32x16_f16
+// i.e. 64 + 64 matrix-pipe cycles where the three-term form spends 192 (the scaled fp8 MFMA runs at 2.3 x the fp16 rate:
+// tools/ubench/mfma_f8_cross.hip), on the same ring, swizzle, fragment-read count and operand registers.
+template <int EPI, typename CFG, int X3 = 0, int ABL = 0>
 __global__ __launch_bounds__(64 * CFG::WGM * CFG::WGN, (CFG::OCC * CFG::WGM * CFG::WGN + 3) / 4)
 void gemm3_kernel(const Gemm3P p, int n_tiles, int total_tiles, int per_xcd, int nsplit) {
   constexpr int BM = CFG::BM, BN = CFG::BN, BK = CFG::BK, NST = CFG::NST;
@@ -145,6 +175,7 @@ void gemm3_kernel(const Gemm3P p, int n_tiles, int total_tiles, int per_xcd, int
   static_assert(EPI != G3_QKV || TB == FB, "the V columns swap the operand roles: square wave tile needed");
   static_assert(BN / CFG::WGN == 64, "ssq partials are per 64 columns = one wave");
   static_assert(!X3 || ROWB == 128 || ROWB == 64, "hl32: a k-step is a whole group (128 B per row) or half of one (64 B)");
+  static_assert(X3 != 2 || ROWB == 128, "hl8: a k-step is a whole 32-column group");
   static_assert(NST * ST_BYTES >= NW * 8192, "the epilogues stage 8 KB per wave in the ring's LDS");
   __shared__ __attribute__((aligned(16))) char smem[NST * ST_BYTES];
   // XCD-aware tile order (block b -> XCD b % 8).  nsplit = 1: the n-tiles sharing one A panel run on the same XCD, an XCD
@@ -345,7 +376,45 @@ void gemm3_kernel(const Gemm3P p, int n_tiles, int total_tiles, int per_xcd, int
     if constexpr ((ABL & 8) != 0) { const long long tq2 = clock64(); t_wait += tq1 - tq0; t_bar += tq2 - tq1; }
     if (kt + NST - 1 < nk && !(ABL & 1)) G3_ISSUE(kt + NST - 1, stage2);
     const char* st = smem + stage * ST_BYTES;
-    if constexpr (!X3) {
+    if constexpr (X3 == 2) {
+      // chunks of a 128-byte row: 0 .. 3 the hi halves (k16 piece m = chunks 2 m, 2 m + 1), 4, 5 the hi bytes, 6, 7 the lo
+      // bytes.  P side: lane half 0 supplies its row's hi bytes, half 1 its lo bytes; Q side the other way round.
+      typedef __attribute__((ext_vector_type(8))) int i32x8;
+      const int cP = 4 + 2 * g, cQ = 6 - 2 * g;
+      const int kP0 = (cP ^ sw) * 16, kP1 = ((cP + 1) ^ sw) * 16, kQ0 = (cQ ^ sw) * 16, kQ1 = ((cQ + 1) ^ sw) * 16;
+      {
+        i32x8 p8[NP], q8[NQ];
+#pragma unroll
+        for (int a = 0; a < NP; ++a) {
+          const u32x4 lo = *reinterpret_cast<const u32x4*>(st + pofs + a * 32 * ROWB + kP0);
+          const u32x4 hi = *reinterpret_cast<const u32x4*>(st + pofs + a * 32 * ROWB + kP1);
+          p8[a] = i32x8{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
+        }
+#pragma unroll
+        for (int b = 0; b < NQ; ++b) {
+          const u32x4 lo = *reinterpret_cast<const u32x4*>(st + qofs + b * 32 * ROWB + kQ0);
+          const u32x4 hi = *reinterpret_cast<const u32x4*>(st + qofs + b * 32 * ROWB + kQ1);
+          q8[b] = i32x8{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
+        }
+#pragma unroll
+        for (int a = 0; a < NP; ++a)
+#pragma unroll
+          for (int b = 0; b < NQ; ++b)   // scale of the first operand 2^-11 (E8M0 byte 116), of the second 1 (127)
+            acc[a][b] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(p8[a], q8[b], acc[a][b], 0, 0, 0, 0x74747474, 0, 0x7f7f7f7f);
+      }
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        hfx8 ph[NP], qh[NQ];
+#pragma unroll
+        for (int a = 0; a < NP; ++a) ph[a] = *reinterpret_cast<const hfx8*>(st + pofs + a * 32 * ROWB + kc[m]);
+#pragma unroll
+        for (int b = 0; b < NQ; ++b) qh[b] = *reinterpret_cast<const hfx8*>(st + qofs + b * 32 * ROWB + kc[m]);
+#pragma unroll
+        for (int a = 0; a < NP; ++a)
+#pragma unroll
+          for (int b = 0; b < NQ; ++b) acc[a][b] = MFMA32_H(ph[a], qh[b], acc[a][b]);
+      }
+    } else if constexpr (!X3) {
 #pragma unroll
       for (int m = 0; m < ((ABL & 4) ? 0 : MS); ++m) {
         hfx8 fp[NP], fq[NQ];
@@ -416,12 +485,24 @@ void gemm3_kernel(const Gemm3P p, int n_tiles, int total_tiles, int per_xcd, int
         float v[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) v[r] = gelu_erf(fmaf(acc[a][b][r], rs[b], bqv[a][r >> 2][r & 3]));
+        if (p.x3 & G3_X3_OUT_F8) {   // hl8 hidden activation (the next GEMM runs the fp8 cross terms): [hi halves | hi bytes | lo bytes]
+          u32x4 hi[2];
+          u32x2 h8[2], l8[2];
+          pack_row_f8(v, hi, h8, l8, amax);
+#pragma unroll
+          for (int k = 0; k < 2; ++k) {   // chunks 8 a + 0 .. 3 the halves, 8 a + 4, 5 the hi bytes (features 16 k ..), 8 a + 6, 7 the lo bytes
+            *reinterpret_cast<u32x4*>(wst + lr * 256 + (((8 * a + 2 * k + g) ^ (lr & 15)) << 4)) = hi[k];
+            *reinterpret_cast<u32x2*>(wst + lr * 256 + (((8 * a + 4 + k) ^ (lr & 15)) << 4) + 8 * g) = h8[k];
+            *reinterpret_cast<u32x2*>(wst + lr * 256 + (((8 * a + 6 + k) ^ (lr & 15)) << 4) + 8 * g) = l8[k];
+          }
+        } else {
         u32x4 hi[2], lo[2];
         pack_row_hl(v, hi, lo, amax);
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
           *reinterpret_cast<u32x4*>(wst + lr * 256 + (((8 * a + 2 * k + g) ^ (lr & 15)) << 4)) = hi[k];
           *reinterpret_cast<u32x4*>(wst + lr * 256 + (((8 * a + 4 + 2 * k + g) ^ (lr & 15)) << 4)) = lo[k];
+        }
         }
       }
       static_assert(FB == 2, "row = 64 features = 256 B of hl32");
@@ -534,7 +615,13 @@ void gemm3_kernel(const Gemm3P p, int n_tiles, int total_tiles, int per_xcd, int
               split2(v[2], v[3], wh[1], wl[1], amax);
               hf* d = xb + (2u * off - (f & 31u));
               *reinterpret_cast<u32x2*>(d) = u32x2{wh[0], wh[1]};
-              *reinterpret_cast<u32x2*>(d + 32) = u32x2{wl[0], wl[1]};
+              if (p.x3 & G3_X3_OUT_F8) {   // hl8 shadow: the group's hi bytes start 64 B, its lo bytes 96 B behind its first hi half
+                char* gb = reinterpret_cast<char*>(d) - (f & 31u);   // = group base + (f & 31)
+                *reinterpret_cast<unsigned*>(gb + 64) = pk4_f8(v[0], v[1], v[2], v[3]);
+                *reinterpret_cast<unsigned*>(gb + 96) = lo4_f8(v[0], v[1], v[2], v[3], wh[0], wh[1]);
+              } else {
+                *reinterpret_cast<u32x2*>(d + 32) = u32x2{wl[0], wl[1]};
+              }
             }
           } else {
             if (xb) *reinterpret_cast<u32x2*>(xb + off) = u32x2{pk2(v[0], v[1]), pk2(v[2], v[3])};
@@ -632,7 +719,7 @@ void gemm3_kernel(const Gemm3P p, int n_tiles, int total_tiles, int per_xcd, int
   }
 }
 
-template <int EPI, typename CFG, bool X3 = false, int ABL = 0>
+template <int EPI, typename CFG, int X3 = 0, int ABL = 0>
 void launch_cfg(const Gemm3P& p, hipStream_t s) {
   const int n_tiles = (p.N + CFG::BN - 1) / CFG::BN;
   const long rows = p.epi == G3_QKV ? (long)p.n_seq * p.nblk * 32 : (long)p.M;
@@ -640,7 +727,7 @@ void launch_cfg(const Gemm3P& p, hipStream_t s) {
   const long total = m_tiles * n_tiles;
   // W split over XCD groups (see the kernel): forced through x3 >> 4 by tools/x3_probe.py, otherwise for an x3 weight matrix
   // beyond ~2.5 MB whose n-tiles divide evenly
-  int nsplit = p.x3 >> 4;
+  int nsplit = (p.x3 >> 4) & 15;
   if (nsplit == 0) nsplit = (X3 && X3_NSPLIT > 1 && (long)n_tiles * CFG::BN * p.K * 4 > (5L << 19) && n_tiles % X3_NSPLIT == 0) ? X3_NSPLIT : 1;
   if (nsplit != 2 && nsplit != 4 && nsplit != 8) nsplit = 1;
   if (n_tiles % nsplit) nsplit = 1;
@@ -709,7 +796,8 @@ int launch_gemm3(const Gemm3P& p, hipStream_t s) {
   // (taken when its 256-row tiles still give every CU its two workgroups: a 2-chunk single-file forward stays on the
   // 128 x 128 tiles, whose grid is twice as large)
   const long mx_tiles = ((long)p.M + 255) / 256 * ((p.N + 127) / 128);
-  const bool mx = p.x3 && p.epi != G3_QKV && !big && !rows192 && force != 0 && ((p.x3 & 15) == 4 || (X3_MX && mx_tiles >= 512));
+  const bool f8 = (p.x3 & G3_X3_F8) != 0;   // A and W are hl8 (the kernel's X3 = 2 form: 128-byte rows only)
+  const bool mx = p.x3 && !f8 && p.epi != G3_QKV && !big && !rows192 && force != 0 && ((p.x3 & 15) == 4 || (X3_MX && mx_tiles >= 512));
   // the 64-row tiles for residual GEMMs whose 128 x 128 grid leaves CUs idle (a single-file forward); x3 & 15 = 5 forces them
   const long sx_tiles = ((long)p.M + 127) / 128 * ((p.N + 127) / 128);
   const bool hx = p.x3 && p.epi == G3_RESID && !big && !rows192 && !mx && ((p.x3 & 15) == 5 || ((p.x3 & 15) <= 1 && force_big < 0 && sx_tiles < 256));
@@ -727,6 +815,15 @@ int launch_gemm3(const Gemm3P& p, hipStream_t s) {
       return (int)hipGetLastError();
     }
 #endif
+    if (f8) {
+      if (p.epi == G3_QKV) launch_cfg<G3_QKV, G3CfgSX, 2>(p, s);
+      else if (p.epi == G3_FF1) { if (big) launch_cfg<G3_FF1, G3CfgBX, 2>(p, s); else launch_cfg<G3_FF1, G3CfgSX, 2>(p, s); }
+      else if (hx) launch_cfg<G3_RESID, G3CfgHX, 2>(p, s);
+      else if (rows192) launch_cfg<G3_RESID, G3CfgTX, 2>(p, s);
+      else if (big) launch_cfg<G3_RESID, G3CfgBX, 2>(p, s);
+      else launch_cfg<G3_RESID, G3CfgSX, 2>(p, s);
+      return (int)hipGetLastError();
+    }
     switch (p.epi) {
       case G3_FF1:
         if (mx) launch_cfg<G3_FF1, G3CfgMX, true>(p, s);

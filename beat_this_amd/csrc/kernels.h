@@ -77,9 +77,12 @@ struct Gemm3P {
   // [N padded, 2 K], out = half [M, 2 ldo], xb = half [M, 2 ldx], attention blocks of 4 KB ([hi 2 KB | lo 2 KB]); K, lda,
   // ldo, ldx stay in fp32 elements.  FF1 uses the exact erf GELU.  status (may be null): set to 1 when a value beyond
   // the fp16 range went through a hi + lo split (the caller then repeats the forward in BT_PREC_F32).
+  // x3 + G3_X3_F8: A and W are "hl8" (per 32 columns 32 hi halves | 32 hi bytes | 32 lo bytes: gemm3.hip, X3 = 2) -- FF1 and
+  // RESID epilogues only; x3 + G3_X3_OUT_F8: the activation this launch writes for the next GEMM (FF1: out; RESID: xb) is hl8.
   int x3;
   int* status;
 };
+enum { G3_X3_F8 = 0x100, G3_X3_OUT_F8 = 0x200 };
 bool gemm3_supported(const Gemm3P& p);
 int launch_gemm3(const Gemm3P& p, hipStream_t s);
 
@@ -105,7 +108,7 @@ struct AttnFragP {
   int o_div;
   long o_outer, o_inner, o_tok;
   // BT_PREC_F32X3: x3 != 0 -> q, k, v blocks are 4 KB ([hi block | lo block], attn2.hip); out is fp32 [rows, inner]
-  // (out_f32 != 0) or hl32 planes half [rows, 2 inner]; status: range flag of the hl32 output (may be null).
+  // (out_f32 = 1), hl32 planes half [rows, 2 inner] (0) or hl8 rows (2; gemm3.hip X3 = 2); status: range flag of the hl32 output (may be null).
   // x3 = 1: 128-key LDS tiles, x3 = 2: 64-key tiles (same results)
   int x3, out_f32;
   int* status;

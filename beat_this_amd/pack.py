@@ -207,6 +207,25 @@ class PackedModel:
         self._keep.append(t)
         return t.data_ptr()
 
+    def _hl8(self, w: torch.Tensor) -> int:
+        """BT_OPT_X3_GEMM_FP8 form of a GEMM weight for csrc/gemm3.hip (X3 = 2): fp32 [N, K] (K % 32 == 0) -> [N padded to 256]
+        rows of 128 B per 32 columns like ``_hl32``: the 32 hi halves (half(w)), the 32 hi bytes (e4m3(w)) and the 32 lo bytes
+        (e4m3(2^11 (w - hi))) -- the two cross terms of the hi + lo product then run on one block-scaled fp8 MFMA per 32-k
+        step.  0 (NULL) in a bfloat16 build or where torch has no float8_e4m3fn."""
+        if _lib.lib().bt_half_is_bf16() or not hasattr(torch, "float8_e4m3fn"):
+            return 0
+        w = _pad_rows(w.to(torch.float32), 256)
+        n, k = w.shape
+        hi = w.to(torch.float16)
+        lo = (w - hi.to(torch.float32)) * 2048.0
+        t = torch.empty((n, k // 32, 128), dtype=torch.uint8)
+        t[:, :, :64] = hi.contiguous().view(n, k // 32, 32).view(torch.uint8)
+        t[:, :, 64:96] = w.clamp(-448, 448).to(torch.float8_e4m3fn).view(torch.uint8).view(n, k // 32, 32)
+        t[:, :, 96:] = lo.clamp(-448, 448).to(torch.float8_e4m3fn).view(torch.uint8).view(n, k // 32, 32)
+        t = t.contiguous().to(self.device)
+        self._keep.append(t)
+        return t.data_ptr()
+
     def _pair(self, pw, sd, pa: str, pf: str, dim: int, x3: bool = False) -> None:
         heads = dim // 32
         pw.dim, pw.heads = dim, heads
@@ -230,6 +249,11 @@ class PackedModel:
             pw.w_out_x3 = self._hl32(sd[pa + "to_out.0.weight"])
             pw.w_ff1_x3 = self._hl32(sd[pf + "net.1.weight"] * sd[pf + "net.0.gamma"][None, :])
             pw.w_ff2_x3 = self._hl32(sd[pf + "net.4.weight"])
+            # BT_OPT_X3_GEMM_FP8: the same four matrices with the lo halves as (hi byte, lo byte) pairs
+            pw.w_qkvg_f8 = self._hl8(w)
+            pw.w_out_f8 = self._hl8(sd[pa + "to_out.0.weight"])
+            pw.w_ff1_f8 = self._hl8(sd[pf + "net.1.weight"] * sd[pf + "net.0.gamma"][None, :])
+            pw.w_ff2_f8 = self._hl8(sd[pf + "net.4.weight"])
         # (the register-chained kernels of fused.hip / fused2.hip are built for a hidden width of 4 dim: a main layer with
         # another ff_mult and dim <= 128 runs on the plain GEMM path)
         if dim <= 128 and sd[pf + "net.1.weight"].shape[0] == 4 * dim:
@@ -298,6 +322,7 @@ class PackedPair:
     _f32 = PackedModel._f32
     _mat = PackedModel._mat
     _hl32 = PackedModel._hl32
+    _hl8 = PackedModel._hl8
     _x3_stream = PackedModel._x3_stream
 
 
@@ -332,11 +357,12 @@ class Engine:
 
     MAX_WORKSPACES = 4
     SHRINK_AFTER = 8   # consecutive requests of < 1/4 of a stream's workspace before it is given back
-    OPTIONS = {"x3_attn_p16": 1}   # name -> BT_OPT_* of include/beat_this_amd.h
+    OPTIONS = {"x3_attn_p16": 1, "x3_gemm_fp8": 2}   # name -> BT_OPT_* of include/beat_this_amd.h
 
     def set_options(self, opts: dict) -> None:
         """Arithmetic variants of the engine (bt_engine_set_option), e.g. ``{"x3_attn_p16": 0}`` for the three-term P.V of
-        rounds 3 - 4 everywhere, ``1`` for P16 in the main layers only, ``2`` (default) main layers + frontend.  Captured forwards are dropped: a graph replays the kernels it was recorded with."""
+        rounds 3 - 4 everywhere, ``1`` for P16 in the main layers only, ``2`` (default) main layers + frontend;
+        ``{"x3_gemm_fp8": 1 | 2}`` for BASELINE config 5 (fp8 cross terms in the feed-forward / in all main-layer GEMMs).  Captured forwards are dropped: a graph replays the kernels it was recorded with."""
         for name, value in opts.items():
             if name not in self.OPTIONS:
                 raise ValueError(f"unknown engine option {name!r} (known: {sorted(self.OPTIONS)})")

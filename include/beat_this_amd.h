@@ -108,6 +108,13 @@ typedef struct {
   const void* w_ff1_x3;
   const void* w_ff2_x3;
   const void* w_qkv_frag_x3;
+  /* BT_OPT_X3_GEMM_FP8 (BASELINE config 5): the four matrices of w_*_x3 as "hl8" half arrays [N padded to 256][2 K] -- per 32
+   * columns 32 hi halves, 32 hi bytes e4m3(w), 32 lo bytes e4m3(2^11 (w - hi)): 128 B like an hl32 group.  NULL: the hl32
+   * form runs for that GEMM. */
+  const void* w_qkvg_f8;
+  const void* w_out_f8;
+  const void* w_ff1_f8;
+  const void* w_ff2_f8;
 } bt_pair_weights;
 
 /* Packed BeatThis weights (beat_tracker.py:38-106).  Host-side packing is done by
@@ -153,7 +160,7 @@ typedef struct {
 const char* bt_last_error(void);
 /* ABI version of this header: bumped whenever an entry point's signature, a struct layout or a BT_PREC_* value changes; a
  * binding must see exactly the value it was written against (beat_this_amd/_lib.py does) */
-#define BT_ABI_VERSION 500
+#define BT_ABI_VERSION 510
 int bt_version(void);
 /* operand type of the half-precision path (BT_PREC_HALF slot of the weight arrays) this library was built
  * with: 0 = IEEE fp16 (default), 1 = bfloat16 (-DBT_HALF_BF16) */
@@ -173,8 +180,14 @@ void bt_engine_destroy(bt_engine* e);
  *                       three), row sums from the same rounded values:  2 (default) in the main layers and in the frontend's
  *                       time-direction attention;  1 in the main layers only (logit error of the three-term form: the frontend's
  *                       three attention layers carry 3/4 of what P16 adds);  0: three-term P.V with the probabilities split
- *                       hi + lo everywhere (rounds 3 - 4). */
+ *                       hi + lo everywhere (rounds 3 - 4).
+ *   BT_OPT_X3_GEMM_FP8  0 (default);  BASELINE config 5 -- GEMMs of the main layers run the two cross terms of every hi + lo product
+ *                       (hi . lo + lo . hi: 2^-11 of the product) on ONE block-scaled fp8 MFMA per 32-k step instead of four fp16
+ *                       ones, operands travelling as hl8 (bt_pair_weights.w_*_f8): 2 MFMA units per product instead of 3.
+ *                       1: the feed-forward GEMMs (FF1, FF2);  2: out-projection and QKV as well.  An opt-in speed setting inside
+ *                       the 1e-3 gate, reported beside the default (bench.py: configs.cfg5; flip rates: DESIGN.md section 3). */
 #define BT_OPT_X3_ATTN_P16 1
+#define BT_OPT_X3_GEMM_FP8 2
 int bt_engine_set_option(bt_engine* e, int option, int value);
 int bt_engine_get_option(const bt_engine* e, int option, int* value);
 /* bytes of scratch bt_forward needs for a [B,T,128] batch (its first int32 is the BT_PREC_F32X3 range flag) */
@@ -306,7 +319,9 @@ int bt_attention(void* stream, int prec, const bt_attn_args* a);
  * [8 tokens 16 s + 8 (j >> 2) + 4 g + (j & 3)]; gates [n_seq * heads][nbp * 32] fp32.  q must be
  * pre-scaled by log2(e)/sqrt(32).  nbp >= bt_attn_frag_blocks(L).  Output as bt_attention (half).
  * x3 != 0 (BT_PREC_F32X3): blocks of 4 KB = [hi block | lo block] of the fp32 values, three MFMAs per product; output
- * fp32 [rows, inner] (out_f32 != 0) or hl32 half [rows, 2 inner]; status (may be NULL) = range flag of the hl32 output;
+ * fp32 [rows, inner] (out_f32 = 1), hl32 half [rows, 2 inner] (0) or hl8 rows of the same size (2: per 32 columns 32 hi halves |
+ * 32 e4m3 bytes of the value | 32 e4m3 bytes of 2^11 (value - hi), what bt_gemm3 reads with x3 flag 0x100); status (may be NULL) =
+ * range flag of the hl32 / hl8 output;
  * x3 = 1: 128-key LDS tiles, x3 = 2: 64-key tiles, x3 = 5: two query blocks per wave on a hand-scheduled key loop -- the same
  * arithmetic in all three, bit-identical results; x3 = 4 (the forward's choice since round 4): 5 for launches of at least
  * 1024 of its workgroups, 2 below.  + 8 (BT_X3_P16): the P16 arithmetic (BT_OPT_X3_ATTN_P16) on the same kernel choice. */
@@ -323,7 +338,9 @@ typedef struct {
  * rms(A) uses ssq_in[ssq_parts][M] (partial row sums of squares of the fp32 source of A), NULL = no RMSNorm.
  * x3 != 0 (BT_PREC_F32X3): A half [M, 2 lda], W half [N padded to 256, 2 K], out half [M, 2 ldo], xb half [M, 2 ldx]
  * are hl32 (interleaved hi / lo planes of the fp32 values; K, lda, ldo, ldx count fp32 elements), q / k / v blocks are
- * 4 KB, epi 0 uses the exact erf GELU; status (may be NULL) = range flag. */
+ * 4 KB, epi 0 uses the exact erf GELU; status (may be NULL) = range flag.  x3 + 0x100: A and W are hl8 (see
+ * bt_pair_weights.w_ff1_f8); x3 + 0x200: the activation the launch writes for the next GEMM (epi 0: out,
+ * epi 1: xb) is hl8. */
 typedef struct {
   const void* A; int64_t lda; int32_t M, K; const void* W; int32_t N, epi; const float* bias;
   const float* ssq_in; int32_t ssq_parts; void* out; int64_t ldo; float* x; int64_t ldx; void* xb; float* ssq_out;

@@ -136,6 +136,37 @@ def from_hl32(h):
     return (t[:, :, 0] + t[:, :, 1]).reshape(m, k2 // 2)
 
 
+def to_hl8(x):
+    """fp32 [M, K] (K % 32 == 0) -> the "hl8" operand form of csrc/gemm3.hip (X3 = 2), returned as fp16 [M, 2 K] (128 B per 32
+    columns like hl32): 32 hi halves | 32 hi bytes = e4m3(x) | 32 lo bytes = e4m3(2^11 (x - hi))."""
+    x = x.float()
+    m, k = x.shape
+    hi = x.to(torch.float16)
+    lo = (x - hi.float()) * 2048.0
+    out = torch.empty((m, k // 32, 128), dtype=torch.uint8)
+    out[:, :, :64] = hi.contiguous().view(m, k // 32, 32).view(torch.uint8)
+    out[:, :, 64:96] = x.clamp(-448, 448).to(torch.float8_e4m3fn).view(torch.uint8).view(m, k // 32, 32)
+    out[:, :, 96:] = lo.clamp(-448, 448).to(torch.float8_e4m3fn).view(torch.uint8).view(m, k // 32, 32)
+    return out.view(m, k // 32 * 128).view(torch.float16).contiguous()
+
+
+def hl8_parts(h):
+    """fp16 [M, 2 K] hl8 -> float64 (hi halves, hi bytes, lo bytes / 2^11), each [M, K]"""
+    m, k2 = h.shape
+    b = h.contiguous().view(torch.uint8).view(m, k2 // 64, 128)
+    hi = b[:, :, :64].contiguous().view(torch.float16).double().reshape(m, k2 // 2)
+    h8 = b[:, :, 64:96].contiguous().view(torch.float8_e4m3fn).double().reshape(m, k2 // 2)
+    l8 = b[:, :, 96:].contiguous().view(torch.float8_e4m3fn).double().reshape(m, k2 // 2) / 2048.0
+    return hi, h8, l8
+
+
+def hl8_matmul(a, w):
+    """what the hl8 GEMM computes (float64): hi . hi + e4m3(a) . lo8(w) + lo8(a) . e4m3(w), operands as hl8_parts"""
+    ah, a8, al = hl8_parts(a)
+    wh, w8, wl = hl8_parts(w)
+    return ah @ wh.T + a8 @ wl.T + al @ w8.T
+
+
 def frag_x3(x, nbp, kind):
     """[SH, L, 32] fp32-valued -> fp16 [SH, nbp, 2 (hi | lo), 1024]: the 4 KB blocks of the X3 attention operands"""
     f = frag_qk if kind == "qk" else frag_v

@@ -53,13 +53,13 @@ def _oracle(sd, x, idx):
 X3_TOL = 3e-4   # the default precision (BT_PREC_F32X3 with the P16 attention): admission bound of profiles/r05_flip_frontier.txt
 
 
-def _check(name, hp_name, B, half, x3, oracle_idx, tol, flips_allowed, p16=2):
+def _check(name, hp_name, B, half, x3, oracle_idx, tol, flips_allowed, p16=2, fp8=0):
     from beat_this_amd.postprocessor import Postprocessor
 
     sd, m, x = _setup(hp_name, B)
     xd = x.to(dev())
     m.fp32_split_gemms = x3     # BT_PREC_F32X3 (hi + lo operands) instead of the exact fp32 MFMA path
-    m.engine().set_options({"x3_attn_p16": p16})
+    m.engine().set_options({"x3_attn_p16": p16, "x3_gemm_fp8": fp8})
     with torch.inference_mode(), torch.autocast("cuda", enabled=half):
         r = m(xd)
         # every chunk of the batch alone (16 at a time to keep it quick): must reproduce the batched result
@@ -117,6 +117,14 @@ def test_cfg2_final0_16_chunks_f32x3_vs_oracle():
 
 def test_cfg2_final0_16_chunks_f32x3_three_term_vs_oracle():
     _check("cfg2_f32x3_p16off", "final0", 16, half=False, x3=True, oracle_idx=range(0, 16, 3), tol=1e-4, flips_allowed=(0, 0), p16=0)
+
+
+@pytest.mark.parametrize("level", [1, 2])
+def test_cfg5_final0_fp8_cross_terms_vs_oracle(level):
+    """BASELINE config 5 as offered (BT_OPT_X3_GEMM_FP8): the cross terms of the main layers' GEMMs on block-scaled fp8 MFMAs.  Inside
+    the 1e-3 gate on the logits; beats reported (an opt-in speed setting: its flip rate over the soak is in DESIGN.md section 3);
+    every chunk the same bits alone and in the batch, like the default."""
+    _check(f"cfg5_fp8_level{level}", "final0", 16, half=False, x3=True, oracle_idx=range(0, 16, 3), tol=1e-3, flips_allowed=None, fp8=level)
 
 
 def test_bench_slice_final0_33_chunks_f32x3_vs_oracle():

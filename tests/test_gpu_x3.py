@@ -9,7 +9,7 @@ import math
 import pytest
 import torch
 
-from gpu_util import dev, frag_x3, from_hl32, pad_rows, report, to_hl32, unfrag_x3
+from gpu_util import dev, frag_x3, from_hl32, hl8_matmul, hl8_parts, pad_rows, report, to_hl8, to_hl32, unfrag_x3
 
 pytestmark = pytest.mark.gpu
 
@@ -93,6 +93,116 @@ def test_gemm3_x3_resid(M, K, N, bias, nsplit, cfg):
     assert err < 2e-6 and errb < 1e-6 and errs < 1e-5 and int(st.item()) == 0
 
 
+# ---- hl8 operands (round 5, BASELINE config 5): the cross terms of the hi + lo product on one block-scaled fp8 MFMA --------------
+F8_IN, F8_OUT = 0x100, 0x200   # bt_gemm3_args.x3 flags (csrc/kernels.h: G3_X3_F8, G3_X3_OUT_F8)
+
+
+@pytest.mark.parametrize("M,K,N", [(1500, 512, 2048), (333, 128, 512), (24000, 512, 2048), (3000, 512, 2048)])
+def test_gemm3_f8_ff1(M, K, N):
+    """FF1 on hl8 operands (hl32 output): against the float64 evaluation of the same arithmetic -- hi . hi + 2^-11 (hi bytes .
+    lo bytes + lo bytes . hi bytes) -- to fp32 rounding, and against the exact product within the e4m3 cross terms' 2^-14."""
+    x = _mk((M, K), 1, 2.0).float()
+    W, b = _mk((N, K), 2, 1 / math.sqrt(K)).float(), _mk((N,), 3)
+    a8, w8 = to_hl8(x), to_hl8(pad_rows(W, 256))
+    out = torch.zeros((M, 2 * N), dtype=torch.float16, device=dev())
+    st = _status()
+    _call(0, 1 | F8_IN, A=a8.to(dev()), lda=K, M=M, K=K, W=w8.to(dev()), N=N, epi=0, bias=b.float().to(dev()),
+          ssq_in=_ssq_parts(x).to(dev()), ssq_parts=K // 64, out=out, ldo=N, status=st)
+    rs = math.sqrt(K) / x.double().norm(dim=-1, keepdim=True).clamp_min(1e-12)
+    emu = torch.nn.functional.gelu(hl8_matmul(a8, w8)[:, :N] * rs + b)
+    exact = torch.nn.functional.gelu(x.double() @ W.double().T * rs + b)
+    got = from_hl32(out.cpu())
+    e_emu, e_exact = _rel(got, emu), _rel(got, exact)
+    report("gemm3_f8_ff1", M=M, K=K, N=N, rel_vs_same_arithmetic=e_emu, rel_vs_exact=e_exact)
+    assert e_emu < 3e-6 and e_exact < 2e-4 and int(st.item()) == 0
+
+
+@pytest.mark.parametrize("M,K,N", [(1500, 2048, 512), (777, 512, 512), (24000, 2048, 512), (32768, 1024, 512), (3000, 2048, 512)])
+def test_gemm3_f8_resid(M, K, N):
+    A = _mk((M, K), 4).float()
+    W = _mk((N, K), 5, 0.5 / math.sqrt(K)).float()
+    b = _mk((N,), 6)
+    x0 = _mk((M, N), 7).float()
+    x = x0.to(dev()).clone()
+    xb = torch.full((M, 2 * N), float("nan"), dtype=torch.float16, device=dev())
+    ssq = torch.full((N // 64, M), -1.0, dtype=torch.float32, device=dev())
+    a8, w8 = to_hl8(A), to_hl8(pad_rows(W, 256))
+    st = _status()
+    _call(0, 1 | F8_IN, A=a8.to(dev()), lda=K, M=M, K=K, W=w8.to(dev()), N=N, epi=1, bias=b.float().to(dev()), x=x, ldx=N, xb=xb,
+          ssq_out=ssq, status=st)
+    emu = x0.double() + hl8_matmul(a8, w8)[:, :N] + b
+    exact = x0.double() + A.double() @ W.double().T + b
+    e_emu, e_exact = _rel(x, emu), _rel(x, exact)
+    xc = x.double().cpu()
+    errb = float((from_hl32(xb.cpu()) - xc).abs().max() / xc.abs().max())
+    report("gemm3_f8_resid", M=M, K=K, N=N, rel_vs_same_arithmetic=e_emu, rel_vs_exact=e_exact, shadow=errb)
+    assert e_emu < 2e-6 and e_exact < 2e-4 and errb < 1e-6 and int(st.item()) == 0
+
+
+def _check_hl8_against_hl32(o8, o32, what):
+    """an hl8 activation a kernel wrote against the hl32 form of the same launch: the hi halves are the same bits, the hi bytes
+    are e4m3 of the value and the lo bytes e4m3 of 2^11 (value - hi) -- up to the rare tie that the 22-bit hl32 value rounds the
+    other way"""
+    hi, h8, l8 = hl8_parts(o8)
+    m, k2 = o32.shape
+    p32 = o32.view(m, k2 // 64, 2, 32)
+    hi32, lo32 = p32[:, :, 0].reshape(m, k2 // 2).double(), p32[:, :, 1].reshape(m, k2 // 2).double()
+    assert torch.equal(hi, hi32), what
+    v = hi32 + lo32
+    want_h8 = v.float().clamp(-448, 448).to(torch.float8_e4m3fn).double()
+    want_l8 = (lo32 * 2048.0).float().clamp(-448, 448).to(torch.float8_e4m3fn).double() / 2048.0
+    bad_h = float((h8 != want_h8).double().mean())
+    bad_l = float((l8 != want_l8).double().mean())
+    # a mismatch is one e4m3 step at most (3 mantissa bits: 12.5 % of the value; subnormal step 2^-9 for the hi bytes, 2^-20 for the lo bytes)
+    assert float(((h8 - want_h8).abs() - 0.126 * want_h8.abs() - 2.0 ** -9).max()) <= 0, what
+    assert float(((l8 - want_l8).abs() - 0.126 * want_l8.abs() - 2.0 ** -20).max()) <= 0, what
+    assert bad_h < 1e-3 and bad_l < 0.05, (what, bad_h, bad_l)
+    return bad_h, bad_l
+
+
+def test_gemm3_hl8_producers_and_the_feed_forward_chain():
+    """What the fp8-cross-term feed-forward of a main layer runs (BT_OPT_X3_FF_FP8): the out-projection leaves an hl8 shadow of the
+    residual stream, FF1 reads it and leaves an hl8 hidden activation, FF2 reads that.  Producers against the hl32 form of the
+    same launch, the chain against the exact float64 feed-forward."""
+    M, D, HID = 3000, 512, 2048
+    ao = _mk((M, D), 1).float()
+    x0 = _mk((M, D), 2, 2.0).float()
+    Wo = _mk((D, D), 3, 1 / math.sqrt(D)).float()
+    W1, b1 = _mk((HID, D), 4, 1 / math.sqrt(D)).float(), _mk((HID,), 5)
+    W2, b2 = _mk((D, HID), 6, 0.5 / math.sqrt(HID)).float(), _mk((D,), 7)
+    res = {}
+    for mode in ("hl32", "hl8"):
+        f8_out = F8_OUT if mode == "hl8" else 0
+        f8_in = F8_IN if mode == "hl8" else 0
+        pack = to_hl8 if mode == "hl8" else to_hl32
+        x = x0.to(dev()).clone()
+        xb = torch.zeros((M, 2 * D), dtype=torch.float16, device=dev())
+        ssq = torch.zeros((D // 64, M), dtype=torch.float32, device=dev())
+        _call(0, 1 | f8_out, A=to_hl32(ao).to(dev()), lda=D, M=M, K=D, W=to_hl32(pad_rows(Wo, 256)).to(dev()), N=D, epi=1, x=x, ldx=D, xb=xb,
+              ssq_out=ssq, status=_status())                       # out-projection: hl32 operands, shadow in `mode`
+        hid = torch.zeros((M, 2 * HID), dtype=torch.float16, device=dev())
+        _call(0, 1 | f8_in | f8_out, A=xb, lda=D, M=M, K=D, W=pack(pad_rows(W1, 256)).to(dev()), N=HID, epi=0, bias=b1.float().to(dev()),
+              ssq_in=ssq, ssq_parts=D // 64, out=hid, ldo=HID, status=_status())
+        x2 = x.clone()
+        xb2 = torch.zeros((M, 2 * D), dtype=torch.float16, device=dev())
+        _call(0, 1 | f8_in, A=hid, lda=HID, M=M, K=HID, W=pack(pad_rows(W2, 256)).to(dev()), N=D, epi=1, bias=b2.float().to(dev()), x=x2, ldx=D,
+              xb=xb2, ssq_out=torch.zeros((D // 64, M), device=dev()), status=_status())
+        res[mode] = (xb.cpu(), hid.cpu(), x2.double().cpu(), xb2.cpu(), x.double().cpu())
+    bh, bl = _check_hl8_against_hl32(res["hl8"][0], res["hl32"][0], "residual shadow")
+    assert torch.equal(res["hl8"][4], res["hl32"][4])               # (the out-projection itself is the same launch)
+    x1 = x0.double() + ao.double() @ Wo.double().T
+    xn = x1 / x1.norm(dim=-1, keepdim=True).clamp_min(1e-12) * math.sqrt(D)
+    h = torch.nn.functional.gelu(xn @ W1.double().T + b1)
+    ref = x1 + h @ W2.double().T + b2
+    e32, e8 = _rel(res["hl32"][2], ref), _rel(res["hl8"][2], ref)
+    # the hidden activation of the hl8 chain was computed from hl8 operands, so it is compared with the exact one, not bit for bit
+    hi, h8, l8 = hl8_parts(res["hl8"][1])
+    eh = float(((hi + l8) - h).abs().max() / h.abs().max())
+    report("gemm3_hl8_chain", M=M, rel_hl32=e32, rel_hl8=e8, hidden_rel=eh, shadow_hi_byte_mismatch=bh, shadow_lo_byte_mismatch=bl)
+    assert e32 < 3e-6 and e8 < 1e-4 and eh < 1e-4
+    assert float((from_hl32(res["hl8"][3]) - res["hl8"][2]).abs().max() / res["hl8"][2].abs().max()) < 1e-6   # FF2 leaves an hl32 shadow
+
+
 def test_gemm3_x3_tile_configurations_agree_bit_for_bit():
     """128 x 128 tiles on k-steps of 32 and 256 x 128 tiles on k-steps of 16 issue the same MFMAs on the same operand pieces
     in the same order per output element: identical bits (a piece's result must not depend on the batch it ran in)."""
@@ -114,8 +224,9 @@ def test_gemm3_x3_tile_configurations_agree_bit_for_bit():
             assert torch.equal(a, c)
 
 
+@pytest.mark.parametrize("f8", [False, True])   # (True: hl8 operands, BT_OPT_X3_GEMM_FP8 = 2)
 @pytest.mark.parametrize("n_seq,L,heads", [(2, 1500, 4), (3, 77, 4), (1, 1, 4), (5, 130, 8), (16, 1500, 16)])
-def test_gemm3_x3_qkv(n_seq, L, heads):
+def test_gemm3_x3_qkv(n_seq, L, heads, f8):
     from beat_this_amd import _lib as Lb
     from beat_this_amd.pack import LOG2E
     from beat_this_amd.tables import rope_table
@@ -135,12 +246,14 @@ def test_gemm3_x3_qkv(n_seq, L, heads):
     kf, vf = qf.clone(), qf.clone()
     gh = torch.zeros((SH, nbp * 32), dtype=torch.float32, device=dev())
     st = _status()
-    _call(A=to_hl32(x).to(dev()), lda=D, M=M, K=D, W=to_hl32(W).to(dev()), N=3 * D + heads, epi=2, ssq_in=_ssq_parts(x).to(dev()),
-          ssq_parts=D // 64, n_seq=n_seq, L=L, nbp=nbp, heads=heads, rope=rope, qf=qf, kf=kf, vf=vf, gates=gh,
-          b_gates=bg.float().to(dev()), status=st)
+    pack = to_hl8 if f8 else to_hl32
+    _call(0, 1 | (F8_IN if f8 else 0), A=pack(x).to(dev()), lda=D, M=M, K=D, W=pack(W).to(dev()), N=3 * D + heads, epi=2,
+          ssq_in=_ssq_parts(x).to(dev()), ssq_parts=D // 64, n_seq=n_seq, L=L, nbp=nbp, heads=heads, rope=rope, qf=qf, kf=kf, vf=vf,
+          gates=gh, b_gates=bg.float().to(dev()), status=st)
     rs = math.sqrt(D) / x.double().norm(dim=-1, keepdim=True).clamp_min(1e-12)
     Wd, xd = from_hl32(to_hl32(W)), from_hl32(to_hl32(x))
-    qkv = (xd @ Wd[:3 * D].T * rs).view(n_seq, L, 3, heads, 32).permute(2, 0, 3, 1, 4)  # qkv s h t d
+    prod = hl8_matmul(pack(x), pack(W)) if f8 else xd @ Wd.T   # (hl8: against the float64 evaluation of the same arithmetic)
+    qkv = (prod[:, :3 * D] * rs).view(n_seq, L, 3, heads, 32).permute(2, 0, 3, 1, 4)  # qkv s h t d
     ang = torch.arange(L, dtype=torch.float64)[:, None] * freqs.double()[None, :]
     cos, sin = ang.cos().repeat_interleave(2, -1), ang.sin().repeat_interleave(2, -1)
 
@@ -148,13 +261,13 @@ def test_gemm3_x3_qkv(n_seq, L, heads):
         te, to = t[..., 0::2], t[..., 1::2]
         return t * cos + torch.stack((-to, te), -1).flatten(-2) * sin
     q, k, v = rot(qkv[0]).reshape(SH, L, 32), rot(qkv[1]).reshape(SH, L, 32), qkv[2].reshape(SH, L, 32)
-    gates = torch.sigmoid(xd @ Wd[3 * D:3 * D + heads].T * rs + bg).view(n_seq, L, heads).permute(0, 2, 1).reshape(SH, L)
+    gates = torch.sigmoid(prod[:, 3 * D:3 * D + heads] * rs + bg).view(n_seq, L, heads).permute(0, 2, 1).reshape(SH, L)
     nblk = (L + 31) // 32
     eq = _rel(unfrag_x3(qf.cpu()[:, :nblk], L, "qk"), q)
     ek = _rel(unfrag_x3(kf.cpu()[:, :nblk], L, "qk"), k)
     ev = _rel(unfrag_x3(vf.cpu()[:, :nblk], L, "v"), v)
     eg = _rel(gh.cpu()[:, :L], gates)
-    report("gemm3_x3_qkv", n_seq=n_seq, L=L, heads=heads, q=eq, k=ek, v=ev, gates=eg)
+    report("gemm3_x3_qkv", n_seq=n_seq, L=L, heads=heads, f8=f8, q=eq, k=ek, v=ev, gates=eg)
     # (q, k: the rotary angles pos * freq are fp32 products like rotary-embedding-torch's -- 1e-4 rad at position 1500 -- so
     # against this float64 restatement the rotated values are 2e-5 off at L = 1500; v has no rotation)
     assert max(eq, ek) < (3e-6 if L < 200 else 4e-5) and ev < 3e-6 and eg < 3e-6 and int(st.item()) == 0
@@ -207,7 +320,7 @@ def _attn_ref(q, k, v, gates):
     return torch.softmax(s, -1) @ v * gates[..., None]
 
 
-def _run_attn(q, k, v, gates, n_seq, L, heads, out_f32, variant=1, **omap):
+def _run_attn(q, k, v, gates, n_seq, L, heads, out_f32, variant=1, raw=False, **omap):
     from beat_this_amd import _lib as Lb
 
     nbp = Lb.lib().bt_attn_frag_blocks(L)
@@ -216,7 +329,7 @@ def _run_attn(q, k, v, gates, n_seq, L, heads, out_f32, variant=1, **omap):
     gh[:, :L] = gates.float()
     rows = n_seq * L
     inner = heads * 32
-    out = torch.zeros((rows, inner), dtype=torch.float32, device=dev()) if out_f32 else \
+    out = torch.zeros((rows, inner), dtype=torch.float32, device=dev()) if int(out_f32) == 1 else \
         torch.zeros((rows, 2 * inner), dtype=torch.float16, device=dev())
     qf, kf, vf = frag_x3(q, nbp, "qk"), frag_x3(k, nbp, "qk"), frag_x3(v, nbp, "v")
     nblk = (L + 31) // 32
@@ -232,7 +345,9 @@ def _run_attn(q, k, v, gates, n_seq, L, heads, out_f32, variant=1, **omap):
     Lb.check(Lb.lib().bt_attention_frag(Lb.stream_ptr(dev()), C.byref(a)))
     torch.cuda.synchronize()
     assert int(st.item()) == 0
-    return out.double().cpu() if out_f32 else from_hl32(out.cpu())
+    if raw:
+        return out.cpu()
+    return out.double().cpu() if out_f32 == 1 else from_hl32(out.cpu())
 
 
 @pytest.mark.parametrize("variant", [1, 2, 5])   # bt_attn_frag_args.x3: keys per LDS tile / 5 = the hand-scheduled two-query-block kernel, forced (4 = by launch size; attn2.hip)
@@ -329,6 +444,22 @@ def test_attention_frag_x3_p16_variants_agree_bit_for_bit(n_seq, L, heads, out_f
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[1], outs[2])
     three_term = _run_attn(q, k, v, gates, n_seq, L, heads, out_f32, 2)
     assert not torch.equal(outs[0], three_term) or L == 1   # (the option does select another arithmetic)
+
+
+@pytest.mark.parametrize("variant", [1, 5, 9, 10, 13])
+@pytest.mark.parametrize("n_seq,L,heads", [(3, 1500, 2), (2, 77, 1), (1, 128, 4), (2, 1, 1), (2, 33, 2), (4, 1500, 16)])
+def test_attention_frag_x3_hl8_rows(n_seq, L, heads, variant):
+    """bt_attn_frag_args.out_f32 = 2 (BT_OPT_X3_GEMM_FP8 = 2: the out-projection reads hl8 rows): the same launch as the hl32 one
+    -- hi halves bit for bit, the byte sections e4m3 of the value and of 2^11 (value - hi)"""
+    SH = n_seq * heads
+    q = _mk((SH, L, 32), 30, 0.6).float().double()
+    k = _mk((SH, L, 32), 31).float().double()
+    v = _mk((SH, L, 32), 32).float().double()
+    gates = torch.sigmoid(_mk((SH, L), 33)).float().double()
+    o32 = _run_attn(q, k, v, gates, n_seq, L, heads, 0, variant, raw=True)
+    o8 = _run_attn(q, k, v, gates, n_seq, L, heads, 2, variant, raw=True)
+    bh, bl = _check_hl8_against_hl32(o8, o32, "attention rows")
+    report("attn_frag_x3_hl8_rows", n_seq=n_seq, L=L, heads=heads, variant=variant, hi_byte_mismatch=bh, lo_byte_mismatch=bl)
 
 
 @pytest.mark.parametrize("variant", [9, 10, 13])
