@@ -1075,7 +1075,7 @@ __global__ __launch_bounds__(256, MINW) void attn_frag_x3_kernel(const AttnFragP
       }
     }
   }
-  if (OUT == 0 && p.status && __any(!(amax <= 65504.f)) && lane == 0) atomicOr(p.status, 1);
+  if (OUT == 0 && p.status && __any(!(amax <= (p.out_f32 == 2 ? HL8_ACT_MAX : 65504.f))) && lane == 0) atomicOr(p.status, 1);
 }
 
 
@@ -1324,7 +1324,7 @@ __global__ __launch_bounds__(256, 2) void attn_frag_x3q2_kernel(const AttnFragP 
       }
     }
   }
-  if (OUT == 0 && p.status && __any(!(amax <= 65504.f)) && laneE == 0) atomicOr(p.status, 1);
+  if (OUT == 0 && p.status && __any(!(amax <= (p.out_f32 == 2 ? HL8_ACT_MAX : 65504.f))) && laneE == 0) atomicOr(p.status, 1);
 }
 
 }  // namespace

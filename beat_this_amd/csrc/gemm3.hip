@@ -143,17 +143,18 @@ DEVI void pack_row_f8(const float (&v)[16], u32x4 (&hi)[2], u32x2 (&h8)[2], u32x
   }
 }
 // range guard: one flag word per forward (Gemm3P.status), set when a value beyond the fp16 range went through a split
-DEVI void flag_range(int* status, float amax) {
-  if (status && __any(!(amax <= 65504.f)) && (threadIdx.x & 63) == 0) atomicOr(status, 1);
+DEVI void flag_range(int* status, float amax, float limit = 65504.f) {
+  if (status && __any(!(amax <= limit)) && (threadIdx.x & 63) == 0) atomicOr(status, 1);
 }
 
 // ABL (development, BT_G3_ABL = 8): per-wave timing dump (k-loop, waits, epilogue) read by tools/gemm3_probe.py;
 // bits 0 - 2 (no LDS-DMA after the prologue / no GELU / no MFMAs) are ablations that can be instantiated by hand
 // X3: 0 = half operands, 1 = hl32 operands (BT_PREC_F32X3), 2 = "hl8" operands (round 5, BASELINE config 5: the cross terms
 // of the hi + lo product on ONE block-scaled fp8 MFMA per 32-k step).  An hl8 group of 32 columns is 128 B like an hl32 one:
-// [32 hi halves | 32 hi bytes = e4m3(v) | 32 lo bytes = e4m3(2^11 (v - hi))]; per 32-k step and tile pair
-//   acc += 2^-11 [hi bytes(P) | lo bytes(P)] . [lo bytes(Q) | hi bytes(Q)]     v_mfma_scale_f32_32x32x64_f8f6f4, K = 64 = both
-//                                                                               cross terms, the 2^-11 in its E8M0 scale operand
+// [32 hi halves | 32 hi bytes = e4m3(v) | 32 lo bytes = e4m3(2^11 (v - hi))] for a weight, 2^-3 of that in the byte sections of an
+// activation (common.h: range); per 32-k step and tile pair
+//   acc += 2^-8 [hi bytes(P) | lo bytes(P)] . [lo bytes(Q) | hi bytes(Q)]      v_mfma_scale_f32_32x32x64_f8f6f4, K = 64 = both
+//                                                                               cross terms, the 2^-8 in its E8M0 scale operand
 //   acc += hi(P) . hi(Q)                                                        two v_mfma_f32_32x32x16_f16
 // i.e. 64 + 64 matrix-pipe cycles where the three-term form spends 192 (the scaled fp8 MFMA runs at 2.3 x the fp16 rate:
 // tools/ubench/mfma_f8_cross.hip), on the same ring, swizzle, fragment-read count and operand registers.
@@ -399,8 +400,8 @@ void gemm3_kernel(const Gemm3P p, int n_tiles, int total_tiles, int per_xcd, int
 #pragma unroll
         for (int a = 0; a < NP; ++a)
 #pragma unroll
-          for (int b = 0; b < NQ; ++b)   // scale of the first operand 2^-11 (E8M0 byte 116), of the second 1 (127)
-            acc[a][b] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(p8[a], q8[b], acc[a][b], 0, 0, 0, 0x74747474, 0, 0x7f7f7f7f);
+          for (int b = 0; b < NQ; ++b)   // scale of the first operand 2^-8 (E8M0 byte 119: activation bytes carry 2^-3, weight lo bytes 2^11; common.h), of the second 1 (127)
+            acc[a][b] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(p8[a], q8[b], acc[a][b], 0, 0, 0, HL8_SCALE_WORD, 0, 0x7f7f7f7f);
       }
 #pragma unroll
       for (int m = 0; m < 2; ++m) {
@@ -707,7 +708,7 @@ void gemm3_kernel(const Gemm3P p, int n_tiles, int total_tiles, int per_xcd, int
       }
     }
   }
-  if constexpr (X3) flag_range(p.status, amax);
+  if constexpr (X3) flag_range(p.status, amax, (p.x3 & G3_X3_OUT_F8) ? HL8_ACT_MAX : 65504.f);   // (hl8 activations end earlier: common.h)
   if constexpr ((ABL & 8) != 0) {  // development timing dump over the head of the (already written) output
     const long long t_end = clock64();
     __syncthreads();

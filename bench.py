@@ -35,7 +35,8 @@ Extra objects on the JSON line:
                 in half precision.
   configs       the other BASELINE.json configurations as short legs: cfg3 (small0 exact fp32, 128 chunks: fp32-FLOP
                 fraction AND counter-measured HBM GB/s), cfg4_share (final0, 64 chunks = one GPU's share of the 512-chunk
-                job, both precisions), cfg5 (withdrawn: no fp8 path is offered).
+                job, both precisions), cfg5 (the 64-chunk batch with the cross terms of the hi + lo products on the block-scaled
+                fp8 MFMA, opt-in levels 1 and 2, next to the default path).
   strong_scaling_cfg4  BASELINE config 4 itself: 512 chunks sharded over the N ranks (512 / N each), logits all-gathered.
   timed_region  the K steps are repeated until the timed region holds >= 2 s of GPU work (clocks and temperatures settle);
                 ms_per_step = region / (K x repeats).  rccl_ranks = ranks counted by an RCCL all-reduce (the process group
@@ -538,14 +539,38 @@ def main():
                             "(rocprofv3 PMC passes of this configuration; bytes per forward / this run's time)")
             except (OSError, ValueError, KeyError):
                 pass
+            # ---- BASELINE config 5: the 64-chunk batch with the cross terms of the hi + lo products on the block-scaled fp8 MFMA
+            # (opt-in BT_OPT_X3_GEMM_FP8; the default path for comparison is t64 above when --prec f32x3)
+            cfg5 = None
+            if args.prec == "f32x3":
+                eng = a2b.model.engine()
+                lv = {}
+                with torch.inference_mode():
+                    ref64 = a2b.model(x64)
+                    ref64 = torch.stack([ref64["beat"].float(), ref64["downbeat"].float()])
+                for level in (1, 2):
+                    eng.set_options({"x3_gemm_fp8": level})
+                    fb0 = eng.last_fallbacks
+                    t5 = time_forward(a2b.model, x64, "f32x3", 3, 5)
+                    with torch.inference_mode():
+                        o5 = a2b.model(x64)
+                    d5 = float((torch.stack([o5["beat"].float(), o5["downbeat"].float()]) - ref64).abs().max())
+                    lv[f"level{level}"] = {**fwd_obj(t5, 64), "max_abs_logit_vs_default_path": d5, "range_fallbacks": int(eng.last_fallbacks - fb0)}
+                eng.set_options({"x3_gemm_fp8": 0})
+                cfg5 = {"workload": "BASELINE config 5: final0, 64 chunks x 1500 frames resident; hi . hi on fp16 MFMAs, both cross terms "
+                                    "(hi . lo + lo . hi) of every product on ONE v_mfma_scale_f32_32x32x64_f8f6f4 (e4m3 bytes of the value "
+                                    "and of its lo part, the power of two in the E8M0 scale) -- level 1: feed-forward GEMMs, level 2: QKV and "
+                                    "out-projection as well",
+                        "default_path": fwd_obj(t64, 64), **lv, "default": "off (opt-in Engine.set_options / bt_engine_set_option)",
+                        "parity": "tests/test_gpu_scale.py::test_cfg5_final0_fp8_cross_terms_vs_oracle (logits within 3e-4 of the fp32 "
+                                  "oracle, same beats); flip rates over 48 tracks x 3 weight styles: profiles/r05_flip_frontier.txt "
+                                  "(x3p16f8ff / x3p16f8)"}
             configs = {
                 "cfg2": "= forward_only",
                 "cfg3": cfg3,
                 "cfg4_share": {"workload": "BASELINE config 4, one GPU's share: final0, 64 chunks x 1500 frames resident",
                                **fwd_obj(t64, 64), "dtype": args.prec, other: fwd_obj(t64o, 64)},
-                "cfg5": "withdrawn: no fp8 path is offered (rounds 1-2: e4m3 feed-forward GEMMs moved 47 of 194 beats at 0.28 "
-                        "logit error and were no faster than the half path; round 4's study of narrow formats for the hi + lo "
-                        "correction terms only: DESIGN.md)"}
+                "cfg5": cfg5 or "measured with --prec f32x3 only"}
             del m_s, x64, x128
 
             # ---- the same job from HOST buffers (PCIe-inclusive; never `value`): waveforms in pinned host memory, uploaded

@@ -110,7 +110,9 @@ typedef struct {
   const void* w_qkv_frag_x3;
   /* BT_OPT_X3_GEMM_FP8 (BASELINE config 5): the four matrices of w_*_x3 as "hl8" half arrays [N padded to 256][2 K] -- per 32
    * columns 32 hi halves, 32 hi bytes e4m3(w), 32 lo bytes e4m3(2^11 (w - hi)): 128 B like an hl32 group.  NULL: the hl32
-   * form runs for that GEMM. */
+   * form runs for that GEMM.  (An hl8 ACTIVATION, written by the kernels for each other, carries 2^-3 of that in its byte
+   * sections -- e4m3(a / 8), e4m3(2^8 (a - hi)) -- so that it reaches |a| = 3584 where e4m3 alone ends at 448; beyond it the
+   * producer raises the range flag.) */
   const void* w_qkvg_f8;
   const void* w_out_f8;
   const void* w_ff1_f8;
@@ -185,7 +187,10 @@ void bt_engine_destroy(bt_engine* e);
  *                       (hi . lo + lo . hi: 2^-11 of the product) on ONE block-scaled fp8 MFMA per 32-k step instead of four fp16
  *                       ones, operands travelling as hl8 (bt_pair_weights.w_*_f8): 2 MFMA units per product instead of 3.
  *                       1: the feed-forward GEMMs (FF1, FF2);  2: out-projection and QKV as well.  An opt-in speed setting inside
- *                       the 1e-3 gate, reported beside the default (bench.py: configs.cfg5; flip rates: DESIGN.md section 3). */
+ *                       the 1e-3 gate, reported beside the default (bench.py: configs.cfg5; flip rates: DESIGN.md section 3):
+ *                       measured at level 2 -4 % forward time, 1.7e-4 .. 2.5e-4 on the logits against the oracle (default 7e-5),
+ *                       3 x (lively weights) to 10 x (freshly initialised) the default's beat flips over the 48-track soak.
+ *                       Activations beyond 3584 (hl8's range) raise the range flag like those beyond 65504 on the default path. */
 #define BT_OPT_X3_ATTN_P16 1
 #define BT_OPT_X3_GEMM_FP8 2
 int bt_engine_set_option(bt_engine* e, int option, int value);
@@ -320,7 +325,7 @@ int bt_attention(void* stream, int prec, const bt_attn_args* a);
  * pre-scaled by log2(e)/sqrt(32).  nbp >= bt_attn_frag_blocks(L).  Output as bt_attention (half).
  * x3 != 0 (BT_PREC_F32X3): blocks of 4 KB = [hi block | lo block] of the fp32 values, three MFMAs per product; output
  * fp32 [rows, inner] (out_f32 = 1), hl32 half [rows, 2 inner] (0) or hl8 rows of the same size (2: per 32 columns 32 hi halves |
- * 32 e4m3 bytes of the value | 32 e4m3 bytes of 2^11 (value - hi), what bt_gemm3 reads with x3 flag 0x100); status (may be NULL) =
+ * 32 e4m3 bytes of value / 8 | 32 e4m3 bytes of 2^8 (value - hi), what bt_gemm3 reads as A with x3 flag 0x100); status (may be NULL) =
  * range flag of the hl32 / hl8 output;
  * x3 = 1: 128-key LDS tiles, x3 = 2: 64-key tiles, x3 = 5: two query blocks per wave on a hand-scheduled key loop -- the same
  * arithmetic in all three, bit-identical results; x3 = 4 (the forward's choice since round 4): 5 for launches of at least

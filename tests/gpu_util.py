@@ -136,33 +136,43 @@ def from_hl32(h):
     return (t[:, :, 0] + t[:, :, 1]).reshape(m, k2 // 2)
 
 
-def to_hl8(x):
+HL8_ACT_SHIFT = 8.0   # the byte sections of an hl8 ACTIVATION carry 2^-3 of what a weight's carry (csrc/common.h: range to 3584)
+
+
+def to_hl8(x, act=False):
     """fp32 [M, K] (K % 32 == 0) -> the "hl8" operand form of csrc/gemm3.hip (X3 = 2), returned as fp16 [M, 2 K] (128 B per 32
-    columns like hl32): 32 hi halves | 32 hi bytes = e4m3(x) | 32 lo bytes = e4m3(2^11 (x - hi))."""
+    columns like hl32): 32 hi halves | 32 hi bytes = e4m3(x) | 32 lo bytes = e4m3(2^11 (x - hi)) for a weight; an activation
+    (act=True) carries e4m3(x / 8) and e4m3(2^8 (x - hi))."""
     x = x.float()
     m, k = x.shape
     hi = x.to(torch.float16)
-    lo = (x - hi.float()) * 2048.0
+    s = HL8_ACT_SHIFT if act else 1.0
+    lo = (x - hi.float()) * (2048.0 / s)
     out = torch.empty((m, k // 32, 128), dtype=torch.uint8)
     out[:, :, :64] = hi.contiguous().view(m, k // 32, 32).view(torch.uint8)
-    out[:, :, 64:96] = x.clamp(-448, 448).to(torch.float8_e4m3fn).view(torch.uint8).view(m, k // 32, 32)
+    out[:, :, 64:96] = (x / s).clamp(-448, 448).to(torch.float8_e4m3fn).view(torch.uint8).view(m, k // 32, 32)
     out[:, :, 96:] = lo.clamp(-448, 448).to(torch.float8_e4m3fn).view(torch.uint8).view(m, k // 32, 32)
     return out.view(m, k // 32 * 128).view(torch.float16).contiguous()
 
 
-def hl8_parts(h):
-    """fp16 [M, 2 K] hl8 -> float64 (hi halves, hi bytes, lo bytes / 2^11), each [M, K]"""
+def to_hl8a(x):
+    return to_hl8(x, act=True)
+
+
+def hl8_parts(h, act=False):
+    """fp16 [M, 2 K] hl8 -> float64 (hi halves, the value the hi bytes stand for, the value the lo bytes stand for), each [M, K]"""
     m, k2 = h.shape
+    s = HL8_ACT_SHIFT if act else 1.0
     b = h.contiguous().view(torch.uint8).view(m, k2 // 64, 128)
     hi = b[:, :, :64].contiguous().view(torch.float16).double().reshape(m, k2 // 2)
-    h8 = b[:, :, 64:96].contiguous().view(torch.float8_e4m3fn).double().reshape(m, k2 // 2)
-    l8 = b[:, :, 96:].contiguous().view(torch.float8_e4m3fn).double().reshape(m, k2 // 2) / 2048.0
+    h8 = b[:, :, 64:96].contiguous().view(torch.float8_e4m3fn).double().reshape(m, k2 // 2) * s
+    l8 = b[:, :, 96:].contiguous().view(torch.float8_e4m3fn).double().reshape(m, k2 // 2) / 2048.0 * s
     return hi, h8, l8
 
 
 def hl8_matmul(a, w):
-    """what the hl8 GEMM computes (float64): hi . hi + e4m3(a) . lo8(w) + lo8(a) . e4m3(w), operands as hl8_parts"""
-    ah, a8, al = hl8_parts(a)
+    """what the hl8 GEMM computes (float64): hi . hi + e4m3(a) . lo8(w) + lo8(a) . e4m3(w); a an hl8 activation, w an hl8 weight"""
+    ah, a8, al = hl8_parts(a, act=True)
     wh, w8, wl = hl8_parts(w)
     return ah @ wh.T + a8 @ wl.T + al @ w8.T
 

@@ -250,8 +250,9 @@ def test_outlier_weights_in_three_precisions(hp_name, B):
     ref = _oracle(sd, x, range(B))
     pp = Postprocessor("minimal")
     res = {}
-    for mode in ("f32", "f32x3", "half"):
-        m.fp32_split_gemms = mode == "f32x3"
+    for mode in ("f32", "f32x3", "f32x3_fp8", "half"):
+        m.fp32_split_gemms = mode.startswith("f32x3")
+        m.engine().set_options({"x3_gemm_fp8": 2 if mode == "f32x3_fp8" else 0})   # (BASELINE config 5's opt-in arithmetic)
         before = m.engine().last_fallbacks
         with torch.inference_mode(), torch.autocast("cuda", enabled=mode == "half"):
             r = m(xd)
@@ -267,4 +268,8 @@ def test_outlier_weights_in_three_precisions(hp_name, B):
     assert res["f32"][0] < 1e-3 and res["f32"][1:3] == (0, 0)
     assert res["f32x3"][3] == 0, "BT_PREC_F32X3 fell back to the exact path on outlier channels of ~10^3"
     assert res["f32x3"][0] < 1e-3 and res["f32x3"][1:3] == (0, 0)
+    # the fp8 cross terms too: their activations' byte sections reach 3584 (csrc/common.h), the outlier channels stay below
+    assert res["f32x3_fp8"][3] == 0, "BT_OPT_X3_GEMM_FP8 fell back to the exact path on outlier channels of ~10^3"
+    assert res["f32x3_fp8"][0] < 1e-3
+    m.engine().set_options({"x3_gemm_fp8": 0})
     assert np.isfinite(res["half"][0])

@@ -9,7 +9,7 @@ import math
 import pytest
 import torch
 
-from gpu_util import dev, frag_x3, from_hl32, hl8_matmul, hl8_parts, pad_rows, report, to_hl8, to_hl32, unfrag_x3
+from gpu_util import HL8_ACT_SHIFT, dev, frag_x3, from_hl32, hl8_matmul, hl8_parts, pad_rows, report, to_hl8, to_hl8a, to_hl32, unfrag_x3
 
 pytestmark = pytest.mark.gpu
 
@@ -103,7 +103,7 @@ def test_gemm3_f8_ff1(M, K, N):
     lo bytes + lo bytes . hi bytes) -- to fp32 rounding, and against the exact product within the e4m3 cross terms' 2^-14."""
     x = _mk((M, K), 1, 2.0).float()
     W, b = _mk((N, K), 2, 1 / math.sqrt(K)).float(), _mk((N,), 3)
-    a8, w8 = to_hl8(x), to_hl8(pad_rows(W, 256))
+    a8, w8 = to_hl8a(x), to_hl8(pad_rows(W, 256))
     out = torch.zeros((M, 2 * N), dtype=torch.float16, device=dev())
     st = _status()
     _call(0, 1 | F8_IN, A=a8.to(dev()), lda=K, M=M, K=K, W=w8.to(dev()), N=N, epi=0, bias=b.float().to(dev()),
@@ -126,7 +126,7 @@ def test_gemm3_f8_resid(M, K, N):
     x = x0.to(dev()).clone()
     xb = torch.full((M, 2 * N), float("nan"), dtype=torch.float16, device=dev())
     ssq = torch.full((N // 64, M), -1.0, dtype=torch.float32, device=dev())
-    a8, w8 = to_hl8(A), to_hl8(pad_rows(W, 256))
+    a8, w8 = to_hl8a(A), to_hl8(pad_rows(W, 256))
     st = _status()
     _call(0, 1 | F8_IN, A=a8.to(dev()), lda=K, M=M, K=K, W=w8.to(dev()), N=N, epi=1, bias=b.float().to(dev()), x=x, ldx=N, xb=xb,
           ssq_out=ssq, status=st)
@@ -139,23 +139,45 @@ def test_gemm3_f8_resid(M, K, N):
     assert e_emu < 2e-6 and e_exact < 2e-4 and errb < 1e-6 and int(st.item()) == 0
 
 
+@pytest.mark.parametrize("big,flag", [(1000.0, 0), (3500.0, 0), (3700.0, 1), (60000.0, 1)])
+def test_gemm3_hl8_range_flag(big, flag):
+    """the byte sections of an hl8 activation end at 3584 (e4m3's 448 x the 2^3 an activation's bytes are shifted by): a producer
+    that writes a larger value raises the range flag (the forward is then repeated in exact fp32), below it the product is right"""
+    M, K, N = 256, 128, 128
+    A, W = _mk((M, K), 1).float(), torch.eye(N, K)
+    x0 = torch.zeros((M, N))
+    x0[5, 7] = big
+    x = x0.to(dev()).clone()
+    xb = torch.zeros((M, 2 * N), dtype=torch.float16, device=dev())
+    st = _status()
+    _call(0, 1 | F8_OUT, A=to_hl32(A).to(dev()), lda=K, M=M, K=K, W=to_hl32(pad_rows(W, 256)).to(dev()), N=N, epi=1, x=x, ldx=N, xb=xb,
+          ssq_out=torch.zeros((N // 64, M), device=dev()), status=st)
+    torch.cuda.synchronize()
+    assert int(st.item()) == flag
+    if not flag:
+        hi, h8, l8 = hl8_parts(xb.cpu(), act=True)
+        want = x.double().cpu()
+        assert float((hi + l8 - want).abs().max() / big) < 2e-5 and float(((h8 - want).abs() - 0.07 * want.abs() - 0.02).max()) <= 0
+
+
 def _check_hl8_against_hl32(o8, o32, what):
     """an hl8 activation a kernel wrote against the hl32 form of the same launch: the hi halves are the same bits, the hi bytes
     are e4m3 of the value and the lo bytes e4m3 of 2^11 (value - hi) -- up to the rare tie that the 22-bit hl32 value rounds the
     other way"""
-    hi, h8, l8 = hl8_parts(o8)
+    hi, h8, l8 = hl8_parts(o8, act=True)
     m, k2 = o32.shape
     p32 = o32.view(m, k2 // 64, 2, 32)
     hi32, lo32 = p32[:, :, 0].reshape(m, k2 // 2).double(), p32[:, :, 1].reshape(m, k2 // 2).double()
     assert torch.equal(hi, hi32), what
     v = hi32 + lo32
-    want_h8 = v.float().clamp(-448, 448).to(torch.float8_e4m3fn).double()
-    want_l8 = (lo32 * 2048.0).float().clamp(-448, 448).to(torch.float8_e4m3fn).double() / 2048.0
+    s = HL8_ACT_SHIFT
+    want_h8 = (v / s).float().clamp(-448, 448).to(torch.float8_e4m3fn).double() * s
+    want_l8 = (lo32 * 2048.0 / s).float().clamp(-448, 448).to(torch.float8_e4m3fn).double() / 2048.0 * s
     bad_h = float((h8 != want_h8).double().mean())
     bad_l = float((l8 != want_l8).double().mean())
     # a mismatch is one e4m3 step at most (3 mantissa bits: 12.5 % of the value; subnormal step 2^-9 for the hi bytes, 2^-20 for the lo bytes)
-    assert float(((h8 - want_h8).abs() - 0.126 * want_h8.abs() - 2.0 ** -9).max()) <= 0, what
-    assert float(((l8 - want_l8).abs() - 0.126 * want_l8.abs() - 2.0 ** -20).max()) <= 0, what
+    assert float(((h8 - want_h8).abs() - 0.126 * want_h8.abs() - s * 2.0 ** -9).max()) <= 0, what
+    assert float(((l8 - want_l8).abs() - 0.126 * want_l8.abs() - s * 2.0 ** -20).max()) <= 0, what
     assert bad_h < 1e-3 and bad_l < 0.05, (what, bad_h, bad_l)
     return bad_h, bad_l
 
@@ -196,7 +218,7 @@ def test_gemm3_hl8_producers_and_the_feed_forward_chain():
     ref = x1 + h @ W2.double().T + b2
     e32, e8 = _rel(res["hl32"][2], ref), _rel(res["hl8"][2], ref)
     # the hidden activation of the hl8 chain was computed from hl8 operands, so it is compared with the exact one, not bit for bit
-    hi, h8, l8 = hl8_parts(res["hl8"][1])
+    hi, h8, l8 = hl8_parts(res["hl8"][1], act=True)
     eh = float(((hi + l8) - h).abs().max() / h.abs().max())
     report("gemm3_hl8_chain", M=M, rel_hl32=e32, rel_hl8=e8, hidden_rel=eh, shadow_hi_byte_mismatch=bh, shadow_lo_byte_mismatch=bl)
     assert e32 < 3e-6 and e8 < 1e-4 and eh < 1e-4
@@ -247,12 +269,13 @@ def test_gemm3_x3_qkv(n_seq, L, heads, f8):
     gh = torch.zeros((SH, nbp * 32), dtype=torch.float32, device=dev())
     st = _status()
     pack = to_hl8 if f8 else to_hl32
-    _call(0, 1 | (F8_IN if f8 else 0), A=pack(x).to(dev()), lda=D, M=M, K=D, W=pack(W).to(dev()), N=3 * D + heads, epi=2,
+    packa = to_hl8a if f8 else to_hl32
+    _call(0, 1 | (F8_IN if f8 else 0), A=packa(x).to(dev()), lda=D, M=M, K=D, W=pack(W).to(dev()), N=3 * D + heads, epi=2,
           ssq_in=_ssq_parts(x).to(dev()), ssq_parts=D // 64, n_seq=n_seq, L=L, nbp=nbp, heads=heads, rope=rope, qf=qf, kf=kf, vf=vf,
           gates=gh, b_gates=bg.float().to(dev()), status=st)
     rs = math.sqrt(D) / x.double().norm(dim=-1, keepdim=True).clamp_min(1e-12)
     Wd, xd = from_hl32(to_hl32(W)), from_hl32(to_hl32(x))
-    prod = hl8_matmul(pack(x), pack(W)) if f8 else xd @ Wd.T   # (hl8: against the float64 evaluation of the same arithmetic)
+    prod = hl8_matmul(packa(x), pack(W)) if f8 else xd @ Wd.T   # (hl8: against the float64 evaluation of the same arithmetic)
     qkv = (prod[:, :3 * D] * rs).view(n_seq, L, 3, heads, 32).permute(2, 0, 3, 1, 4)  # qkv s h t d
     ang = torch.arange(L, dtype=torch.float64)[:, None] * freqs.double()[None, :]
     cos, sin = ang.cos().repeat_interleave(2, -1), ang.sin().repeat_interleave(2, -1)

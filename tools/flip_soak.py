@@ -11,7 +11,7 @@ across machines / BLAS builds.
         CPU (build container): soak_cache/<style>_<k>.npz = fp32 + fp64 framewise logits of the oracle for a 300 s
         22.05 kHz synthetic track (seed 1000 + k) on seeded final0 weights.  soak_cache/ is git-ignored but travels to the
         GPU box with the snapshot.
-    python tools/flip_soak.py gpu [--schemes exact,x3,x3p16m,x3p16,half] [--tracks N]
+    python tools/flip_soak.py gpu [--schemes exact,x3,x3p16m,x3p16,x3p16f8ff,x3p16f8,half] [--tracks N]
         GPU box: the real kernels (Audio2Frames.many from the same waveforms) against the cached oracle logits.
     python tools/flip_soak.py sim [--schemes p16,vhi,e4m3,e2m3] [--device cuda|cpu] [--tracks N]
         operand-rounding simulations of schemes that are not built (tools/x3_narrow_study.py's forward, per site).
@@ -156,11 +156,13 @@ def cmd_gpu(args):
         for scheme in args.schemes.split(","):
             # exact = exact fp32 MFMAs; x3 = hi + lo operands with the three-term P.V of rounds 3 - 4; x3p16 = the same with the
             # probabilities as fp16 hi parts in P.V (round 5 default; x3p16m: in the main layers only); half = fp16 operands
-            mode, p16 = {"exact": ("exact", 2), "x3": (False, 0), "x3p16m": (False, 1), "x3p16": (False, 2), "half": (True, 2)}[scheme]
+            # x3p16f8ff / x3p16f8 = x3p16 with the cross terms of the feed-forward / of all main-layer GEMMs on fp8 (BT_OPT_X3_GEMM_FP8 = 1 / 2)
+            mode, p16, f8 = {"exact": ("exact", 2, 0), "x3": (False, 0, 0), "x3p16m": (False, 1, 0), "x3p16": (False, 2, 0), "half": (True, 2, 0),
+                             "x3p16f8ff": (False, 2, 1), "x3p16f8": (False, 2, 2)}[scheme]
             a2f = Audio2Frames(checkpoint_path=None, device=dev, float16=mode)
             m.fp32_split_gemms = True
             a2f.model = m
-            m.engine().set_options({"x3_attn_p16": p16})
+            m.engine().set_options({"x3_attn_p16": p16, "x3_gemm_fp8": f8})
             fb0 = m.engine().last_fallbacks
             t0 = time.time()
             for i in range(0, len(ks), 6):
@@ -173,7 +175,7 @@ def cmd_gpu(args):
                   f"flips {sum(r['flips_beat'] for r in mine)} / {sum(r['flips_down'] for r in mine)} of "
                   f"{sum(r['n_beats'] for r in mine)} / {sum(r['n_down'] for r in mine)}, range fallbacks "
                   f"{m.engine().last_fallbacks - fb0}", flush=True)
-        m.engine().set_options({"x3_attn_p16": 2})
+        m.engine().set_options({"x3_attn_p16": 2, "x3_gemm_fp8": 0})
     json.dump(rows, open(os.path.join(OUT, f"gpu_{args.tag}.json"), "w"))
 
 

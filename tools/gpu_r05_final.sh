@@ -16,4 +16,5 @@ import json
 d=json.loads(open("$O/bench.json").read().strip().splitlines()[-1])
 print("value", d["value"], d["ms_per_step"], json.dumps(d["parity"]), json.dumps(d["energy"]))
 print("latency", json.dumps(d["latency"]["f32x3"]))
+print("cfg5", json.dumps(d["configs"]["cfg5"]))
 PY
