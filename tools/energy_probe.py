@@ -19,7 +19,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
 from beat_this_amd import _lib as L  # noqa: E402
-from gpu_util import pad_rows, to_hl32  # noqa: E402
+from gpu_util import pad_rows, to_hl8, to_hl8a, to_hl32  # noqa: E402
 from tools.smi import Smi  # noqa: E402
 
 dev = torch.device("cuda:0")
@@ -74,12 +74,14 @@ def attention(SH_seq, heads, variant, label, per_step, out_f32=0):
     del qd, kd, vd, out
 
 
-def gemm(M, K, N, epi, label, per_step, heads=0, n_seq=0):
+def gemm(M, K, N, epi, label, per_step, heads=0, n_seq=0, f8=False, cfg=1):
+    """f8: hl8 operands, the cross terms on the block-scaled fp8 MFMA (BT_OPT_X3_GEMM_FP8; epi 0 / 1 also WRITE their activation as
+    hl8, like the engine's level 2); pipe flops are counted as 3 per product in both forms, so that the columns compare"""
     g = torch.Generator().manual_seed(2)
-    A = to_hl32(torch.randn((M, K), generator=g)).to(dev)
-    W = to_hl32(pad_rows(torch.randn((N, K), generator=g) / K ** 0.5, 256)).to(dev)
+    A = (to_hl8a if f8 else to_hl32)(torch.randn((M, K), generator=g)).to(dev)
+    W = (to_hl8 if f8 else to_hl32)(pad_rows(torch.randn((N, K), generator=g) / K ** 0.5, 256)).to(dev)
     a = L.Gemm3Args()
-    a.A, a.lda, a.M, a.K, a.W, a.N, a.epi, a.x3 = A.data_ptr(), K, M, K, W.data_ptr(), N, epi, 1
+    a.A, a.lda, a.M, a.K, a.W, a.N, a.epi, a.x3 = A.data_ptr(), K, M, K, W.data_ptr(), N, epi, 1 | ((0x100 | (0x200 if epi < 2 else 0)) if f8 else 0)
     keep = []
     if epi == 0:
         bias = torch.zeros(N, device=dev)
@@ -129,6 +131,17 @@ gemm(M, 512, 512, 1, "out-projection (gemm3 epi 1)", 6 * S)
 gemm(M, 512, 2048, 0, "FF1 + GELU (gemm3 epi 0)", 6 * S)
 gemm(M, 2048, 512, 1, "FF2 (gemm3 epi 1)", 6 * S)
 gemm(M, 1024, 512, 1, "frontend.linear (gemm3 epi 1)", 1 * S)
+if not lib.bt_half_is_bf16():   # BASELINE config 5: the same launches with the cross terms on the block-scaled fp8 MFMA (not in the step's sum)
+    gemm(M, 512, 3 * 512 + 16, 2, "QKV + RoPE + gates, fp8 cross terms", 0, heads=16, n_seq=B, f8=True)
+    gemm(M, 512, 512, 1, "out-projection, fp8 cross terms", 0, f8=True)
+    gemm(M, 512, 2048, 0, "FF1 + GELU, fp8 cross terms", 0, f8=True)
+    gemm(M, 2048, 512, 1, "FF2, fp8 cross terms", 0, f8=True)
+    if len(sys.argv) > 3:   # tile-configuration study (bt_gemm3_args.x3 & 15: 2 = 256-row tiles forced, 3 = 128 x 128 forced)
+        gemm(M, 512, 2048, 0, "FF1, fp8 cross terms, 256 x 256 tiles", 0, f8=True, cfg=2)
+        gemm(M, 512, 512, 1, "out-projection, fp8 cross terms, 256 x 256 tiles", 0, f8=True, cfg=2)
+        gemm(M, 2048, 512, 1, "FF2, fp8 cross terms, 128 x 128 tiles", 0, f8=True, cfg=3)
+        gemm(M, 512, 2048, 0, "FF1, hl32, 128 x 128 tiles", 0, cfg=3)
+        gemm(M, 512, 2048, 0, "FF1, hl32, 256 x 256 tiles", 0, cfg=2)
 known = sum(r["joules"] * r["launches_per_step"] for r in rows)
 known_ms = sum(r["us"] * r["launches_per_step"] for r in rows) * 1e-3
 print(f"sum over the launches of one 66-chunk step that were probed here: {known:.2f} J in {known_ms:.2f} ms of kernel time "
