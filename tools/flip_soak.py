@@ -332,7 +332,7 @@ def main():
     ap.add_argument("--out", default=None)
     args = ap.parse_args()
     if args.schemes is None:
-        args.schemes = {"gpu": "exact,x3,x3p16m,x3p16,half", "sim": "p16,vhi,e4m3,e2m3"}.get(args.cmd, "")
+        args.schemes = {"gpu": "exact,x3,x3p16m,x3p16,x3p16f8ff,x3p16f8,half", "sim": "p16,vhi,e4m3,e2m3"}.get(args.cmd, "")
     {"oracle": cmd_oracle, "gpu": cmd_gpu, "sim": cmd_sim, "report": cmd_report}[args.cmd](args)
 
 
