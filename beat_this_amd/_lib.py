@@ -22,7 +22,7 @@ SOURCES = ["gemm.hip", "gemm2.hip", "gemm3.hip", "attn.hip", "attn2.hip", "fused
 HEADERS = ["common.h", "chain.h", "kernels.h", "attn_x3_loop.inc", os.path.join("..", "..", "include", "beat_this_amd.h")]
 
 BT_OK, BT_ERR_ARG, BT_ERR_HIP, BT_ERR_WORKSPACE = 0, -1, -2, -3
-ABI_VERSION = 510   # BT_ABI_VERSION of include/beat_this_amd.h this binding was written against
+ABI_VERSION = 520   # BT_ABI_VERSION of include/beat_this_amd.h this binding was written against
 PREC_F32, PREC_HALF, PREC_F32X3 = 0, 1, 3   # (2 was the withdrawn e4m3 experiment)
 MAX_LAYERS = 32
 PROFILE_CATEGORIES = ["stem", "qkv_gemm", "attn_flash", "out_gemm", "ff1_gemm", "ff2_gemm", "conv_gemm",
@@ -82,7 +82,8 @@ class AttnFragArgs(C.Structure):
     _fields_ = [("q", C.c_void_p), ("k", C.c_void_p), ("v", C.c_void_p), ("gates", C.c_void_p), ("out", C.c_void_p),
                 ("n_seq", C.c_int32), ("L", C.c_int32), ("heads", C.c_int32), ("inner", C.c_int32),
                 ("nbp", C.c_int32), ("o_div", C.c_int32), ("o_outer", C.c_int64), ("o_inner", C.c_int64),
-                ("o_tok", C.c_int64), ("x3", C.c_int32), ("out_f32", C.c_int32), ("status", C.c_void_p)]
+                ("o_tok", C.c_int64), ("x3", C.c_int32), ("out_f32", C.c_int32), ("status", C.c_void_p),
+                ("scratch", C.c_void_p)]
 
 
 class Gemm3Args(C.Structure):

@@ -629,7 +629,7 @@ DEVI void score_x(const KFragX& kf, const QStateX (&st)[QB], f32x16 (&sc)[QB]) {
 // row sums are taken from the SAME rounded values (v_mfma_f32_4x4x4_16b_f16 with an all-ones A operand, like the half
 // kernel): numerator and denominator of the softmax see identical probabilities, fp16 subnormals included, so what the
 // rounding leaves in O / l is sum_j p_j d_j (v_j - o) / sum_j p_j with |d_j| <= 2^-12 -- the spread of V around the output, not V
-// itself.  An fp16 overflow of a probability is inf in the row sum (-> the re-run on the row maxima, as before).
+// itself.  An fp16 overflow of a probability is inf in the row sum (-> the query is left to attn_fix_x3_kernel).
 DEVI unsigned cvt_pk_rn(float a, float b) {   // (the instruction the hand-scheduled loop uses; leading wait state: a and b may
   unsigned w;                                  // be v_exp results, which a non-transcendental VALU may not read right away)
   asm("s_nop 0\n\tv_cvt_pk_f16_f32 %0, %1, %2" : "=v"(w) : "v"(a), "v"(b));
@@ -769,13 +769,14 @@ DEVI void attn_tiles_x(rsrc_t rk, rsrc_t rv, char* smem, int tid, int wave, int 
 // deeper into fp16's subnormal range, and with 4 + rounding the three-term kernels' error went from 6e-6 to 1e-5.)
 // Round 5: the reference point is rounded UP to a whole octave.  Probabilities relative to two reference points that differ
 // by whole octaves differ by a power of two, and both the hi + lo split and the fp16 rounding of P16 commute with that
-// (outside fp16's subnormal range): a workgroup that re-runs on its row maxima (row_max_pass_x) then reproduces what the
-// fast pass would have given without the overflow, so a query's result does not depend on which other queries share its
-// workgroup -- 128 or 256 of them, by the kernel a launch size selects -- beyond the subnormal tail.
+// (outside fp16's subnormal range): the reference point is a function of the query's own scores, in whole octaves, whichever
+// kernel form computes it -- and a query whose fast pass overflows is computed by attn_fix_x3_kernel on a reference point of
+// its own (its row maximum), so no query's result depends on which other queries share its workgroup, 128 or 256 of them by
+// the kernel a launch size selects.
 // Round 5, second change: the query's OWN key block joins the two leading ones (`kdiag[j]`: the K fragments of key block
 // qblk[j], fetched from global memory with the Q fragments).  With rotary positions the largest scores of a query sit near
-// its own position far more often than among the first 64 frames of the piece: the re-run rate of the benchmark's forward
-// fell from 1.1 % of the attention workgroups to the figure in DESIGN.md section 5 (21 % on the outlier stress weights before).
+// its own position far more often than among the first 64 frames of the piece: the workgroups of the benchmark's forward with an
+// overflowing query fell from 1.1 % to the figure in DESIGN.md section 5 (21 % on the outlier stress weights before).
 // (diag_max_x: that block's part, computed right behind the loads -- before any LDS-DMA is issued -- so that its fragments are
 // dead when the passes start; dmax[j] = this lane's maximum over its 16 keys of the block.)
 template <int QB>
@@ -824,76 +825,12 @@ DEVI void ref_max_x(const char* smem, int g, int lr, QStateX (&st)[QB], int L, i
   }
 }
 
-// The fallback of a workgroup whose fast pass overflowed (a key scored more than 16 + P_SHIFT octaves above the reference
-// point): the maxima of its queries over ALL keys -- from the hi . hi products alone, two MFMAs per block: a reference point
-// needs no more -- after which the SAME fast pass runs again and cannot overflow (every probability <= 2^-P_SHIFT).  About a
-// quarter of a fast pass on top of the two, against three to four for the classic running-maximum loop this replaces
-// (round 4: 2.7 % of the workgroups of the benchmark's forward take this path, 30 % on the outlier stress weights).
-// Plain double-buffered tiles in LDS buffers 0 / 1 (as attn_tiles_x); every LDS-DMA is drained on return.
-// Round 5: only the queries that DID overflow (`redo`, per lane) take the new reference point; their neighbours in the
-// workgroup run the fast pass again on the reference they had and reproduce their first result bit for bit.  A query's
-// result is then a function of its own scores alone -- not of which other queries share its workgroup (128 or 256 of them,
-// by the kernel a launch size selects): a chunk gives the same bits alone and inside any batch.
-template <int QB, int KBX>
-DEVI void row_max_pass_x(rsrc_t rk, rsrc_t rv, char* smem, int tid, int wave, int g, int lr, QStateX (&st)[QB], int L, int nblk,
-                         const float (&l_first)[QB], const char* kseq, const int (&qblk)[QB]) {
-  // l_first: the fast pass's row sums (redo = not below 65504).  The reference points of the queries that keep theirs are
-  // computed AGAIN from tile 0 (ref_max_x: a function of the query and the first two key blocks, so the same bits) rather than
-  // kept in registers across the passes: the hand-scheduled kernel has none to spare.
-  constexpr int TILEX_BYTES = KBX * BLKX_BYTES;
-  const int ntiles = (nblk + KBX - 1) / KBX;
-  float bm[QB], keep[QB], dmax[QB];
-  diag_max_x<QB>(kseq, qblk, g, lr, st, L, dmax);
-  stage_tile_x<KBX>(rk, rv, 0, smem, 0, tid, wave);
-  __syncthreads();
-  ref_max_x<QB>(smem, g, lr, st, L, nblk, dmax);
-#pragma unroll
-  for (int j = 0; j < QB; ++j) {
-    bm[j] = -1e30f;
-    keep[j] = st[j].negm[0];
-  }
-  for (int t = 0; t < ntiles; ++t) {
-    if (t + 1 < ntiles) stage_tile_x<KBX>(rk, rv, t + 1, smem, (t + 1) & 1, tid, wave);
-    const char* kb = smem + (t & 1) * 2 * TILEX_BYTES;
-    const int nb = min(KBX, nblk - t * KBX);
-    for (int c = 0; c < nb; ++c) {
-      const char* blk = kb + c * BLKX_BYTES;
-      const hfx8 k0 = *reinterpret_cast<const hfx8*>(blk + ((2 * g) * 32 + lr) * 16);
-      const hfx8 k1 = *reinterpret_cast<const hfx8*>(blk + ((2 * g + 1) * 32 + lr) * 16);
-      const int key0 = (t * KBX + c) * 32;
-#pragma unroll
-      for (int j = 0; j < QB; ++j) {
-        f32x16 sc;
-        zero16(sc);
-        sc = MFMA32_H(k0, st[j].q0, sc);
-        sc = MFMA32_H(k1, st[j].q1, sc);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) bm[j] = fmaxf(bm[j], (key0 + crow(r, g) < L) ? sc[r] : -1e30f);
-      }
-    }
-    __syncthreads();  // tile t + 1 has landed (every wave waited for its own copies), tile t is free
-  }
-  // The reference point of the re-run puts the row maximum at 2^14 .. 2^15 (the largest probability an fp16 hi part holds is
-  // 65504; the maximum comes from hi . hi scores and may sit 0.05 octaves low): the fast pass's own shift (P_SHIFT octaves
-  // BELOW its reference point) buys headroom for keys that have not been seen yet; here all have been, and every octave not
-  // spent on headroom keeps one more octave of small probabilities out of fp16's subnormal range (absolute 2^-25 per term:
-  // with the maximum at 2^-4 the row sums were 1.3e-5 off; rounds 3 - 4 had it at 4; row sums are fp32 and are not tested again).
-#pragma unroll
-  for (int j = 0; j < QB; ++j) {
-    const float m = ceilf(fmaxf(bm[j], __shfl_xor(bm[j], 32)));   // (whole octaves: see ref_max_x)
-    const float nm = !(l_first[j] < 65504.f) ? 14.0f - m : keep[j];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) st[j].negm[r] = nm;
-  }
-}
-
 // Fast pass: reference maximum of every query from key block 0, then the key loop software-pipelined by hand over the
 // tiles of KB unmasked blocks: the scores of block c + 1 are issued BEFORE the exponentials of block c (two score
 // buffers alternate: the loop is unrolled over the tile, no register copies), one barrier per tile at its last block.
 template <int QB, int KBX, bool P16 = false>
 DEVI void attn_fast_x(rsrc_t rk, rsrc_t rv, char* smem, int tid, int wave, int lane, int g, int lr, QStateX (&st)[QB], int L,
-                      int nblk, const float (&dmax)[QB],
-                      bool have_ref = false) {   // have_ref: st[j].negm is set (the re-run behind row_max_pass_x; dmax unused)
+                      int nblk, const float (&dmax)[QB]) {
   constexpr int TILEX_BYTES = KBX * BLKX_BYTES;
   static_assert(KBX % 2 == 0, "two score buffers alternate over the blocks of a tile");
   const int ntiles = (nblk + KBX - 1) / KBX;
@@ -915,7 +852,7 @@ DEVI void attn_fast_x(rsrc_t rk, rsrc_t rv, char* smem, int tid, int wave, int l
   // fit the register file): there the scores of the next block follow the current block's products.
   constexpr bool PIPE = QB == 1;
   f32x16 s2[PIPE ? 2 : 1][QB];  // scores of the current / the next block (compile-time indices: the tile loop is unrolled)
-  if (!have_ref) ref_max_x<QB>(smem, g, lr, st, L, nblk, dmax);   // (workgroup-uniform)
+  ref_max_x<QB>(smem, g, lr, st, L, nblk, dmax);   // (workgroup-uniform)
   KFragX kf = ld_kx(smem, g, lr);
   // the scores of block 0 of tile 0 (one query block per wave: on the reference maximum, which rides on the accumulator input)
   if (QB == 1 && nfull > 0) score_x<true, QB>(kf, st, s2[0]);
@@ -949,6 +886,64 @@ DEVI void attn_fast_x(rsrc_t rk, rsrc_t rv, char* smem, int tid, int wave, int l
     __syncthreads();
 }
 
+// The rows of one query block (this lane: query qi, valid when okq) scaled by gate / row sum and stored in the launch's output form
+// (OUT: 0 = hl32 / hl8 rows of the main layers, 1 = fp32 rows of the frontend); amax: range guard of the split.
+template <int OUT>
+DEVI void store_rows_x(const AttnFragP& p, const QStateX& st, float l_tot, int qi, bool okq, int sh, int g, float& amax) {
+  const int seq = sh / p.heads, head = sh - seq * p.heads;
+  const float gatev = okq ? p.gates[(long)sh * p.nbp * 32 + qi] : 0.f;
+  const long orow = okq ? (long)(seq / p.o_div) * p.o_outer + (long)(seq % p.o_div) * p.o_inner + (long)qi * p.o_tok : 0;
+  const float scale = okq ? gatev / l_tot : 0.f;
+  if constexpr (OUT == 1) {
+    float* op = reinterpret_cast<float*>(p.out) + orow * p.inner + head * 32 + 4 * g;
+    if (okq) {
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+        *reinterpret_cast<f32x4*>(op + 8 * a) = f32x4{st.acc[4 * a] * scale, st.acc[4 * a + 1] * scale,
+                                                       st.acc[4 * a + 2] * scale, st.acc[4 * a + 3] * scale};
+    }
+  } else {
+    // hl32 row: the head's 32 features are one [hi 32 | lo 32] group at half offset 64 head.  A lane holds 4-feature
+    // runs 8 a + 4 g; the two halves of the wave exchange runs so that every lane stores 16-byte pieces (features
+    // 16 k + 8 g .. + 7), for the hi and for the lo part.  (The exchange is executed by all lanes.)
+    hf* op = reinterpret_cast<hf*>(p.out) + orow * 2 * p.inner + head * 64 + 8 * g;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      unsigned xh[2], xl[2], yh[2], yl[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const float a0 = st.acc[8 * k + 2 * i] * scale, a1 = st.acc[8 * k + 2 * i + 1] * scale;
+        const float b0 = st.acc[8 * k + 4 + 2 * i] * scale, b1 = st.acc[8 * k + 4 + 2 * i + 1] * scale;
+        split_hl4(a0, a1, b0, b1, xh[i], xl[i], yh[i], yl[i]);   // (common.h)
+        amax = fmaxf(amax, fmaxf(fmaxf(fabsf(a0), fabsf(a1)), fmaxf(fabsf(b0), fabsf(b1))));
+      }
+      auto h0 = __builtin_amdgcn_permlane32_swap(xh[0], yh[0], false, false);
+      auto h1 = __builtin_amdgcn_permlane32_swap(xh[1], yh[1], false, false);
+      if (p.out_f32 == 2) {
+        // hl8 row (BT_OPT_X3_GEMM_FP8 = 2: the out-projection runs the fp8 cross terms): the group is [32 hi halves | 32 hi bytes |
+        // 32 lo bytes]; this lane's 8 features 16 k + 8 g .. + 7 are 8 bytes in each byte section
+        const float s0 = st.acc[8 * k] * scale, s1 = st.acc[8 * k + 1] * scale, s2 = st.acc[8 * k + 2] * scale, s3 = st.acc[8 * k + 3] * scale;
+        const float t0 = st.acc[8 * k + 4] * scale, t1 = st.acc[8 * k + 5] * scale, t2 = st.acc[8 * k + 6] * scale, t3 = st.acc[8 * k + 7] * scale;
+        auto b8 = __builtin_amdgcn_permlane32_swap(pk4_f8(s0, s1, s2, s3), pk4_f8(t0, t1, t2, t3), false, false);
+        auto c8 = __builtin_amdgcn_permlane32_swap(lo4_f8(s0, s1, s2, s3, xh[0], xh[1]), lo4_f8(t0, t1, t2, t3, yh[0], yh[1]), false, false);
+        if (okq) {
+          *reinterpret_cast<u32x4*>(op + 16 * k) = u32x4{h0[0], h1[0], h0[1], h1[1]};
+          char* gb = reinterpret_cast<char*>(op) - 16 * g;   // the group's first byte
+          *reinterpret_cast<u32x2*>(gb + 64 + 16 * k + 8 * g) = u32x2{b8[0], b8[1]};
+          *reinterpret_cast<u32x2*>(gb + 96 + 16 * k + 8 * g) = u32x2{c8[0], c8[1]};
+        }
+      } else {
+      auto l0 = __builtin_amdgcn_permlane32_swap(xl[0], yl[0], false, false);
+      auto l1 = __builtin_amdgcn_permlane32_swap(xl[1], yl[1], false, false);
+      if (okq) {
+        *reinterpret_cast<u32x4*>(op + 16 * k) = u32x4{h0[0], h1[0], h0[1], h1[1]};
+        *reinterpret_cast<u32x4*>(op + 32 + 16 * k) = u32x4{l0[0], l1[0], l0[1], l1[1]};
+      }
+      }
+    }
+  }
+}
+
 // OUT: 0 = hl32 planes [rows, 2 inner] (main layers), 1 = fp32 [rows, inner] (frontend)
 template <int QB, int OUT, int KBX, int MINW, bool P16>
 __global__ __launch_bounds__(256, MINW) void attn_frag_x3_kernel(const AttnFragP p, int nqt, int sh_total) {
@@ -966,9 +961,6 @@ __global__ __launch_bounds__(256, MINW) void attn_frag_x3_kernel(const AttnFragP
   const long seq_off = (long)sh * p.nbp * BLKX_BYTES;
   const char* kseq = reinterpret_cast<const char*>(p.k) + seq_off;
   const char* vseq = reinterpret_cast<const char*>(p.v) + seq_off;
-  int* flag = reinterpret_cast<int*>(smem + 4 * TILEX_BYTES);
-  if (tid == 0) *flag = 0;
-
   QStateX st[QB];
   int qbi[QB];
   const int qb0 = (qt * 4 + wave) * QB;  // this wave's first query block
@@ -994,86 +986,29 @@ __global__ __launch_bounds__(256, MINW) void attn_frag_x3_kernel(const AttnFragP
   attn_fast_x<QB, KBX, P16>(rk, rv, smem, tid, wave, lane, g, lr, st, L, nblk, dmax);
   auto lane_sum = [&](int j) { return P16 ? st[j].l4[0] : st[j].l; };
   float l_tot[QB];
-  bool bad = false;
+  bool bad[QB];
 #pragma unroll
   for (int j = 0; j < QB; ++j) {
     l_tot[j] = lane_sum(j) + __shfl_xor(lane_sum(j), 32);
     const bool valid = qb0 + j < nblk && (qb0 + j) * 32 + lr < L;
     // the row sum is taken from the UNSPLIT fp32 probabilities, so an fp16 overflow of a hi part (p > 65504) does not turn
-    // it into inf: but such a p makes the sum exceed 65504 as well -> this query needs the running-max pass (a sum that
-    // large without any single overflow only costs the re-run).  (P16: the sum is taken from the rounded values -- inf then)
-    bad = bad || (valid && !(l_tot[j] < 65504.f));
+    // it into inf: but such a p makes the sum exceed 65504 as well -> this query needs its row maximum as the reference point
+    // (a sum that large without any single overflow only costs the repeat).  (P16: the sum is taken from the rounded values --
+    // inf then.)  Such a query is not stored here: its bit goes into the launch's overflow map and attn_fix_x3_kernel, the
+    // next launch on the stream, computes it (round 5; rounds 3 - 5 repeated the whole workgroup's pass in place).
+    bad[j] = valid && !(l_tot[j] < 65504.f);
+    const unsigned long long bw = __ballot(bad[j]);
+    if (lane == 0 && qb0 + j < nblk) p.fix_mask[(long)sh * p.nbp + qb0 + j] = (int)(unsigned)bw;
   }
-  if (__any(bad) && lane == 0) *flag = 1;
-  __syncthreads();
-#ifdef BT_DEV
-  if (p.status && tid == 0) { atomicAdd(p.status + 2, 1); if (*flag) atomicAdd(p.status + 1, 1); }
+#ifdef BT_DEV   // development: workgroups of the launch (word 2 of the status block; attn_fix_x3_kernel counts words 1 and 3)
+  if (p.status && tid == 0) atomicAdd(p.status + 2, 1);
 #endif
-  if (*flag) {  // workgroup-uniform: row maxima over all keys, then the same fast pass on them (row_max_pass_x)
-    __syncthreads();
-    row_max_pass_x<QB, KBX>(rk, rv, smem, tid, wave, g, lr, st, L, nblk, l_tot, kseq, qbi);
-    attn_fast_x<QB, KBX, P16>(rk, rv, smem, tid, wave, lane, g, lr, st, L, nblk, dmax, true);
-#pragma unroll
-    for (int j = 0; j < QB; ++j) l_tot[j] = lane_sum(j) + __shfl_xor(lane_sum(j), 32);
-  }
 
-  const int seq = sh / p.heads, head = sh - seq * p.heads;
   float amax = 0.f;
 #pragma unroll
   for (int j = 0; j < QB; ++j) {
     const int qi = (qb0 + j) * 32 + lr;
-    const bool okq = qb0 + j < nblk && qi < L;
-    const float gatev = okq ? p.gates[(long)sh * p.nbp * 32 + qi] : 0.f;
-    const long orow = okq ? (long)(seq / p.o_div) * p.o_outer + (long)(seq % p.o_div) * p.o_inner + (long)qi * p.o_tok : 0;
-    const float scale = okq ? gatev / l_tot[j] : 0.f;
-    if constexpr (OUT == 1) {
-      float* op = reinterpret_cast<float*>(p.out) + orow * p.inner + head * 32 + 4 * g;
-      if (okq) {
-#pragma unroll
-        for (int a = 0; a < 4; ++a)
-          *reinterpret_cast<f32x4*>(op + 8 * a) = f32x4{st[j].acc[4 * a] * scale, st[j].acc[4 * a + 1] * scale,
-                                                         st[j].acc[4 * a + 2] * scale, st[j].acc[4 * a + 3] * scale};
-      }
-    } else {
-      // hl32 row: the head's 32 features are one [hi 32 | lo 32] group at half offset 64 head.  A lane holds 4-feature
-      // runs 8 a + 4 g; the two halves of the wave exchange runs so that every lane stores 16-byte pieces (features
-      // 16 k + 8 g .. + 7), for the hi and for the lo part.  (The exchange is executed by all lanes.)
-      hf* op = reinterpret_cast<hf*>(p.out) + orow * 2 * p.inner + head * 64 + 8 * g;
-#pragma unroll
-      for (int k = 0; k < 2; ++k) {
-        unsigned xh[2], xl[2], yh[2], yl[2];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          const float a0 = st[j].acc[8 * k + 2 * i] * scale, a1 = st[j].acc[8 * k + 2 * i + 1] * scale;
-          const float b0 = st[j].acc[8 * k + 4 + 2 * i] * scale, b1 = st[j].acc[8 * k + 4 + 2 * i + 1] * scale;
-          split_hl4(a0, a1, b0, b1, xh[i], xl[i], yh[i], yl[i]);   // (common.h)
-          amax = fmaxf(amax, fmaxf(fmaxf(fabsf(a0), fabsf(a1)), fmaxf(fabsf(b0), fabsf(b1))));
-        }
-        auto h0 = __builtin_amdgcn_permlane32_swap(xh[0], yh[0], false, false);
-        auto h1 = __builtin_amdgcn_permlane32_swap(xh[1], yh[1], false, false);
-        if (p.out_f32 == 2) {
-          // hl8 row (BT_OPT_X3_GEMM_FP8 = 2: the out-projection runs the fp8 cross terms): the group is [32 hi halves | 32 hi bytes |
-          // 32 lo bytes]; this lane's 8 features 16 k + 8 g .. + 7 are 8 bytes in each byte section
-          const float s0 = st[j].acc[8 * k] * scale, s1 = st[j].acc[8 * k + 1] * scale, s2 = st[j].acc[8 * k + 2] * scale, s3 = st[j].acc[8 * k + 3] * scale;
-          const float t0 = st[j].acc[8 * k + 4] * scale, t1 = st[j].acc[8 * k + 5] * scale, t2 = st[j].acc[8 * k + 6] * scale, t3 = st[j].acc[8 * k + 7] * scale;
-          auto b8 = __builtin_amdgcn_permlane32_swap(pk4_f8(s0, s1, s2, s3), pk4_f8(t0, t1, t2, t3), false, false);
-          auto c8 = __builtin_amdgcn_permlane32_swap(lo4_f8(s0, s1, s2, s3, xh[0], xh[1]), lo4_f8(t0, t1, t2, t3, yh[0], yh[1]), false, false);
-          if (okq) {
-            *reinterpret_cast<u32x4*>(op + 16 * k) = u32x4{h0[0], h1[0], h0[1], h1[1]};
-            char* gb = reinterpret_cast<char*>(op) - 16 * g;   // the group's first byte
-            *reinterpret_cast<u32x2*>(gb + 64 + 16 * k + 8 * g) = u32x2{b8[0], b8[1]};
-            *reinterpret_cast<u32x2*>(gb + 96 + 16 * k + 8 * g) = u32x2{c8[0], c8[1]};
-          }
-        } else {
-        auto l0 = __builtin_amdgcn_permlane32_swap(xl[0], yl[0], false, false);
-        auto l1 = __builtin_amdgcn_permlane32_swap(xl[1], yl[1], false, false);
-        if (okq) {
-          *reinterpret_cast<u32x4*>(op + 16 * k) = u32x4{h0[0], h1[0], h0[1], h1[1]};
-          *reinterpret_cast<u32x4*>(op + 32 + 16 * k) = u32x4{l0[0], l1[0], l0[1], l1[1]};
-        }
-        }
-      }
-    }
+    store_rows_x<OUT>(p, st[j], l_tot[j], qi, qb0 + j < nblk && qi < L && !bad[j], sh, g, amax);
   }
   if (OUT == 0 && p.status && __any(!(amax <= (p.out_f32 == 2 ? HL8_ACT_MAX : 65504.f))) && lane == 0) atomicOr(p.status, 1);
 }
@@ -1089,7 +1024,7 @@ __global__ __launch_bounds__(256, MINW) void attn_frag_x3_kernel(const AttnFragP
 // instructions per 32-cycle MFMA gap, which is what one wave can issue beside a saturated matrix pipe
 // (MI355X_MICROARCH.md).  hipcc's own schedule of the same work (attn_frag_x3_kernel above) clusters the split blocks and
 // leaves runs of four back-to-back MFMAs next to runs of twenty VALU instructions: 45 - 50 % matrix-pipe busy.
-// Prologue (Q fragments, reference maximum), the ragged / masked last tile, the overflow fallback (SAFE pass) and the output
+// Prologue (Q fragments, reference maximum), the ragged / masked last tile, the overflow map and the output
 // stores are the C++ of the kernel above, instantiated for two query blocks per wave.
 #include "attn_x3_loop.inc"
 
@@ -1111,9 +1046,6 @@ __global__ __launch_bounds__(256, 2) void attn_frag_x3q2_kernel(const AttnFragP 
   const long seq_off = (long)sh * p.nbp * BLKX_BYTES;
   const char* kseq = reinterpret_cast<const char*>(p.k) + seq_off;
   const char* vseq = reinterpret_cast<const char*>(p.v) + seq_off;
-  int* flag = reinterpret_cast<int*>(smem + NBUF * BUF_BYTES);
-  if (tid == 0) *flag = 0;
-
   QStateX st[QB];
   const int qb0 = (qt * 4 + wave) * QB;  // this wave's first query block
   // (the Q fragments are loaded twice: the asm statement below takes 140 of the 256 registers for itself, and what is
@@ -1229,52 +1161,29 @@ __global__ __launch_bounds__(256, 2) void attn_frag_x3q2_kernel(const AttnFragP 
   fast_pass();
   // (Lane-derived values are taken again from an operand hipcc cannot see through wherever they are needed: nothing but the
   // softmax state may stay live across an asm statement -- the three-term one leaves 18 registers -- and a value kept was a
-  // spill, which the ISA lint does not allow next to LDS-DMA.  That includes the second statement on the re-run path: the
-  // row sums and lane ids of the epilogue are formed behind it, not carried around it.)
+  // spill, which the ISA lint does not allow next to LDS-DMA.)
   auto lane_sum = [&](int j) { return P16 ? st[j].l4[0] : st[j].l; };
-  {
-    const int ln = lane_id_fresh();
-    bool bad = false;
-#pragma unroll
-    for (int j = 0; j < QB; ++j) {
-      const float lt = lane_sum(j) + __shfl_xor(lane_sum(j), 32);
-      const bool valid = qb0 + j < nblk && (qb0 + j) * 32 + (ln & 31) < L;
-      bad = bad || (valid && !(lt < 65504.f));   // (see attn_frag_x3_kernel)
-    }
-    if (__any(bad) && ln == 0) *flag = 1;
-  }
-  __syncthreads();
-#ifdef BT_DEV   // development: how many workgroups re-run on their row maxima (words 1, 2 of the status block)
-  if (p.status && tid == 0) { atomicAdd(p.status + 2, 1); if (*flag) atomicAdd(p.status + 1, 1); }
-#endif
-  if (*flag) {  // workgroup-uniform: row maxima over all keys for the queries that overflowed (row_max_pass_x), then the same pass again
-    __syncthreads();
-    load_q();
-    const int ln = lane_id_fresh();
-    const int qb0r = __builtin_amdgcn_readfirstlane((qt * 4 + wave) * QB);
-    const int qbi[QB] = {min(qb0r, nblk - 1), min(qb0r + 1, nblk - 1)};
-    float l_first[QB];
-#pragma unroll
-    for (int j = 0; j < QB; ++j) l_first[j] = lane_sum(j) + __shfl_xor(lane_sum(j), 32);
-    row_max_pass_x<QB, KBX>(rk, rv, smem, wave * 64 + ln, wave, ln >> 5, ln & 31, st, L, nblk, l_first, kseq, qbi);
-    stage_ring(0);
-    stage_ring(1);
-    stage_ring(2);
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    __syncthreads();
-    fast_pass();
-  }
   const int laneE = lane_id_fresh(), gE = laneE >> 5, lrE = laneE & 31;
   float l_tot[QB];
+  bool bad[QB];
 #pragma unroll
-  for (int j = 0; j < QB; ++j) l_tot[j] = lane_sum(j) + __shfl_xor(lane_sum(j), 32);
+  for (int j = 0; j < QB; ++j) {
+    l_tot[j] = lane_sum(j) + __shfl_xor(lane_sum(j), 32);
+    const bool valid = qb0 + j < nblk && (qb0 + j) * 32 + lrE < L;
+    bad[j] = valid && !(l_tot[j] < 65504.f);   // (see attn_frag_x3_kernel: left to attn_fix_x3_kernel, through the overflow map)
+    const unsigned long long bw = __ballot(bad[j]);
+    if (laneE == 0 && qb0 + j < nblk) p.fix_mask[(long)sh * p.nbp + qb0 + j] = (int)(unsigned)bw;
+  }
+#ifdef BT_DEV
+  if (p.status && tid == 0) atomicAdd(p.status + 2, 1);
+#endif
 
   const int seq = sh / p.heads, head = sh - seq * p.heads;
   float amax = 0.f;
 #pragma unroll
   for (int j = 0; j < QB; ++j) {
     const int qi = (qb0 + j) * 32 + lrE;
-    const bool okq = qb0 + j < nblk && qi < L;
+    const bool okq = qb0 + j < nblk && qi < L && !bad[j];
     const float gatev = okq ? p.gates[(long)sh * p.nbp * 32 + qi] : 0.f;
     const long orow = okq ? (long)(seq / p.o_div) * p.o_outer + (long)(seq % p.o_div) * p.o_inner + (long)qi * p.o_tok : 0;
     const float scale = okq ? gatev / l_tot[j] : 0.f;
@@ -1327,6 +1236,181 @@ __global__ __launch_bounds__(256, 2) void attn_frag_x3q2_kernel(const AttnFragP 
   if (OUT == 0 && p.status && __any(!(amax <= (p.out_f32 == 2 ? HL8_ACT_MAX : 65504.f))) && laneE == 0) atomicOr(p.status, 1);
 }
 
+
+// =====================================================================================================================
+// The queries whose fast pass overflowed fp16 (a key more than 16 + P_SHIFT octaves above their reference point), round 5.
+// The kernels above leave them out and set their bits in the launch's overflow map (p.fix_mask: one word per (sequence, head)
+// pair and query block); this launch follows on the stream, its workgroups walk the pairs: no bit -> next pair (188 bytes read); else the
+// overflowed queries of the pair are GATHERED, 32 per round, and computed the way the in-place repeat of rounds 3 - 5 did --
+// row maxima over all keys from the hi . hi scores, then the fast pass's own arithmetic (score_x / finish_x) on the reference
+// point 14 - ceil(maximum) -- with the KEYS split over the four waves: wave w takes key blocks [w n, (w + 1) n), n =
+// ceil(blocks / 4), fragments straight from global memory (the K / V blocks are fragment-major: no LDS staging, no barrier in
+// the loops), the partial maxima, outputs and row sums meet in LDS and are added in wave order.  A query's result is a
+// function of its own scores and of L alone -- not of its neighbours, the batch, or the kernel form in front.
+// Why a launch of its own: the in-place repeat cost a workgroup 2.4 passes for a handful of queries (0.6 % of the queries of
+// the outlier stress weights sit in 18 % of the frontend's workgroups: 11.8 % of all attention workgroups repeated); gathered,
+// a pair's overflowed queries cost two quarter-passes of ONE query block per 32 of them, and the kernels in front lose the
+// repeat's code, barrier and registers.
+// (Four waves of <= 256 registers, two workgroups per CU: eight waves per workgroup -- half the key blocks per wave -- need a whole
+// CU's registers at once and wait for the other stream's kernels to drain: +0.5 % on the benchmark step, same box, A/B.)
+constexpr int FIX_GRID = 512, FIX_NW = 4;   // workgroups of the fix-up launch and waves per workgroup
+template <int OUT, bool P16>
+__global__ __launch_bounds__(64 * FIX_NW, 2) void attn_fix_x3_kernel(const AttnFragP p, int sh_total) {
+  __shared__ float s_max[FIX_NW][32];
+  __shared__ float s_part[FIX_NW][64][17];   // [wave][lane][16 outputs + row sum] (17: conflict-free columns)
+  __shared__ int s_tot[FIX_NW];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 5, lr = lane & 31;
+  const int L = p.L;
+  const int nblk = (L + 31) >> 5;
+  const int per = (nblk + FIX_NW - 1) / FIX_NW;
+  const int b0 = min(wave * per, nblk), b1 = min(b0 + per, nblk);   // this wave's key blocks
+  const bool partial = (L & 31) != 0;
+  float amax = 0.f;
+  for (int sweep = 0; sweep * FIX_GRID * FIX_NW < sh_total; ++sweep) {
+    // every wave counts the bits of ONE pair's map (one load per sweep; L <= 2048 frames in one piece): pair blockIdx + FIX_GRID wave
+    const int first = sweep * FIX_GRID * FIX_NW + blockIdx.x;
+    {
+      const int shw = first + FIX_GRID * wave;
+      int total = 0;
+      if (shw < sh_total) {
+        const int* mww = p.fix_mask + (long)shw * p.nbp;
+        for (int c0 = 0; c0 < nblk; c0 += 64) {
+          int c = c0 + lane < nblk ? __popc((unsigned)mww[c0 + lane]) : 0;
+#pragma unroll
+          for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+          total += c;
+        }
+      }
+      if (lane == 0) s_tot[wave] = total;
+    }
+    __syncthreads();
+    for (int w2 = 0; w2 < FIX_NW; ++w2) {
+      const int total = s_tot[w2];   // (uniform)
+      if (total == 0) continue;
+      const int sh = first + FIX_GRID * w2;
+      const int* mw = p.fix_mask + (long)sh * p.nbp;
+#ifdef BT_DEV   // development: queries recomputed here / pairs with any (words 1, 3 of the status block)
+      if (p.status && tid == 0) { atomicAdd(p.status + 1, total); atomicAdd(p.status + 3, 1); }
+#endif
+      const long seq_off = (long)sh * p.nbp * BLKX_BYTES;
+      const char* kseq = reinterpret_cast<const char*>(p.k) + seq_off;
+      const char* vseq = reinterpret_cast<const char*>(p.v) + seq_off;
+      for (int base = 0; base < total; base += 32) {
+        // this lane's query: the r-th set bit of the pair's map (lanes lr and lr + 32 hold the same query, as everywhere)
+        const int r = base + lr;
+        const bool okq = r < total;
+        int blk = 0, tok = 0, pre = 0;
+        unsigned wsel = 0;
+        for (int c0 = 0; c0 < nblk; c0 += 64) {
+          const int wl = c0 + lane < nblk ? mw[c0 + lane] : 0;
+          const int nb = min(64, nblk - c0);
+          for (int b = 0; b < nb; ++b) {
+            const unsigned wb = (unsigned)__builtin_amdgcn_readlane(wl, b);
+            const int c = __popc(wb);
+            if (r >= pre && r < pre + c) { blk = c0 + b; wsel = wb; tok = r - pre; }
+            pre += c;
+          }
+        }
+        for (int i = tok; i > 0; --i) wsel &= wsel - 1;   // drop the lower set bits
+        tok = okq ? __ffs((int)wsel) - 1 : 0;
+        const int qi = blk * 32 + tok;
+        QStateX st[1];
+        const char* qblk = reinterpret_cast<const char*>(p.q) + seq_off + (long)blk * BLKX_BYTES;
+        st[0].q0 = *reinterpret_cast<const hfx8*>(qblk + ((2 * g) * 32 + tok) * 16);
+        st[0].q1 = *reinterpret_cast<const hfx8*>(qblk + ((2 * g + 1) * 32 + tok) * 16);
+        st[0].q0l = *reinterpret_cast<const hfx8*>(qblk + BLK_BYTES + ((2 * g) * 32 + tok) * 16);
+        st[0].q1l = *reinterpret_cast<const hfx8*>(qblk + BLK_BYTES + ((2 * g + 1) * 32 + tok) * 16);
+        // row maxima over this wave's keys: hi . hi scores, two MFMAs per block (a reference point needs no more).  The loop is
+        // latency, not work: the fragments of up to FIX_A blocks are requested at once and consumed as they arrive.
+        float bm = -1e30f;
+        constexpr int FIX_A = 6, FIX_B = 2;
+        for (int c0 = b0; c0 < b1; c0 += FIX_A) {
+          hfx8 ka[FIX_A][2];
+#pragma unroll
+          for (int c = 0; c < FIX_A; ++c)
+            if (c0 + c < b1) {
+              const char* kb = kseq + (long)(c0 + c) * BLKX_BYTES;
+              ka[c][0] = *reinterpret_cast<const hfx8*>(kb + ((2 * g) * 32 + lr) * 16);
+              ka[c][1] = *reinterpret_cast<const hfx8*>(kb + ((2 * g + 1) * 32 + lr) * 16);
+            }
+#pragma unroll
+          for (int c = 0; c < FIX_A; ++c)
+            if (c0 + c < b1) {
+              f32x16 sc;
+              zero16(sc);
+              sc = MFMA32_H(ka[c][0], st[0].q0, sc);
+              sc = MFMA32_H(ka[c][1], st[0].q1, sc);
+#pragma unroll
+              for (int i = 0; i < 16; ++i) bm = fmaxf(bm, ((c0 + c) * 32 + crow(i, g) < L) ? sc[i] : -1e30f);
+            }
+        }
+        bm = fmaxf(bm, __shfl_xor(bm, 32));
+        if (g == 0) s_max[wave][lr] = bm;
+        __syncthreads();
+        {
+          // The reference point puts the row maximum at 2^14 .. 2^15 (the largest probability an fp16 hi part holds is 65504;
+          // the maximum comes from hi . hi scores and may sit 0.05 octaves low): the fast pass's own shift (P_SHIFT octaves
+          // BELOW its reference point) buys headroom for keys that have not been seen yet; here all have been, and every octave
+          // not spent on headroom keeps one more octave of small probabilities out of fp16's subnormal range.  Whole octaves:
+          // see ref_max_x.
+          float m = s_max[0][lr];
+#pragma unroll
+          for (int w = 1; w < FIX_NW; ++w) m = fmaxf(m, s_max[w][lr]);
+          m = ceilf(m);
+#pragma unroll
+          for (int i = 0; i < 16; ++i) st[0].negm[i] = 14.0f - m;
+        }
+        zero16(st[0].acc);
+        st[0].l = 0.f;
+        st[0].l4 = f32x4{0.f, 0.f, 0.f, 0.f};
+        st[0].m = -1e30f;
+        for (int c0 = b0; c0 < b1; c0 += FIX_B) {   // (FIX_B blocks' K and V fragments in flight at once)
+          KFragX kq[FIX_B];
+          VFragX vq[FIX_B];
+#pragma unroll
+          for (int c = 0; c < FIX_B; ++c)
+            if (c0 + c < b1) {
+              kq[c] = ld_kx(kseq + (long)(c0 + c) * BLKX_BYTES, g, lr);
+              vq[c] = ld_vx(vseq + (long)(c0 + c) * BLKX_BYTES, lane);
+            }
+#pragma unroll
+          for (int c = 0; c < FIX_B; ++c)
+            if (c0 + c < b1) {
+              const int b = c0 + c;
+              f32x16 sc[1];
+              score_x<true, 1>(kq[c], st, sc);
+              if (partial && b == nblk - 1) finish_x<false, true, 1, true, P16>(sc, vq[c], g, st, b * 32, L);
+              else finish_x<false, false, 1, true, P16>(sc, vq[c], g, st, b * 32, L);
+            }
+        }
+        {
+          const float ls = P16 ? st[0].l4[0] : st[0].l;
+#pragma unroll
+          for (int i = 0; i < 16; ++i) s_part[wave][lane][i] = st[0].acc[i];
+          s_part[wave][lane][16] = ls + __shfl_xor(ls, 32);
+        }
+        __syncthreads();
+        if (wave == 0) {   // the partial results in wave order
+          float l_tot = s_part[0][lane][16];
+#pragma unroll
+          for (int i = 0; i < 16; ++i) st[0].acc[i] = s_part[0][lane][i];
+#pragma unroll
+          for (int w = 1; w < FIX_NW; ++w) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) st[0].acc[i] += s_part[w][lane][i];
+            l_tot += s_part[w][lane][16];
+          }
+          store_rows_x<OUT>(p, st[0], l_tot, qi, okq, sh, g, amax);
+        }
+        __syncthreads();   // (s_max / s_part are free for the next 32 queries)
+      }
+    }
+    __syncthreads();   // (s_tot is free for the next sweep)
+  }
+  if (OUT == 0 && p.status && __any(!(amax <= (p.out_f32 == 2 ? HL8_ACT_MAX : 65504.f))) && lane == 0) atomicOr(p.status, 1);
+}
+
 }  // namespace
 
 int attn_frag_blocks(int L) { return ((L + 31) / 32 + KB - 1) / KB * KB; }
@@ -1362,7 +1446,7 @@ int launch_attn_frag(const AttnFragP& p, hipStream_t s) {
   if (p.L <= 0 || p.n_seq <= 0 || p.heads <= 0 || p.inner != p.heads * 32 || p.nbp < attn_frag_blocks(p.L)) return -2;
   if ((long)p.n_seq * p.heads * ((p.L + 127) / 128) > 0x3fffffffL) return -3;
   if (p.x3) {
-    if (BT_HALF_IS_BF16 || (long)p.nbp * 4096 >= 0x7fffffffL) return -2;
+    if (BT_HALF_IS_BF16 || (long)p.nbp * 4096 >= 0x7fffffffL || !p.fix_mask) return -2;
     // x3 selects the LDS tile (tools/x3_probe.py, 16 chunks, +-3 % run to run):
     //   1 = 128-key tiles, 64 KB, two workgroups per CU:   main-layer shape 290 us, frontend shapes 590 us per launch;
     //   2 = 64-key tiles, 32 KB, three / four workgroups per CU (registers / LDS): main-layer shape 250 us, frontend shapes
@@ -1393,6 +1477,15 @@ int launch_attn_frag(const AttnFragP& p, hipStream_t s) {
       case 9: launch_x3<1, 0, 4, 2, true>(p, s); break;
       case 10: launch_x3<1, 1, 4, 2, false>(p, s); break;
       default: launch_x3<1, 1, 4, 2, true>(p, s); break;
+    }
+    {  // the queries the launch left to the fix-up (its overflow map): one workgroup per (sequence, head) pair, most return at once
+      const unsigned sh = (unsigned)((long)p.n_seq * p.heads);
+      switch ((p.out_f32 == 1 ? 2 : 0) + ((p.x3 & 8) ? 1 : 0)) {
+        case 0: hipLaunchKernelGGL((attn_fix_x3_kernel<0, false>), dim3(sh < FIX_GRID ? sh : FIX_GRID), dim3(64 * FIX_NW), 0, s, p, (int)sh); break;
+        case 1: hipLaunchKernelGGL((attn_fix_x3_kernel<0, true>), dim3(sh < FIX_GRID ? sh : FIX_GRID), dim3(64 * FIX_NW), 0, s, p, (int)sh); break;
+        case 2: hipLaunchKernelGGL((attn_fix_x3_kernel<1, false>), dim3(sh < FIX_GRID ? sh : FIX_GRID), dim3(64 * FIX_NW), 0, s, p, (int)sh); break;
+        default: hipLaunchKernelGGL((attn_fix_x3_kernel<1, true>), dim3(sh < FIX_GRID ? sh : FIX_GRID), dim3(64 * FIX_NW), 0, s, p, (int)sh); break;
+      }
     }
     return (int)hipGetLastError();
   }

@@ -64,6 +64,7 @@ struct Workspace {
   void* qf; void* kf; void* vf; float* gates_h; int nbp;  // fragment-major attention operands (half path)
   float* ssq[2];  // [D / 64][B T] partial row sums of squares of the main residual stream (ping-pong)
   int* status;    // BT_PREC_F32X3 range flag: the FIRST word of the workspace (include/beat_this_amd.h)
+  int* fix_mask;  // BT_PREC_F32X3: overflow map of the attention launches, [(sequences x heads)][nbp] words (attn2.hip)
   int x3_gemm_fp8;              // BT_OPT_X3_GEMM_FP8 of this forward
   int x3_attn, x3_attn_front;   // bt_attn_frag_args.x3 of this forward's attention launches, main layers / frontend (kernel choice + BT_X3_P16)
   size_t total;
@@ -96,10 +97,12 @@ Workspace carve(char* base, int B, int T, int D, int ff_mult, int prec) {
     const size_t blk = x3 ? 4096 : 2048;  // bytes per 32-token block (x3: [hi block | lo block])
     w.qf = take(sh * w.nbp * blk); w.kf = take(sh * w.nbp * blk); w.vf = take(sh * w.nbp * blk);
     w.gates_h = (float*)take(sh * w.nbp * 32 * 4);
+    w.fix_mask = x3 ? (int*)take(sh * w.nbp * 4) : nullptr;
     w.ssq[0] = (float*)take(bt * (D / 64 + 1) * 4);
     w.ssq[1] = (float*)take(bt * (D / 64 + 1) * 4);
   } else {
     w.ssq[0] = w.ssq[1] = nullptr;
+    w.fix_mask = nullptr;
   }
   w.total = off;
   return w;
@@ -186,7 +189,7 @@ int run_layer_x3(prof::State* pf, const bt_pair_weights& pw, const float* rope, 
   a.inner = D; a.nbp = ws.nbp; a.o_div = 1; a.o_outer = T; a.o_inner = 0; a.o_tok = 1;
   // BT_OPT_X3_GEMM_FP8 = 2: out-projection (and QKV) on hl8 operands as well -- the attention writes its rows in that form
   const bool out8 = ws.x3_gemm_fp8 >= 2 && pw.w_out_f8;
-  a.x3 = ws.x3_attn; a.out_f32 = out8 ? 2 : 0; a.status = ws.status;   // (which x3 attention kernel / arithmetic: attn2.hip launch_attn_frag)
+  a.x3 = ws.x3_attn; a.out_f32 = out8 ? 2 : 0; a.status = ws.status; a.fix_mask = ws.fix_mask;   // (which x3 attention kernel / arithmetic: attn2.hip launch_attn_frag)
   LAUNCH_CAT(CAT_ATTN_FLASH, s, launch_attn_frag(a, s), "attention (hi + lo)");
   // BT_OPT_X3_GEMM_FP8 >= 1: the feed-forward GEMMs on hl8 operands (fp8 cross terms): the out-projection leaves its shadow of
   // the residual stream in that form, FF1 its hidden activation; FF2's shadow feeds the next layer's QKV and stays hl32
@@ -267,7 +270,7 @@ int run_pair(prof::State* pf, const bt_pair_weights& pw, const float* rope, floa
     memset(&a, 0, sizeof a);
     a.q = ws.qf; a.k = ws.kf; a.v = ws.vf; a.gates = ws.gates_h; a.out = ws.ao; a.n_seq = B * F; a.L = T; a.heads = H;
     a.inner = C; a.nbp = ws.nbp; a.o_div = F; a.o_outer = (long)T * F; a.o_inner = 1; a.o_tok = F;
-    a.x3 = t2x3 ? ws.x3_attn_front : 0; a.out_f32 = 1; a.status = ws.status;
+    a.x3 = t2x3 ? ws.x3_attn_front : 0; a.out_f32 = 1; a.status = ws.status; a.fix_mask = ws.fix_mask;
     LAUNCH_CAT(CAT_ATTN_FLASH, s, launch_attn_frag(a, s), "time attention");
     if (fused2_ok) return outff();
     memset(&g, 0, sizeof g);
@@ -898,7 +901,8 @@ int bt_attention_frag(void* stream, const bt_attn_frag_args* a) {
   p.q = a->q; p.k = a->k; p.v = a->v; p.gates = a->gates; p.out = a->out; p.n_seq = a->n_seq; p.L = a->L;
   p.heads = a->heads; p.inner = a->inner; p.nbp = a->nbp; p.o_div = a->o_div; p.o_outer = a->o_outer;
   p.o_inner = a->o_inner; p.o_tok = a->o_tok;
-  p.x3 = a->x3; p.out_f32 = a->out_f32; p.status = a->status;
+  p.x3 = a->x3; p.out_f32 = a->out_f32; p.status = a->status; p.fix_mask = a->scratch;
+  if (p.x3 && !p.fix_mask) return bt_set_error(BT_ERR_ARG, "bt_attention_frag: x3 needs the scratch words (overflow map)");
   LAUNCH(launch_attn_frag(p, (hipStream_t)stream), "attention (fragment-major)");
   return BT_OK;
 }

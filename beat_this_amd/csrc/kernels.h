@@ -112,6 +112,9 @@ struct AttnFragP {
   // x3 = 1: 128-key LDS tiles, x3 = 2: 64-key tiles (same results)
   int x3, out_f32;
   int* status;
+  // x3: the launch's overflow map, [n_seq * heads][nbp] words (one per query block, bit = query whose fast pass overflowed fp16:
+  // written by the attention kernel, consumed by the fix-up launch that follows it inside launch_attn_frag; scratch, required)
+  int* fix_mask;
 };
 int attn_frag_blocks(int L);  // 32-token blocks to allocate per (sequence, head): ceil(L/32) rounded up to a tile
 int launch_attn_frag(const AttnFragP& p, hipStream_t s);

@@ -211,7 +211,7 @@ def main():
     hp = W.resolve_hparams(args.model)
     # "lively" seeded weights (O(1) logits, sharp softmaxes, beats to pick): same FLOPs as any other weights of this
     # architecture, but the post-processor has real work and the parity figures mean something
-    sd = W.random_state_dict(hp, seed=1, style="lively")
+    sd = W.random_state_dict(hp, seed=1, style=os.environ.get("BT_BENCH_STYLE", "lively"))   # (BT_BENCH_STYLE=outlier: development A/B of the stress weights)
     model = BeatThis(**{k: hp[k] for k in ("spect_dim", "transformer_dim", "ff_mult", "n_layers", "head_dim", "stem_dim")})
     model.load_state_dict(sd)
     a2b = Audio2Beats(checkpoint_path=None, device=dev, float16={"half": True, "f32": "exact", "f32x3": False}[args.prec], dbn=False)

@@ -162,7 +162,7 @@ typedef struct {
 const char* bt_last_error(void);
 /* ABI version of this header: bumped whenever an entry point's signature, a struct layout or a BT_PREC_* value changes; a
  * binding must see exactly the value it was written against (beat_this_amd/_lib.py does) */
-#define BT_ABI_VERSION 510
+#define BT_ABI_VERSION 520
 int bt_version(void);
 /* operand type of the half-precision path (BT_PREC_HALF slot of the weight arrays) this library was built
  * with: 0 = IEEE fp16 (default), 1 = bfloat16 (-DBT_HALF_BF16) */
@@ -329,12 +329,15 @@ int bt_attention(void* stream, int prec, const bt_attn_args* a);
  * range flag of the hl32 / hl8 output;
  * x3 = 1: 128-key LDS tiles, x3 = 2: 64-key tiles, x3 = 5: two query blocks per wave on a hand-scheduled key loop -- the same
  * arithmetic in all three, bit-identical results; x3 = 4 (the forward's choice since round 4): 5 for launches of at least
- * 1024 of its workgroups, 2 below.  + 8 (BT_X3_P16): the P16 arithmetic (BT_OPT_X3_ATTN_P16) on the same kernel choice. */
+ * 1024 of its workgroups, 2 below.  + 8 (BT_X3_P16): the P16 arithmetic (BT_OPT_X3_ATTN_P16) on the same kernel choice.
+ * x3 != 0 needs `scratch`: n_seq * heads * nbp int32 words (the launch's overflow map: queries whose probabilities left fp16's
+ * range in the fast pass are recomputed on their row maxima by a second, gathered launch; contents undefined afterwards). */
 #define BT_X3_P16 8
 typedef struct {
   const void* q; const void* k; const void* v; const float* gates; void* out;
   int32_t n_seq, L, heads, inner, nbp, o_div; int64_t o_outer, o_inner, o_tok;
   int32_t x3, out_f32; int32_t* status;
+  int32_t* scratch;
 } bt_attn_frag_args;
 /* half GEMM of the main layers (csrc/gemm3.hip), single-operator entry for the parity tests.
  * epi 0: out[M,ldo] (half) = gelu(rms(A) W^T + bias);  epi 1: x[M,ldx] (fp32) += A W^T + bias, half shadow xb,

@@ -365,12 +365,17 @@ def _run_attn(q, k, v, gates, n_seq, L, heads, out_f32, variant=1, raw=False, **
     a.n_seq, a.L, a.heads, a.inner, a.nbp, a.o_div = n_seq, L, heads, inner, nbp, omap.get("o_div", 1)
     a.o_outer, a.o_inner, a.o_tok = omap.get("o_outer", L), omap.get("o_inner", 0), omap.get("o_tok", 1)
     a.x3, a.out_f32, a.status = variant, int(out_f32), st.data_ptr()
+    scratch = torch.full((SH, nbp), -1, dtype=torch.int32, device=dev())   # the launch's overflow map (stale bits must not matter)
+    a.scratch = scratch.data_ptr()
     Lb.check(Lb.lib().bt_attention_frag(Lb.stream_ptr(dev()), C.byref(a)))
     torch.cuda.synchronize()
     assert int(st.item()) == 0
     if raw:
         return out.cpu()
-    return out.double().cpu() if out_f32 == 1 else from_hl32(out.cpu())
+    if int(out_f32) == 2:   # hl8 rows: hi halves + what the lo bytes stand for
+        hi, _, l8 = hl8_parts(out.cpu(), act=True)
+        return hi + l8
+    return out.double().cpu() if int(out_f32) == 1 else from_hl32(out.cpu())
 
 
 @pytest.mark.parametrize("variant", [1, 2, 5])   # bt_attn_frag_args.x3: keys per LDS tile / 5 = the hand-scheduled two-query-block kernel, forced (4 = by launch size; attn2.hip)
@@ -508,6 +513,39 @@ def test_attention_frag_x3_p16_overflow_fallback(L, variant):
     assert err < 3e-4
 
 
+@pytest.mark.parametrize("out_f32", [0, 1, 2])
+@pytest.mark.parametrize("variant", [5, 13])
+@pytest.mark.parametrize("L,heads,n_over", [(1500, 2, 1), (1500, 1, 40), (1500, 1, 200), (2300, 1, 70), (77, 2, 5), (33, 1, 33)])
+def test_attention_frag_x3_fixup_launch(L, heads, n_over, variant, out_f32):
+    """The queries whose fast pass overflows fp16 are left to the gathered fix-up launch (attn_fix_x3_kernel: 32 per round, keys
+    split over the waves): one, more than a round, more than four rounds of them in a pair, sequences of more than 64 key blocks
+    (the map is read 64 words at a time), short ones (waves without keys), in every output form -- against the exact softmax, and
+    the other queries bit for bit what a launch without the overflowing key gives."""
+    n_seq = 2
+    SH = n_seq * heads
+    q = _mk((SH, L, 32), 60, 0.5)
+    k = _mk((SH, L, 32), 61)
+    v = _mk((SH, L, 32), 62)
+    q, k, v = (t.float().double() for t in (q, k, v))
+    gates = torch.ones((SH, L), dtype=torch.float64)
+    idx = [(37 * j + 5) % L for j in range(n_over)]
+    q[SH - 1, idx] = 0.0
+    q[SH - 1, idx, 1] = 25.0                 # these queries score key L - 9 at 600: far beyond the fast pass's headroom ...
+    clean = _run_attn(q, k, v, gates, n_seq, L, heads, out_f32, variant)
+    k[SH - 1, L - 9] = 0.0
+    k[SH - 1, L - 9, 1] = 24.0               # ... once it is there (the other queries of the pair see it at |24 q_1| <= 25 or so)
+    out = _run_attn(q, k, v, gates, n_seq, L, heads, out_f32, variant)
+    assert torch.isfinite(out).all()
+    ref = _attn_ref(q, k, v, gates).view(n_seq, heads, L, 32).permute(0, 2, 1, 3).reshape(n_seq * L, heads * 32)
+    err = _rel(out, ref)
+    report("attn_frag_x3_fixup", L=L, heads=heads, n_over=n_over, variant=variant, out_f32=out_f32, rel=err)
+    assert err < (1e-5 if variant < 8 else 3e-4) + (1e-4 if out_f32 == 2 else 0)   # (hl8 rows: read back through their hi halves + lo bytes)
+    if heads > 1:   # the other head of the last sequence never sees the changed key: the same bits with and without it
+        cols = slice(0, 32 * (heads - 1))
+        assert torch.equal(out[:, cols], clean[:, cols])
+    assert torch.equal(out[:L], clean[:L])   # (the first sequence)
+
+
 @pytest.mark.parametrize("base", [0, 8])
 def test_attention_frag_x3_overflow_rerun_is_per_query(base):
     """A query whose fast pass overflows re-runs its WORKGROUP, but only that query takes the new reference point: the other
@@ -592,9 +630,12 @@ def test_attention_frag_x3_at_scale_is_repeatable(variant):
         a.q, a.k, a.v, a.gates, a.out = qd.data_ptr(), kd.data_ptr(), vd.data_ptr(), gd.data_ptr(), out.data_ptr()
         a.n_seq, a.L, a.heads, a.inner, a.nbp, a.o_div, a.o_outer, a.o_inner, a.o_tok = n_seq, L, heads, heads * 32, nbp, 1, L, 0, 1
         a.x3, a.out_f32, a.status = variant, 0, 0
+        scratch = torch.zeros((SH, nbp), dtype=torch.int32, device=dev())
+        a.scratch = scratch.data_ptr()
         Lb.check(Lb.lib().bt_attention_frag(Lb.stream_ptr(dev()), C.byref(a)))
-        outs.append(out)
+        outs.append((out, scratch))
     torch.cuda.synchronize()
+    outs = [o for o, _ in outs]
     assert all(torch.equal(o, outs[0]) for o in outs[1:])
     # spot check of two sequence-heads against fp64
     for sh in (0, SH - 1):

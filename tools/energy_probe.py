@@ -69,9 +69,11 @@ def attention(SH_seq, heads, variant, label, per_step, out_f32=0):
     a.q, a.k, a.v, a.gates, a.out = qd.data_ptr(), kd.data_ptr(), vd.data_ptr(), gates.data_ptr(), out.data_ptr()
     a.n_seq, a.L, a.heads, a.inner, a.nbp, a.o_div, a.o_outer, a.o_inner, a.o_tok = SH_seq, T, heads, heads * 32, nbp, 1, T, 0, 1
     a.x3, a.out_f32, a.status = variant, out_f32, 0
+    scratch = torch.zeros((SH, nbp), dtype=torch.int32, device=dev)
+    a.scratch = scratch.data_ptr()
     mf = (2.5 if variant & 8 else 3.0) * 2 * 2 * SH * T * T * 32
     loop(label, lambda: L.check(lib.bt_attention_frag(st, C.byref(a))), mf, per_step)
-    del qd, kd, vd, out
+    del qd, kd, vd, out, scratch
 
 
 def gemm(M, K, N, epi, label, per_step, heads=0, n_seq=0, f8=False, cfg=1):

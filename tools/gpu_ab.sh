@@ -1,0 +1,7 @@
+#!/bin/bash
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+cd $R
+echo "== lively (the benchmark's weights)"
+bash tools/ab.sh tools/variants/lib_old.so 2>&1 | grep -v amdgpu.ids | cut -c1-60
+echo "== outlier"
+BT_BENCH_STYLE=outlier bash tools/ab.sh tools/variants/lib_old.so 2>&1 | grep -v amdgpu.ids | cut -c1-60

@@ -29,6 +29,12 @@ span = int(call[-1]["End_Timestamp"]) - t0
 print(f"one call (stem to stem): {len(call)} kernels, span {span / 1e3:.1f} us, kernel time {busy / 1e3:.1f} us, gaps {(span - busy) / 1e3:.1f} us")
 for n, (c, d) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
     print(f"  {n:50s} {c:3d} {d / 1e3:8.1f} us")
+gaps = sorted(((int(call[i + 1]["Start_Timestamp"]) - int(call[i]["End_Timestamp"])) / 1e3, i) for i in range(len(call) - 1))
+short = lambda r: re.sub(r"\(.*$", "", re.sub(r"\(anonymous namespace\)::|^void ", "", r["Kernel_Name"]))[:44]  # noqa: E731
+print("largest gaps (us: after kernel -> before kernel):")
+for g, i in gaps[::-1][:12]:
+    print(f"  {g:7.1f}  {short(call[i]):44s} -> {short(call[i + 1])}")
+print(f"median gap {gaps[len(gaps) // 2][0]:.1f} us; sum of the 12 largest {sum(g for g, _ in gaps[::-1][:12]):.1f} us")
 cp = []
 for f in glob.glob(os.path.join(src, "**", "*memory_copy_trace.csv"), recursive=True):
     cp += list(csv.DictReader(open(f)))

@@ -1,6 +1,7 @@
 #!/usr/bin/env python
-"""Development (-DBT_DEV build): share of x3 attention workgroups that re-run on the running-maximum (SAFE) pass in a forward of
-the benchmark's weights -- words 1 / 2 of the workspace's status block count them (attn2.hip).
+"""Development (-DBT_DEV build): how many queries of a forward's x3 attention launches overflow fp16 in the fast pass and are
+recomputed by the gathered fix-up launch (attn_fix_x3_kernel), and in how many (sequence, head) pairs they sit -- words 1 / 3 of
+the workspace's status block; word 2 counts the workgroups of the attention kernels in front (attn2.hip).
     BT_DEV=1 BT_LIB_PATH=tools/variants/lib_dev.so python tools/safe_rate_probe.py [chunks] [style]"""
 import os
 import sys
@@ -29,5 +30,7 @@ torch.cuda.synchronize()
 eng = m.engine()
 ws = list(eng._ws.values())[-1][0]
 st = ws[:16].view(torch.int32).cpu().tolist()
-print(f"{style}, {B} chunks: status words {st}: {st[1]} of {st[2]} attention workgroups of one forward took the SAFE pass "
-      f"({100.0 * st[1] / max(st[2], 1):.2f} %)")
+queries = B * 1500 * (3 * 32 + 6 * hp["transformer_dim"] // 32)   # query rows of the nine attention launches of one forward
+pairs = B * (3 * 32 + 6 * hp["transformer_dim"] // 32)
+print(f"{style}, {B} chunks: status words {st}: {st[1]} of {queries} queries of one forward ({100.0 * st[1] / queries:.3f} %) were left to "
+      f"the fix-up launch, in {st[3]} of {pairs} (sequence, head) pairs ({100.0 * st[3] / pairs:.1f} %); {st[2]} attention workgroups in front")

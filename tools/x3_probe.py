@@ -52,6 +52,8 @@ def attention(n_seq, heads, Lq, label):
         a.q, a.k, a.v, a.gates, a.out = qd.data_ptr(), kd.data_ptr(), vd.data_ptr(), gates.data_ptr(), out.data_ptr()
         a.n_seq, a.L, a.heads, a.inner, a.nbp, a.o_div, a.o_outer, a.o_inner, a.o_tok = n_seq, Lq, heads, heads * 32, nbp, 1, Lq, 0, 1
         a.x3, a.out_f32, a.status = variant, 0, 0
+        scratch = torch.zeros((SH, nbp), dtype=torch.int32, device=dev)
+        a.scratch = scratch.data_ptr()
         st = L.stream_ptr(dev)
         us = timeit(lambda: L.check(lib.bt_attention_frag(st, C.byref(a))))
         flop = 2 * 2 * SH * Lq * Lq * 32
@@ -116,6 +118,8 @@ if len(sys.argv) > 2 and sys.argv[2].startswith("loop"):
     a.q, a.k, a.v, a.gates, a.out = qd.data_ptr(), kd.data_ptr(), vd.data_ptr(), gates.data_ptr(), out.data_ptr()
     a.n_seq, a.L, a.heads, a.inner, a.nbp, a.o_div, a.o_outer, a.o_inner, a.o_tok = SH, T, 1, 32, nbp, 1, T, 0, 1
     a.x3, a.out_f32, a.status = want, 0, 0
+    scratch = torch.zeros((SH, nbp), dtype=torch.int32, device=dev)
+    a.scratch = scratch.data_ptr()
     st = L.stream_ptr(dev)
     t0, n = time.time(), 0
     while time.time() - t0 < secs:
