@@ -1,4 +1,5 @@
 #!/bin/bash
+# tools/ab.sh on the benchmark's weights and on the outlier stress weights: tools/variants/lib_old.so against the in-tree build
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $R
 echo "== lively (the benchmark's weights)"

@@ -1,3 +1,6 @@
+"""Development: the fix-up launch of the x3 attention (attn_fix_x3_kernel) alone -- a main-layer launch of the benchmark's slice
+(33 x 16 pairs, 1500 frames) with no, few and many overflowing queries; tools/attn_fix_probe.sh adds the kernel trace.
+profiles/r05_fixup_ab.txt."""
 import ctypes as C, os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]

@@ -1,16 +1,16 @@
 #!/bin/bash
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $R
-O=$R/gpurun_out/fix3
+O=$R/gpurun_out/attn_fix
 rm -rf $O; mkdir -p $O
 export TMPDIR=/tmp
-python tools/_fix_probe.py 2>&1 | grep -v amdgpu.ids
+python tools/attn_fix_probe.py 2>&1 | grep -v amdgpu.ids
 cd /tmp
-timeout 300 rocprofv3 --kernel-trace -d $O/tr -o p --output-format csv -- python $R/tools/_fix_probe.py > $O/trace.log 2>&1
+timeout 300 rocprofv3 --kernel-trace -d $O/tr -o p --output-format csv -- python $R/tools/attn_fix_probe.py > $O/trace.log 2>&1
 cd $R
 python - <<'PY'
 import csv, glob
-f = glob.glob("gpurun_out/fix3/tr/**/*kernel_trace.csv", recursive=True)[0]
+f = glob.glob("gpurun_out/attn_fix/tr/**/*kernel_trace.csv", recursive=True)[0]
 rows = [r for r in csv.DictReader(open(f)) if "attn_fix" in r["Kernel_Name"]]
 d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rows]
 # 23 launches per case

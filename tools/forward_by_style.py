@@ -1,3 +1,4 @@
+"""Development: wall time of a 33-chunk forward of the default path on one weight style (lively | outlier | init)."""
 import sys, time, numpy as np, torch
 import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from beat_this_amd import weights as W
