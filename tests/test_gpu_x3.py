@@ -536,6 +536,9 @@ def test_attention_frag_x3_fixup_launch(L, heads, n_over, variant, out_f32):
     k[SH - 1, L - 9, 1] = 24.0               # ... once it is there (the other queries of the pair see it at |24 q_1| <= 25 or so)
     out = _run_attn(q, k, v, gates, n_seq, L, heads, out_f32, variant)
     assert torch.isfinite(out).all()
+    assert torch.equal(out, _run_attn(q, k, v, gates, n_seq, L, heads, out_f32, variant))   # (no atomics, fixed summation order)
+    if variant == 13:   # the kernel form in front does not matter: the 64-key-tile kernels leave the same queries to the same launch
+        assert torch.equal(out, _run_attn(q, k, v, gates, n_seq, L, heads, out_f32, 10))
     ref = _attn_ref(q, k, v, gates).view(n_seq, heads, L, 32).permute(0, 2, 1, 3).reshape(n_seq * L, heads * 32)
     err = _rel(out, ref)
     report("attn_frag_x3_fixup", L=L, heads=heads, n_over=n_over, variant=variant, out_f32=out_f32, rel=err)
