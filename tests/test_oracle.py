@@ -165,3 +165,31 @@ def test_oracle_port_is_as_fast_as_the_live_reference():
     r = port_speed.measure("small0", threads=4, repeats=4)
     assert r["max_abs_logit_difference"] < 5e-5
     assert r["port_vs_reference"] < 1.15, r
+
+
+def test_third_party_leaves_against_independent_implementations():
+    """rotary-embedding-torch, torchaudio and soxr are absent here, so the oracle restates their published algorithms
+    ("parity unpinned" at those three leaves).  Two of them can at least be held against INDEPENDENT implementations of the same
+    published conventions that this image does carry (transformers 5.x) -- a shared misreading of the convention (pair
+    interleaving, frequency order, sign of the rotation; slaney break point, triangle normalisation) would show as O(1), not
+    as the last-digit differences of two fp32 evaluations:
+      * RoPE: GPT-J's rotate_every_two / apply_rotary_pos_emb -- the interleaved-pair convention of the RoFormer paper that
+        rotary-embedding-torch implements (angle(p, 2j) = angle(p, 2j + 1) = p * 10000^(-2j/d));
+      * mel filterbank: transformers.audio_utils.mel_filter_bank(norm=None, mel_scale="slaney") on the same 513 bins."""
+    transformers = pytest.importorskip("transformers")
+    from transformers.audio_utils import mel_filter_bank
+    from transformers.models.gptj import modeling_gptj as G
+
+    b, h, n, d = 2, 3, 1500, 32
+    t = torch.randn((b, h, n, d), generator=torch.Generator().manual_seed(3))
+    freqs = 10000.0 ** (-torch.arange(0, d, 2).float() / d)        # (what the reference stores as rotary_embed.freqs)
+    mine = O.rope(t, freqs)
+    sc = G.create_sinusoidal_positions(n, d)                         # [n, d] = sin | cos of p * inv_freq
+    sin, cos = sc[None, :, : d // 2].expand(b, -1, -1), sc[None, :, d // 2:].expand(b, -1, -1)
+    theirs = G.apply_rotary_pos_emb(t.permute(0, 2, 1, 3), sin, cos).permute(0, 2, 1, 3)
+    assert float((mine - theirs).abs().max()) < 2e-4                 # (fp32 angles at position 1500: 1e-4 rad apart)
+    assert float((mine - t).abs().max()) > 1.0                       # (... and the rotation is not the identity)
+    fb = mel_filter_bank(num_frequency_bins=513, num_mel_filters=128, min_frequency=30.0, max_frequency=11000.0,
+                         sampling_rate=22050, norm=None, mel_scale="slaney", triangularize_in_mel_space=False)
+    assert float(np.abs(fb - O.mel_filterbank().numpy()).max()) < 5e-5
+    assert transformers.__version__
