@@ -20,9 +20,27 @@ from .pack import Engine, PackedModel
 from .weights import random_state_dict, resolve_hparams, state_dict_shapes
 
 _BUFFER_LEAVES = ("running_mean", "running_var", "num_batches_tracked")
+_TREE_EPOCH = [0]   # bumped whenever a module is assigned to / removed from a node of a BeatThis tree (_hooked_below's cache)
 
 
-class _Node(nn.Module):
+class _TracksChildren:
+    """nn.Module mix-in: assigning, adding or deleting a sub-module bumps _TREE_EPOCH."""
+
+    def __setattr__(self, name, value):
+        if isinstance(value, nn.Module):
+            _TREE_EPOCH[0] += 1
+        super().__setattr__(name, value)
+
+    def __delattr__(self, name):
+        _TREE_EPOCH[0] += 1
+        super().__delattr__(name)
+
+    def add_module(self, name, module):
+        _TREE_EPOCH[0] += 1
+        super().add_module(name, module)
+
+
+class _Node(_TracksChildren, nn.Module):
     """Container that carries the reference's dotted parameter names.  The nodes that are callable sub-modules in the
     reference -- ``frontend.stem``, ``.blocks``, ``.blocks[i]``, ``.blocks[i].partial``, ``.concat``, ``.linear``,
     ``transformer_blocks.layers[l][0]`` (Attention), ``[l][1]`` (FeedForward), ``.norm`` (beat_tracker.py:54-80,108-168,
@@ -99,8 +117,19 @@ class _Stage(_Node):
 
 
 def _hooked_below(node: nn.Module) -> bool:
-    """A forward (pre-)hook is registered on a sub-module of ``node`` (not on ``node`` itself)."""
-    return any(m is not node and (m._forward_hooks or m._forward_pre_hooks) for m in node.modules())
+    """A forward (pre-)hook is registered on a sub-module of ``node`` (not on ``node`` itself).  Asked on every forward and every
+    single-file call: walking ``node.modules()`` costs 0.1 ms for final0's ~200 nodes, so the hook dictionaries of the tree
+    (created once per module, mutated in place by ``register_forward_*hook``) are collected once and only looked at afterwards;
+    the collection is redone when any node of a BeatThis tree had a sub-module assigned, added or removed (_TREE_EPOCH)."""
+    epoch = _TREE_EPOCH[0]
+    cache = node.__dict__.get("_bt_hook_dicts")
+    if cache is None or cache[0] != epoch:
+        cache = (epoch, [(m._forward_hooks, m._forward_pre_hooks) for m in node.modules() if m is not node])
+        node.__dict__["_bt_hook_dicts"] = cache
+    for fwd, pre in cache[1]:
+        if fwd or pre:
+            return True
+    return False
 
 
 def _attach(root: nn.Module, key: str, value: torch.Tensor) -> None:
@@ -116,7 +145,7 @@ def _attach(root: nn.Module, key: str, value: torch.Tensor) -> None:
         node.register_parameter(leaf, nn.Parameter(value, requires_grad=False))
 
 
-class BeatThis(nn.Module):
+class BeatThis(_TracksChildren, nn.Module):
     def __init__(self, spect_dim: int = 128, transformer_dim: int = 512, ff_mult: int = 4, n_layers: int = 6,
                  head_dim: int = 32, stem_dim: int = 32, dropout: dict = {"frontend": 0.1, "transformer": 0.2},
                  sum_head: bool = True, partial_transformers: bool = True):
