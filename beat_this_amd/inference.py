@@ -217,8 +217,8 @@ def split_predict_aggregate(spect: torch.Tensor, chunk_size: int, border_size: i
         preds = [{"beat": cb[i], "downbeat": cd[i]} for i in range(len(starts))]
         beat, down = aggregate_prediction(preds, starts, n, chunk_size, border_size, overlap_mode, spect.device)
         return {"beat": beat, "downbeat": down}
-    beat = torch.empty((n,), dtype=torch.float32, device=spect.device)
-    down = torch.empty((n,), dtype=torch.float32, device=spect.device)
+    both = torch.empty((2, n), dtype=torch.float32, device=spect.device)   # (adjacent rows: the peak picker takes them as they lie)
+    beat, down = both[0], both[1]
     with torch.cuda.device(spect.device):
         _lib.check(_lib.lib().bt_aggregate(_lib.stream_ptr(spect.device), cb.data_ptr(), cd.data_ptr(),
                                            d_starts.data_ptr(), len(starts), T, border_size, n, beat.data_ptr(),

@@ -80,7 +80,12 @@ class Postprocessor:
 
     def postp_minimal(self, beat, downbeat, padding_mask=None):
         B, T = beat.shape
-        logits = torch.stack([beat, downbeat], 1).to(torch.float32)  # (B, 2, T)
+        if (B == 1 and padding_mask is None and beat.is_cuda and beat.dtype == downbeat.dtype == torch.float32 and beat.is_contiguous()
+                and downbeat.is_contiguous() and beat.untyped_storage().data_ptr() == downbeat.untyped_storage().data_ptr()
+                and downbeat.data_ptr() == beat.data_ptr() + 4 * T):
+            logits = torch.as_strided(beat, (1, 2, T), (2 * T, T, 1))   # (the two rows of one buffer, as split_predict_aggregate leaves them: no copy)
+        else:
+            logits = torch.stack([beat, downbeat], 1).to(torch.float32)  # (B, 2, T)
         if padding_mask is not None:
             logits = logits.masked_fill(~padding_mask.bool().unsqueeze(1), -1000.0)
         logits = logits.contiguous()
