@@ -54,5 +54,15 @@ def test_lint_sees_the_pattern(tmp_path):
         assert len(isa_lint.lint("x.hip")) == 1
         isa_lint.asm_of = lambda src: spilly.replace("_Zk:", "_Z17layer_tail_kernelILi512EEv:")
         assert isa_lint.lint("x.hip") == []
+        # fifth rule: scratch without LDS-DMA is never wrong, and never intended: any access outside a kernel's budget is reported
+        quiet = "\n".join(["_Zk:", "\tscratch_store_dword off, v1, off", "\tscratch_load_dword v1, off, off", "\ts_waitcnt vmcnt(0)",
+                           "\tv_add_u32_e32 v2, s1, v1", "\ts_endpgm"])
+        isa_lint.asm_of = lambda src: quiet
+        assert len(isa_lint.lint("x.hip")) == 1
+        isa_lint.asm_of = lambda src: quiet.replace("_Zk:", "_Z17layer_tail_kernelILi512EEv:")
+        assert isa_lint.lint("x.hip") == []
+        isa_lint.asm_of = lambda src: quiet.replace("_Zk:", "_Z17layer_tail_kernelILi512EEv:").replace(
+            "\tscratch_load_dword v1, off, off", "\n".join(["\tscratch_load_dword v1, off, off"] * 50))
+        assert len(isa_lint.lint("x.hip")) == 1   # (over its budget of 40)
     finally:
         isa_lint.asm_of = orig
