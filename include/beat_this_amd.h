@@ -189,7 +189,7 @@ void bt_engine_destroy(bt_engine* e);
  *                       1: the feed-forward GEMMs (FF1, FF2);  2: out-projection and QKV as well.  An opt-in speed setting inside
  *                       the 1e-3 gate, reported beside the default (bench.py: configs.cfg5; flip rates: DESIGN.md section 3):
  *                       measured at level 2 -4 % forward time, 1.7e-4 .. 2.5e-4 on the logits against the oracle (default 7e-5),
- *                       3 x (lively weights) to 10 x (freshly initialised) the default's beat flips over the 48-track soak.
+ *                       1.1 x (outlier weights) to 14 x (freshly initialised) the default's beat flips over the 96-track soak.
  *                       Activations beyond 3584 (hl8's range) raise the range flag like those beyond 65504 on the default path. */
 #define BT_OPT_X3_ATTN_P16 1
 #define BT_OPT_X3_GEMM_FP8 2
