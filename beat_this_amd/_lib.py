@@ -22,7 +22,7 @@ SOURCES = ["gemm.hip", "gemm2.hip", "gemm3.hip", "attn.hip", "attn2.hip", "fused
 HEADERS = ["common.h", "chain.h", "kernels.h", "attn_x3_loop.inc", os.path.join("..", "..", "include", "beat_this_amd.h")]
 
 BT_OK, BT_ERR_ARG, BT_ERR_HIP, BT_ERR_WORKSPACE = 0, -1, -2, -3
-ABI_VERSION = 520   # BT_ABI_VERSION of include/beat_this_amd.h this binding was written against
+ABI_VERSION = 600   # BT_ABI_VERSION of include/beat_this_amd.h this binding was written against
 PREC_F32, PREC_HALF, PREC_F32X3 = 0, 1, 3   # (2 was the withdrawn e4m3 experiment)
 MAX_LAYERS = 32
 PROFILE_CATEGORIES = ["stem", "qkv_gemm", "attn_flash", "out_gemm", "ff1_gemm", "ff2_gemm", "conv_gemm",
@@ -98,7 +98,7 @@ class Gemm3Args(C.Structure):
 
 
 G3_FF1, G3_RESID, G3_QKV = 0, 1, 2
-UNIT_STEM, UNIT_PARTIAL, UNIT_CONV, UNIT_LINEAR, UNIT_ATTN, UNIT_FF, UNIT_NORM = range(7)
+UNIT_STEM, UNIT_PARTIAL, UNIT_CONV, UNIT_LINEAR, UNIT_ATTN, UNIT_FF, UNIT_NORM, UNIT_FRONT_ATTN, UNIT_FRONT_FF = range(9)
 
 EXPORTS = {
     "bt_last_error": (C.c_char_p, []),

@@ -916,6 +916,9 @@ DEVI void store_rows_x(const AttnFragP& p, const QStateX& st, float l_tot, int q
         const float b0 = st.acc[8 * k + 4 + 2 * i] * scale, b1 = st.acc[8 * k + 4 + 2 * i + 1] * scale;
         split_hl4(a0, a1, b0, b1, xh[i], xl[i], yh[i], yl[i]);   // (common.h)
         amax = fmaxf(amax, fmaxf(fmaxf(fabsf(a0), fabsf(a1)), fmaxf(fabsf(b0), fabsf(b1))));
+        // (fmaxf drops NaNs: a NaN row -- acc(inf) x scale(0) -- must raise the range flag like an inf one)
+        const float nan_probe = (a0 + a1) + (b0 + b1);
+        amax = nan_probe != nan_probe ? __builtin_inff() : amax;
       }
       auto h0 = __builtin_amdgcn_permlane32_swap(xh[0], yh[0], false, false);
       auto h1 = __builtin_amdgcn_permlane32_swap(xh[1], yh[1], false, false);
@@ -1401,6 +1404,10 @@ __global__ __launch_bounds__(64 * FIX_NW, 2) void attn_fix_x3_kernel(const AttnF
             for (int i = 0; i < 16; ++i) st[0].acc[i] += s_part[w][lane][i];
             l_tot += s_part[w][lane][16];
           }
+          // this kernel is the last resort of a query: a row sum that still is not a finite number (a probability beyond fp16
+          // even relative to the hi . hi row maximum, P16: l4 = inf) would be stored as gate / inf = 0 times inf = NaN, which no
+          // amax sees -- raise the range flag instead, the forward is then repeated on the exact fp32 path
+          if (okq && !(l_tot < __builtin_inff())) amax = __builtin_inff();
           store_rows_x<OUT>(p, st[0], l_tot, qi, okq, sh, g, amax);
         }
         __syncthreads();   // (s_max / s_part are free for the next 32 queries)
@@ -1408,7 +1415,7 @@ __global__ __launch_bounds__(64 * FIX_NW, 2) void attn_fix_x3_kernel(const AttnF
     }
     __syncthreads();   // (s_tot is free for the next sweep)
   }
-  if (OUT == 0 && p.status && __any(!(amax <= (p.out_f32 == 2 ? HL8_ACT_MAX : 65504.f))) && lane == 0) atomicOr(p.status, 1);
+  if (p.status && __any(!(amax <= (p.out_f32 == 2 ? HL8_ACT_MAX : 65504.f))) && lane == 0) atomicOr(p.status, 1);   // (OUT = 1: amax is 0 or inf)
 }
 
 }  // namespace

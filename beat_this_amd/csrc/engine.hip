@@ -48,7 +48,7 @@ struct Scope {
 struct bt_engine {
   bt_model_desc d;
   prof::State prof;
-  int x3_attn_p16 = 2;   // BT_OPT_X3_ATTN_P16
+  int x3_attn_p16 = 1;   // BT_OPT_X3_ATTN_P16 (default chosen by the flip-soak rule: DESIGN.md section 3)
   int x3_gemm_fp8 = 0;   // BT_OPT_X3_GEMM_FP8
 };
 enum { CAT_STEM = 0, CAT_QKV, CAT_ATTN_FLASH, CAT_OUT, CAT_FF1, CAT_FF2, CAT_CONV, CAT_LINEAR,
@@ -564,6 +564,8 @@ int bt_forward_unit(bt_engine* e, void* stream, int prec, int unit, int index, c
   hipStream_t s = (hipStream_t)stream;
   const bool block_unit = unit == BT_UNIT_PARTIAL || unit == BT_UNIT_CONV;
   const bool layer_unit = unit == BT_UNIT_ATTN || unit == BT_UNIT_FF;
+  const bool leaf_unit = unit == BT_UNIT_FRONT_ATTN || unit == BT_UNIT_FRONT_FF;
+  if (leaf_unit && (index < 0 || index > 5 || !d.partial_transformers)) return bt_set_error(BT_ERR_ARG, "partial-transformer leaf index out of range");
   if (block_unit && (index < 0 || index > 2)) return bt_set_error(BT_ERR_ARG, "frontend block index out of range");
   if (layer_unit && (index < 0 || index >= d.n_layers)) return bt_set_error(BT_ERR_ARG, "layer index out of range");
   auto copy_in = [&](size_t bytes) -> int {
@@ -611,6 +613,13 @@ int bt_forward_unit(bt_engine* e, void* stream, int prec, int unit, int index, c
       if (int rc = copy_in((size_t)B * T * D * 4)) return rc;
       return run_pair(pf, d.layers[index], d.rope, d_out, nullptr, ws, B, T, 1, 0, prec, s, nullptr, d.ff_mult, false,
                       unit == BT_UNIT_ATTN ? 1 : 2);
+    }
+    case BT_UNIT_FRONT_ATTN:
+    case BT_UNIT_FRONT_FF: {
+      // a leaf of a partial transformer on its own: [sequences, tokens, C] rows like a main layer's (mode 0), generic kernels
+      const bt_pair_weights& pw = d.front[index >> 1][index & 1];
+      if (int rc = copy_in((size_t)B * T * pw.dim * 4)) return rc;
+      return run_pair(pf, pw, d.rope, d_out, nullptr, ws, B, T, 1, 0, prec, s, nullptr, 4, false, unit == BT_UNIT_FRONT_ATTN ? 1 : 2);
     }
     case BT_UNIT_NORM:
       if (!d.norm_out_g) return bt_set_error(BT_ERR_ARG, "bt_model_desc.norm_out_g is not set");

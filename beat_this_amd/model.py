@@ -45,9 +45,11 @@ class _Node(_TracksChildren, nn.Module):
     reference -- ``frontend.stem``, ``.blocks``, ``.blocks[i]``, ``.blocks[i].partial``, ``.concat``, ``.linear``,
     ``transformer_blocks.layers[l][0]`` (Attention), ``[l][1]`` (FeedForward), ``.norm`` (beat_tracker.py:54-80,108-168,
     roformer.py:138-181) -- are bound to a unit of the owning model's engine (BeatThis._bind_units, bt_forward_unit) and can
-    be called with the reference's tensor layouts: (b, c, f, t) inside the frontend, (b, n, dim) in the transformer.  They
-    run on the generic kernels (exact fp32, or half operands under autocast), one launch group per call; the fused fast
-    path is ``BeatThis.forward`` / the three stages.  Nodes below them (``partial.attnF`` ...) hold parameters only.
+    be called with the reference's tensor layouts: (b, c, f, t) inside the frontend, (b, n, dim) in the transformer; so are
+    the four leaves of a partial transformer (``partial.attnF / .ffF / .attnT / .ffT``: (sequences, tokens, C), the branch
+    without its residual, beat_tracker.py:251-301).  They run on the generic kernels (exact fp32, or half operands under
+    autocast), one launch group per call; the fused fast path is ``BeatThis.forward`` / the three stages.  Nodes below them
+    (``...norm``, ``.to_qkv``, ``.net`` ...) hold parameters only.
     Digit-named children index like the reference's ModuleList / Sequential (``layers[3][0]``, ``blocks[1]``)."""
 
     _unit = None   # (kind, index) once bound
@@ -80,8 +82,8 @@ class _Node(_TracksChildren, nn.Module):
         if self._unit is None:
             raise NotImplementedError(
                 "this node only carries parameters under the reference's names; the callable sub-modules are frontend.stem / "
-                ".blocks / .blocks[i] / .blocks[i].partial / .concat / .linear, transformer_blocks.layers[l][0] / [l][1] / .norm "
-                "and the three stages")
+                ".blocks / .blocks[i] / .blocks[i].partial (and its attnF / ffF / attnT / ffT) / .concat / .linear, "
+                "transformer_blocks.layers[l][0] / [l][1] / .norm and the three stages")
         return self._root()._run_unit(x, *self._unit)
 
 
@@ -195,6 +197,10 @@ class BeatThis(_TracksChildren, nn.Module):
             bind(blk, "block", i)
             if "partial" in blk._modules:
                 bind(blk.partial, "partial", i)
+                # its four leaves are ordinary Attention / FeedForward modules in the reference (beat_tracker.py:251-301)
+                for j, (attn, ff) in enumerate((("attnF", "ffF"), ("attnT", "ffT"))):
+                    bind(blk.partial._modules[attn], "fattn", 2 * i + j)
+                    bind(blk.partial._modules[ff], "fff", 2 * i + j)
         bind(fr.concat, "concat")
         bind(fr.linear, "linear")
         for l, layer in enumerate(self.transformer_blocks.layers):
@@ -314,6 +320,15 @@ class BeatThis(_TracksChildren, nn.Module):
             b, n, _ = x.shape
             t = x.reshape(b, n, 256, 4).transpose(2, 3).contiguous()   # (c f) -> (f c): the packed weight's column order
             return eng.forward_unit(t, prec, _lib.UNIT_LINEAR, 0, (b, n, D))
+        if kind in ("fattn", "fff"):
+            # leaves of a PartialFTTransformer: Attention / FeedForward of width C on "(b t) f c" or "(b f) t c" rows; the branch
+            # WITHOUT the residual like the main layers' (see below)
+            c = 32 << (index >> 1)
+            if x.dim() != 3 or x.shape[2] != c:
+                raise ValueError(f"expected a (sequences, tokens, {c}) input, got {tuple(x.shape)}")
+            xf = x.to(torch.float32).contiguous()
+            y = eng.forward_unit(xf, prec, _lib.UNIT_FRONT_ATTN if kind == "fattn" else _lib.UNIT_FRONT_FF, index, xf.shape)
+            return y - xf
         if x.dim() != 3 or x.shape[2] != D:
             raise ValueError(f"expected a (batch, time, {D}) input, got {tuple(x.shape)}")
         if kind == "norm":

@@ -98,6 +98,8 @@ class PackedModel:
               for k, v in state_dict.items()}
         self.device = torch.device(device)
         self._keep: list[torch.Tensor] = []
+        self._hl8_todo: list = []    # (pair weights, hl8 field, fp32 field, rows) of the main layers' GEMM weights: ensure_hl8
+        self._by_ptr: dict = {}      # data_ptr -> fp32 device copy written by _mat
         self.desc = _lib.ModelDesc()
         d = self.desc
         D = int(hparams["transformer_dim"])
@@ -191,6 +193,8 @@ class PackedModel:
         hi = w.to(ht)
         b = torch.cat([hi, (w - hi.to(torch.float32)).to(ht)]).to(self.device)
         self._keep += [a, b]
+        if hasattr(self, "_by_ptr"):
+            self._by_ptr[a.data_ptr()] = a
         return a.data_ptr(), b.data_ptr()
 
     def _hl32(self, w: torch.Tensor) -> int:
@@ -226,6 +230,15 @@ class PackedModel:
         self._keep.append(t)
         return t.data_ptr()
 
+    def ensure_hl8(self) -> bool:
+        """Pack the hl8 (BT_OPT_X3_GEMM_FP8) forms of the main layers' GEMM weights if that has not happened yet; -> True when
+        bt_pair_weights fields changed (a bt_engine copies its description at creation: the caller re-creates the handle)."""
+        todo, self._hl8_todo = self._hl8_todo, []
+        for pw, field, src, rows in todo:
+            w = self._by_ptr[getattr(pw, src)[0]][:rows].cpu()
+            setattr(pw, field, self._hl8(w))
+        return bool(todo)
+
     def _pair(self, pw, sd, pa: str, pf: str, dim: int, x3: bool = False) -> None:
         heads = dim // 32
         pw.dim, pw.heads = dim, heads
@@ -249,11 +262,12 @@ class PackedModel:
             pw.w_out_x3 = self._hl32(sd[pa + "to_out.0.weight"])
             pw.w_ff1_x3 = self._hl32(sd[pf + "net.1.weight"] * sd[pf + "net.0.gamma"][None, :])
             pw.w_ff2_x3 = self._hl32(sd[pf + "net.4.weight"])
-            # BT_OPT_X3_GEMM_FP8: the same four matrices with the lo halves as (hi byte, lo byte) pairs
-            pw.w_qkvg_f8 = self._hl8(w)
-            pw.w_out_f8 = self._hl8(sd[pa + "to_out.0.weight"])
-            pw.w_ff1_f8 = self._hl8(sd[pf + "net.1.weight"] * sd[pf + "net.0.gamma"][None, :])
-            pw.w_ff2_f8 = self._hl8(sd[pf + "net.4.weight"])
+            # BT_OPT_X3_GEMM_FP8 (opt-in, off by default): the same four matrices with the lo halves as (hi byte, lo byte) pairs are
+            # packed LAZILY, when the option is first switched on (ensure_hl8: from the fp32 device copies _mat keeps anyway) --
+            # packed unconditionally they doubled the x3 weight memory of every engine for an option almost nobody sets
+            if hasattr(self, "_hl8_todo"):
+                self._hl8_todo += [(pw, "w_qkvg_f8", "w_qkvg", w.shape[0]), (pw, "w_out_f8", "w_out", dim),
+                                   (pw, "w_ff1_f8", "w_ff1", sd[pf + "net.1.weight"].shape[0]), (pw, "w_ff2_f8", "w_ff2", dim)]
         # (the register-chained kernels of fused.hip / fused2.hip are built for a hidden width of 4 dim: a main layer with
         # another ff_mult and dim <= 128 runs on the plain GEMM path)
         if dim <= 128 and sd[pf + "net.1.weight"].shape[0] == 4 * dim:
@@ -361,13 +375,35 @@ class Engine:
 
     def set_options(self, opts: dict) -> None:
         """Arithmetic variants of the engine (bt_engine_set_option), e.g. ``{"x3_attn_p16": 0}`` for the three-term P.V of
-        rounds 3 - 4 everywhere, ``1`` for P16 in the main layers only, ``2`` (default) main layers + frontend;
+        rounds 3 - 4 everywhere, ``1`` (default) for P16 in the main layers only, ``2`` main layers + frontend (round 5's default);
         ``{"x3_gemm_fp8": 1 | 2}`` for BASELINE config 5 (fp8 cross terms in the feed-forward / in all main-layer GEMMs).  Captured forwards are dropped: a graph replays the kernels it was recorded with."""
-        for name, value in opts.items():
+        for name in opts:
             if name not in self.OPTIONS:
                 raise ValueError(f"unknown engine option {name!r} (known: {sorted(self.OPTIONS)})")
+        if int(opts.get("x3_gemm_fp8", 0)) > 0 and self.packed.ensure_hl8():
+            self._recreate_handle()   # (the hl8 weights were packed just now: the handle's copy of the description is stale)
+        for name, value in opts.items():
             _lib.check(_lib.lib().bt_engine_set_option(self._h, self.OPTIONS[name], int(value)))
+        self._drop_graphs()
+
+    def _drop_graphs(self) -> None:
+        """Captured forwards replay the kernels / tables they were recorded with: dropped together with their per-stream
+        workspaces (up to ~0.9 GB for 11 chunks), which nothing else refers to."""
         self.__dict__.pop("_graphs", None)
+        self.__dict__.pop("_graph_ws", None)
+
+    def _recreate_handle(self) -> None:
+        """A new bt_engine from the (changed) description, options carried over; the old handle is released afterwards."""
+        if self._deferred is not None:
+            raise RuntimeError("the engine cannot be re-created while range checks of earlier forwards are pending")
+        torch.cuda.synchronize(self.device)
+        h = C.c_void_p()
+        _lib.check(_lib.lib().bt_engine_create(C.byref(self.packed.desc), C.byref(h)))
+        for name in self.OPTIONS:
+            _lib.check(_lib.lib().bt_engine_set_option(h, self.OPTIONS[name], self.get_option(name)))
+        old_h, self._h = self._h, h
+        _lib.lib().bt_engine_destroy(old_h)
+        self._drop_graphs()
 
     def get_option(self, name: str) -> int:
         v = C.c_int(0)
@@ -390,7 +426,7 @@ class Engine:
         except Exception:   # the old handle (and its table) stay valid
             self.packed.desc.rope, self.packed.desc.rope_len, self.packed._rope_t = old_rope, old_len, old_t
             raise
-        self.__dict__.pop("_graphs", None)   # (captured forwards hold the old table's address)
+        self._drop_graphs()   # (captured forwards hold the old table's address)
         for name in self.OPTIONS:            # the new handle inherits the old one's options
             _lib.check(_lib.lib().bt_engine_set_option(h, self.OPTIONS[name], self.get_option(name)))
         old_h, self._h = self._h, h       # swap first, then release: self._h never dangles

@@ -19,7 +19,9 @@ Extra objects on the JSON line:
                 max |logit difference|, beat / downbeat frame flips.
   roofline      dominant launch category of the forward (attention, MFMA bound): algorithmic FLOP per launch / average
                 launch duration from HIP events on the launch stream (bt_profile_*, a profiled pass of the same workload
-                right after the timed region); peak = a third of the dense fp16 MFMA peak (three MFMAs per product);
+                right after the timed region); peak = the dense fp16 MFMA peak of MI355X_MICROARCH.md (2.5 PFLOP/s), frac =
+                achieved / peak; pipe_utilisation = frac x the fp16 MFMAs this arithmetic issues per product (3; 2.5 - 3 in the
+                attention); whole_step_frac = SURVEY 8d's 134.71 GFLOP x chunks / ms_per_step / peak;
                 traffic = HBM bytes per launch from the committed PMC passes (labelled).
   half_path     the same workload with float16=True (fp16 MFMA operands, what BASELINE configs 2 / 4 call bf16): NOT under the
                 gate -- its parity object says by how much, next to the reference's own fp16-autocast error -- with its own
@@ -62,9 +64,12 @@ FRESH_SECONDS_PER_CHUNK = 29.76   # 1488 fresh frames at 50 fps
 TRACK_SECONDS = 300.0
 TRACK_SR = 44100
 TRACKS_PER_GPU = 6
-# MI355X_MICROARCH.md: dense MFMA peaks.  f32x3: every product costs three fp16 MFMAs, so the matrix pipe can deliver at most
-# a third of its fp16 rate in ALGORITHMIC flops on that path
-PEAK_TFLOPS = {"half": 2500.0, "f32": 157.3, "f32x3": 2500.0 / 3}
+# MI355X_MICROARCH.md: dense MFMA peaks.  roofline.frac is ALGORITHMIC flops / the guide's dense peak of the MFMA the path
+# issues (fp16 for half and f32x3, fp32 for the exact path).  The hi + lo path spends three fp16 MFMAs per product (its
+# attention 2.5 / 2.75 / 3 by BT_OPT_X3_ATTN_P16): that is a cost of the chosen arithmetic, not a lower ceiling -- the pipe's
+# own occupancy is reported beside it as `pipe_utilisation` = frac x MFMAs per product.
+PEAK_TFLOPS = {"half": 2500.0, "f32": 157.3, "f32x3": 2500.0}
+MFMAS_PER_PRODUCT = {"half": 1.0, "f32": 1.0, "f32x3": 3.0}
 PEAK_HBM_GBS = 8000.0
 
 
@@ -138,9 +143,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the side legs (other precisions, latency, configs, frontend)")
     ap.add_argument("--no-dist", action="store_true", help="N = 1 without bringing up the RCCL process group")
-    ap.add_argument("--x3-p16", type=int, default=2, choices=[0, 1, 2],
-                    help="BT_OPT_X3_ATTN_P16 of the default precision: probabilities enter P.V as fp16 hi parts in the main layers and "
-                         "the frontend (2, default), in the main layers only (1), nowhere = three-term P.V of rounds 3 - 4 (0)")
+    ap.add_argument("--x3-p16", type=int, default=1, choices=[0, 1, 2],
+                    help="BT_OPT_X3_ATTN_P16 of the default precision: probabilities enter P.V as fp16 hi parts in the main layers only "
+                         "(1, the library's default: chosen by the flip-soak rule, DESIGN.md section 3), in the frontend as well (2, "
+                         "round 5's default), nowhere = three-term P.V of rounds 3 - 4 (0)")
     ap.add_argument("--min-seconds", type=float, default=2.0,
                     help="the K timed steps are repeated until the timed region is at least this long (0: exactly K steps)")
     ap.add_argument("--watchdog", type=int, default=900, help="seconds after which a stuck run dumps its stacks and exits")
@@ -150,6 +156,14 @@ def main():
     faulthandler.dump_traceback_later(args.watchdog, exit=True)  # a hang becomes a traceback on stderr, not a silent timeout
 
     if args.gpus > 1 and "RANK" not in os.environ:
+        # fail fast with a clear message when the box does not have the GPUs asked for (instead of N ranks fighting over
+        # cuda:0 until a collective's watchdog fires)
+        import torch
+
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but this node shows {have} GPU(s) (torch.cuda.device_count()); "
+                             "run with --gpus <= that, one process per GPU")
         # self-launch: one process per GPU under torch.distributed.run (RCCL rendezvous on 127.0.0.1)
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
                "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__), *sys.argv[1:]]
@@ -170,6 +184,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"bench.py: LOCAL_RANK {local_rank} but this node shows {torch.cuda.device_count()} GPU(s)")
+    if world > 1:
+        # N launch loops on one host: give every rank its own slice of the cores (affinity by LOCAL_RANK) and size torch's
+        # intra-op pool to it, so that eight Python launch threads + their helpers do not migrate over / fight for the same cores
+        try:
+            cores = sorted(os.sched_getaffinity(0))
+            per_rank = max(1, len(cores) // int(os.environ.get("LOCAL_WORLD_SIZE", world)))
+            mine = cores[local_rank * per_rank: (local_rank + 1) * per_rank] or cores
+            os.sched_setaffinity(0, mine)
+            torch.set_num_threads(max(1, min(len(mine), 16)))
+        except (AttributeError, OSError) as e:  # noqa: PERF203  (no affinity interface: leave the scheduler alone)
+            log(f"rank {rank}: host threads not pinned ({type(e).__name__})")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     # N = 1 brings the RCCL process group up as well (a world of one): the logits all-gather, the barriers and the
@@ -183,7 +210,11 @@ def main():
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         try:
-            dist.init_process_group("nccl", device_id=dev)
+            from datetime import timedelta
+
+            # (a collective whose peer died is aborted after three minutes instead of RCCL's default ten; a rank that RAISES
+            # takes the whole job down at once: see the wrapper around main())
+            dist.init_process_group("nccl", device_id=dev, timeout=timedelta(seconds=180))
         except Exception as e:  # noqa: BLE001
             if world > 1:
                 raise
@@ -337,8 +368,12 @@ def main():
                   "source": "rsmi_dev_energy_count_get before / after the timed region (idle power of the package included)"}
         log(f"energy: {energy['joules_per_step']} J / step, {energy['avg_package_power_W']} W average")
     log(f"timed region done: {1e3 * elapsed / n_timed:.3f} ms / step over {elapsed:.2f} s")
+    per_rank_ms = [round(1e3 * elapsed / n_timed, 3)]
     if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        allt = torch.empty(world, dtype=torch.float64, device=dev)
+        dist.all_gather_into_tensor(allt, t)
+        per_rank_ms = [round(1e3 * float(v) / n_timed, 3) for v in allt.tolist()]   # (which rank is the slow one, if any)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ms_per_step = 1e3 * elapsed / n_timed
@@ -353,12 +388,22 @@ def main():
         xs = xs.repeat(-(-per // xs.shape[0]), 1, 1)[:per]   # (per-rank share; distinct seeds for the first 64, repeated beyond)
         g512 = torch.empty((world * per, 2, CHUNK_FRAMES), dtype=torch.float32, device=dev) if use_dist else None
 
-        def sstep():
+        ev_s = []   # (start, forward done, gather done) stream events per timed step
+
+        def sstep(record=False):
+            e = [torch.cuda.Event(enable_timing=True) for _ in range(3)] if record else None
+            if e:
+                e[0].record()
             with torch.inference_mode(), torch.autocast("cuda", enabled=half):
                 outs = [a2b.model(xs[i: i + 64]) for i in range(0, per, 64)]
                 r = torch.stack((torch.cat([o["beat"] for o in outs]), torch.cat([o["downbeat"] for o in outs])), 1)
+            if e:
+                e[1].record()
             if use_dist:
                 dist.all_gather_into_tensor(g512, r)
+            if e:
+                e[2].record()
+                ev_s.append(e)
             return r
         for _ in range(2):
             sstep()
@@ -366,18 +411,31 @@ def main():
         ts = time.perf_counter()
         n_s = 3 if world == 1 else 6
         for _ in range(n_s):
-            sstep()
+            sstep(True)
         fence()
         ts = time.perf_counter() - ts
+        # this rank's own forward time and what the collective added behind it (stream events: the gather's interval includes
+        # the wait for the slowest rank, which is what a strong-scaling step pays)
+        fwd_ms = sum(a.elapsed_time(b) for a, b, _ in ev_s) / n_s
+        gat_ms = sum(b.elapsed_time(c) for _, b, c in ev_s) / n_s
+        s_per_rank, s_gather = [round(fwd_ms, 3)], [round(gat_ms, 3)]
         if use_dist:
             t = torch.tensor([ts], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             ts = float(t.item())
+            mine = torch.tensor([fwd_ms, gat_ms], dtype=torch.float64, device=dev)
+            allm = torch.empty((world, 2), dtype=torch.float64, device=dev)
+            dist.all_gather_into_tensor(allm, mine)
+            s_per_rank = [round(float(v), 3) for v in allm[:, 0].tolist()]
+            s_gather = [round(float(v), 3) for v in allm[:, 1].tolist()]
         ts /= n_s
         strong = {"workload": f"BASELINE config 4: 512 x 1500-frame chunks, {per} per GPU in slices of 64, {args.prec} forward, "
                               "logits all-gathered (RCCL)" + ("" if use_dist else " -- one GPU: no collective"),
                   "global_chunks": world * per, "chunks_per_gpu": per, "ms_per_step": round(ts * 1e3, 3),
-                  "audio_seconds_per_s": round(world * per * FRESH_SECONDS_PER_CHUNK / ts, 1), "scaling": "strong"}
+                  "audio_seconds_per_s": round(world * per * FRESH_SECONDS_PER_CHUNK / ts, 1), "scaling": "strong",
+                  "per_rank_ms": s_per_rank, "gather_ms": s_gather,
+                  "per_rank_note": "stream events on every rank: per_rank_ms = its own forward slices, gather_ms = from the end of "
+                                   "its forward to the end of the all-gather (includes waiting for the slowest rank)"}
         del xs, g512
 
     out = None
@@ -416,16 +474,41 @@ def main():
             breakdown = profile_forward(lambda: a2b.many(tracks, TRACK_SR), 2, chunks_per_step)
         else:
             breakdown = profile_forward(step, 3, chunks_per_step)
-        def roofline_of(bd, prec, chunks):
-            """roofline object of a profiled forward: its dominant launch category against the matrix peak of `prec`"""
+        def soak_of(scheme):
+            """what the committed flip soak (tools/flip_soak.py: many 300 s tracks x 3 weight styles against the fp32 CPU oracle)
+            says about `scheme`: flips per 1000 beat / downbeat decisions, next to the exact fp32 MFMA path's -- the rule the
+            default arithmetic is chosen by -- with the sha256 of the table it is read from"""
+            import glob
+            import hashlib
+
+            try:
+                path = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_flip_frontier.json")))[-1]
+                sj = json.load(open(path))
+                txt = os.path.splitext(path)[0] + ".txt"
+                sha = hashlib.sha256(open(txt, "rb").read()).hexdigest()[:16]
+
+                def rate(name):
+                    rows = [v for k, v in sj[name].items() if k != "rule"]
+                    return round(1000.0 * sum(v["flips"] for v in rows) / max(1, sum(v["decisions"] for v in rows)), 4)
+                return {"flips_per_1000": rate(scheme), "flips_per_1000_exact_fp32_path": rate("exact"),
+                        "flips_per_1000_by_style": {k: v["flips_per_1000"] for k, v in sj[scheme].items() if k != "rule"},
+                        "soak_rule": sj[scheme].get("rule"), "soak_scheme": scheme,
+                        "soak_tracks_per_style": min(v["tracks"] for k, v in sj[scheme].items() if k != "rule"),
+                        "soak_file": os.path.relpath(txt, ROOT), "soak_sha256_16": sha}
+            except (OSError, IndexError, KeyError, ValueError) as e:
+                return {"flips_per_1000": None, "soak_note": f"no committed soak summary for {scheme} ({type(e).__name__})"}
+
+        def roofline_of(bd, prec, chunks, step_ms=None):
+            """roofline object of a profiled forward: its dominant launch category against the guide's dense matrix peak of
+            the MFMA `prec` issues (no self-derated peak)"""
             dom = max(bd, key=lambda k: bd[k]["ms_per_step"])
             d = bd[dom]
             peak = PEAK_TFLOPS[prec]
-            p16 = prec == "f32x3" and dom == "attn_flash" and args.x3_p16 == 2
-            if p16:   # scores on three MFMAs per product, P.V on two (BT_OPT_X3_ATTN_P16): 2.5 pipe flops per algorithmic flop
-                peak = PEAK_TFLOPS["half"] / 2.5
-            elif prec == "f32x3" and dom == "attn_flash" and args.x3_p16 == 1:   # (half of the attention flops in either form)
-                peak = PEAK_TFLOPS["half"] / 2.75
+            per_product = MFMAS_PER_PRODUCT[prec]
+            if prec == "f32x3" and dom == "attn_flash":
+                # scores on three MFMAs per product; P.V on two where the probabilities enter as fp16 hi parts (BT_OPT_X3_ATTN_P16:
+                # 2 = everywhere, 1 = main layers only = half of the attention flops, 0 = nowhere)
+                per_product = {0: 3.0, 1: 2.75, 2: 2.5}[args.x3_p16]
             traffic, traffic_src = None, None
             try:  # HBM bytes per launch of the dominant category: PMC counters of separate rocprofv3 passes, committed
                 name = "pmc_traffic.json" if prec == "half" else f"pmc_traffic_{prec}.json"
@@ -437,20 +520,24 @@ def main():
             except (OSError, ValueError, KeyError, ZeroDivisionError):
                 pass
             tot = sum(v["ms_per_step"] for v in bd.values())
-            return {"kernel": dom, "bound": "mfma", "achieved": d["tflops"], "peak": round(peak, 1), "unit": "TFLOP/s",
-                    "frac": round(d["tflops"] / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
-                    "avg_launch_ms": round(d["ms_per_step"] / d["launches_per_step"], 4),
-                    "flop_per_launch": fl[dom] * chunks / d["launches_per_step"],
-                    "forward_ms_per_step": round(tot, 3),
-                    "whole_forward_tflops": round(FLOP_PER_CHUNK * chunks / (tot * 1e-3) / 1e12, 2),
-                    "whole_forward_frac": round(FLOP_PER_CHUNK * chunks / (tot * 1e-3) / 1e12 / PEAK_TFLOPS[prec], 4),
-                    "frac_of_dense_fp16_peak": round(d["tflops"] / PEAK_TFLOPS["half"], 4) if prec != "f32" else None,
-                    "peak_note": "dense fp16 MFMA peak / 2.5: the attention's scores run three fp16 MFMAs per product, its P.V two "
-                                 "(whole_forward_frac is against a third of the dense peak: the GEMMs run three)" if p16 else
-                                 {"half": "dense fp16 MFMA peak", "f32": "fp32 MFMA peak",
-                                  "f32x3": "a third of the dense fp16 MFMA peak: every product is three fp16 MFMAs"}[prec]}
+            r = {"kernel": dom, "bound": "mfma", "achieved": d["tflops"], "peak": round(peak, 1), "unit": "TFLOP/s",
+                 "frac": round(d["tflops"] / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
+                 "avg_launch_ms": round(d["ms_per_step"] / d["launches_per_step"], 4),
+                 "flop_per_launch": fl[dom] * chunks / d["launches_per_step"],
+                 "mfmas_per_product": per_product,
+                 "pipe_utilisation": round(d["tflops"] * per_product / peak, 4),
+                 "forward_ms_per_step": round(tot, 3),
+                 "whole_forward_tflops": round(FLOP_PER_CHUNK * chunks / (tot * 1e-3) / 1e12, 2),
+                 "whole_forward_frac": round(FLOP_PER_CHUNK * chunks / (tot * 1e-3) / 1e12 / peak, 4),
+                 "peak_note": {"half": "dense fp16 MFMA peak (MI355X_MICROARCH.md)", "f32": "fp32 MFMA peak (MI355X_MICROARCH.md)",
+                               "f32x3": "dense fp16 MFMA peak (MI355X_MICROARCH.md); the path issues mfmas_per_product fp16 MFMAs "
+                                        "per algorithmic product, pipe_utilisation = frac x that"}[prec]}
+            if step_ms is not None:   # the timed region itself (two streams, steps pipelined): SURVEY 8d flops / ms_per_step / peak
+                r["whole_step_tflops"] = round(FLOP_PER_CHUNK * chunks / (step_ms * 1e-3) / 1e12, 2)
+                r["whole_step_frac"] = round(FLOP_PER_CHUNK * chunks / (step_ms * 1e-3) / 1e12 / peak, 4)
+            return r
 
-        roofline = roofline_of(breakdown, args.prec, chunks_per_step)
+        roofline = roofline_of(breakdown, args.prec, chunks_per_step, ms_per_step)
 
         frontend = forward_only = host_inclusive = configs = None
         if args.workload == "tracks" and not args.no_extras:
@@ -602,6 +689,7 @@ def main():
 
         # ---- CPU baseline + in-run parity: the oracle's Audio2Beats on track 0, bounded sample ------------------------
         cpu = parity = half_path = fp32_exact_path = f32x3_path = latency = stress = None
+        p16_legs = {}
         if world == 1 and not args.no_cpu_baseline and args.workload == "tracks":
             from oracle import beat_this_oracle as O
 
@@ -666,6 +754,8 @@ def main():
                         "against": f"CPU oracle (fp32) on the same {sample_s:.0f} s waveform, {len(ob)} frames"}
             log(f"cpu baseline done ({tc:.1f} s fastest); parity")
             parity = parity_of(a2b)
+            parity.update(soak_of({0: "x3", 1: "x3p16m", 2: "x3p16"}[args.x3_p16] if args.prec == "f32x3" else
+                                  {"half": "half", "f32": "exact"}[args.prec]))
 
             def path_leg(prec, seconds):
                 """the headline workload in another precision: ~`seconds` of pipelined steps, parity, per-launch profile"""
@@ -712,6 +802,28 @@ def main():
                 if args.prec != "f32x3" and not _lib.lib().bt_half_is_bf16():
                     log("f32x3 path leg")
                     f32x3_path = path_leg("f32x3", 1.0)
+
+                # ---- the other arithmetic levels of the default precision (BT_OPT_X3_ATTN_P16), same workload, ~0.7 s each -----
+                if args.prec == "f32x3":
+                    log("P16 level legs")
+                    for level in (0, 1, 2):
+                        if level == args.x3_p16:
+                            continue
+                        eng.set_options({"x3_attn_p16": level})
+                        for _ in range(3):
+                            step()
+                        drain()
+                        torch.cuda.synchronize(dev)
+                        n = max(3, int(0.7 / max(ms_per_step * 1e-3, 1e-3)))
+                        t_ = time.perf_counter()
+                        for _ in range(n):
+                            step()
+                        drain()
+                        torch.cuda.synchronize(dev)
+                        t_ = (time.perf_counter() - t_) / n
+                        p16_legs[f"value_p16_{level}"] = {"value": round(units_per_step / t_, 1), "ms_per_step": round(t_ * 1e3, 3), "steps": n,
+                                                          "parity": {**parity_of(a2b), **soak_of({0: "x3", 1: "x3p16m", 2: "x3p16"}[level])}}
+                    eng.set_options({"x3_attn_p16": args.x3_p16})
 
                 # ---- single-file latency (BASELINE config 1): one call at a time, host waveform in, beat times out ---------
                 log("latency leg")
@@ -790,7 +902,7 @@ def main():
             "metric": "audio-seconds processed/sec", "value": round(value, 1), "unit": "audio-seconds/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": {"half": half_name, "f32": "f32", "f32x3": "f32 activations, f16x3 products (3 x f16 MFMA on hi+lo operand halves, f32 accumulate; attention P.V: 2 x, probabilities as fp16 hi parts)" if args.x3_p16 else "f32 activations, f16x3 products (3 x f16 MFMA on hi+lo operand halves, f32 accumulate)"}[args.prec],
+            "dtype": {"half": half_name, "f32": "f32", "f32x3": "f32 activations, f16x3 products (3 x f16 MFMA on hi+lo operand halves, f32 accumulate)" + {0: "", 1: "; main-layer attention P.V: 2 x, probabilities as fp16 hi parts", 2: "; attention P.V: 2 x, probabilities as fp16 hi parts (opt-in level 2)"}[args.x3_p16]}[args.prec],
             "data": "synthetic",
             "config": {"workload": workload, "tracks_per_gpu": args.tracks if args.workload == "tracks" else None,
                        "chunks_per_gpu": chunks_per_step, "global_chunks": world * chunks_per_step,
@@ -800,8 +912,9 @@ def main():
             "half_path": half_path, "fp32_exact_path": fp32_exact_path, "latency": latency,
             "stress_weights": stress, "host_inclusive": host_inclusive, "configs": configs,
             "strong_scaling_cfg4": strong, "rccl_ranks": rccl_ranks, "rccl_note": dist_note,
-            "timed_region": {"steps": args.steps, "repeats": repeats, "steps_timed": n_timed, "seconds": round(elapsed, 3)},
-            "breakdown": breakdown,
+            "timed_region": {"steps": args.steps, "repeats": repeats, "steps_timed": n_timed, "seconds": round(elapsed, 3),
+                             "per_rank_ms_per_step": per_rank_ms},
+            "breakdown": breakdown, **p16_legs,
         }
         if f32x3_path is not None:   # (only when the headline is another precision: --prec half / f32)
             out["f32x3_path"] = f32x3_path
@@ -814,5 +927,25 @@ def main():
         dist.destroy_process_group()
 
 
+def _guarded_main():
+    """main() with the N > 1 failure rule: a rank that raises must not leave the others inside a collective until a watchdog
+    fires.  The traceback goes to stderr, then the process leaves with os._exit (no interpreter teardown: the RCCL process
+    group's destructor would wait for the collectives the dead step never issued) -- torch.distributed.run sees a failed
+    worker and terminates the rest of the group at once."""
+    try:
+        main()
+    except SystemExit:
+        raise
+    except BaseException:  # noqa: BLE001
+        import traceback
+
+        traceback.print_exc()
+        sys.stderr.write(f"[bench] rank {os.environ.get('RANK', '0')} failed: aborting the job\n")
+        sys.stderr.flush()
+        if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+            os._exit(1)
+        raise
+
+
 if __name__ == "__main__":
-    main()
+    _guarded_main()

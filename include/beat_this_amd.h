@@ -162,7 +162,7 @@ typedef struct {
 const char* bt_last_error(void);
 /* ABI version of this header: bumped whenever an entry point's signature, a struct layout or a BT_PREC_* value changes; a
  * binding must see exactly the value it was written against (beat_this_amd/_lib.py does) */
-#define BT_ABI_VERSION 520
+#define BT_ABI_VERSION 600
 int bt_version(void);
 /* operand type of the half-precision path (BT_PREC_HALF slot of the weight arrays) this library was built
  * with: 0 = IEEE fp16 (default), 1 = bfloat16 (-DBT_HALF_BF16) */
@@ -179,10 +179,11 @@ void bt_engine_destroy(bt_engine* e);
  * are not bit-identical to each other; both are kept so that the choice can be measured: tools/flip_soak.py,
  * profiles/r05_flip_frontier.txt).  bt_engine_set_option returns BT_ERR_ARG for an unknown option / value.
  *   BT_OPT_X3_ATTN_P16  the attention probabilities enter P.V as their fp16 hi parts (two MFMAs per fragment pair instead of
- *                       three), row sums from the same rounded values:  2 (default) in the main layers and in the frontend's
- *                       time-direction attention;  1 in the main layers only (logit error of the three-term form: the frontend's
- *                       three attention layers carry 3/4 of what P16 adds);  0: three-term P.V with the probabilities split
- *                       hi + lo everywhere (rounds 3 - 4).
+ *                       three), row sums from the same rounded values:  1 (default since round 6) in the main layers only;
+ *                       2 in the frontend's time-direction attention as well (round 5's default: +2 % throughput, 2.7 x the
+ *                       exact path's beat flips on trained-like weights over the soak -- an opt-in, not the default: the default
+ *                       is chosen by the flip-soak rule of DESIGN.md section 3);  0: three-term P.V with the probabilities
+ *                       split hi + lo everywhere (rounds 3 - 4).
  *   BT_OPT_X3_GEMM_FP8  0 (default);  BASELINE config 5 -- GEMMs of the main layers run the two cross terms of every hi + lo product
  *                       (hi . lo + lo . hi: 2^-11 of the product) on ONE block-scaled fp8 MFMA per 32-k step instead of four fp16
  *                       ones, operands travelling as hl8 (bt_pair_weights.w_*_f8): 2 MFMA units per product instead of 3.
@@ -223,8 +224,13 @@ int bt_forward_stages(bt_engine* e, void* stream, int prec, int first, int last,
  *   BT_UNIT_ATTN     index = layer: d_in [B,T,D]       -> d_out = x + Attention(x)      (the residual form the layer computes)
  *   BT_UNIT_FF       index = layer: d_in [B,T,D]       -> d_out = x + FeedForward(x)
  *   BT_UNIT_NORM     d_in [B,T,D]                      -> d_out = RMSNorm(x)
- * d_out may equal d_in for the in-place units (PARTIAL, ATTN, FF).  Workspace as for bt_forward. */
-enum { BT_UNIT_STEM = 0, BT_UNIT_PARTIAL = 1, BT_UNIT_CONV = 2, BT_UNIT_LINEAR = 3, BT_UNIT_ATTN = 4, BT_UNIT_FF = 5, BT_UNIT_NORM = 6 };
+ *   BT_UNIT_FRONT_ATTN / BT_UNIT_FRONT_FF   the four leaves of a PartialFTTransformer (beat_tracker.py:251-301: attnF, ffF, attnT,
+ *                    ffT -- ordinary Attention / FeedForward modules of width C = 32 << block on "(b t) f c" / "(b f) t c" rows):
+ *                    index = 2 block + direction (0 = F, 1 = T); here B = sequences, T = tokens per sequence:
+ *                    d_in [B,T,C] -> d_out = x + Attention(x) / x + FeedForward(x)
+ * d_out may equal d_in for the in-place units (PARTIAL, ATTN, FF, FRONT_*).  Workspace as for bt_forward. */
+enum { BT_UNIT_STEM = 0, BT_UNIT_PARTIAL = 1, BT_UNIT_CONV = 2, BT_UNIT_LINEAR = 3, BT_UNIT_ATTN = 4, BT_UNIT_FF = 5, BT_UNIT_NORM = 6,
+       BT_UNIT_FRONT_ATTN = 7, BT_UNIT_FRONT_FF = 8 };
 int bt_forward_unit(bt_engine* e, void* stream, int prec, int unit, int index, const float* d_in, float* d_out, int B, int T,
                     void* d_ws, size_t ws_bytes);
 

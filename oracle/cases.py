@@ -97,3 +97,11 @@ def padding_mask_case(name):
         mask[0, 290:] = False
         return beat[0], down[0], mask[0]
     return beat, down, mask
+
+
+# ---- final0 at piece / end-to-end level and on the "outlier" weight style; generator: oracle/make_golden_final0.py -------------
+FINAL0_CASES = {
+    "piece": dict(weight_seed=1, style="lively", frames=3100, input_seed=30),
+    "e2e": dict(weight_seed=1, style="lively", seconds=40.0, audio_seed=13),
+    "outlier": dict(weight_seed=1, frames=1500, input_seed=3),
+}

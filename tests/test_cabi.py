@@ -25,13 +25,13 @@ def test_library_exports_every_declared_symbol():
     L = _lib()
     header = open(os.path.join(ROOT, "include", "beat_this_amd.h")).read()
     declared = set(re.findall(r"\b(bt_[a-z_0-9]+)\s*\(", header))
-    assert re.search(r"#define BT_ABI_VERSION 520\b", header)
+    assert re.search(r"#define BT_ABI_VERSION 600\b", header)
     assert {"bt_forward", "bt_logmel", "bt_peaks", "bt_aggregate", "bt_split_chunks", "bt_engine_create"} <= declared
     handle = L.lib()
     for name in declared:
         assert hasattr(handle, name), f"{name} declared in the header but not exported"
     assert set(L.EXPORTS) == declared
-    assert handle.bt_version() == L.ABI_VERSION == 520   # (BT_ABI_VERSION of include/beat_this_amd.h)
+    assert handle.bt_version() == L.ABI_VERSION == 600   # (BT_ABI_VERSION of include/beat_this_amd.h)
 
 
 def test_argument_errors_map_to_exceptions():
@@ -210,5 +210,6 @@ def test_submodule_tree_mirrors_the_reference_containers():
     assert m2.frontend.linear._root() is m2 and set(m2.state_dict()) == keys
     with pytest.raises(RuntimeError, match="ROCm GPUs only"):
         m.frontend.stem(torch.zeros(1, 10, 128))
+    assert m.frontend.blocks[1].partial.attnT._unit == ("fattn", 3) and m.frontend.blocks[2].partial.ffF._unit == ("fff", 4)
     with pytest.raises(NotImplementedError):
-        m.frontend.blocks[0].partial.attnF(torch.zeros(1))
+        m.frontend.blocks[0].partial.attnF.norm(torch.zeros(1))   # (parameter-only nodes below the callable leaves)

@@ -114,7 +114,43 @@ def test_submodules_under_autocast_and_without_partial_transformers():
     with pytest.raises(ValueError):
         m.frontend.blocks[1](s.to(dev()))            # block 1 takes (b, 64, 16, t)
     with pytest.raises(NotImplementedError):
-        m.frontend.blocks[0].partial.attnF(s.to(dev()))
+        m.frontend.blocks[0].partial.attnF.to_qkv(s.to(dev()))    # (parameter-only nodes below the callable leaves)
+    with pytest.raises(ValueError):
+        m.frontend.blocks[0].partial.attnF(s.to(dev()))           # (sequences, tokens, 32) expected
+
+
+def test_partial_transformer_leaves_match_the_oracle():
+    """partial.attnF / .ffF / .attnT / .ffT are ordinary Attention / FeedForward modules in the reference (beat_tracker.py:251-301),
+    called on "(b t) f c" / "(b f) t c" rows: each against the oracle's operator, and the reference's own composition of the four
+    (with its rearranges) against the .partial unit."""
+    from oracle import beat_this_oracle as O
+
+    m, sd, _ = _model()
+    g = torch.Generator().manual_seed(9)
+    errs = {}
+    with torch.inference_mode():
+        for i in range(3):
+            c, f, t, b = 32 << i, 32 >> i, 70, 2
+            p = f"frontend.blocks.{i}.partial."
+            part = m.frontend.blocks[i].partial
+            xf = torch.randn((b * t, f, c), generator=g)
+            xt = torch.randn((b * f, t, c), generator=g)
+            errs[f"attnF{i}"] = _rel(part.attnF(xf.to(dev())), O.attention(xf.double(), sd, p + "attnF.", c // 32))
+            errs[f"ffF{i}"] = _rel(part.ffF(xf.to(dev())), O.feedforward(xf.double(), sd, p + "ffF."))
+            errs[f"attnT{i}"] = _rel(part.attnT(xt.to(dev())), O.attention(xt.double(), sd, p + "attnT.", c // 32))
+            errs[f"ffT{i}"] = _rel(part.ffT(xt.to(dev())), O.feedforward(xt.double(), sd, p + "ffT."))
+            # PartialFTTransformer.forward written against this model's leaves (beat_tracker.py:290-301)
+            x = torch.randn((b, c, f, t), generator=g).to(dev())
+            y = x.permute(0, 3, 2, 1).reshape(b * t, f, c)
+            y = y + part.attnF(y)
+            y = y + part.ffF(y)
+            y = y.view(b, t, f, c).permute(0, 2, 1, 3).reshape(b * f, t, c)
+            y = y + part.attnT(y)
+            y = y + part.ffT(y)
+            y = y.view(b, f, t, c).permute(0, 3, 1, 2)
+            errs[f"composed{i}"] = _rel(y, part(x).double().cpu())
+    report("submodules_partial_leaves", **errs)
+    assert max(errs.values()) < 2e-5, errs
 
 
 def test_hooks_on_deep_submodules_fire_in_the_whole_forward():

@@ -177,3 +177,88 @@ def test_two_rank_sharding_matches_single_process():
     for r in range(2):
         for (b, d), (sb, sd_) in zip(got[r], single):
             assert np.array_equal(b, sb.numpy()) and np.array_equal(d, sd_.numpy())
+
+
+# ---- eight ranks (the node the driver scales on): BASELINE config 4's 512 chunks, and 509 (a ragged last block) -------------
+def _big_pieces(n_chunks):
+    """pieces whose full-length chunks add up to n_chunks: 5-minute tracks (11 chunks each) + one shorter track, plus a short
+    clip (one odd-length chunk, computed by every rank) in the middle; frame value = f(piece, frame) so that a chunk that lands in
+    the wrong place changes the result"""
+    counts = [11] * (n_chunks // 11) + ([n_chunks % 11] if n_chunks % 11 else [])
+    pieces = []
+    for i, c in enumerate(counts):
+        n = 1488 * c - 200 if c > 1 else 1495          # ceil(n / 1488) chunks; 1495 frames (> 1488) give two
+        pieces.append((torch.arange(n, dtype=torch.float32)[:, None] % 997 + 1000.0 * i).expand(n, 128).contiguous())
+        if i == 3:
+            pieces.append(torch.full((700, 128), -5.0))   # a short clip: one 712-frame chunk, computed by every rank
+    return pieces
+
+
+def _digest(results):
+    import hashlib
+
+    h = hashlib.sha1()
+    for b, d in results:
+        h.update(np.ascontiguousarray(b.numpy()).tobytes())
+        h.update(np.ascontiguousarray(d.numpy()).tobytes())
+    return h.hexdigest()
+
+
+def _worker8(rank, world, port, q, n_chunks):
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from beat_this_amd.parallel import forward_chunks_sharded
+
+    seen = []
+
+    def run(model, chunks):
+        seen.append(int(chunks.shape[0]))
+        return _run(model, chunks)
+
+    res = forward_chunks_sharded(_fake_model, _big_pieces(n_chunks), 1500, 6, None, gather=_oracle_gather,
+                                 aggregate=_oracle_aggregate, run=run)
+    q.put((rank, _digest(res), seen))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("n_chunks", [512, 509])
+def test_eight_rank_sharding_of_512_and_509_chunks(n_chunks):
+    """World of 8 (gloo): every rank computes its block of the global chunk list (64 each; 509 -> seven of 64 and one of 61, the
+    all-gathered tensor padded to 8 x 64 with zero chunks that no piece reads), and every rank ends up with the results of the
+    single-process run, bit for bit."""
+    from beat_this_amd.parallel import forward_chunks_sharded, partition
+
+    pieces = _big_pieces(n_chunks)
+    from beat_this_amd import inference as inf
+    full = sum(len(inf.chunk_starts(p.shape[0], 1500, 6)) for p in pieces if inf.chunk_length(p.shape[0], 1500, 6) == 1500)
+    assert full == n_chunks
+    single = _digest(forward_chunks_sharded(_fake_model, pieces, 1500, 6, None, gather=_oracle_gather,
+                                            aggregate=_oracle_aggregate, run=_run))
+    del pieces
+    world = 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker8, args=(r, world, port, q, n_chunks)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(world):
+        r, dig, seen = q.get(timeout=240)
+        got[r] = (dig, seen)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in range(world):
+        lo, hi, per = partition(n_chunks, world, r)
+        assert per == 64
+        dig, seen = got[r]
+        assert dig == single, f"rank {r} assembled different logits"
+        # run() saw the short clip (1 chunk, every rank) and this rank's block -- 64 chunks, 61 on the last rank of the 509 case
+        assert sorted(seen) == sorted([1, hi - lo]), (r, seen)
