@@ -97,6 +97,13 @@ class Gemm3Args(C.Structure):
                 ("conv_T", C.c_int32), ("conv_F", C.c_int32), ("x3", C.c_int32), ("status", C.c_void_p)]
 
 
+class A2BPlan(C.Structure):   # bt_a2b_plan
+    _fields_ = [("n22", C.c_int64), ("n_frames", C.c_int64), ("result_words", C.c_int64), ("B", C.c_int32), ("T", C.c_int32),
+                ("ws_bytes", C.c_size_t), ("off_wave22", C.c_size_t), ("off_spect", C.c_size_t), ("off_chunks", C.c_size_t),
+                ("off_chunk_logits", C.c_size_t), ("off_logits", C.c_size_t), ("off_result", C.c_size_t),
+                ("off_forward", C.c_size_t), ("forward_bytes", C.c_size_t)]
+
+
 G3_FF1, G3_RESID, G3_QKV = 0, 1, 2
 UNIT_STEM, UNIT_PARTIAL, UNIT_CONV, UNIT_LINEAR, UNIT_ATTN, UNIT_FF, UNIT_NORM, UNIT_FRONT_ATTN, UNIT_FRONT_FF = range(9)
 
@@ -125,6 +132,9 @@ EXPORTS = {
     "bt_peaks": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]),
     "bt_postprocess_host": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_double, C.c_void_p,
                                       C.POINTER(C.c_int32), C.c_void_p, C.POINTER(C.c_int32)]),
+    "bt_audio2beats_plan": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.POINTER(A2BPlan)]),
+    "bt_audio2beats_enqueue": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(LogmelTables), C.c_void_p, C.c_int64, C.c_int, C.c_int,
+                                         C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int]),
     "bt_profile_begin": (None, [C.c_void_p]),
     "bt_profile_end": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     "bt_resample_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_int,

@@ -916,9 +916,11 @@ DEVI void store_rows_x(const AttnFragP& p, const QStateX& st, float l_tot, int q
         const float b0 = st.acc[8 * k + 4 + 2 * i] * scale, b1 = st.acc[8 * k + 4 + 2 * i + 1] * scale;
         split_hl4(a0, a1, b0, b1, xh[i], xl[i], yh[i], yl[i]);   // (common.h)
         amax = fmaxf(amax, fmaxf(fmaxf(fabsf(a0), fabsf(a1)), fmaxf(fabsf(b0), fabsf(b1))));
-        // (fmaxf drops NaNs: a NaN row -- acc(inf) x scale(0) -- must raise the range flag like an inf one)
+        // (fmaxf drops NaNs: a NaN row of a VALID query -- acc(inf) x scale(0) -- must raise the range flag like an inf one,
+        // ADVICE r5; lanes without a query (padding rows of the last block, queries left to the fix-up launch) hold whatever
+        // their accumulators hold and are not stored)
         const float nan_probe = (a0 + a1) + (b0 + b1);
-        amax = nan_probe != nan_probe ? __builtin_inff() : amax;
+        amax = (okq && nan_probe != nan_probe) ? __builtin_inff() : amax;
       }
       auto h0 = __builtin_amdgcn_permlane32_swap(xh[0], yh[0], false, false);
       auto h1 = __builtin_amdgcn_permlane32_swap(xh[1], yh[1], false, false);

@@ -45,9 +45,16 @@ struct Scope {
 };
 }  // namespace prof
 
+// a captured forward of bt_audio2beats_enqueue: key = everything the recorded launches depend on
+struct FwdGraph { int B, T, prec; void* ws; hipGraphExec_t exec; unsigned long stamp; };
+
 struct bt_engine {
   bt_model_desc d;
   prof::State prof;
+  std::vector<FwdGraph> graphs;   // (at most 8, least recently used goes first; dropped when an option changes)
+  unsigned long graph_clock = 0;
+  hipStream_t cap_stream = nullptr;   // private stream the forward is recorded on (the caller's may be the legacy default stream, which cannot capture)
+  bool warm[4] = {false, false, false, false};   // precision ran plainly once (lazy module loading, function attributes)
   int x3_attn_p16 = 1;   // BT_OPT_X3_ATTN_P16 (default chosen by the flip-soak rule: DESIGN.md section 3)
   int x3_gemm_fp8 = 0;   // BT_OPT_X3_GEMM_FP8
 };
@@ -354,16 +361,23 @@ int bt_engine_create(const bt_model_desc* desc, bt_engine** out) {
   *out = e;
   return BT_OK;
 }
+static void drop_graphs(bt_engine* e) {
+  for (auto& g : e->graphs) (void)hipGraphExecDestroy(g.exec);
+  e->graphs.clear();
+}
 void bt_engine_destroy(bt_engine* e) {
   if (!e) return;
   for (auto& r : e->prof.recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+  drop_graphs(e);
+  if (e->cap_stream) (void)hipStreamDestroy(e->cap_stream);
   delete e;
 }
 
 int bt_engine_set_option(bt_engine* e, int option, int value) {
   if (!e) return bt_set_error(BT_ERR_ARG, "null argument");
-  if (option == BT_OPT_X3_ATTN_P16 && value >= 0 && value <= 2) { e->x3_attn_p16 = value; return BT_OK; }
-  if (option == BT_OPT_X3_GEMM_FP8 && value >= 0 && value <= 2) { e->x3_gemm_fp8 = value; return BT_OK; }
+  // (a captured forward replays the kernels it was recorded with: an option change drops them)
+  if (option == BT_OPT_X3_ATTN_P16 && value >= 0 && value <= 2) { if (e->x3_attn_p16 != value) drop_graphs(e); e->x3_attn_p16 = value; return BT_OK; }
+  if (option == BT_OPT_X3_GEMM_FP8 && value >= 0 && value <= 2) { if (e->x3_gemm_fp8 != value) drop_graphs(e); e->x3_gemm_fp8 = value; return BT_OK; }
   return bt_set_error(BT_ERR_ARG, "unknown engine option / value");
 }
 int bt_engine_get_option(const bt_engine* e, int option, int* value) {
@@ -790,6 +804,121 @@ int bt_postprocess_host(const int32_t* beat_idx, int nb, const int32_t* down_idx
   md = (int)(std::unique(downbeats, downbeats + md) - downbeats);
   *n_beats = mb;
   *n_downbeats = md;
+  return BT_OK;
+}
+
+// ---- Audio2Beats for one track in one call -------------------------------------------------------------------------------
+int bt_audio2beats_plan(const bt_engine* e, int64_t n_in, int up, int down, int prec, bt_a2b_plan* plan) {
+  if (!e || !plan || n_in <= 0 || up <= 0 || down <= 0) return bt_set_error(BT_ERR_ARG, "bad argument to bt_audio2beats_plan");
+  if (prec != BT_PREC_F32 && prec != BT_PREC_HALF && prec != BT_PREC_F32X3) return bt_set_error(BT_ERR_ARG, "unknown precision");
+  const int64_t n22 = up == down ? n_in : (n_in * up + down - 1) / down;
+  if (n22 <= 512) return bt_set_error(BT_ERR_ARG, "signal too short: reflect padding needs more than 512 samples");
+  const int64_t n = 1 + n22 / 441;
+  const int chunk = 1500, border = 6, fresh = chunk - 2 * border;
+  if (n + chunk >= 0x7fffffffL) return bt_set_error(BT_ERR_ARG, "track too long for 32-bit frame indices");
+  memset(plan, 0, sizeof *plan);
+  plan->n22 = n22; plan->n_frames = n;
+  plan->T = n > fresh ? chunk : (int)n + 2 * border;
+  plan->B = (int)((n + fresh - 1) / fresh);
+  plan->result_words = 2 * n + 3;
+  size_t off = 0;
+  auto take = [&](size_t bytes) { size_t o = off; off += align_up(bytes, 256); return o; };
+  // what the forward's launches address comes FIRST, at offsets that depend on (B, T, precision) only: a captured forward is
+  // then valid for every track of the same chunk count on the same allocation, whatever its exact length
+  plan->forward_bytes = bt_workspace_bytes(e, plan->B, plan->T, prec);
+  plan->off_forward = take(plan->forward_bytes);
+  plan->off_chunks = take((size_t)plan->B * plan->T * 128 * 4);
+  plan->off_chunk_logits = take((size_t)2 * plan->B * plan->T * 4);
+  plan->off_wave22 = take(up == down ? 0 : (size_t)n22 * 4);
+  plan->off_spect = take((size_t)n * 128 * 4);
+  plan->off_logits = take((size_t)2 * n * 4);
+  plan->off_result = take((size_t)plan->result_words * 4);
+  plan->ws_bytes = off;
+  return BT_OK;
+}
+
+int bt_audio2beats_enqueue(bt_engine* e, void* stream, int prec, const bt_logmel_tables* t, const float* d_audio, int64_t n_in,
+                           int up, int down, const float* d_filter, int half_len, void* d_ws, size_t ws_bytes, int32_t* h_result,
+                           int use_graph) {
+  if (!e || !t || !d_audio || !d_ws || !h_result) return bt_set_error(BT_ERR_ARG, "null argument");
+  if (up != down && (!d_filter || half_len < 0)) return bt_set_error(BT_ERR_ARG, "resampling needs the polyphase filter");
+  bt_a2b_plan pl;
+  if (int rc = bt_audio2beats_plan(e, n_in, up, down, prec, &pl)) return rc;
+  if (pl.ws_bytes > ws_bytes) return bt_set_error(BT_ERR_WORKSPACE, "workspace too small (bt_audio2beats_plan)");
+  const int max_T = e->d.rope_len > 0 ? e->d.rope_len : 1536;
+  if (pl.T > max_T) return bt_set_error(BT_ERR_ARG, "chunk longer than the rotary table");
+  hipStream_t s = (hipStream_t)stream;
+  char* ws = (char*)d_ws;
+  float* wave22 = (float*)(ws + pl.off_wave22);
+  float* spect = (float*)(ws + pl.off_spect);
+  float* chunks = (float*)(ws + pl.off_chunks);
+  float* cb = (float*)(ws + pl.off_chunk_logits);
+  float* cd = cb + (size_t)pl.B * pl.T;
+  float* beat = (float*)(ws + pl.off_logits);
+  float* downb = beat + pl.n_frames;
+  int32_t* res = (int32_t*)(ws + pl.off_result);
+  void* fws = ws + pl.off_forward;
+  const int border = 6;
+  const float* a22 = d_audio;
+  if (up != down) {
+    const bt_span_t one{d_audio, (long)n_in, 0, (long)pl.n22};
+    LAUNCH(launch_resample(one, nullptr, 1, (long)pl.n22, up, down, d_filter, half_len, wave22, s), "resample");
+    a22 = wave22;
+  }
+  LogmelP lp;
+  fill_logmel(lp, t, spect);
+  lp.one = bt_span_t{a22, (long)pl.n22, 0, (long)pl.n_frames};
+  lp.tracks = nullptr; lp.n_tracks = 1; lp.max_frames = (long)pl.n_frames;
+  LAUNCH(launch_logmel(lp, s), "logmel");
+  LAUNCH(launch_split(spect, (long)pl.n_frames, nullptr, nullptr, pl.B, pl.T, chunks, s, border), "split");
+  // ---- the forward: plain launches, or the replay of a graph captured here -------------------------------------------------
+  const bool graphable = use_graph && pl.T == 1500 && pl.B <= 16 && !e->prof.on && e->warm[prec & 3];
+  FwdGraph* g = nullptr;
+  if (graphable) {
+    for (auto& c : e->graphs)
+      if (c.B == pl.B && c.T == pl.T && c.prec == prec && c.ws == d_ws) g = &c;
+    if (!g) {
+      // recorded on a private stream (thread-local capture mode: other threads' HIP calls are not affected); nothing runs
+      hipGraph_t graph = nullptr;
+      if (!e->cap_stream && hipStreamCreateWithFlags(&e->cap_stream, hipStreamNonBlocking) != hipSuccess) e->cap_stream = nullptr;
+      if (e->cap_stream && hipStreamBeginCapture(e->cap_stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+        const int rc = bt_forward_stages(e, e->cap_stream, prec, 0, 2, chunks, pl.B, pl.T, fws, pl.forward_bytes, nullptr, cb, cd);
+        const hipError_t he = hipStreamEndCapture(e->cap_stream, &graph);
+        hipGraphExec_t exec = nullptr;
+        if (rc == BT_OK && he == hipSuccess && graph && hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess) {
+          if (e->graphs.size() >= 8) {   // least recently used goes
+            size_t old = 0;
+            for (size_t i = 1; i < e->graphs.size(); ++i)
+              if (e->graphs[i].stamp < e->graphs[old].stamp) old = i;
+            (void)hipGraphExecDestroy(e->graphs[old].exec);
+            e->graphs.erase(e->graphs.begin() + old);
+          }
+          e->graphs.push_back(FwdGraph{pl.B, pl.T, prec, d_ws, exec, 0});
+          g = &e->graphs.back();
+        }
+        if (graph) (void)hipGraphDestroy(graph);
+        (void)hipGetLastError();   // (a failed capture must not poison the plain launches below)
+      }
+    }
+  }
+  if (g) {
+    g->stamp = ++e->graph_clock;
+    if (hipGraphLaunch(g->exec, s) != hipSuccess) return bt_set_error(BT_ERR_HIP, "replay of the captured forward");
+  } else {
+    if (int rc = bt_forward_stages(e, s, prec, 0, 2, chunks, pl.B, pl.T, fws, pl.forward_bytes, nullptr, cb, cd)) return rc;
+    e->warm[prec & 3] = true;
+  }
+  LAUNCH(launch_aggregate(cb, cd, nullptr, nullptr, nullptr, 1, pl.B, pl.T, border, (long)pl.n_frames, beat, downb, s), "aggregate");
+  LAUNCH(launch_peaks(beat, (long)pl.n_frames, nullptr, 2, res, res + 2 * pl.n_frames, s), "peaks");
+  // the range flag of the forward (first word of ITS workspace; zero for the other precisions) rides behind the counts
+  if (prec == BT_PREC_F32X3) {
+    if (hipMemcpyAsync(res + 2 * pl.n_frames + 2, fws, 4, hipMemcpyDeviceToDevice, s) != hipSuccess)
+      return bt_set_error(BT_ERR_HIP, "copy of the range flag");
+  } else if (hipMemsetAsync(res + 2 * pl.n_frames + 2, 0, 4, s) != hipSuccess) {
+    return bt_set_error(BT_ERR_HIP, "clearing the range flag");
+  }
+  if (hipMemcpyAsync(h_result, res, (size_t)pl.result_words * 4, hipMemcpyDeviceToHost, s) != hipSuccess)
+    return bt_set_error(BT_ERR_HIP, "device-to-host copy of the result");
   return BT_OK;
 }
 

@@ -152,8 +152,14 @@ __global__ __launch_bounds__(256) void shadow_ssq_kernel(const float* __restrict
 // chunk table row (int32 x 4): {first source frame (may be negative / before the piece), first frame of the piece,
 // end frame of the piece, unused}, all ABSOLUTE frame indices of the (concatenated) spectrogram buffer; frames of a
 // chunk outside [lo, hi) read as zeros (split_piece / zeropad, inference.py:90-135).
+// start frame of chunk b of a piece of n frames cut into B chunks of T frames (inference.py:120-125: arange(-border, n - border,
+// T - 2 border), the last one moved back to n - (T - border) when the piece is longer than one chunk's fresh span)
+__device__ __forceinline__ long piece_chunk_start(int b, int B, long n, int T, int border) {
+  return (b == B - 1 && n > T - 2 * border) ? n - (T - border) : (long)b * (T - 2 * border) - border;
+}
+
 __global__ void split_kernel(const float* __restrict__ spect, const int* __restrict__ table, const int* __restrict__ starts,
-                             long n_frames, int B, int T, float* __restrict__ chunks) {
+                             long n_frames, int B, int T, float* __restrict__ chunks, int border) {
   const long total = (long)B * T * 32;  // float4 units
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     long row = i >> 5;
@@ -161,7 +167,8 @@ __global__ void split_kernel(const float* __restrict__ spect, const int* __restr
     int b = (int)(row / T), t = (int)(row - (long)b * T);
     long src, lo = 0, hi = n_frames;
     if (table) { src = (long)table[4 * b] + t; lo = table[4 * b + 1]; hi = table[4 * b + 2]; }
-    else src = (long)starts[b] + t;
+    else if (starts) src = (long)starts[b] + t;
+    else src = piece_chunk_start(b, B, n_frames, T, border) + t;   // (one piece, starts computed here: bt_audio2beats_enqueue)
     f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
     if (src >= lo && src < hi) v = reinterpret_cast<const f32x4*>(spect + src * 128)[c4];
     reinterpret_cast<f32x4*>(chunks + row * 128)[c4] = v;
@@ -184,7 +191,7 @@ __global__ void aggregate_kernel(const float* __restrict__ cb, const float* __re
   for (long i = f_lo + (long)blockIdx.x * blockDim.x + threadIdx.x; i < f_hi; i += (long)gridDim.x * blockDim.x) {
     float vb = -1000.0f, vd = -1000.0f;
     for (int c = c_lo; c < c_hi; ++c) {  // first (earliest) chunk whose kept span covers frame i wins
-      long s = table ? table[4 * c] : starts[c];
+      long s = table ? table[4 * c] : starts ? starts[c] : piece_chunk_start(c, B, n_frames, T, border);
       if (i >= s + border && i < s + T - border) {
         vb = cb[(long)c * T + (i - s)];
         vd = cd[(long)c * T + (i - s)];
@@ -414,10 +421,10 @@ int launch_shadow_ssq(const float* x, void* xb, float* ssq, long M, int D, hipSt
   return (int)hipGetLastError();
 }
 int launch_split(const float* spect, long n_frames, const int* starts, const int* table, int B, int T, float* chunks,
-                 hipStream_t s) {
+                 hipStream_t s, int border) {
   long total = (long)B * T * 32;
   unsigned grid = (unsigned)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
-  hipLaunchKernelGGL(split_kernel, dim3(grid), dim3(256), 0, s, spect, table, starts, n_frames, B, T, chunks);
+  hipLaunchKernelGGL(split_kernel, dim3(grid), dim3(256), 0, s, spect, table, starts, n_frames, B, T, chunks, border);
   return (int)hipGetLastError();
 }
 int launch_aggregate(const float* cb, const float* cd, const int* starts, const int* table, const int* pieces, int n_pieces,

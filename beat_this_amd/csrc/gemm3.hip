@@ -232,6 +232,9 @@ void gemm3_kernel(const Gemm3P p, int n_tiles, int total_tiles, int per_xcd, int
       ok = seq < p.n_seq && t < p.L;
       row = (long)seq * p.L + t;
     }
+#ifdef BT_ABL_HID_WRAP   // development ablation (tools/build_variant.py): see the FF1 store below
+    if (EPI == G3_RESID && X3 && p.K >= 1024 && p.conv_C2 == 0) row &= BT_ABL_HID_WRAP - 1;
+#endif
     // (HL16: LDS chunks 0, 1 = the hi halves of the step's 16 k values, 2, 3 = their lo halves, 64 B further in the group)
     voffA[i] = ok ? (unsigned)(row * p.lda * EB + (HL16 ? (c >> 1) * 64 + (c & 1) * 16 : c * 16)) : OOB;
     if constexpr (EPI == G3_RESID) {  // conv: which of the three time taps exist for this row
@@ -512,7 +515,15 @@ void gemm3_kernel(const Gemm3P p, int n_tiles, int total_tiles, int per_xcd, int
         const int r = ps * 4 + r4;
         const u32x4 w = *reinterpret_cast<const u32x4*>(wst + r * 256 + (cp << 4));
         const long row = (long)row0 + 32 * b + r;
+#ifdef BT_ABL_HID_WRAP
+        // Development ablation, results are garbage by construction: the hidden activation of row r lives at row r mod
+        // BT_ABL_HID_WRAP (a power of two; 2048 rows = 16.8 MB of hl32: resident in L2 / MALL), FF2 reads it from there -- the
+        // forward then runs every MFMA, LDS-DMA and epilogue instruction of the real one but the hidden activation's HBM round
+        // trip: an UPPER BOUND on what a fused layer tail that never writes it could save.
+        if (row < p.M) *reinterpret_cast<u32x4*>(out8 + ((row & (BT_ABL_HID_WRAP - 1)) * p.ldo + nb0) * 4 + ((cp ^ (r & 15)) << 4)) = w;
+#else
         if (row < p.M) *reinterpret_cast<u32x4*>(out8 + (row * p.ldo + nb0) * 4 + ((cp ^ (r & 15)) << 4)) = w;
+#endif
       }
     }
   } else if constexpr (EPI == G3_FF1) {

@@ -208,9 +208,10 @@ int launch_shadow_ssq(const float* x, void* xb, float* ssq, long M, int D, hipSt
 // Same layout as bt_span of include/beat_this_amd.h.
 struct bt_span_t { const float* data; long n; long out_off; long n_out; };
 
-// starts (one piece, frames relative to spect) or table ([B][4] absolute chunk table, see frontend.hip)
+// starts (one piece, frames relative to spect) or table ([B][4] absolute chunk table, see frontend.hip); neither: one piece
+// whose chunk starts are computed on the device from (n_frames, B, T, border) -- launch_aggregate likewise
 int launch_split(const float* spect, long n_frames, const int* starts, const int* table, int B, int T, float* chunks,
-                 hipStream_t s);
+                 hipStream_t s, int border = 0);
 int launch_aggregate(const float* cb, const float* cd, const int* starts, const int* table, const int* pieces, int n_pieces,
                      int B, int T, int border, long n_frames, float* beat, float* downbeat, hipStream_t s);
 int launch_resample(const bt_span_t& one, const bt_span_t* tracks, int n_tracks, long max_n_out, int up, int down,

@@ -151,6 +151,8 @@ def _gather_chunks(spect: torch.Tensor, starts: np.ndarray, T: int):
 
 
 USE_GRAPHS = True   # single-file path: the forward of up to Engine.GRAPH_MAX_CHUNKS chunks is replayed as one hipGraph
+USE_ONE_CALL = True  # Audio2Beats.__call__: one track = ONE library call (bt_audio2beats_enqueue), no Python between the stages
+ONE_CALL_MAX_CHUNKS = 96   # longer tracks (> 47 minutes) take the sliced path
 
 
 def _graphed_forward(model, spect: torch.Tensor, starts: np.ndarray, T: int):
@@ -400,8 +402,76 @@ class Audio2Beats(Audio2Frames):
         self.frames2beats = Postprocessor(type="dbn" if dbn else "minimal")
 
     def __call__(self, signal, sr):
+        out = self._one_call(signal, sr) if USE_ONE_CALL else None
+        if out is not None:
+            return out
         beat_logits, downbeat_logits = super().__call__(signal, sr)
         return self.frames2beats(beat_logits, downbeat_logits)
+
+    def _one_call(self, signal, sr, exact=False):
+        """``__call__`` as ONE library call (bt_audio2beats_enqueue, include/beat_this_amd.h): the mono mix and the upload of the
+        waveform happen here like in ``signal2spect`` (inference.py:269-277), then resampler, log-mel, chunk gather, the forward
+        (a hipGraph the library captures itself), aggregation, peak picking and the device-to-host copy of the peak frames are
+        enqueued by the library in one go -- round 5's path came back to Python five times per file, and the GPU waited each time
+        (profiles/r05_latency_trace.txt).  Same kernels in the same order: bit-identical to the stage-by-stage path (tested).
+        -> (beats, downbeats), or None where the call does not apply (DBN post-processing, a model that is not a plain BeatThis,
+        hooks, a replaced ``self.spect``, very long tracks) and the caller takes the ordinary path."""
+        import ctypes as C
+        from math import gcd
+
+        model = self.model
+        if (self.frames2beats.type != "minimal" or not isinstance(model, BeatThis) or _model_hooked(model)
+                or type(self.spect) is not LogMelSpect or model.device != self.device):
+            return None
+        signal = np.asarray(signal) if not isinstance(signal, torch.Tensor) else signal
+        if signal.ndim == 2:
+            signal = signal.mean(1)
+        elif signal.ndim != 1:
+            raise ValueError(f"Expected 1D or 2D signal, got shape {signal.shape}")
+        dev = self.device
+        sr = int(sr)
+        g = gcd(sr, 22050)
+        up, down = 22050 // g, sr // g
+        eng = model.engine()
+        if eng._h_prof_on() or eng._deferred is not None:
+            return None
+        with torch.inference_mode(), torch.autocast(enabled=self.float16, device_type=dev.type):
+            prec = _lib.PREC_F32 if exact else model._precision()
+        lib = _lib.lib()
+        plan = _lib.A2BPlan()
+        n_in = int(signal.shape[0])
+        if n_in == 0:
+            return None
+        _lib.check(lib.bt_audio2beats_plan(eng._h, n_in, up, down, prec, C.byref(plan)))
+        if plan.B > ONE_CALL_MAX_CHUNKS:
+            return None
+        eng.ensure_positions(plan.T)
+        with torch.cuda.device(dev):
+            # (from_numpy + one H2D copy: torch.tensor(array, device=...) copies the 5 MB of a 30 s file on the host first)
+            wave = torch.from_numpy(np.ascontiguousarray(signal, dtype=np.float32)).to(dev) if not isinstance(signal, torch.Tensor) \
+                else signal.to(dev, torch.float32).contiguous()
+            if self.spect.device != dev:
+                self.spect.to(dev)
+            h, half = _resample_filter(up, down, dev) if up != down else (None, 0)
+            ws = eng._a2b_workspace(plan.ws_bytes)
+            host = self.frames2beats._pinned(plan.result_words)
+            _lib.check(lib.bt_audio2beats_enqueue(eng._h, _lib.stream_ptr(dev), prec, C.byref(self.spect._get_tables()),
+                                                  wave.data_ptr(), n_in, up, down, _lib.ptr(h), half, ws.data_ptr(), ws.numel(),
+                                                  host.data_ptr(), int(USE_GRAPHS and plan.T == Engine.GRAPH_T)))
+            torch.cuda.current_stream(dev).synchronize()
+        res = host.numpy()
+        n = int(plan.n_frames)
+        nb, nd, flag = int(res[2 * n]), int(res[2 * n + 1]), int(res[2 * n + 2])
+        out = None
+        if flag == 0:
+            from .postprocessor import _host_post
+
+            out = _host_post(res[:nb], res[n: n + nd], self.frames2beats.fps)
+        self.frames2beats.__dict__.setdefault("_pin_pool", []).append(host)
+        if flag != 0:   # BT_PREC_F32X3: an operand left the fp16 range of a hi part -- the exact fp32 path repeats the call
+            eng.last_fallbacks += 1
+            return self._one_call(signal, sr, exact=True)
+        return out
 
     def many(self, signals, sr):
         """Extension: [(beats, downbeats)] (seconds, float64 arrays as ``__call__`` returns them) for a list of waveforms

@@ -563,6 +563,17 @@ class Engine:
             ws = pool[stream] = torch.empty(need, dtype=torch.uint8, device=self.device)
         return ws
 
+    def _a2b_workspace(self, need: int) -> torch.Tensor:
+        """Device scratch of Audio2Beats' one-call path (bt_audio2beats_enqueue), one per stream, grown in steps: the forward
+        graph the library captures is keyed by this allocation, so it stays put from call to call (a longer file than any
+        before re-allocates -- and re-captures -- once)."""
+        stream = torch.cuda.current_stream(self.device)
+        pool = self.__dict__.setdefault("_a2b_ws", {})
+        ws = pool.get(stream)
+        if ws is None or ws.numel() < need:
+            ws = pool[stream] = torch.empty(int(need * 1.25) if ws is not None else need, dtype=torch.uint8, device=self.device)
+        return ws
+
     def _h_prof_on(self) -> bool:
         return bool(getattr(self, "profiling", False))
 

@@ -249,7 +249,12 @@ def main():
     a2b.model = model.to(dev)
     a2b.model.engine().set_options({"x3_attn_p16": args.x3_p16})
     half_name = _lib.half_dtype_name()
-    DTYPE = {"half": half_name, "f32": "f32 (v_mfma_f32_32x32x2_f32)",
+    # BASELINE configs 2 / 4 say "bf16": the reference's float16=True on a GPU IS fp16 autocast (inference.py:245-246, cli.py:82),
+    # which is what this path runs; bfloat16 operands are a build switch of the same kernels (tools/build_variant.py -DBT_HALF_BF16,
+    # report of the round: profiles/r06_bf16_variant.txt), 8x coarser at the same MFMA rate
+    half_desc = "fp16 operands, f32 accumulate (= the reference's GPU autocast); bf16 build of the same kernels: -DBT_HALF_BF16" \
+        if half_name == "f16" else "bf16 operands, f32 accumulate (-DBT_HALF_BF16 build)"
+    DTYPE = {"half": half_desc, "f32": "f32 (v_mfma_f32_32x32x2_f32)",
              "f32x3": "f32 activations; every product: 3 x v_mfma_f32_32x32x16_f16 on hi + lo operands (BT_PREC_F32X3)"}
 
     def set_prec(prec):
@@ -902,7 +907,7 @@ def main():
             "metric": "audio-seconds processed/sec", "value": round(value, 1), "unit": "audio-seconds/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": {"half": half_name, "f32": "f32", "f32x3": "f32 activations, f16x3 products (3 x f16 MFMA on hi+lo operand halves, f32 accumulate)" + {0: "", 1: "; main-layer attention P.V: 2 x, probabilities as fp16 hi parts", 2: "; attention P.V: 2 x, probabilities as fp16 hi parts (opt-in level 2)"}[args.x3_p16]}[args.prec],
+            "dtype": {"half": half_desc, "f32": "f32", "f32x3": "f32 activations, f16x3 products (3 x f16 MFMA on hi+lo operand halves, f32 accumulate)" + {0: "", 1: "; main-layer attention P.V: 2 x, probabilities as fp16 hi parts", 2: "; attention P.V: 2 x, probabilities as fp16 hi parts (opt-in level 2)"}[args.x3_p16]}[args.prec],
             "data": "synthetic",
             "config": {"workload": workload, "tracks_per_gpu": args.tracks if args.workload == "tracks" else None,
                        "chunks_per_gpu": chunks_per_step, "global_chunks": world * chunks_per_step,

@@ -290,6 +290,30 @@ int bt_peaks_host(const float* logits, int64_t n, int32_t* idx, int32_t* count);
 int bt_postprocess_host(const int32_t* beat_idx, int n_beat_idx, const int32_t* down_idx, int n_down_idx,
                         double fps, double* beats, int32_t* n_beats, double* downbeats, int32_t* n_downbeats);
 
+/* Audio2Beats.__call__ for ONE track in ONE call (inference.py:269-281,301-303 without the audio decoder and the host
+ * post-processing): resample (when up != down) -> log-mel -> split_piece -> BeatThis.forward -> keep_first aggregation -> peak
+ * mask -> ONE device-to-host copy of the result, all enqueued on `stream` by this function -- the host language is not in the
+ * loop between the stages (single-file latency, BASELINE config 1; round 5: five places where the GPU waited for Python).
+ * bt_audio2beats_plan sizes the call: a track of n_in samples at a rate with 22050 / rate = up / down in lowest terms gives
+ * n22 samples at 22.05 kHz, n_frames = 1 + n22 / 441 spectrogram rows and B chunks of T frames (T = 1500, or n_frames + 12 for a
+ * piece of <= 1488 frames); ws_bytes of device scratch; result_words int32 of PINNED host memory:
+ *     h_result = [beat peak frames: n_frames slots | downbeat peak frames: n_frames slots | n_beat, n_down | range flag]
+ * (ascending frame indices as bt_peaks writes them, then the two counts, then the BT_PREC_F32X3 range flag of the forward: non-zero
+ * = repeat the call with BT_PREC_F32), valid once `stream` has drained.  d_audio: mono fp32 on the device (the caller's mono mix
+ * and upload).  use_graph != 0: the forward's launches are replayed as a hipGraph the engine captures itself on first use and keeps
+ * per (B, T, precision, d_ws) -- d_ws must then be the same allocation from call to call (T == 1500 and B <= 16 only; other shapes
+ * launch plainly).  Same kernels in the same order as the separate entry points: bit-identical results.  Framewise logits of the
+ * call stay readable in d_ws at plan.off_logits ([beat n_frames | downbeat n_frames] fp32) until the next call on d_ws. */
+typedef struct {
+  int64_t n22, n_frames, result_words;
+  int32_t B, T;
+  size_t ws_bytes, off_wave22, off_spect, off_chunks, off_chunk_logits, off_logits, off_result, off_forward, forward_bytes;
+} bt_a2b_plan;
+int bt_audio2beats_plan(const bt_engine* e, int64_t n_in, int up, int down, int prec, bt_a2b_plan* plan);
+int bt_audio2beats_enqueue(bt_engine* e, void* stream, int prec, const bt_logmel_tables* tables, const float* d_audio, int64_t n_in,
+                           int up, int down, const float* d_filter, int half_len, void* d_ws, size_t ws_bytes, int32_t* h_result,
+                           int use_graph);
+
 /* Per-launch timing of bt_forward with HIP events recorded on the caller's stream (bench.py's
  * roofline leg); per engine handle.  bt_profile_begin(e) arms it; every bt_forward(e, ...) until bt_profile_end(e, ...)
  * records one event pair per kernel launch; bt_profile_end() synchronises on the events and returns summed

@@ -762,3 +762,85 @@ def test_single_file_path_on_a_captured_forward_matches_plain_launches(mode):
         inf.USE_GRAPHS = True
     for (b1, d1), (b2, d2), (b0, d0) in zip(got, again, plain):
         assert torch.equal(b1, b0) and torch.equal(d1, d0) and torch.equal(b2, b0) and torch.equal(d2, d0)
+
+
+@pytest.mark.parametrize("mode", [False, True, "exact"])
+def test_audio2beats_one_call_is_bit_identical_to_the_stage_by_stage_path(mode):
+    """Audio2Beats.__call__ as ONE library call (bt_audio2beats_enqueue: resample -> log-mel -> split -> forward, replayed as a
+    hipGraph the library captures itself -> aggregate -> peaks -> one D2H copy) against the stage-by-stage path of rounds 1 - 5
+    (one library call per stage from Python): identical beat / downbeat times AND identical framewise logits (read back from the
+    call's workspace), for short clips (one odd-length chunk), pieces around the 1488 / 1489-frame edge, multi-chunk pieces,
+    44.1 kHz / 48 kHz / stereo float64 input, repeated calls (graph replays) and interleaved lengths (same chunk count, other
+    length: the captured forward is reused; other chunk count: a new capture)."""
+    import ctypes as C
+
+    from beat_this_amd import _lib as Lb
+    from beat_this_amd import inference as inf
+    from beat_this_amd import weights as W
+    from beat_this_amd.inference import Audio2Beats
+
+    a2b = Audio2Beats(checkpoint_path=None, device=dev(), float16=mode, dbn=False)
+    a2b.model = _model("small0", 4, "lively")
+    cases = [(7.0, 22050, 1), (29.75, 22050, 1), (29.77, 22050, 1), (40.0, 22050, 1), (41.3, 22050, 1), (65.3, 44100, 1),
+             (12.0, 48000, 2), (40.0, 22050, 1), (100.0, 44100, 1), (7.0, 22050, 1)]
+    n_fast = 0
+    for secs, sr, ch in cases:
+        sig = W.synthetic_audio(secs, seed=int(secs * 10) + sr // 1000, sr=sr)
+        if ch == 2:
+            sig = np.stack([sig, 0.5 * sig[::-1]], 1).astype(np.float64)
+        inf.USE_ONE_CALL = False
+        try:
+            want_b, want_d = a2b(sig, sr)
+            lb, ld = a2b.spect2frames(a2b.signal2spect(sig, sr))
+        finally:
+            inf.USE_ONE_CALL = True
+        fast = a2b._one_call(sig, sr)
+        assert fast is not None
+        n_fast += 1
+        assert np.array_equal(fast[0], want_b) and np.array_equal(fast[1], want_d), (secs, sr, ch)
+        got_b, got_d = a2b(sig, sr)            # (the public call takes the same route)
+        assert np.array_equal(got_b, want_b) and np.array_equal(got_d, want_d)
+        # framewise logits of the call, from its workspace
+        eng = a2b.model.engine()
+        with torch.autocast("cuda", enabled=a2b.float16):
+            prec = a2b.model._precision()
+        plan = Lb.A2BPlan()
+        from math import gcd
+        g = gcd(sr, 22050)
+        Lb.check(Lb.lib().bt_audio2beats_plan(eng._h, sig.shape[0], 22050 // g, sr // g, prec, C.byref(plan)))
+        ws = eng._a2b_workspace(plan.ws_bytes)
+        logits = ws[plan.off_logits: plan.off_logits + 8 * plan.n_frames].view(torch.float32)
+        assert plan.n_frames == lb.shape[0]
+        assert torch.equal(logits[: plan.n_frames], lb) and torch.equal(logits[plan.n_frames:], ld), (secs, sr, ch)
+    report("a2b_one_call", mode=str(mode), cases=n_fast)
+
+
+def test_audio2beats_one_call_repeats_an_overflowing_track_on_the_exact_path():
+    """The range flag of a BT_PREC_F32X3 forward travels with the peak frames; a call whose flag is up is repeated on the exact
+    fp32 path (same result as float16="exact"), and the fallback is counted."""
+    from beat_this_amd import inference as inf
+    from beat_this_amd import weights as W
+    from beat_this_amd.inference import Audio2Beats
+    from beat_this_amd.model import BeatThis
+
+    hp = W.resolve_hparams("small0")
+    sd = W.random_state_dict(hp, seed=6, style="lively")
+    sd["frontend.linear.weight"] = sd["frontend.linear.weight"] * 3.0e5
+    sd["frontend.linear.bias"] = sd["frontend.linear.bias"] * 3.0e5
+    m = BeatThis(**{k: hp[k] for k in ("spect_dim", "transformer_dim", "ff_mult", "n_layers", "head_dim", "stem_dim")})
+    m.load_state_dict(sd)
+    a2b = Audio2Beats(checkpoint_path=None, device=dev(), float16=False)
+    a2b.model = m.to(dev())
+    sig = W.synthetic_audio(40.0, seed=90)
+    before = m.engine().last_fallbacks
+    got = a2b(sig, 22050)
+    assert m.engine().last_fallbacks == before + 1
+    ex = Audio2Beats(checkpoint_path=None, device=dev(), float16="exact")
+    ex.model = m
+    inf.USE_ONE_CALL = False
+    try:
+        want = ex(sig, 22050)
+    finally:
+        inf.USE_ONE_CALL = True
+        m.fp32_split_gemms = True
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])

@@ -200,6 +200,15 @@ def cmd_sim(args):
         bh, bl = split(b)
         if s == "x3sim":
             return ah @ bh + (ah @ bl + al @ bh)
+        # BASELINE config 5 as written, report-only: the main layers' QKV / out-projection / FF1 / FF2 with BOTH
+        # operands as OCP MX e4m3 (blocks of 32 along k share an E8M0 scale: what v_mfma_scale_f32_32x32x64_f8f6f4 multiplies at
+        # twice the fp16 rate), everything else -- frontend, frontend.linear, attention scores and P.V -- on fp16 operands like
+        # the half path; fp32 accumulation, residual stream, norms and GELU everywhere.  "halfsim" = the half path itself in the
+        # same simulation (all sites fp16 operands): the yardstick config 5 has to be read against.
+        if s in ("mxfp8", "halfsim"):
+            if s == "mxfp8" and site in ("m_qkv", "m_out", "m_ff1", "m_ff2"):
+                return N.q_mx(a, "e4m3", -1) @ N.q_mx(b, "e4m3", -2)
+            return ah @ bh
         if s == "p16":
             return ah @ bh + ah @ bl if site.endswith("pv") else ah @ bh + (ah @ bl + al @ bh)
         if s == "p16m":      # main layers only
@@ -223,7 +232,7 @@ def cmd_sim(args):
         q, k = O.rope(q, fr), O.rope(k, fr)
         s = mm_site(q, k.transpose(-1, -2), tag + "qk") * (d ** -0.5)
         p = torch.exp(s - s.amax(-1, keepdim=True))
-        hi_only = SCHEME["name"] in ("p16", "p16vhi") or (SCHEME["name"] == "p16m" and tag == "m_")
+        hi_only = SCHEME["name"] in ("p16", "p16vhi", "mxfp8", "halfsim") or (SCHEME["name"] == "p16m" and tag == "m_")
         den = p.to(torch.float16).float().sum(-1, keepdim=True) if hi_only else p.sum(-1, keepdim=True)
         out = mm_site(p, v, tag + "pv") / den
         gates = mm_site(xn, sd[pfx + "to_gates.weight"].T, tag + "qkv") + sd[pfx + "to_gates.bias"]

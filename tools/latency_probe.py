@@ -44,6 +44,15 @@ for _ in range(20):
     gpu.append(a.elapsed_time(b) * 1e-3)
     host.append((t1 - t0, t2 - t1, t3 - t2))
 med = lambda x: sorted(x)[len(x) // 2]  # noqa: E731
+# the public call (round 6: ONE library call per track, bt_audio2beats_enqueue) next to the stage-by-stage route timed above
+one = []
+for _ in range(25):
+    t0 = time.perf_counter()
+    out1 = a2b(sig, 44100)
+    one.append(time.perf_counter() - t0)
+one = one[5:]
+assert np.array_equal(out1[0], out[0]) and np.array_equal(out1[1], out[1])
+print(f"{prec} {secs:.0f} s: Audio2Beats.__call__ (one library call) wall {med(one) * 1e3:.3f} ms (min {min(one) * 1e3:.3f}); stage by stage:")
 print(f"{prec} {secs:.0f} s: wall {med(wall) * 1e3:.3f} ms (min {min(wall) * 1e3:.3f}), stream time {med(gpu) * 1e3:.3f} ms; "
       f"host: signal2spect {med([h[0] for h in host]) * 1e3:.3f}, spect2frames {med([h[1] for h in host]) * 1e3:.3f}, "
       f"frames2beats {med([h[2] for h in host]) * 1e3:.3f} ms; {len(out[0])} beats")

@@ -59,7 +59,8 @@ def write(name, lines):
     print(f"-> profiles/{name}\n")
 
 
-for tag in ("head", "head1s", "fwd", "fwd_x3", "head_x3", "head_x3_2s"):
+CMD["fwd_x3_hidwrap"] = CMD["fwd_x3"] + "   [ABLATION build -DBT_ABL_HID_WRAP=2048: FF hidden activation kept in L2 / MALL, results garbage]"
+for tag in ("head", "head1s", "fwd", "fwd_x3", "head_x3", "head_x3_2s", "fwd_x3_hidwrap"):
     tr = read_trace("trace_" + tag)
     if not tr:
         continue
@@ -104,6 +105,7 @@ CATS = {"attn_flash": ("attn_frag_kernel", "attn_frag_x3_kernel", "attn_frag_x3q
 for tag, wl, jname, meta in (("", "BeatThis.forward, final0, 16 chunks, half operands", "pmc_traffic.json", {"model": "final0", "prec": "half", "chunks": 16}),
                              ("_x3", "BeatThis.forward, final0, 16 chunks, BT_PREC_F32X3", "pmc_traffic_f32x3.json", {"model": "final0", "prec": "f32x3", "chunks": 16}),
                              ("_cfg3", "BASELINE config 3: BeatThis.forward, small0, exact fp32, 128 chunks", "pmc_traffic_cfg3.json", {"model": "small0", "prec": "f32", "chunks": 128}),
+                             ("_x3_hidwrap", "ABLATION build -DBT_ABL_HID_WRAP=2048 (FF hidden activation kept in L2 / MALL; results garbage): BeatThis.forward, final0, 16 chunks, BT_PREC_F32X3", None, None),
                              ("_head", "headline (6 x 300 s tracks through Audio2Beats, default precision)", None, None)):
     fetch, wr = read_pmc("pmc_fetch" + tag), read_pmc("pmc_write" + tag)
     if not fetch:
