@@ -17,7 +17,7 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(PKG_DIR, "libbeat_this_amd.so")
 if os.environ.get("BT_DEV") == "1" and os.environ.get("BT_LIB_PATH"):  # development only (tools/ab.sh: A/B of two builds)
     LIB_PATH = os.environ["BT_LIB_PATH"]
-SOURCES = ["gemm.hip", "gemm2.hip", "gemm3.hip", "attn.hip", "attn2.hip", "fused.hip", "fused2.hip", "qkv_front.hip", "frontend.hip", "logmel.hip",
+SOURCES = ["gemm.hip", "gemm2.hip", "gemm3.hip", "gemm_mx8.hip", "attn.hip", "attn2.hip", "fused.hip", "fused2.hip", "qkv_front.hip", "frontend.hip", "logmel.hip",
            "tail.hip", "engine.hip"]
 HEADERS = ["common.h", "chain.h", "kernels.h", "attn_x3_loop.inc", os.path.join("..", "..", "include", "beat_this_amd.h")]
 
@@ -148,6 +148,7 @@ EXPORTS = {
     "bt_gemm": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(GemmArgs)]),
     "bt_attention": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(AttnArgs)]),
     "bt_gemm3": (C.c_int, [C.c_void_p, C.POINTER(Gemm3Args)]),
+    "bt_gemm_mx8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int64]),
     "bt_attn_frag_blocks": (C.c_int, [C.c_int]),
     "bt_attention_frag": (C.c_int, [C.c_void_p, C.POINTER(AttnFragArgs)]),
     "bt_qkv_front": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(PairWeights), C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,

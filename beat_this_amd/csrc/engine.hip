@@ -1030,6 +1030,15 @@ int bt_gemm3(void* stream, const bt_gemm3_args* a) {
   return BT_OK;
 }
 
+int bt_gemm_mx8(void* stream, const void* d_A, const void* d_SA, const void* d_W, const void* d_SW, float* d_out, int M, int N, int K,
+                int64_t ldo) {
+  GemmMx8P g;
+  g.A = d_A; g.SA = d_SA; g.W = d_W; g.SW = d_SW; g.out = d_out; g.ldo = (long)ldo; g.M = M; g.N = N; g.K = K;
+  if (!d_A || !d_SA || !d_W || !d_SW || !d_out || !gemm_mx8_supported(g)) return bt_set_error(BT_ERR_ARG, "bad argument to bt_gemm_mx8");
+  LAUNCH(launch_gemm_mx8(g, (hipStream_t)stream), "MX e4m3 gemm");
+  return BT_OK;
+}
+
 int bt_attn_frag_blocks(int L) { return L > 0 ? attn_frag_blocks(L) : 0; }
 
 int bt_attention_frag(void* stream, const bt_attn_frag_args* a) {

@@ -74,6 +74,20 @@ typedef G3CfgB CfgB;
 
 constexpr unsigned OOB = 0x80000000u;         // voffset of a lane that must read zeros (beyond num_records)
 
+// The big streaming outputs (FF1's hidden activation, the q / k / v fragment blocks of the hi + lo QKV projection) leave with
+// the non-temporal hint (global_store ... nt): they are read by the NEXT launch, and written plainly they displace the weight
+// matrix -- 2 - 4 MB of hl32, the size of an XCD's L2 -- that every tile of this launch re-reads.  Round 6, same-box A/B, three
+// alternations (profiles/r06_ab_ntstore.txt): FF1 4.37 -> 4.20 ms per 66-chunk step (-3.8 %), QKV -0.5 %, FF2 -0.6 %, step
+// 29.61 -> 29.47 ms (-0.5 %), joules -0.45 %.  -DBT_NT_STORE=0 builds the plain stores.
+#ifndef BT_NT_STORE
+#define BT_NT_STORE 1
+#endif
+#if BT_NT_STORE
+#define ST_STREAM(ptr, val) __builtin_nontemporal_store((val), (ptr))
+#else
+#define ST_STREAM(ptr, val) (*(ptr) = (val))
+#endif
+
 typedef __amdgpu_buffer_rsrc_t rsrc_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
@@ -522,7 +536,7 @@ void gemm3_kernel(const Gemm3P p, int n_tiles, int total_tiles, int per_xcd, int
         // trip: an UPPER BOUND on what a fused layer tail that never writes it could save.
         if (row < p.M) *reinterpret_cast<u32x4*>(out8 + ((row & (BT_ABL_HID_WRAP - 1)) * p.ldo + nb0) * 4 + ((cp ^ (r & 15)) << 4)) = w;
 #else
-        if (row < p.M) *reinterpret_cast<u32x4*>(out8 + (row * p.ldo + nb0) * 4 + ((cp ^ (r & 15)) << 4)) = w;
+        if (row < p.M) ST_STREAM(reinterpret_cast<u32x4*>(out8 + (row * p.ldo + nb0) * 4 + ((cp ^ (r & 15)) << 4)), w);
 #endif
       }
     }
@@ -669,8 +683,8 @@ void gemm3_kernel(const Gemm3P p, int n_tiles, int total_tiles, int per_xcd, int
               unsigned wh[2], wl[2];
               split2(r0, r1, wh[0], wl[0], amax);
               split2(r2, r3, wh[1], wl[1], amax);
-              *reinterpret_cast<u32x2*>(blk + (q * 32 + lr) * 8 + 4 * g) = u32x2{wh[0], wh[1]};
-              *reinterpret_cast<u32x2*>(blk + 1024 + (q * 32 + lr) * 8 + 4 * g) = u32x2{wl[0], wl[1]};
+              ST_STREAM(reinterpret_cast<u32x2*>(blk + (q * 32 + lr) * 8 + 4 * g), (u32x2{wh[0], wh[1]}));
+              ST_STREAM(reinterpret_cast<u32x2*>(blk + 1024 + (q * 32 + lr) * 8 + 4 * g), (u32x2{wl[0], wl[1]}));
             } else {
               *reinterpret_cast<u32x2*>(blk + (q * 32 + lr) * 8 + 4 * g) = u32x2{pk2(r0, r1), pk2(r2, r3)};
             }
@@ -698,8 +712,8 @@ void gemm3_kernel(const Gemm3P p, int n_tiles, int total_tiles, int per_xcd, int
               if constexpr (X3) split2(v0, v1, w[i], wl[i], amax);
               else w[i] = pk2(v0, v1);
             }
-            *reinterpret_cast<u32x4*>(blk + (s * 64 + lane) * 8) = u32x4{w[0], w[1], w[2], w[3]};
-            if constexpr (X3) *reinterpret_cast<u32x4*>(blk + 1024 + (s * 64 + lane) * 8) = u32x4{wl[0], wl[1], wl[2], wl[3]};
+            ST_STREAM(reinterpret_cast<u32x4*>(blk + (s * 64 + lane) * 8), (u32x4{w[0], w[1], w[2], w[3]}));
+            if constexpr (X3) ST_STREAM(reinterpret_cast<u32x4*>(blk + 1024 + (s * 64 + lane) * 8), (u32x4{wl[0], wl[1], wl[2], wl[3]}));
           }
         }
       }

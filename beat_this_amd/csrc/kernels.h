@@ -86,6 +86,16 @@ enum { G3_X3_F8 = 0x100, G3_X3_OUT_F8 = 0x200 };
 bool gemm3_supported(const Gemm3P& p);
 int launch_gemm3(const Gemm3P& p, hipStream_t s);
 
+// ---- MX e4m3 GEMM (gemm_mx8.hip): BASELINE config 5 at operator level, report-only ------------------------------------------
+struct GemmMx8P {
+  const void* A; const void* SA;   // e4m3 bytes [M][K], E8M0 block scales [M][K / 32]
+  const void* W; const void* SW;   // e4m3 bytes [N padded to 128][K], scales [N padded to 128][K / 32]
+  float* out; long ldo;            // fp32 [M][ldo]
+  int M, N, K;                     // K = 512 | 1024 | 2048
+};
+bool gemm_mx8_supported(const GemmMx8P& p);
+int launch_gemm_mx8(const GemmMx8P& p, hipStream_t s);
+
 // ---- attention ---------------------------------------------------------------------
 struct AttnP {
   const void* qkv;    // [n_seq * L rows, ld] compute dtype; q | k | v column blocks of width inner

@@ -369,6 +369,15 @@ typedef struct {
   int32_t x3, out_f32; int32_t* status;
   int32_t* scratch;
 } bt_attn_frag_args;
+/* BASELINE.json config 5 ("final0 fp8 MFMA weights ... CDNA4 fp8 attention/FFN path") at OPERATOR level, report-only: the GEMM of a
+ * main layer's to_qkv / to_out / FeedForward linears (roformer.py:38-61,99-132) with both operands in the OCP MX e4m3 format --
+ * d_A [M][K] and d_W [N padded to 128][K] e4m3 bytes, d_SA [M][K / 32] and d_SW [N padded to 128][K / 32] E8M0 scale bytes (value
+ * = 2^(byte - 127) x element), K = 512 | 1024 | 2048, N % 64 == 0 -- on v_mfma_scale_f32_32x32x64_f8f6f4, fp32 accumulation,
+ * d_out fp32 [M][ldo].  No forward calls it: it is measured beside the fp16 GEMM (tools/mx8_probe.py) and its arithmetic is
+ * priced on the oracle (tools/flip_soak.py sim --schemes mxfp8) -- DESIGN.md, config 5. */
+int bt_gemm_mx8(void* stream, const void* d_A, const void* d_SA, const void* d_W, const void* d_SW, float* d_out, int M, int N,
+                int K, int64_t ldo);
+
 /* half GEMM of the main layers (csrc/gemm3.hip), single-operator entry for the parity tests.
  * epi 0: out[M,ldo] (half) = gelu(rms(A) W^T + bias);  epi 1: x[M,ldx] (fp32) += A W^T + bias, half shadow xb,
  * partial row sums of squares ssq_out[N/64][M];  epi 2: q|k|v|gates = rms(A) W^T with RoPE / sigmoid, written
