@@ -657,6 +657,31 @@ def main():
                         "parity": "tests/test_gpu_scale.py::test_cfg5_final0_fp8_cross_terms_vs_oracle (logits within 3e-4 of the fp32 "
                                   "oracle, same beats); flip rates over 48 tracks x 3 weight styles: profiles/r05_flip_frontier.txt "
                                   "(x3p16f8ff / x3p16f8)"}
+            # ... and config 5 AS WRITTEN (MX e4m3 operands), report-only: the GEMM itself measured here at the 64-chunk batch's shape next
+            # to the fp16 GEMM (tools/mx8_probe.py), the arithmetic's price from the committed simulation on the oracle
+            if cfg5 is not None:
+                try:
+                    from tools.mx8_probe import measure as mx8_measure
+
+                    mx = mx8_measure(chunks=64, seconds=0.15, dev=dev, energy=False, with_hl32=False)
+                    t16_, t8_ = sum(r["fp16_us"] for r in mx), sum(r["mx8_us"] for r in mx)
+                    t_half = t64 if args.prec == "half" else t64o
+                    gemm_ms = 6 * t16_ * 1e-3
+                    cfg5["as_written_mx_e4m3_operands"] = {
+                        "status": "report-only, no forward built on it: closed with numbers (profiles/r06_cfg5_mx8.txt)",
+                        "gemm_us_one_main_layer_fp16": round(t16_, 1), "gemm_us_one_main_layer_mx_e4m3": round(t8_, 1),
+                        "gemm_speedup_upper_bound": round(t16_ / t8_, 3),
+                        "projected_forward_speedup_over_fp16_path": round(t_half * 1e3 / max(t_half * 1e3 - gemm_ms * (1 - t8_ / t16_), 1e-6), 3),
+                        "keep_bar": 1.25,
+                        "simulated_max_abs_logit_vs_fp32_oracle": {"lively": 0.465, "outlier": 0.412, "init": 0.093},
+                        "simulated_flips_per_1000": {"lively": 341.3, "outlier": 227.9, "init": 1310.4},
+                        "fp16_path_same_simulation": {"max_abs_logit": {"lively": 0.006, "outlier": 0.0088, "init": 0.0011},
+                                                      "flips_per_1000": {"lively": 5.9, "outlier": 5.8, "init": 30.6}},
+                        "note": "GEMM speedup = bt_gemm_mx8 (fp32 results, no quantising epilogue) against bt_gemm3 fp16 with a residual-type "
+                                "epilogue, the four GEMM shapes of a main layer at 96000 rows, measured in this run; projection = only those "
+                                "GEMMs get faster; error / flips: tools/flip_soak.py sim, 8 tracks x 3 styles (committed table)"}
+                except Exception as e:  # noqa: BLE001
+                    cfg5["as_written_mx_e4m3_operands"] = {"status": f"not measured in this run ({type(e).__name__}: {e})"}
             configs = {
                 "cfg2": "= forward_only",
                 "cfg3": cfg3,
