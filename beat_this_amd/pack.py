@@ -569,9 +569,20 @@ class Engine:
         before re-allocates -- and re-captures -- once)."""
         stream = torch.cuda.current_stream(self.device)
         pool = self.__dict__.setdefault("_a2b_ws", {})
-        ws = pool.get(stream)
+        ws, small = pool.get(stream, (None, 0))
+        if ws is not None and ws.numel() > 4 * need:
+            # far larger than this call needs (one very long file among short ones: ~80 MB per chunk): kept for a while, given
+            # back after SHRINK_AFTER consecutive small requests -- the same policy as the forward's workspaces
+            small += 1
+            if small >= self.SHRINK_AFTER:
+                ws = None
+        else:
+            small = 0
         if ws is None or ws.numel() < need:
-            ws = pool[stream] = torch.empty(int(need * 1.25) if ws is not None else need, dtype=torch.uint8, device=self.device)
+            ws, small = torch.empty(int(need * 1.25) if ws is not None else need, dtype=torch.uint8, device=self.device), 0
+        pool[stream] = (ws, small)
+        while len(pool) > self.MAX_WORKSPACES:
+            pool.pop(next(iter(pool)))
         return ws
 
     def _h_prof_on(self) -> bool:

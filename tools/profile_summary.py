@@ -1,9 +1,9 @@
 #!/usr/bin/env python
-"""Summarise a profile collection (tools/profile_r05.sh -> gpurun_out/prof_r05) into profiles/r03_*: per-kernel trace
+"""Summarise a profile collection (tools/profile_r06.sh -> gpurun_out/prof_r06) into profiles/rNN_*: per-kernel trace
 statistics, MFMA-busy / wave-cycle counters with the derived utilisation and effective shader clock, HBM traffic per
 kernel (FETCH_SIZE x 2 on gfx950 as MI355X_MICROARCH.md prescribes, WRITE_SIZE as reported) and the rocm-smi power /
 clock samples; plus the small json files bench.py reads for `roofline.traffic` and config 3's counter GB/s.
-    python tools/profile_summary.py [gpurun_out/prof_r05] [round tag, default r05]"""
+    python tools/profile_summary.py [gpurun_out/prof_r06] [round tag, default r06]"""
 import collections
 import csv
 import glob
@@ -13,8 +13,8 @@ import re
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "prof_r05")
-RND = sys.argv[2] if len(sys.argv) > 2 else "r05"
+src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "prof_r06")
+RND = sys.argv[2] if len(sys.argv) > 2 else "r06"
 out_dir = os.path.join(ROOT, "profiles")
 B = "python bench.py --no-cpu-baseline --no-extras --no-dist --min-seconds 0"
 CMD = {"head": f"{B} --steps 5 --warmup 1 --prec half", "head1s": f"{B} --steps 5 --warmup 1 --prec half --streams 1   (the launch "

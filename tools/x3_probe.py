@@ -101,7 +101,7 @@ def gemm(M, K, N, epi, label, heads=0, n_seq=0, Lq=0, force=1, nsplit=0):
 T = 1500
 if len(sys.argv) > 2 and sys.argv[2].startswith("loop"):
     # python tools/x3_probe.py 16 loop:5 [seconds] -- one attention variant back to back for a few seconds (power / clock sampling
-    # from outside: tools/power_probe.sh)
+    # from outside with rocm-smi)
     import time
     want = int(sys.argv[2].split(":")[1])
     secs = float(sys.argv[3]) if len(sys.argv) > 3 else 4.0
