@@ -19,7 +19,7 @@ if os.environ.get("BT_DEV") == "1" and os.environ.get("BT_LIB_PATH"):  # develop
     LIB_PATH = os.environ["BT_LIB_PATH"]
 SOURCES = ["gemm.hip", "gemm2.hip", "gemm3.hip", "gemm_mx8.hip", "attn.hip", "attn2.hip", "fused.hip", "fused2.hip", "qkv_front.hip", "frontend.hip", "logmel.hip",
            "tail.hip", "engine.hip"]
-HEADERS = ["common.h", "chain.h", "kernels.h", "attn_x3_loop.inc", os.path.join("..", "..", "include", "beat_this_amd.h")]
+HEADERS = ["common.h", "chain.h", "kernels.h", "attn_x3_loop.inc", "attn_hq2_loop.inc", os.path.join("..", "..", "include", "beat_this_amd.h")]
 
 BT_OK, BT_ERR_ARG, BT_ERR_HIP, BT_ERR_WORKSPACE = 0, -1, -2, -3
 ABI_VERSION = 600   # BT_ABI_VERSION of include/beat_this_amd.h this binding was written against

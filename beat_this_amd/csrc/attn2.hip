@@ -227,19 +227,23 @@ DEVI void stage_tile(rsrc_t rk, rsrc_t rv, int tile, char* smem, int buf, int ti
   static_assert(TILE_BYTES == 8192, "stage_tile copies two 4 KB pieces per operand");
 }
 
+// compute (wave-uniform): false = this wave only takes part in the staging and the barriers and keeps its state (the two-query-
+// block kernel repeats HALF a workgroup -- the 128 queries that are one workgroup of attn_frag_kernel -- and nobody else)
 template <bool SAFE, int QB>
 DEVI void attn_pass(rsrc_t rk, rsrc_t rv, char* smem, int tid, int wave, int lane, int g, int lr, QState (&st)[QB],
-                    int L, int nblk) {
+                    int L, int nblk, bool compute = true) {
   const int ntiles = (nblk + KB - 1) / KB;
   const bool partial = (L & 31) != 0;
   stage_tile(rk, rv, 0, smem, 0, tid, wave);
   __syncthreads();
+  if (compute) {
 #pragma unroll
   for (int j = 0; j < QB; ++j) {
     zero16(st[j].negm);
     zero16(st[j].acc);
     st[j].l = f32x4{0.f, 0.f, 0.f, 0.f};
     st[j].m = -1e30f;
+  }
   }
   if constexpr (!SAFE) {  // reference max of each query: its scores against key block 0
     const KFrag k00 = ld_k(smem, g, lr);
@@ -268,7 +272,9 @@ DEVI void attn_pass(rsrc_t rk, rsrc_t rv, char* smem, int tid, int wave, int lan
     const char* kb = smem + (t & 1) * 2 * TILE_BYTES;
     const char* vb = kb + TILE_BYTES;
     const int nb = min(KB, nblk - t * KB);
-    if (nb == KB && !(partial && t == ntiles - 1)) {
+    if (!compute) {
+      // (nothing to multiply here)
+    } else if (nb == KB && !(partial && t == ntiles - 1)) {
 #pragma unroll
       for (int c = 0; c < KB; ++c) {
         const VFrag vf = ld_v(vb + c * BLK_BYTES, lane);
@@ -544,6 +550,199 @@ __global__ __launch_bounds__(256, (QB == 1 ? 4 : 2)) void attn_frag_kernel(const
     }
   }
 }
+
+
+// =====================================================================================================================
+// Round 6: the fp16 attention on TWO query blocks per wave and a hand-scheduled key loop (tools/gen/attn_hq2_loop.py ->
+// attn_hq2_loop.inc: one asm statement, 4 big + 4 small MFMAs beside 24 VALU instructions per step and query block, every K / V
+// fragment read feeding both blocks), the design of attn_frag_x3q2_kernel without the lo terms.  256 queries per workgroup, a
+// ring of four 8 KB [K tile | V tile] buffers of 64 keys, two workgroups per CU.
+//
+// SAME BITS AS attn_frag_kernel<0, 1> for every query (the forward picks the kernel by launch size; a chunk must not depend on
+// its batch): same reference point (the query's maximum over key block 0, minus P_SHIFT, on the score MFMA's accumulator input),
+// same order of the products, the packing, the row-sum MFMAs and the P.V MFMAs, the ragged last tile on the same plain code --
+// and the same REPEAT UNITS: a fast pass that overflowed re-runs the 128 queries that are one workgroup of attn_frag_kernel
+// (here: a wave pair) on the running-maximum pass, nobody else; the other wave pair takes part in that pass's staging and
+// barriers only.
+#if !BT_HALF_IS_BF16
+#include "attn_hq2_loop.inc"
+
+// the plain form of one key block for QB query blocks of the fast pass (do_block<false, MASK, 1>'s arithmetic for each of them)
+template <bool MASK, int QB>
+DEVI void block_fast_plain(const KFrag& kf, const VFrag& vf, int g, QState (&st)[QB], int key0, int L) {
+#pragma unroll
+  for (int j = 0; j < QB; ++j) {
+    f32x16 sc = MFMA32_H(kf.k0, st[j].q0, st[j].negm);
+    sc = MFMA32_H(kf.k1, st[j].q1, sc);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sc[r] = __builtin_amdgcn_exp2f(sc[r]);
+    if constexpr (MASK) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        if (key0 + crow(r, g) >= L) sc[r] = 0.f;
+    }
+    const u32x4 w0 = pack8(sc, 0), w1 = pack8(sc, 1);
+    rowsum8(st[j].l, w0);
+    rowsum8(st[j].l, w1);
+    st[j].acc = MFMA32_H(vf.v0, __builtin_bit_cast(hfx8, w0), st[j].acc);
+    st[j].acc = MFMA32_H(vf.v1, __builtin_bit_cast(hfx8, w1), st[j].acc);
+  }
+}
+
+__global__ __launch_bounds__(256, 2) void attn_frag_hq2_kernel(const AttnFragP p, int nqt, int sh_total) {
+  constexpr int QB = 2, KBX = ATTN_HQ2_KBX, NBUF = ATTN_HQ2_NBUF;
+  constexpr int TILEH = KBX * BLK_BYTES, BUFH = 2 * TILEH;
+  static_assert(KBX == 2 && NBUF == 4 && BUFH == 8192 && NBUF * BUFH == 4 * TILE_BYTES, "the generated loop is written for four 8 KB ring buffers");
+  static_assert(BT_ATTN_ROWSUM == 0 && !BT_ATTN_PKRTZ, "the generated loop runs the row sums on the matrix pipe and packs round-to-nearest");
+  __shared__ __attribute__((aligned(16))) char smem[SMEM_BYTES];   // (the running-maximum pass re-uses it as two 16 KB stages)
+  const int bid = blockIdx.x;
+  const int idx = bid >> 3;
+  const int sh = (idx / nqt) * 8 + (bid & 7);
+  const int qt = idx % nqt;
+  if (sh >= sh_total) return;
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int L = p.L;
+  const int nblk = (L + 31) >> 5;
+  const long seq_off = (long)sh * p.nbp * BLK_BYTES;
+  const char* kseq = reinterpret_cast<const char*>(p.k) + seq_off;
+  const char* vseq = reinterpret_cast<const char*>(p.v) + seq_off;
+  int* flag = reinterpret_cast<int*>(smem + 4 * TILE_BYTES);   // [2]: one per wave pair
+  if (tid < 2) flag[tid] = 0;
+
+  QState st[QB];
+  const int qb0 = (qt * 4 + wave) * QB;  // this wave's first query block
+  {
+    const int ln = lane_id_fresh(), gg = ln >> 5, ll = ln & 31;
+#pragma unroll
+    for (int j = 0; j < QB; ++j) {
+      const int qbc = min(qb0 + j, nblk - 1);
+      const char* qblk = reinterpret_cast<const char*>(p.q) + seq_off + (long)qbc * BLK_BYTES;
+      st[j].q0 = *reinterpret_cast<const hfx8*>(qblk + ((2 * gg) * 32 + ll) * 16);
+      st[j].q1 = *reinterpret_cast<const hfx8*>(qblk + ((2 * gg + 1) * 32 + ll) * 16);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (VGPR-returning loads and LDS-DMA do not retire in one order)
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  const unsigned seq_bytes = (unsigned)p.nbp * BLK_BYTES;   // (tiles beyond it read as zeros: the ring is always refilled)
+  const rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(kseq), 0, seq_bytes, 0x00020000);
+  const rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(vseq), 0, seq_bytes, 0x00020000);
+  const int ntiles = (nblk + KBX - 1) / KBX;
+  const bool partial = (L & 31) != 0;
+  int nfull = nblk / KBX;  // tiles of KBX unmasked blocks
+  if (partial && nfull * KBX == nblk) --nfull;
+  nfull = __builtin_amdgcn_readfirstlane(nfull);
+  auto stage_ring = [&](int tile) {   // tile t lives in buffer t & 3 = [K tile | V tile]: one 1 KB piece of each per wave
+    char* kd = smem + (tile & (NBUF - 1)) * BUFH + wave * 1024;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, (lptr_t)kd, 16, tid * 16, tile * TILEH, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (lptr_t)(kd + TILEH), 16, tid * 16, tile * TILEH, 0, 0);
+  };
+  stage_ring(0);
+  stage_ring(1);
+  stage_ring(2);
+  asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // tile 0 (this wave's two pieces of it) has landed
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < QB; ++j) {
+    zero16(st[j].acc);
+    st[j].l = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  {  // reference point of each query: its maximum over key block 0 (attn_pass_pipe's prologue)
+    const int ln = lane_id_fresh(), gg = ln >> 5, ll = ln & 31;
+    const KFrag k00 = ld_k(smem, gg, ll);
+#pragma unroll
+    for (int j = 0; j < QB; ++j) {
+      f32x16 sc;
+      zero16(sc);
+      sc = MFMA32_H(k00.k0, st[j].q0, sc);
+      sc = MFMA32_H(k00.k1, st[j].q1, sc);
+      float bm = -1e30f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) bm = fmaxf(bm, (crow(r, gg) < L) ? sc[r] : -1e30f);
+      bm = fmaxf(bm, __shfl_xor(bm, 32));
+      st[j].m = bm;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) st[j].negm[r] = -bm - P_SHIFT;
+    }
+  }
+  if (nfull > 0) {
+    // operand words of the two buffer descriptors as plain SGPR quads (an asm operand cannot be a __amdgpu_buffer_rsrc_t)
+    const unsigned long long ka = (unsigned long long)kseq, va = (unsigned long long)vseq;
+    const u32x4 dk = {(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)ka), (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((ka >> 32) & 0xffffu)),
+                      (unsigned)__builtin_amdgcn_readfirstlane((int)seq_bytes), 0x00020000u};
+    const u32x4 dv = {(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)va), (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((va >> 32) & 0xffffu)),
+                      (unsigned)__builtin_amdgcn_readfirstlane((int)seq_bytes), 0x00020000u};
+    const int ln = lane_id_fresh();
+    const unsigned lds0 = (unsigned)(unsigned long long)(lptr_t)smem;   // LDS byte address of the ring
+    const unsigned klane = lds0 + ((2 * (ln >> 5)) * 32 + (ln & 31)) * 16, vlane = lds0 + ln * 16, dmaoff = (wave * 64 + ln) * 16;
+    const unsigned m0base = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + wave * 1024));
+    int t = 0, soff = 3 * TILEH;
+    asm volatile(ATTN_HQ2_ASM
+                 : "+v"(st[0].acc), "+v"(st[1].acc), "+v"(st[0].l), "+v"(st[1].l), "+s"(t), "+s"(soff)
+                 : "v"(st[0].q0), "v"(st[0].q1), "v"(st[1].q0), "v"(st[1].q1), "v"(st[0].negm), "v"(st[1].negm),
+                   "v"(klane), "v"(vlane), "v"(dmaoff), "s"(dk), "s"(dv), "s"(m0base), "s"(nfull)
+                 : ATTN_HQ2_CLOBBERS);
+  }
+  // every piece of the ring this wave asked for has landed, and so has everybody else's: the last tile (fewer than KBX blocks
+  // and / or a masked last block) is read from its ring buffer by the plain code
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (nfull < ntiles) {
+    const int lane2 = lane_id_fresh(), g2 = lane2 >> 5, lr2 = lane2 & 31;
+    const char* kb = smem + (nfull & (NBUF - 1)) * BUFH;
+    const char* vb = kb + TILEH;
+    const int nb = nblk - nfull * KBX;
+    for (int c = 0; c < nb; ++c) {
+      const int blk = nfull * KBX + c;
+      const KFrag kf = ld_k(kb + c * BLK_BYTES, g2, lr2);
+      const VFrag vf = ld_v(vb + c * BLK_BYTES, lane2);
+      if (partial && blk == nblk - 1) block_fast_plain<true, QB>(kf, vf, g2, st, blk * 32, L);
+      else block_fast_plain<false, QB>(kf, vf, g2, st, blk * 32, L);
+    }
+    __syncthreads();
+  }
+  const int lane = lane_id_fresh(), g = lane >> 5, lr = lane & 31;
+  float l_tot[QB];
+  bool bad = false;
+#pragma unroll
+  for (int j = 0; j < QB; ++j) {
+    l_tot[j] = st[j].l[0] + __shfl_xor(st[j].l[0], 32);
+    const bool valid = qb0 + j < nblk && (qb0 + j) * 32 + lr < L;
+    bad = bad || (valid && !(l_tot[j] < L_OVERFLOW));  // overflow / NaN: this query needs the running-max pass
+  }
+  if (__any(bad) && lane == 0) flag[wave >> 1] = 1;
+  __syncthreads();
+  if (flag[0] | flag[1]) {  // workgroup-uniform: the wave pair(s) whose flag is up repeat, the other keeps what it has
+    const bool mine = flag[wave >> 1] != 0;
+    __syncthreads();
+    attn_pass<true, QB>(rk, rv, smem, wave * 64 + lane, wave, lane, g, lr, st, L, nblk, mine);
+    if (mine) {
+#pragma unroll
+      for (int j = 0; j < QB; ++j) l_tot[j] = st[j].l[0] + __shfl_xor(st[j].l[0], 32);
+    }
+  }
+
+  const int seq = sh / p.heads, head = sh - seq * p.heads;
+#pragma unroll
+  for (int j = 0; j < QB; ++j) {
+    const int qi = (qb0 + j) * 32 + lr;
+    const bool okq = qb0 + j < nblk && qi < L;
+    const float gatev = okq ? p.gates[(long)sh * p.nbp * 32 + qi] : 0.f;
+    const long orow = okq ? (long)(seq / p.o_div) * p.o_outer + (long)(seq % p.o_div) * p.o_inner + (long)qi * p.o_tok : 0;
+    hf* op = reinterpret_cast<hf*>(p.out) + orow * p.inner + head * 32 + 8 * g;
+    const float scale = okq ? gatev / l_tot[j] : 0.f;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {   // (the two halves of the wave exchange 4-feature runs: 16-byte stores, attn_frag_kernel)
+      const unsigned x0 = pk2(st[j].acc[8 * k] * scale, st[j].acc[8 * k + 1] * scale);
+      const unsigned x1 = pk2(st[j].acc[8 * k + 2] * scale, st[j].acc[8 * k + 3] * scale);
+      const unsigned y0 = pk2(st[j].acc[8 * k + 4] * scale, st[j].acc[8 * k + 5] * scale);
+      const unsigned y1 = pk2(st[j].acc[8 * k + 6] * scale, st[j].acc[8 * k + 7] * scale);
+      auto r0 = __builtin_amdgcn_permlane32_swap(x0, y0, false, false);
+      auto r1 = __builtin_amdgcn_permlane32_swap(x1, y1, false, false);
+      if (okq) *reinterpret_cast<u32x4*>(op + 16 * k) = u32x4{r0[0], r1[0], r0[1], r1[1]};
+    }
+  }
+}
+#endif   // !BT_HALF_IS_BF16
 
 
 // =====================================================================================================================
@@ -1454,7 +1653,7 @@ static void launch_x3q2(const AttnFragP& p, hipStream_t s) {
 int launch_attn_frag(const AttnFragP& p, hipStream_t s) {
   if (p.L <= 0 || p.n_seq <= 0 || p.heads <= 0 || p.inner != p.heads * 32 || p.nbp < attn_frag_blocks(p.L)) return -2;
   if ((long)p.n_seq * p.heads * ((p.L + 127) / 128) > 0x3fffffffL) return -3;
-  if (p.x3) {
+  if (p.x3 > 0) {
     if (BT_HALF_IS_BF16 || (long)p.nbp * 4096 >= 0x7fffffffL || !p.fix_mask) return -2;
     // x3 selects the LDS tile (tools/x3_probe.py, 16 chunks, +-3 % run to run):
     //   1 = 128-key tiles, 64 KB, two workgroups per CU:   main-layer shape 290 us, frontend shapes 590 us per launch;
@@ -1505,6 +1704,28 @@ int launch_attn_frag(const AttnFragP& p, hipStream_t s) {
   if (abl == 128) { launch_v<128, 1>(p, s); return (int)hipGetLastError(); }
   static const int qb = getenv("BT_ATTN_QB") ? atoi(getenv("BT_ATTN_QB")) : 1;   // two query blocks per wave (A/B only)
   if (qb == 2) { launch_v<0, 2>(p, s); return (int)hipGetLastError(); }
+#endif
+#if !BT_HALF_IS_BF16
+  {
+    // Round 6: two query blocks per wave on the hand-scheduled loop (attn_frag_hq2_kernel), bit-identical to the one-block kernel
+    // (tested) -- and NOT dispatched: same box, three alternations of bench.py --prec half (profiles/r06_ab_hq2.txt), attention
+    // 4.97 against 4.84 ms per 66-chunk step (+2.7 %; the first form of the loop, with the score pair back to back: +5 %) at -0.9 %
+    // joules.  The fp16 attention is bound by its exponentials (16 v_exp_f32 + 8 conversions per MFMA quartet, d = 32: the kernel
+    // header's "VALU-bound"), which four waves per SIMD of the compiler-scheduled kernel keep busier than two waves of a loop that
+    // was scheduled for the matrix pipe.  Kept selectable (x3 = -2) for tests and probes; -DBT_HQ2_MIN_WG=1024 builds the
+    // size-selected dispatch.  x3 = -1 forces the one-block kernel; 0 = the dispatch rule.
+#ifndef BT_HQ2_MIN_WG
+#define BT_HQ2_MIN_WG 2000000000
+#endif
+    const long wg2 = (long)p.n_seq * p.heads * (((p.L + 31) / 32 + 7) / 8);
+    if (p.x3 == -2 || (p.x3 == 0 && wg2 >= BT_HQ2_MIN_WG)) {
+      const long sh = (long)p.n_seq * p.heads;
+      const int nqt = ((p.L + 31) / 32 + 7) / 8;
+      const long grid = (sh + 7) / 8 * 8 * nqt;
+      hipLaunchKernelGGL(attn_frag_hq2_kernel, dim3((unsigned)grid), dim3(256), 0, s, p, nqt, (int)sh);
+      return (int)hipGetLastError();
+    }
+  }
 #endif
   launch_v<0, 1>(p, s);
   return (int)hipGetLastError();

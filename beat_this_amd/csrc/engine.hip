@@ -1049,7 +1049,7 @@ int bt_attention_frag(void* stream, const bt_attn_frag_args* a) {
   p.heads = a->heads; p.inner = a->inner; p.nbp = a->nbp; p.o_div = a->o_div; p.o_outer = a->o_outer;
   p.o_inner = a->o_inner; p.o_tok = a->o_tok;
   p.x3 = a->x3; p.out_f32 = a->out_f32; p.status = a->status; p.fix_mask = a->scratch;
-  if (p.x3 && !p.fix_mask) return bt_set_error(BT_ERR_ARG, "bt_attention_frag: x3 needs the scratch words (overflow map)");
+  if (p.x3 > 0 && !p.fix_mask) return bt_set_error(BT_ERR_ARG, "bt_attention_frag: x3 needs the scratch words (overflow map)");
   LAUNCH(launch_attn_frag(p, (hipStream_t)stream), "attention (fragment-major)");
   return BT_OK;
 }

@@ -353,14 +353,17 @@ int bt_attention(void* stream, int prec, const bt_attn_args* a);
  * 32 tokens, 2 KB each.  Q/K block: [quarter a][token][8 dims 8a..8a+7]; V block: [s][lane = 32 g + d]
  * [8 tokens 16 s + 8 (j >> 2) + 4 g + (j & 3)]; gates [n_seq * heads][nbp * 32] fp32.  q must be
  * pre-scaled by log2(e)/sqrt(32).  nbp >= bt_attn_frag_blocks(L).  Output as bt_attention (half).
- * x3 != 0 (BT_PREC_F32X3): blocks of 4 KB = [hi block | lo block] of the fp32 values, three MFMAs per product; output
+ * x3 <= 0 (half operands): 0 / -1 = the 128-query kernel (what the forward runs); -2 = two query blocks per wave on a
+ * hand-scheduled key loop (round 6: same bits for every query, 2.7 % slower at 0.9 % fewer joules -- the fp16 attention is
+ * bound by its exponentials; kept for tests and probes).
+ * x3 > 0 (BT_PREC_F32X3): blocks of 4 KB = [hi block | lo block] of the fp32 values, three MFMAs per product; output
  * fp32 [rows, inner] (out_f32 = 1), hl32 half [rows, 2 inner] (0) or hl8 rows of the same size (2: per 32 columns 32 hi halves |
  * 32 e4m3 bytes of value / 8 | 32 e4m3 bytes of 2^8 (value - hi), what bt_gemm3 reads as A with x3 flag 0x100); status (may be NULL) =
  * range flag of the hl32 / hl8 output;
  * x3 = 1: 128-key LDS tiles, x3 = 2: 64-key tiles, x3 = 5: two query blocks per wave on a hand-scheduled key loop -- the same
  * arithmetic in all three, bit-identical results; x3 = 4 (the forward's choice since round 4): 5 for launches of at least
  * 1024 of its workgroups, 2 below.  + 8 (BT_X3_P16): the P16 arithmetic (BT_OPT_X3_ATTN_P16) on the same kernel choice.
- * x3 != 0 needs `scratch`: n_seq * heads * nbp int32 words (the launch's overflow map: queries whose probabilities left fp16's
+ * x3 > 0 needs `scratch`: n_seq * heads * nbp int32 words (the launch's overflow map: queries whose probabilities left fp16's
  * range in the fast pass are recomputed on their row maxima by a second, gathered launch; contents undefined afterwards). */
 #define BT_X3_P16 8
 typedef struct {

@@ -107,10 +107,13 @@ def unfrag_v(fr, L):
     return t.permute(0, 1, 2, 5, 3, 6, 4).reshape(SH, nbp * 32, 32)[:, :L]
 
 
-def run_attn_frag(qf, kf, vf, gates, out, n_seq, L, heads, nbp, o_div=1, o_outer=None, o_inner=0, o_tok=1):
+def run_attn_frag(qf, kf, vf, gates, out, n_seq, L, heads, nbp, o_div=1, o_outer=None, o_inner=0, o_tok=1, variant=0):
+    """variant (bt_attn_frag_args.x3 of the half path): 0 = the kernel the launch size selects, -1 = the one-query-block kernel,
+    -2 = two query blocks per wave on the hand-scheduled loop (round 6)"""
     from beat_this_amd import _lib
 
     a = _lib.AttnFragArgs()
+    a.x3 = variant
     a.q, a.k, a.v, a.gates, a.out = qf.data_ptr(), kf.data_ptr(), vf.data_ptr(), gates.data_ptr(), out.data_ptr()
     a.n_seq, a.L, a.heads, a.inner, a.nbp, a.o_div = n_seq, L, heads, heads * 32, nbp, o_div
     a.o_outer = L if o_outer is None else o_outer

@@ -27,6 +27,12 @@ def _attn_ref(q, k, v, gates):
     return torch.softmax(s, -1) @ v * gates[..., None]
 
 
+def _is_f16():
+    from beat_this_amd import _lib as Lb
+
+    return not Lb.lib().bt_half_is_bf16()
+
+
 def _run(q, k, v, gates, n_seq, L, heads, **omap):
     """q, k, v: [SH, L, 32] float64 (already representable in the half type); gates [SH, L]."""
     from beat_this_amd import _lib as Lb
@@ -47,9 +53,12 @@ def _run(q, k, v, gates, n_seq, L, heads, **omap):
     return out
 
 
+@pytest.mark.parametrize("variant", [-1, -2])
 @pytest.mark.parametrize("n_seq,L,heads", [(3, 1500, 2), (2, 77, 1), (1, 128, 4), (5, 1012, 1), (2, 1, 1), (2, 33, 2),
-                                           (1, 1499, 1), (2, 129, 1), (9, 96, 1)])
-def test_attention_frag(n_seq, L, heads):
+                                           (1, 1499, 1), (2, 129, 1), (9, 96, 1), (2, 257, 1), (2, 250, 1), (1, 64, 1), (2, 65, 1)])
+def test_attention_frag(n_seq, L, heads, variant):
+    if variant == -2 and not _is_f16():
+        pytest.skip("the two-query-block kernel is an fp16 kernel")
     SH = n_seq * heads
     q = _mk((SH, L, 32), 30, 0.6).float().to(HALF()).double()
     k = _mk((SH, L, 32), 31).float().to(HALF()).double()
@@ -57,12 +66,35 @@ def test_attention_frag(n_seq, L, heads):
     k[0, 7 % L] *= 6.0  # one outlier key
     k = k.float().to(HALF()).double()
     gates = torch.sigmoid(_mk((SH, L), 33))
-    out = _run(q, k, v, gates, n_seq, L, heads)
+    out = _run(q, k, v, gates, n_seq, L, heads, variant=variant)
     ref = _attn_ref(q, k, v, gates)  # [SH, L, 32]
     ref = ref.view(n_seq, heads, L, 32).permute(0, 2, 1, 3).reshape(n_seq * L, heads * 32)
     err = _rel(out, ref)
-    report("attn_frag", n_seq=n_seq, L=L, heads=heads, rel=err)
+    report("attn_frag", n_seq=n_seq, L=L, heads=heads, variant=variant, rel=err)
     assert err < 2e-2
+
+
+@pytest.mark.parametrize("n_seq,L,heads", [(3, 1500, 2), (2, 77, 1), (1, 128, 4), (5, 1012, 1), (2, 1, 1), (2, 33, 2), (1, 1499, 1),
+                                           (2, 129, 1), (9, 96, 1), (2, 257, 1), (2, 250, 1), (1, 64, 1), (176, 1500, 1)])
+def test_attention_frag_kernels_agree_bit_for_bit(n_seq, L, heads):
+    """The two half attention kernels (128-query workgroups; two query blocks per wave on the hand-scheduled loop of round 6) must
+    give the SAME bits for every query -- same reference point, same order of products, packing, row sums and P.V -- so that a
+    launch-size-selected dispatch (a build switch: the forward runs the 128-query kernel, the faster one) could never make a
+    chunk's logits depend on what else was in its batch.  Includes an outlier key (no overflow) and variant 0 (the dispatch rule)."""
+    if not _is_f16():
+        pytest.skip("the two-query-block kernel is an fp16 kernel")
+    SH = n_seq * heads
+    q = _mk((SH, L, 32), 30, 0.6).float().to(HALF()).double()
+    k = _mk((SH, L, 32), 31).float().to(HALF()).double()
+    v = _mk((SH, L, 32), 32).float().to(HALF()).double()
+    k[0, 7 % L] *= 6.0
+    k = k.float().to(HALF()).double()
+    gates = torch.sigmoid(_mk((SH, L), 33))
+    one = _run(q, k, v, gates, n_seq, L, heads, variant=-1)
+    two = _run(q, k, v, gates, n_seq, L, heads, variant=-2)
+    auto = _run(q, k, v, gates, n_seq, L, heads, variant=0)
+    assert torch.equal(one, two) and torch.equal(one, auto)
+    assert torch.equal(two, _run(q, k, v, gates, n_seq, L, heads, variant=-2))   # (repeatable)
 
 
 def test_attention_frag_time_direction_rowmap():
@@ -77,8 +109,9 @@ def test_attention_frag_time_direction_rowmap():
     assert err < 2e-2
 
 
+@pytest.mark.parametrize("variant", [-1, -2])
 @pytest.mark.parametrize("L", [300, 1500])
-def test_attention_frag_overflow_fallback(L):
+def test_attention_frag_overflow_fallback(L, variant):
     """Scores that exceed the first key block's maximum by more than exp2 can hold force the SAFE
     (running-max) pass; the result must still be the exact softmax."""
     SH = 3
@@ -92,12 +125,24 @@ def test_attention_frag_overflow_fallback(L):
     k[1, L - 40, 0] = 24.0
     q, k, v = (t.float().to(HALF()).double() for t in (q, k, v))
     gates = torch.ones((SH, L), dtype=torch.float64)
-    out = _run(q, k, v, gates, SH, L, 1)
+    if variant == -2 and not _is_f16():
+        pytest.skip("the two-query-block kernel is an fp16 kernel")
+    out = _run(q, k, v, gates, SH, L, 1, variant=variant)
     ref = _attn_ref(q, k, v, gates).reshape(SH * L, 32)
     assert torch.isfinite(out.float()).all()
     err = _rel(out, ref)
-    report("attn_frag_overflow", L=L, rel=err)
+    report("attn_frag_overflow", L=L, variant=variant, rel=err)
     assert err < 2e-2
+    if variant == -2:
+        # the repeat unit is the same 128 queries as in the one-block kernel (a wave pair here): identical bits with an overflow too,
+        # wherever the overflowing query sits inside its 256-query workgroup
+        assert torch.equal(out, _run(q, k, v, gates, SH, L, 1, variant=-1))
+        q2 = q.clone()
+        q2[1, 5] = q[1, 6]
+        q2[1, 200 % L] = 0.0
+        q2[1, 200 % L, 0] = 25.0
+        q2 = q2.float().to(HALF()).double()
+        assert torch.equal(_run(q2, k, v, gates, SH, L, 1, variant=-2), _run(q2, k, v, gates, SH, L, 1, variant=-1))
 
 
 def _pair_sd(C, seed):
