@@ -150,6 +150,11 @@ def main():
     ap.add_argument("--min-seconds", type=float, default=2.0,
                     help="the K timed steps are repeated until the timed region is at least this long (0: exactly K steps)")
     ap.add_argument("--watchdog", type=int, default=900, help="seconds after which a stuck run dumps its stacks and exits")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="development / tests: all N ranks run on cuda:0 and the collectives go over gloo -- the N > 1 code path of "
+                         "this file (sharding, gathers, timing reduction, failure handling) on a box with ONE GPU; not a measurement")
+    ap.add_argument("--fail-rank", type=int, default=-1, help="development / tests: this rank raises inside timed step --fail-step")
+    ap.add_argument("--fail-step", type=int, default=0)
     args = ap.parse_args()
     import faulthandler
 
@@ -161,7 +166,7 @@ def main():
         import torch
 
         have = torch.cuda.device_count()
-        if have < args.gpus:
+        if have < args.gpus and not (args.share_gpu and have >= 1):
             raise SystemExit(f"bench.py: --gpus {args.gpus} but this node shows {have} GPU(s) (torch.cuda.device_count()); "
                              "run with --gpus <= that, one process per GPU")
         # self-launch: one process per GPU under torch.distributed.run (RCCL rendezvous on 127.0.0.1)
@@ -184,6 +189,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.share_gpu:
+        local_rank = 0
     if local_rank >= torch.cuda.device_count():
         raise SystemExit(f"bench.py: LOCAL_RANK {local_rank} but this node shows {torch.cuda.device_count()} GPU(s)")
     if world > 1:
@@ -214,16 +221,36 @@ def main():
 
             # (a collective whose peer died is aborted after three minutes instead of RCCL's default ten; a rank that RAISES
             # takes the whole job down at once: see the wrapper around main())
-            dist.init_process_group("nccl", device_id=dev, timeout=timedelta(seconds=180))
+            if args.share_gpu:
+                dist.init_process_group("gloo", timeout=timedelta(seconds=180))
+            else:
+                dist.init_process_group("nccl", device_id=dev, timeout=timedelta(seconds=180))
         except Exception as e:  # noqa: BLE001
             if world > 1:
                 raise
             use_dist, dist_note = False, f"RCCL group of one did not come up ({type(e).__name__}): single-process run"
             log(dist_note)
+    def all_gather(out_t, in_t):
+        """dist.all_gather_into_tensor; --share-gpu (gloo): through host copies"""
+        if args.share_gpu:
+            tmp = torch.empty(out_t.shape, dtype=out_t.dtype)
+            dist.all_gather_into_tensor(tmp, in_t.cpu().contiguous())
+            out_t.copy_(tmp)
+        else:
+            dist.all_gather_into_tensor(out_t, in_t)
+
+    def all_reduce(t_, op=None):
+        if args.share_gpu:
+            tmp = t_.cpu()
+            dist.all_reduce(tmp, **({} if op is None else {"op": op}))
+            t_.copy_(tmp)
+        else:
+            dist.all_reduce(t_, **({} if op is None else {"op": op}))
+
     rccl_ranks = None
     if use_dist:   # proof of N ranks: an RCCL all-reduce counts them
         one = torch.ones(1, dtype=torch.int32, device=dev)
-        dist.all_reduce(one)
+        all_reduce(one)
         rccl_ranks = int(one.item())
         assert rccl_ranks == dist.get_world_size()
 
@@ -284,7 +311,7 @@ def main():
             h = a2b.many_async(tracks, TRACK_SR)
             if use_dist:
                 beat, down, _ = h.logits
-                dist.all_gather_into_tensor(gathered, torch.stack((beat, down)))
+                all_gather(gathered, torch.stack((beat, down)))
             pending.append(h)
             if len(pending) > 1:
                 return pending.pop(0).result()
@@ -311,7 +338,7 @@ def main():
             with torch.inference_mode(), torch.autocast("cuda", enabled=half):
                 r = a2b.model(x)
             if use_dist:
-                dist.all_gather_into_tensor(gathered, torch.stack((r["beat"], r["downbeat"]), 1))
+                all_gather(gathered, torch.stack((r["beat"], r["downbeat"]), 1))
             return r
 
         def drain():
@@ -343,7 +370,7 @@ def main():
     if args.min_seconds > 0 and args.warmup > 0:
         est = torch.tensor([tw * args.steps], dtype=torch.float64, device=dev)
         if use_dist:
-            dist.all_reduce(est, op=dist.ReduceOp.MIN)
+            all_reduce(est, dist.ReduceOp.MIN)
         repeats = max(1, int(-(-args.min_seconds // max(float(est.item()), 1e-6))))
     log(f"timed region: {args.steps} steps x {repeats}")
     # package energy over the timed region from the SMU's accumulator (tools/smi.py: rsmi_dev_energy_count_get), read right
@@ -353,7 +380,9 @@ def main():
     meter = EnergyMeter(dev)
     meter.start()
     t0 = time.perf_counter()
-    for _ in range(args.steps * repeats):
+    for i_step in range(args.steps * repeats):
+        if rank == args.fail_rank and i_step == args.fail_step:
+            raise RuntimeError(f"--fail-rank {rank}: raising inside timed step {i_step} (test of the N > 1 failure rule)")
         step()
     last = drain()
     fence()
@@ -364,7 +393,7 @@ def main():
     if joules is not None:
         jt = torch.tensor([joules[0]], dtype=torch.float64, device=dev)
         if use_dist:
-            dist.all_reduce(jt)   # whole job: the sum over the ranks' packages
+            all_reduce(jt)   # whole job: the sum over the ranks' packages
         energy = {"available": True, "joules_per_step": round(float(jt.item()) / n_timed, 3),
                   "audio_seconds_per_joule": round(units_per_step * n_timed / max(float(jt.item()), 1e-9), 2),
                   "avg_package_power_W": round(joules[0] / max(joules[1], 1e-9), 1), "packages": world,
@@ -377,9 +406,9 @@ def main():
     if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         allt = torch.empty(world, dtype=torch.float64, device=dev)
-        dist.all_gather_into_tensor(allt, t)
+        all_gather(allt, t)
         per_rank_ms = [round(1e3 * float(v) / n_timed, 3) for v in allt.tolist()]   # (which rank is the slow one, if any)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        all_reduce(t, dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ms_per_step = 1e3 * elapsed / n_timed
     value = units_per_step / (elapsed / n_timed)
@@ -405,7 +434,7 @@ def main():
             if e:
                 e[1].record()
             if use_dist:
-                dist.all_gather_into_tensor(g512, r)
+                all_gather(g512, r)
             if e:
                 e[2].record()
                 ev_s.append(e)
@@ -426,11 +455,11 @@ def main():
         s_per_rank, s_gather = [round(fwd_ms, 3)], [round(gat_ms, 3)]
         if use_dist:
             t = torch.tensor([ts], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            all_reduce(t, dist.ReduceOp.MAX)
             ts = float(t.item())
-            mine = torch.tensor([fwd_ms, gat_ms], dtype=torch.float64, device=dev)
+            mine = torch.tensor([[fwd_ms, gat_ms]], dtype=torch.float64, device=dev)   # (1, 2) -> (world, 2): concatenation along dim 0
             allm = torch.empty((world, 2), dtype=torch.float64, device=dev)
-            dist.all_gather_into_tensor(allm, mine)
+            all_gather(allm, mine)
             s_per_rank = [round(float(v), 3) for v in allm[:, 0].tolist()]
             s_gather = [round(float(v), 3) for v in allm[:, 1].tolist()]
         ts /= n_s
@@ -941,7 +970,8 @@ def main():
             "parity": parity, "roofline": roofline, "cpu_baseline": cpu, "energy": energy, "frontend": frontend, "forward_only": forward_only,
             "half_path": half_path, "fp32_exact_path": fp32_exact_path, "latency": latency,
             "stress_weights": stress, "host_inclusive": host_inclusive, "configs": configs,
-            "strong_scaling_cfg4": strong, "rccl_ranks": rccl_ranks, "rccl_note": dist_note,
+            "strong_scaling_cfg4": strong, "rccl_ranks": rccl_ranks,
+            "rccl_note": "--share-gpu: all ranks on cuda:0, gloo collectives (development run of the N > 1 path, not a measurement)" if args.share_gpu else dist_note,
             "timed_region": {"steps": args.steps, "repeats": repeats, "steps_timed": n_timed, "seconds": round(elapsed, 3),
                              "per_rank_ms_per_step": per_rank_ms},
             "breakdown": breakdown, **p16_legs,
