@@ -376,7 +376,7 @@ void bt_engine_destroy(bt_engine* e) {
 int bt_engine_set_option(bt_engine* e, int option, int value) {
   if (!e) return bt_set_error(BT_ERR_ARG, "null argument");
   // (a captured forward replays the kernels it was recorded with: an option change drops them)
-  if (option == BT_OPT_X3_ATTN_P16 && value >= 0 && value <= 2) { if (e->x3_attn_p16 != value) drop_graphs(e); e->x3_attn_p16 = value; return BT_OK; }
+  if (option == BT_OPT_X3_ATTN_P16 && value >= 0 && value <= 3) { if (e->x3_attn_p16 != value) drop_graphs(e); e->x3_attn_p16 = value; return BT_OK; }
   if (option == BT_OPT_X3_GEMM_FP8 && value >= 0 && value <= 2) { if (e->x3_gemm_fp8 != value) drop_graphs(e); e->x3_gemm_fp8 = value; return BT_OK; }
   return bt_set_error(BT_ERR_ARG, "unknown engine option / value");
 }
@@ -412,7 +412,7 @@ int bt_forward_stages(bt_engine* e, void* stream, int prec, int first, int last,
   const int D = d.transformer_dim;
   Workspace ws = carve((char*)d_ws, B, T, D, d.ff_mult, prec);
   if (ws.total > ws_bytes) return bt_set_error(BT_ERR_WORKSPACE, "workspace too small");
-  ws.x3_attn = BT_X3_ATTN | (e->x3_attn_p16 >= 1 ? BT_X3_P16 : 0);
+  ws.x3_attn = BT_X3_ATTN | ((e->x3_attn_p16 == 1 || e->x3_attn_p16 == 2) ? BT_X3_P16 : 0);   // (3: the frontend only -- a soak variant)
   ws.x3_attn_front = BT_X3_ATTN | (e->x3_attn_p16 >= 2 ? BT_X3_P16 : 0);
   ws.x3_gemm_fp8 = e->x3_gemm_fp8;
   hipStream_t s = (hipStream_t)stream;

@@ -694,13 +694,11 @@ def main():
 
                     mx = mx8_measure(chunks=64, seconds=0.15, dev=dev, energy=False, with_hl32=False)
                     t16_, t8_ = sum(r["fp16_us"] for r in mx), sum(r["mx8_us"] for r in mx)
-                    t_half = t64 if args.prec == "half" else t64o
-                    gemm_ms = 6 * t16_ * 1e-3
                     cfg5["as_written_mx_e4m3_operands"] = {
                         "status": "report-only, no forward built on it: closed with numbers (profiles/r06_cfg5_mx8.txt)",
                         "gemm_us_one_main_layer_fp16": round(t16_, 1), "gemm_us_one_main_layer_mx_e4m3": round(t8_, 1),
                         "gemm_speedup_upper_bound": round(t16_ / t8_, 3),
-                        "projected_forward_speedup_over_fp16_path": round(t_half * 1e3 / max(t_half * 1e3 - gemm_ms * (1 - t8_ / t16_), 1e-6), 3),
+                        "projected_forward_speedup_over_fp16_path": None,   # (filled in below from the fp16 path's own breakdown)
                         "keep_bar": 1.25,
                         "simulated_max_abs_logit_vs_fp32_oracle": {"lively": 0.465, "outlier": 0.412, "init": 0.093},
                         "simulated_flips_per_1000": {"lively": 341.3, "outlier": 227.9, "init": 1310.4},
@@ -855,6 +853,18 @@ def main():
                     except (OSError, KeyError, ValueError):
                         pass
                     half_path["note"] = "float16=True: NOT under the 1e-3 / identical-beats gate (see parity); never `value`"
+                    try:   # config 5 as written: only the main layers' GEMMs of the fp16 path get faster, by the measured GEMM ratio
+                        aw = configs["cfg5"]["as_written_mx_e4m3_operands"]
+                        hb = half_path["breakdown"]
+                        tot = sum(v["ms_per_step"] for v in hb.values())
+                        # (main layers' GEMM time of the fp16 step: the fused layer tail + the six gemm3 launches of the nine QKV launches,
+                        # 72 % of that category's time by profiles/r06_kernel_trace_fwd.txt)
+                        gemm = hb.get("layer_tail", {"ms_per_step": 0})["ms_per_step"] + 0.72 * hb["qkv_gemm"]["ms_per_step"] + sum(
+                            hb.get(k, {"ms_per_step": 0})["ms_per_step"] for k in ("out_gemm", "ff1_gemm", "ff2_gemm"))
+                        aw["main_layer_gemm_share_of_fp16_step"] = round(gemm / tot, 3)
+                        aw["projected_forward_speedup_over_fp16_path"] = round(tot / (tot - gemm * (1 - 1 / aw["gemm_speedup_upper_bound"])), 3)
+                    except (KeyError, TypeError, ZeroDivisionError):
+                        pass
                 if args.prec != "f32":
                     log("exact fp32 path leg")
                     fp32_exact_path = path_leg("f32", 0.4)

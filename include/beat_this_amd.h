@@ -183,7 +183,8 @@ void bt_engine_destroy(bt_engine* e);
  *                       2 in the frontend's time-direction attention as well (round 5's default: +2 % throughput, 2.7 x the
  *                       exact path's beat flips on trained-like weights over the soak -- an opt-in, not the default: the default
  *                       is chosen by the flip-soak rule of DESIGN.md section 3);  0: three-term P.V with the probabilities
- *                       split hi + lo everywhere (rounds 3 - 4).
+ *                       split hi + lo everywhere (rounds 3 - 4);  3: P16 in the frontend only (a variant for the flip soak: which half
+ *                       of the attention launches the flips come from).
  *   BT_OPT_X3_GEMM_FP8  0 (default);  BASELINE config 5 -- GEMMs of the main layers run the two cross terms of every hi + lo product
  *                       (hi . lo + lo . hi: 2^-11 of the product) on ONE block-scaled fp8 MFMA per 32-k step instead of four fp16
  *                       ones, operands travelling as hl8 (bt_pair_weights.w_*_f8): 2 MFMA units per product instead of 3.

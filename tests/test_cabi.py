@@ -213,3 +213,18 @@ def test_submodule_tree_mirrors_the_reference_containers():
     assert m.frontend.blocks[1].partial.attnT._unit == ("fattn", 3) and m.frontend.blocks[2].partial.ffF._unit == ("fff", 4)
     with pytest.raises(NotImplementedError):
         m.frontend.blocks[0].partial.attnF.norm(torch.zeros(1))   # (parameter-only nodes below the callable leaves)
+
+
+def test_hubconf_exports_the_reference_entry_points():
+    """hubconf.py:10-18 of the reference: `beat_this` (= load_model) and the inference classes under the same names."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("bt_hubconf", os.path.join(ROOT, "hubconf.py"))
+    hub = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(hub)
+    from beat_this_amd import inference as inf
+
+    assert hub.beat_this is inf.load_model
+    for name in ("BeatThis", "Spect2Frames", "Audio2Frames", "Audio2Beats", "File2Beats", "File2File"):
+        assert getattr(hub, name) is getattr(inf, name)
+    assert set(hub.dependencies) <= {"torch", "numpy"}

@@ -158,6 +158,7 @@ def cmd_gpu(args):
             # probabilities as fp16 hi parts in P.V (round 5 default; x3p16m: in the main layers only); half = fp16 operands
             # x3p16f8ff / x3p16f8 = x3p16 with the cross terms of the feed-forward / of all main-layer GEMMs on fp8 (BT_OPT_X3_GEMM_FP8 = 1 / 2)
             mode, p16, f8 = {"exact": ("exact", 2, 0), "x3": (False, 0, 0), "x3p16m": (False, 1, 0), "x3p16": (False, 2, 0), "half": (True, 2, 0),
+                             "x3p16f": (False, 3, 0),   # P16 in the frontend's attention only (round 6: where do the flips come from?)
                              "x3p16f8ff": (False, 2, 1), "x3p16f8": (False, 2, 2)}[scheme]
             a2f = Audio2Frames(checkpoint_path=None, device=dev, float16=mode)
             m.fp32_split_gemms = True
