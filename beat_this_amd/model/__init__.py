@@ -2,7 +2,9 @@
 
 Same constructor signature, same ``state_dict`` keys (so reference checkpoints load with
 ``load_state_dict``), same ``forward(x: (B,T,128)) -> {"beat": (B,T), "downbeat": (B,T)}``;
-the arithmetic runs in the hand-written HIP kernels of libbeat_this_amd.so.  Precision
+the arithmetic runs in the hand-written HIP kernels of libbeat_this_amd.so.  (A package like the reference's
+``beat_this.model``: ``beat_this_amd.model.beat_tracker.BeatThis`` and ``beat_this_amd.model.postprocessor.Postprocessor`` resolve
+to the same classes, so ``pl_module.py``-style imports keep working.)  Precision
 follows the caller exactly like the reference: under ``torch.autocast`` (what
 ``Spect2Frames(float16=True)`` enters, inference.py:246) the half-precision (fp16 MFMA operand) path runs, otherwise
 an fp32-class path: exact fp32 MFMAs, or -- ``fp32_split_gemms``, what the inference classes select for
@@ -15,9 +17,9 @@ import weakref
 import torch
 from torch import nn
 
-from . import _lib
-from .pack import Engine, PackedModel
-from .weights import random_state_dict, resolve_hparams, state_dict_shapes
+from .. import _lib
+from ..pack import Engine, PackedModel
+from ..weights import random_state_dict, resolve_hparams, state_dict_shapes
 
 _BUFFER_LEAVES = ("running_mean", "running_var", "num_batches_tracked")
 _TREE_EPOCH = [0]   # bumped whenever a module is assigned to / removed from a node of a BeatThis tree (_hooked_below's cache)

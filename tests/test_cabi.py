@@ -228,3 +228,15 @@ def test_hubconf_exports_the_reference_entry_points():
     for name in ("BeatThis", "Spect2Frames", "Audio2Frames", "Audio2Beats", "File2Beats", "File2File"):
         assert getattr(hub, name) is getattr(inf, name)
     assert set(hub.dependencies) <= {"torch", "numpy"}
+
+
+def test_reference_import_paths_resolve():
+    """beat_this.model is a package in the reference (model/beat_tracker.py, model/postprocessor.py; pl_module.py imports from both):
+    the same dotted paths exist here and give the same classes as the flat names."""
+    from beat_this_amd.inference import BeatThis as B0
+    from beat_this_amd.inference import Postprocessor as P0
+    from beat_this_amd.model import BeatThis as B1
+    from beat_this_amd.model.beat_tracker import BeatThis as B2
+    from beat_this_amd.model.postprocessor import Postprocessor as P1
+
+    assert B0 is B1 is B2 and P0 is P1
