@@ -130,6 +130,7 @@ EXPORTS = {
     "bt_resample": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
                               C.c_int64]),
     "bt_peaks": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]),
+    "bt_deduplicate_peaks_host": (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.POINTER(C.c_int32)]),
     "bt_postprocess_host": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_double, C.c_void_p,
                                       C.POINTER(C.c_int32), C.c_void_p, C.POINTER(C.c_int32)]),
     "bt_audio2beats_plan": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.POINTER(A2BPlan)]),

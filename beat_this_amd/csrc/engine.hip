@@ -757,7 +757,7 @@ int bt_peaks_host(const float* logits, int64_t n, int32_t* idx, int32_t* count) 
   return BT_OK;
 }
 
-static int dedup_host(const int32_t* idx, int n, double* out) {
+static int dedup_host(const int32_t* idx, int n, double* out, double width = 1.0) {
   // running-mean merge of frames not more than 1 apart (postprocessor.py:176-197)
   if (n <= 0) return 0;
   int m = 0;
@@ -765,7 +765,7 @@ static int dedup_host(const int32_t* idx, int n, double* out) {
   int count = 1;
   for (int i = 1; i < n; ++i) {
     double nxt = (double)idx[i];
-    if (nxt - mean <= 1.0) {
+    if (nxt - mean <= width) {
       ++count;
       mean += (nxt - mean) / count;
     } else {
@@ -776,6 +776,12 @@ static int dedup_host(const int32_t* idx, int n, double* out) {
   }
   out[m++] = mean;
   return m;
+}
+
+int bt_deduplicate_peaks_host(const int32_t* idx, int n, double width, double* out, int32_t* n_out) {
+  if ((n > 0 && (!idx || !out)) || !n_out || n < 0) return bt_set_error(BT_ERR_ARG, "bad argument to bt_deduplicate_peaks_host");
+  *n_out = dedup_host(idx, n, out, width);
+  return BT_OK;
 }
 
 int bt_postprocess_host(const int32_t* beat_idx, int nb, const int32_t* down_idx, int nd, double fps, double* beats,

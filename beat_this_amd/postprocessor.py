@@ -28,6 +28,16 @@ def _host_post(bidx: np.ndarray, didx: np.ndarray, fps: float):
     return beats[: nb.value].copy(), downs[: nd.value].copy()
 
 
+def deduplicate_peaks(peaks, width=1) -> np.ndarray:
+    """Groups of adjacent peak frame indices that are each not more than ``width`` frames apart (from the group's running mean)
+    replaced by their mean -- the reference's public helper (postprocessor.py:176-197), on the library's host entry point."""
+    idx = np.ascontiguousarray(np.fromiter(map(int, peaks), dtype=np.int64), dtype=np.int32)
+    out = np.empty(max(len(idx), 1), dtype=np.float64)
+    m = C.c_int32(0)
+    _lib.check(_lib.lib().bt_deduplicate_peaks_host(idx.ctypes.data, len(idx), float(width), out.ctypes.data, C.byref(m)))
+    return out[: m.value].copy()
+
+
 class PendingBeats:
     """Handle of an enqueued ``Postprocessor.ragged_async`` call; ``result()`` -> [(beats, downbeats)] per track."""
 

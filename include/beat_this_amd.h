@@ -285,6 +285,9 @@ int bt_peaks_batch(void* stream, const float* d_logits, const int32_t* d_spans, 
  * postprocessor.py:58-83); idx must hold n entries */
 int bt_peaks_host(const float* logits, int64_t n, int32_t* idx, int32_t* count);
 
+/* HOST: deduplicate_peaks(peaks, width) on its own (postprocessor.py:176-197): groups of ascending frame indices not more than
+ * `width` apart (measured from the running mean) are replaced by their mean; out must hold n doubles */
+int bt_deduplicate_peaks_host(const int32_t* idx, int n, double width, double* out, int32_t* n_out);
 /* HOST: deduplicate_peaks(width=1) (postprocessor.py:176-197), frame/fps, snap every
  * downbeat to the nearest beat, np.unique (postprocessor.py:121-136).  Output buffers
  * must hold n_beat_idx / n_down_idx doubles. */

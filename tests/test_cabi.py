@@ -240,3 +240,18 @@ def test_reference_import_paths_resolve():
     from beat_this_amd.model.postprocessor import Postprocessor as P1
 
     assert B0 is B1 is B2 and P0 is P1
+
+
+def test_deduplicate_peaks_matches_the_oracle_restatement():
+    """the reference's public helper (postprocessor.py:176-197) on the library's host entry point: plateaus, chains that drift
+    with the running mean, other widths, the empty list"""
+    from beat_this_amd.model.postprocessor import deduplicate_peaks
+
+    rng = np.random.default_rng(3)
+    cases = [[], [5], [10, 11], [10, 11, 12], [10, 11, 12, 13, 14, 15], [3, 5, 7], [0, 1, 3, 4, 6, 20, 21, 40],
+             sorted(set(rng.integers(0, 400, 150).tolist()))]
+    for peaks in cases:
+        for width in (1, 2, 3):
+            want = O.deduplicate_peaks(np.asarray(peaks, dtype=np.int64), width) if peaks else np.zeros(0)
+            got = deduplicate_peaks(peaks, width)
+            assert got.dtype == np.float64 and np.array_equal(got, np.asarray(want, dtype=np.float64)), (peaks, width)
