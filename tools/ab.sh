@@ -1,6 +1,9 @@
 #!/bin/bash
-# In-situ A/B of two builds of the library on ONE box (boxes differ by several %): alternating bench runs.
-#   tools/ab.sh tools/bin/lib_a.so [tools/bin/lib_b.so ...]     (the in-tree build is always the last candidate)     [extra bench args via AB_ARGS]
+# In-situ A/B of builds of the library on ONE box (boxes differ by several %): three rounds of alternating bench runs.
+#   tools/ab.sh tools/variants/lib_a.so [tools/variants/lib_b.so ...]     (the in-tree build is always the last candidate)
+#   AB_ARGS="--prec half" tools/ab.sh ...                                   (extra bench.py arguments)
+# Variant builds: python tools/build_variant.py NAME -DSWITCH=...  ->  tools/variants/lib_NAME.so
+# columns: build, ms per step, joules per step, average package W, per-category ms per step (roofline leg, one stream)
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $R
 export BT_DEV=1
@@ -11,6 +14,6 @@ for i in 1 2 3; do
 import sys, json
 d = json.loads(sys.stdin.read())
 b = d['breakdown']
-print('${l:-in-tree}'.ljust(28), d['ms_per_step'], ' '.join('%s=%.3f' % (k[:8], v['ms_per_step']) for k, v in b.items()))"
+print('${l:-in-tree}'.ljust(32), d['ms_per_step'], d['energy'].get('joules_per_step'), d['energy'].get('avg_package_power_W'), ' '.join('%s=%.3f' % (k[:8], v['ms_per_step']) for k, v in b.items()))"
   done
 done
