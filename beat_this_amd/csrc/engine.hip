@@ -54,7 +54,7 @@ struct bt_engine {
   std::vector<FwdGraph> graphs;   // (at most 8, least recently used goes first; dropped when an option changes)
   unsigned long graph_clock = 0;
   hipStream_t cap_stream = nullptr;   // private stream the forward is recorded on (the caller's may be the legacy default stream, which cannot capture)
-  bool warm[4] = {false, false, false, false};   // precision ran plainly once (lazy module loading, function attributes)
+  std::vector<int> warm;   // (precision << 8 | chunks) that ran plainly once: the kernels a shape selects are loaded / configured before they are recorded
   int x3_attn_p16 = 1;   // BT_OPT_X3_ATTN_P16 (default chosen by the flip-soak rule: DESIGN.md section 3)
   int x3_gemm_fp8 = 0;   // BT_OPT_X3_GEMM_FP8
 };
@@ -364,6 +364,7 @@ int bt_engine_create(const bt_model_desc* desc, bt_engine** out) {
 static void drop_graphs(bt_engine* e) {
   for (auto& g : e->graphs) (void)hipGraphExecDestroy(g.exec);
   e->graphs.clear();
+  e->warm.clear();   // (another arithmetic option selects other kernels: they run plainly once before they are recorded again)
 }
 void bt_engine_destroy(bt_engine* e) {
   if (!e) return;
@@ -878,7 +879,9 @@ int bt_audio2beats_enqueue(bt_engine* e, void* stream, int prec, const bt_logmel
   LAUNCH(launch_logmel(lp, s), "logmel");
   LAUNCH(launch_split(spect, (long)pl.n_frames, nullptr, nullptr, pl.B, pl.T, chunks, s, border), "split");
   // ---- the forward: plain launches, or the replay of a graph captured here -------------------------------------------------
-  const bool graphable = use_graph && pl.T == 1500 && pl.B <= 16 && !e->prof.on && e->warm[prec & 3];
+  const int warm_key = prec << 8 | pl.B;
+  const bool graphable = use_graph && pl.T == 1500 && pl.B <= 16 && !e->prof.on &&
+                         std::find(e->warm.begin(), e->warm.end(), warm_key) != e->warm.end();
   FwdGraph* g = nullptr;
   if (graphable) {
     for (auto& c : e->graphs)
@@ -912,7 +915,7 @@ int bt_audio2beats_enqueue(bt_engine* e, void* stream, int prec, const bt_logmel
     if (hipGraphLaunch(g->exec, s) != hipSuccess) return bt_set_error(BT_ERR_HIP, "replay of the captured forward");
   } else {
     if (int rc = bt_forward_stages(e, s, prec, 0, 2, chunks, pl.B, pl.T, fws, pl.forward_bytes, nullptr, cb, cd)) return rc;
-    e->warm[prec & 3] = true;
+    if (pl.T == 1500 && pl.B <= 16 && std::find(e->warm.begin(), e->warm.end(), warm_key) == e->warm.end()) e->warm.push_back(warm_key);
   }
   LAUNCH(launch_aggregate(cb, cd, nullptr, nullptr, nullptr, 1, pl.B, pl.T, border, (long)pl.n_frames, beat, downb, s), "aggregate");
   LAUNCH(launch_peaks(beat, (long)pl.n_frames, nullptr, 2, res, res + 2 * pl.n_frames, s), "peaks");
