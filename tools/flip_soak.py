@@ -210,6 +210,15 @@ def cmd_sim(args):
             if s == "mxfp8" and site in ("m_qkv", "m_out", "m_ff1", "m_ff2"):
                 return N.q_mx(a, "e4m3", -1) @ N.q_mx(b, "e4m3", -2)
             return ah @ bh
+        # round 6 candidates: the ACTIVATION operand of one main-layer GEMM as its fp16 hi part only (two MFMAs instead of three, half the
+        # operand bytes from its producer): ff2ahi = the FF hidden activation into FF2, ff1ahi / qkvahi / outahi likewise
+        if s in ("ff2ahi", "ff1ahi", "qkvahi", "outahi", "ff2ahi_p16m"):
+            site_of = {"ff2ahi": "m_ff2", "ff1ahi": "m_ff1", "qkvahi": "m_qkv", "outahi": "m_out", "ff2ahi_p16m": "m_ff2"}[s]
+            if site == site_of:
+                return ah @ bh + ah @ bl
+            if s == "ff2ahi_p16m" and site == "m_pv":
+                return ah @ bh + ah @ bl
+            return ah @ bh + (ah @ bl + al @ bh)
         if s == "p16":
             return ah @ bh + ah @ bl if site.endswith("pv") else ah @ bh + (ah @ bl + al @ bh)
         if s == "p16m":      # main layers only
@@ -233,7 +242,7 @@ def cmd_sim(args):
         q, k = O.rope(q, fr), O.rope(k, fr)
         s = mm_site(q, k.transpose(-1, -2), tag + "qk") * (d ** -0.5)
         p = torch.exp(s - s.amax(-1, keepdim=True))
-        hi_only = SCHEME["name"] in ("p16", "p16vhi", "mxfp8", "halfsim") or (SCHEME["name"] == "p16m" and tag == "m_")
+        hi_only = SCHEME["name"] in ("p16", "p16vhi", "mxfp8", "halfsim") or (SCHEME["name"] in ("p16m", "ff2ahi_p16m") and tag == "m_")
         den = p.to(torch.float16).float().sum(-1, keepdim=True) if hi_only else p.sum(-1, keepdim=True)
         out = mm_site(p, v, tag + "pv") / den
         gates = mm_site(xn, sd[pfx + "to_gates.weight"].T, tag + "qkv") + sd[pfx + "to_gates.bias"]
