@@ -54,11 +54,15 @@ struct G3CfgTX { static constexpr int BM = 192, BN = 256, BK = 64, WGM = 2, WGN 
 // with 3/4 of the L2 -> LDS operand bytes per flop of the 128 x 128 tiles (the stream every 128 x 128 GEMM here is bound by,
 // DESIGN.md section 5) and 3/4 of the fragment reads per MFMA (a 128 x 64 wave tile: 12 reads per 24 MFMAs).
 struct G3CfgMX { static constexpr int BM = 256, BN = 128, BK = 32, WGM = 2, WGN = 2, NST = 3, OCC = 2; };
-// HX (round 5): 64 x 128 tiles (waves of 32 x 64), 24 KB per stage, 2 stages -> three workgroups per CU: the residual GEMMs of a
+// HX (round 5): 64 x 128 tiles (waves of 32 x 64), 24 KB per stage: the residual GEMMs of a
 // single-file forward (M = 3000 rows: out-projection and FF2 are 24 x 4 = 96 tiles of 128 x 128 on 256 CUs) get twice the
 // workgroups at half the work each.  Same MFMAs on the same operand pieces in the same k order per output element:
 // bit-identical to the other configurations (tested).
-struct G3CfgHX { static constexpr int BM = 64, BN = 128, BK = 64, WGM = 2, WGN = 2, NST = 2, OCC = 3; };
+// Round 6: THREE stages (72 KB, two workgroups per CU -- the grids this configuration is chosen for have at most 512 tiles).  With
+// two stages the k-loop of a launch with one workgroup per CU is a chain of L2 round trips: FF2 of a 2-chunk forward (K = 2048) ran
+// 64 steps of 0.85 us with 0.16 us of MFMA issue each.  30 s file 1.71 -> 1.58 ms (profiles/r06_ab_small_m_tiles.txt; deeper rings,
+// k16 steps and the other tile shapes measured there are no better).
+struct G3CfgHX { static constexpr int BM = 64, BN = 128, BK = 64, WGM = 2, WGN = 2, NST = 3, OCC = 2; };
 
 // BT_PREC_F32X3: XCD groups a large weight matrix is split over (1 = off; launch_cfg).  tools/x3_probe.py, M = 24000:
 // FF1 (W = 4 MB of hl32) 206 / 189 / 202 us with 1 / 2 / 4 groups, FF2 175 / 165 / 164, frontend.linear and the
