@@ -816,7 +816,14 @@ int launch_gemm3(const Gemm3P& p, hipStream_t s) {
   const bool big_ok = p.epi != G3_QKV && p.N % 256 == 0;
   // (x3 = 2 / 3 through the single-operator entry bt_gemm3 forces the 256-row / the 128-row configuration: tools/x3_probe.py)
   const int force = (p.x3 & 15) == 2 ? 1 : (p.x3 & 15) == 3 ? 0 : force_big;
-  const bool big = big_ok && (force == 1 || (force != 0 && p.epi == G3_RESID && p.K >= 1024 && p.M >= 4096) ||
+  // (x3 = 4 / 5 force the 256 x 128 k16 / the 64 x 128 tiles further down)
+  const bool forced_small = (p.x3 & 15) == 4 || (p.x3 & 15) == 5;
+  // BT_PREC_F32X3, round 6: the 256-column tiles only when they fill the chip (>= 160 tiles of 192 rows: M >= 15 k rows at N = 512).  A
+  // 4 - 8 chunk single-file forward (M = 6000 - 12000) ran FF2 on 64 - 126 workgroups: 103 - 115 us against 58 - 91 us on the 128 x 128
+  // tiles (tools/x3_probe.py B cfgs; profiles/r06_ab_small_m_tiles.txt)
+  const long tiles192 = ((long)p.M + 191) / 192 * (p.N / 256);
+  const bool fills = !p.x3 || tiles192 >= 160;
+  const bool big = big_ok && !forced_small && (force == 1 || (force != 0 && p.epi == G3_RESID && p.K >= 1024 && p.M >= 4096 && fills) ||
                               (force != 0 && p.x3 && X3_BIG_FF1 && p.epi == G3_FF1 && p.M >= 4096));
   // 256 or 192 token rows per tile: fewer (rounds over the 256 CUs) x (rows per tile) wins
   auto cost = [&](int bm) { const long t = ((long)p.M + bm - 1) / bm * (p.N / 256); return (t + 255) / 256 * bm; };
@@ -827,10 +834,16 @@ int launch_gemm3(const Gemm3P& p, hipStream_t s) {
   // 128 x 128 tiles, whose grid is twice as large)
   const long mx_tiles = ((long)p.M + 255) / 256 * ((p.N + 127) / 128);
   const bool f8 = (p.x3 & G3_X3_F8) != 0;   // A and W are hl8 (the kernel's X3 = 2 form: 128-byte rows only)
-  const bool mx = p.x3 && !f8 && p.epi != G3_QKV && !big && !rows192 && force != 0 && ((p.x3 & 15) == 4 || (X3_MX && mx_tiles >= 512));
+  // (round 6: ... and from 20 k rows on.  Below that -- single files of up to ~ 13 chunks -- its grid is a round and a fraction of the
+  // 512 slots: FF1 at M = 9000 is 576 tiles, 86 us against 74 us on the 128 x 128 tiles; equal at 12 k and 16.5 k rows)
+  const bool mx = p.x3 && !f8 && p.epi != G3_QKV && !big && !rows192 && force != 0 &&
+                  ((p.x3 & 15) == 4 || (X3_MX && mx_tiles >= 512 && p.M >= 20000));
   // the 64-row tiles for residual GEMMs whose 128 x 128 grid leaves CUs idle (a single-file forward); x3 & 15 = 5 forces them
   const long sx_tiles = ((long)p.M + 127) / 128 * ((p.N + 127) / 128);
-  const bool hx = p.x3 && p.epi == G3_RESID && !big && !rows192 && !mx && ((p.x3 & 15) == 5 || ((p.x3 & 15) <= 1 && force_big < 0 && sx_tiles < 256));
+  // (round 6, on their three-stage ring: also the short-K residual GEMMs -- the out-projection -- of every forward below 20 k rows:
+  // 19.5 / 20.5 / 30.1 / 34.0 / 47.1 us against 22.7 / 23.4 / 32.6 / 35.5 / 51.1 us on the 128 x 128 tiles at M = 4.5 / 6 / 9 / 12 / 16.5 k)
+  const bool hx = p.x3 && p.epi == G3_RESID && !big && !rows192 && !mx &&
+                  ((p.x3 & 15) == 5 || ((p.x3 & 15) <= 1 && force_big < 0 && (sx_tiles < 256 || (p.K < 1024 && p.M < 20000))));
   if (p.x3) {
 #ifdef BT_DEV
     // development: ablations of the x3 kernel (results are garbage): BT_G3_ABL = 1 no LDS-DMA after the prologue, 4 no MFMAs

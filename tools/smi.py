@@ -79,10 +79,6 @@ class Smi:
         rc = self.lib.rsmi_dev_power_cap_range_get(C.c_uint32(self.idx), C.c_uint32(0), C.byref(hi), C.byref(lo))
         return (lo.value / 1e6, hi.value / 1e6) if rc == 0 else None
 
-    def cap_set_w(self, watts):
-        """-> rsmi status (0 = applied; 8 / 2 = no permission / not supported: containers usually may not)"""
-        return int(self.lib.rsmi_dev_power_cap_set(C.c_uint32(self.idx), C.c_uint32(0), C.c_uint64(int(watts * 1e6))))
-
 
 class EnergyMeter:
     """joules between start() and stop(); `ok` False (and a reason) where the accumulator cannot be read"""

@@ -94,7 +94,7 @@ def gemm(M, K, N, epi, label, heads=0, n_seq=0, Lq=0, force=1, nsplit=0):
     st = L.stream_ptr(dev)
     us = timeit(lambda: L.check(lib.bt_gemm3(st, C.byref(a))))
     flop = 2.0 * M * K * a.N
-    print(f"gemm3 x3 {label} [{ {1: 'auto', 2: '256-row tiles', 3: '128-row tiles', 4: '256 x 128 k16 tiles'}[force] }, W over {nsplit or 'auto'} XCD groups] M={M} K={K} N={a.N}: {us:8.1f} us  {flop / us / 1e6:7.1f} TFLOP/s algorithmic "
+    print(f"gemm3 x3 {label} [{ {1: 'auto', 2: '256-row tiles', 3: '128-row tiles', 4: '256 x 128 k16 tiles', 5: '64 x 128 tiles'}[force] }, W over {nsplit or 'auto'} XCD groups] M={M} K={K} N={a.N}: {us:8.1f} us  {flop / us / 1e6:7.1f} TFLOP/s algorithmic "
           f"({3 * flop / us / 1e6:7.1f} on the matrix pipe)", flush=True)
 
 
@@ -153,6 +153,16 @@ if len(sys.argv) > 2 and sys.argv[2].startswith("gloop"):
             k += 20
         return (time.time() - t0) / k * 1e6
     gemm(shape[0], shape[1], shape[2], shape[3], which, **shape[4])
+    sys.exit(0)
+if len(sys.argv) > 2 and sys.argv[2] == "cfgs":
+    # python tools/x3_probe.py B cfgs -- every tile configuration on the residual / FF1 shapes of a B-chunk forward (which one should
+    # launch_gemm3 pick at this M?  isolated launches, operands warm in L2 / MALL)
+    for f in (1, 2, 3, 4, 5):
+        gemm(M, 512, 512, 1, "out-projection", force=f)
+    for f in (1, 2, 3, 4, 5):
+        gemm(M, 2048, 512, 1, "FF2", force=f)
+    for f in (1, 2, 3, 4):
+        gemm(M, 512, 2048, 0, "FF1", force=f)
     sys.exit(0)
 gemm(M, 512, 3 * 512 + 16, 2, "QKV", heads=16, n_seq=B, Lq=T)
 for f in (3, 4, 3, 4):
