@@ -1665,13 +1665,18 @@ int launch_attn_frag(const AttnFragP& p, hipStream_t s) {
     // their reloads raced the LDS-DMA in flight -- different results on every run of a 16-chunk forward; the ISA lint's
     // fourth rule now rejects any scratch access in a kernel with LDS-DMA)
     //   4 = round 4: two query blocks per wave on the hand-scheduled key loop (attn_frag_x3q2_kernel).
-    // 4 is taken for launches of at least two full rounds of its 256-query workgroups (two per CU); below that the 64-key
-    // kernel's finer grain (128 queries per workgroup, three per CU) fills the chip better: a 2-chunk single-file forward is
-    // 192 workgroups of the former against 384 of the latter.
+    // 4 takes it where it pays by the count below; otherwise the 64-key kernel's finer grain (128 queries per workgroup, three
+    // per CU) fills the chip better.
     // + BT_X3_P16 (8): the P16 arithmetic (finish_x) on the same kernel selection; all kernels of one arithmetic agree bit for bit
-    const long wg4 = (long)p.n_seq * p.heads * (((p.L + 31) / 32 + 7) / 8);
+    // Round 6: "at least two full rounds" became a count of per-CU rounds -- a CU works through its share of the grid at the
+    // matrix pipe's pace, so a launch costs ceil(workgroups / 256) x (query blocks per wave), and the hand-scheduled loop does a
+    // query block in 0.88 of the other kernel's time (tools/x3_probe.py B attn, B = 2 .. 14: the rule picks the faster kernel or one
+    // within 4 % of it; the old rule lost 14 - 16 % at 4 - 5 chunks and 7 % on the 2-chunk main layers)
+    const long pairs = (long)p.n_seq * p.heads, nb = (p.L + 31) / 32;
+    const long rounds_q2 = (pairs * ((nb + 7) / 8) + 255) / 256, rounds_q1 = (pairs * ((nb + 3) / 4) + 255) / 256;
+    const bool q2_pays = rounds_q2 * 2 * 88 <= rounds_q1 * 100;
     const int kern = p.x3 & 7;
-    const int form = (kern == 4 && wg4 >= 1024) || kern == 5 ? 0 : (kern == 2 || kern == 4) ? 1 : 2;   // (5 = forced: tests, probes)
+    const int form = (kern == 4 && q2_pays) || kern == 5 ? 0 : (kern == 2 || kern == 4) ? 1 : 2;   // (5 = forced: tests, probes)
     switch (form * 4 + (p.out_f32 == 1 ? 2 : 0) + ((p.x3 & 8) ? 1 : 0)) {   // (out_f32 = 2: hl8 rows, a run-time branch of the hl32 epilogue)
       case 0: launch_x3q2<0, false>(p, s); break;
       case 1: launch_x3q2<0, true>(p, s); break;

@@ -365,8 +365,9 @@ int bt_attention(void* stream, int prec, const bt_attn_args* a);
  * 32 e4m3 bytes of value / 8 | 32 e4m3 bytes of 2^8 (value - hi), what bt_gemm3 reads as A with x3 flag 0x100); status (may be NULL) =
  * range flag of the hl32 / hl8 output;
  * x3 = 1: 128-key LDS tiles, x3 = 2: 64-key tiles, x3 = 5: two query blocks per wave on a hand-scheduled key loop -- the same
- * arithmetic in all three, bit-identical results; x3 = 4 (the forward's choice since round 4): 5 for launches of at least
- * 1024 of its workgroups, 2 below.  + 8 (BT_X3_P16): the P16 arithmetic (BT_OPT_X3_ATTN_P16) on the same kernel choice.
+ * arithmetic in all three, bit-identical results; x3 = 4 (the forward's choice since round 4): 5 where its 256-query
+ * workgroups cost fewer per-CU rounds than the 128-query ones of 2 (launch_attn_frag), 2 otherwise.  + 8 (BT_X3_P16): the P16
+ * arithmetic (BT_OPT_X3_ATTN_P16) on the same kernel choice.
  * x3 > 0 needs `scratch`: n_seq * heads * nbp int32 words (the launch's overflow map: queries whose probabilities left fp16's
  * range in the fast pass are recomputed on their row maxima by a second, gathered launch; contents undefined afterwards). */
 #define BT_X3_P16 8
