@@ -424,7 +424,7 @@ int bt_forward_stages(bt_engine* e, void* stream, int prec, int first, int last,
     // range flag of this forward (first word of the workspace): cleared here; bit 0 is ORed by the gemm3 / attention / QKV
     // kernels when a value beyond the fp16 range goes through a split, bit 1 by whatever ends the call (head, final norm,
     // stage exit) when its output is not finite -- which is where an overflow in any other splitting kernel ends up
-    if (hipMemsetAsync(ws.status, 0, 4, s) != hipSuccess) return bt_set_error(BT_ERR_HIP, "clearing the range flag");
+    LAUNCH(launch_clear_words(ws.status, 1, s), "clearing the range flag");
   }
   const int gp = x3 ? BT_PREC_F32X3 : prec, wp = x3 ? BT_PREC_HALF : prec;   // plain GEMMs: launch / weight precision
 

@@ -403,6 +403,14 @@ int launch_stem(const StemP& p, hipStream_t s) {
   hipLaunchKernelGGL(stem_kernel, dim3((unsigned)((long)p.B * t_tiles)), dim3(256), 0, s, p, t_tiles);
   return (int)hipGetLastError();
 }
+// (the range flag of a BT_PREC_F32X3 forward is cleared by a launch, not by hipMemsetAsync: see bt_forward_stages)
+__global__ void clear_words_kernel(int* __restrict__ w, int n) {
+  if ((int)threadIdx.x < n) w[threadIdx.x] = 0;
+}
+int launch_clear_words(int* w, int n, hipStream_t s) {
+  hipLaunchKernelGGL(clear_words_kernel, dim3(1), dim3(64), 0, s, w, n);
+  return (int)hipGetLastError();
+}
 int launch_head(const HeadP& p, hipStream_t s) {
   hipLaunchKernelGGL(head_kernel, dim3((unsigned)((p.M + 3) / 4)), dim3(256), 0, s, p);
   return (int)hipGetLastError();

@@ -206,6 +206,7 @@ struct HeadP {
   int* status;         // BT_PREC_F32X3 range flag (bit 1 is set when a logit is not finite), may be null
 };
 int launch_head(const HeadP& p, hipStream_t s);
+int launch_clear_words(int* w, int n, hipStream_t s);   // n <= 64 words
 // transformer_blocks' final RMSNorm as a pass of its own: y = x * sqrt(D) / |x| * gamma   (roformer.py:181, stage exit)
 int launch_norm_out(const float* x, const float* gamma, float* y, long M, int D, hipStream_t s, int* status = nullptr);
 int launch_finite_rows(const float* x, long M, int D, int* status, hipStream_t s);

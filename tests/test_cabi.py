@@ -255,3 +255,16 @@ def test_deduplicate_peaks_matches_the_oracle_restatement():
             want = O.deduplicate_peaks(np.asarray(peaks, dtype=np.int64), width) if peaks else np.zeros(0)
             got = deduplicate_peaks(peaks, width)
             assert got.dtype == np.float64 and np.array_equal(got, np.asarray(want, dtype=np.float64)), (peaks, width)
+
+
+def test_the_captured_forward_contains_no_memset_or_memcpy_nodes():
+    """A captured forward must consist of kernel launches only: memset nodes at the head of a hipGraph misbehaved on the default stream
+    (tests/test_gpu_model.py::test_interleaved_graph_replays_on_the_default_stream_never_raise_the_range_flag).  bt_forward_stages may
+    copy device-to-device only on its partial-stage entries / exits (never part of a captured whole forward)."""
+    import re
+
+    src = open(os.path.join(ROOT, "beat_this_amd", "csrc", "engine.hip")).read()
+    body = src[src.index("int bt_forward_stages("):src.index("int bt_forward_unit(") if "int bt_forward_unit(" in src else len(src)]
+    assert "hipMemsetAsync" not in body, "bt_forward_stages clears its flag with launch_clear_words, not with a memset node"
+    copies = re.findall(r"hipMemcpyAsync\(([^;]*);", body)
+    assert all("DeviceToDevice" in c for c in copies)

@@ -844,3 +844,43 @@ def test_audio2beats_one_call_repeats_an_overflowing_track_on_the_exact_path():
         inf.USE_ONE_CALL = True
         m.fp32_split_gemms = True
     assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+
+
+@pytest.mark.timeout(300)
+def test_interleaved_graph_replays_on_the_default_stream_never_raise_the_range_flag():
+    """Round 6, found by tools/length_fuzz.py: with the range flag of a BT_PREC_F32X3 forward cleared by hipMemsetAsync, the memset NODE at
+    the head of a captured forward misbehaved on the legacy default stream once replays of OTHER captured graphs (another engine's, the
+    stage-by-stage route's) had run in between -- the flag word read 0x01010101, the logits were those of a damaged forward, and the call
+    was (correctly, but needlessly) repeated on the exact path: 3 of 40 files in this sequence.  The flag is cleared by a one-block launch
+    since (bt_forward_stages); the sequence must run without a single fallback, on the default stream, with both engines interleaved."""
+    from beat_this_amd import inference as inf
+    from beat_this_amd import weights as W
+    from beat_this_amd.inference import Audio2Beats
+    from beat_this_amd.model import BeatThis
+
+    hp = W.resolve_hparams("final0")
+    sd = W.random_state_dict(hp, seed=1, style="outlier")
+
+    def make(f16):
+        a = Audio2Beats(checkpoint_path=None, device=dev(), float16=f16, dbn=False)
+        m = BeatThis(**{k: hp[k] for k in ("spect_dim", "transformer_dim", "ff_mult", "n_layers", "head_dim", "stem_dim")})
+        m.load_state_dict(sd)
+        a.model = m.to(dev())
+        return a
+
+    assert torch.cuda.current_stream(dev()).cuda_stream == 0, "this test is about the legacy default stream"
+    fast, exact = make(False), make("exact")
+    eng = fast.model.engine()
+    rng = np.random.default_rng(1)
+    n_calls = 0
+    for i in range(36):   # (the sequence of tools/length_fuzz.py 40 outlier 1: files 28, 30 and 34 fell back)
+        secs = float(rng.uniform(0.3, 60.0) if i % 2 == 0 else rng.uniform(60.0, 400.0))
+        sr = int(rng.choice([22050, 44100, 44100, 48000, 16000]))
+        sig = W.synthetic_audio(secs, seed=1000 + i, sr=sr)
+        inf.Audio2Frames.__call__(exact, sig, sr)     # the other engine's stage-by-stage route (a torch-level graph replay)
+        b1, d1 = fast(sig, sr)                        # one library call: the replay under test
+        b2, d2 = exact(sig, sr)                       # the other engine's one-call route
+        n_calls += 1
+        assert eng.last_fallbacks == 0, f"file {i} ({secs:.2f} s at {sr} Hz) raised the range flag"
+        assert abs(len(b1) - len(b2)) <= 2 and abs(len(d1) - len(d2)) <= 2
+    report("interleaved_default_stream", calls=n_calls, fallbacks=eng.last_fallbacks)

@@ -1,0 +1,75 @@
+#!/usr/bin/env python
+"""Length fuzz of the default path on the GPU: random file lengths (0.3 s .. 400 s) and sample rates through Audio2Frames /
+Audio2Beats in the default precision (BT_PREC_F32X3) against the exact fp32 MFMA path of the same library on the same input.
+Every launch-shape regime of the tile / kernel selection rules (csrc/gemm3.hip launch_gemm3, csrc/attn2.hip launch_attn_frag:
+1 .. 14 chunks, ragged last pieces, single short pieces) is crossed many times.  Checks per file: logits within 1.5e-4 (the
+asserted bound of the GPU tests), no range fallback, the one-call Audio2Beats result equal to the stage-by-stage one, and
+the beat / downbeat frames of the two precisions (counted, not asserted: a decision on the margin may flip).
+    python tools/length_fuzz.py [n_files] [style] [seed]"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from beat_this_amd import weights as W  # noqa: E402
+from beat_this_amd import inference as I  # noqa: E402
+from beat_this_amd.model import BeatThis  # noqa: E402
+
+n_files = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+style = sys.argv[2] if len(sys.argv) > 2 else "lively"
+seed = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+TOL = 1.5e-4
+dev = torch.device("cuda:0")
+hp = W.resolve_hparams("final0")
+sd = W.random_state_dict(hp, seed=1, style=style)
+
+
+def make(float16):
+    a = I.Audio2Beats(checkpoint_path=None, device=dev, float16=float16)
+    m = BeatThis(**{k: hp[k] for k in ("spect_dim", "transformer_dim", "ff_mult", "n_layers", "head_dim", "stem_dim")})
+    m.load_state_dict(sd)
+    a.model = m.to(dev)
+    return a
+
+
+fast, exact = make(False), make("exact")
+rng = np.random.default_rng(seed)
+worst, flips, decisions, fallbacks, bad = 0.0, 0, 0, 0, []
+for i in range(n_files):
+    # half of the files below a minute (1 - 2 chunks and short single pieces), the rest up to 400 s
+    secs = float(rng.uniform(0.3, 60.0) if i % 2 == 0 else rng.uniform(60.0, 400.0))
+    sr = int(rng.choice([22050, 44100, 44100, 48000, 16000]))
+    sig = W.synthetic_audio(secs, seed=1000 + i, sr=sr)
+    if i % 7 == 3:
+        sig = np.stack([sig, 0.5 * sig[::-1]], 1)   # stereo input: the mono mix
+    eng = fast.model.engine()
+    fb0 = eng.last_fallbacks
+    bl, dl = I.Audio2Frames.__call__(fast, sig, sr)
+    fb_frames = eng.last_fallbacks - fb0
+    be, de = I.Audio2Frames.__call__(exact, sig, sr)
+    err = max(float((bl.float() - be.float()).abs().max()), float((dl.float() - de.float()).abs().max()))
+    worst = max(worst, err)
+    b1, d1 = fast(sig, sr)                      # one library call
+    fb_one = eng.last_fallbacks - fb0 - fb_frames
+    I.USE_ONE_CALL = False
+    b2, d2 = fast(sig, sr)                      # stage by stage
+    I.USE_ONE_CALL = True
+    same_route = np.array_equal(b1, b2) and np.array_equal(d1, d2)
+    b3, d3 = exact(sig, sr)
+    f = len(np.setxor1d(np.round(b1 * 50), np.round(b3 * 50))) + len(np.setxor1d(np.round(d1 * 50), np.round(d3 * 50)))
+    flips += f
+    decisions += len(b3) + len(d3)
+    fb = eng.last_fallbacks - fb0   # (three calls of the default path per file: logits, one call, stage by stage)
+    fallbacks += fb
+    ok = err < TOL and same_route
+    if not ok:
+        bad.append((i, secs, sr, err, same_route))
+    print(f"{i:3d} {secs:7.2f} s @ {sr:5d} Hz{' stereo' if sig.ndim == 2 else '':7s}: {bl.shape[0]:6d} frames, |x3 - exact| {err:.2e}, "
+          f"{len(b1):4d} / {len(d1):4d} beats / downbeats, flips vs exact {f}, one call == stages {same_route}"
+          f"{', RANGE FALLBACK (logits / one call / stages) %d / %d / %d' % (fb_frames, fb_one, fb - fb_frames - fb_one) if fb else ''}", flush=True)
+print(f"length fuzz ({style}): {n_files} files, worst |x3 - exact| {worst:.2e} (bound {TOL}), {flips} flips of {decisions} decisions against the "
+      f"exact path, {fallbacks} range fallbacks, {len(bad)} file(s) out of bounds {bad}")
+sys.exit(1 if bad else 0)
