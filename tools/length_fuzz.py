@@ -21,7 +21,10 @@ from beat_this_amd.model import BeatThis  # noqa: E402
 n_files = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 style = sys.argv[2] if len(sys.argv) > 2 else "lively"
 seed = int(sys.argv[3]) if len(sys.argv) > 3 else 0
-TOL = 1.5e-4
+# 4th argument "half": the fp16 path (float16=True) instead of the default one, against the exact path within the bound the GPU tests
+# hold it to (3e-2: fp16 operands); "many": groups of 1 - 5 files through Audio2Beats.many against the single-file calls
+what = sys.argv[4] if len(sys.argv) > 4 else "default"
+TOL = 3e-2 if what == "half" else 1.5e-4
 dev = torch.device("cuda:0")
 hp = W.resolve_hparams("final0")
 sd = W.random_state_dict(hp, seed=1, style=style)
@@ -35,8 +38,23 @@ def make(float16):
     return a
 
 
-fast, exact = make(False), make("exact")
+fast, exact = make(what == "half"), make("exact")
 rng = np.random.default_rng(seed)
+if what == "many":
+    n_bad = 0
+    for g in range(n_files):
+        k = int(rng.integers(1, 6))
+        sr = int(rng.choice([22050, 44100, 48000]))
+        sigs = [W.synthetic_audio(float(rng.uniform(0.5, 200.0)), seed=5000 + 10 * g + j, sr=sr) for j in range(k)]
+        got = fast.many(sigs, sr)
+        ok = True
+        for sg, (b, d) in zip(sigs, got):
+            b1, d1 = fast(sg, sr)
+            ok = ok and np.array_equal(b, b1) and np.array_equal(d, d1)
+        n_bad += not ok
+        print(f"{g:3d} {k} tracks @ {sr} Hz, {[round(len(x) / sr, 1) for x in sigs]} s: many == single calls {ok}", flush=True)
+    print(f"length fuzz (many, {style}): {n_files} groups, {n_bad} differ from the single-file calls, {fast.model.engine().last_fallbacks} range fallbacks")
+    sys.exit(1 if n_bad else 0)
 worst, flips, decisions, fallbacks, bad = 0.0, 0, 0, 0, []
 for i in range(n_files):
     # half of the files below a minute (1 - 2 chunks and short single pieces), the rest up to 400 s
