@@ -5,7 +5,7 @@ Every launch-shape regime of the tile / kernel selection rules (csrc/gemm3.hip l
 1 .. 14 chunks, ragged last pieces, single short pieces) is crossed many times.  Checks per file: logits within 1.5e-4 (the
 asserted bound of the GPU tests), no range fallback, the one-call Audio2Beats result equal to the stage-by-stage one, and
 the beat / downbeat frames of the two precisions (counted, not asserted: a decision on the margin may flip).
-    python tools/length_fuzz.py [n_files] [style] [seed]"""
+    python tools/length_fuzz.py [n_files] [style] [seed] [default|half|many] [final0|small0]"""
 import os
 import sys
 
@@ -24,9 +24,14 @@ seed = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 # 4th argument "half": the fp16 path (float16=True) instead of the default one, against the exact path within the bound the GPU tests
 # hold it to (3e-2: fp16 operands); "many": groups of 1 - 5 files through Audio2Beats.many against the single-file calls
 what = sys.argv[4] if len(sys.argv) > 4 else "default"
+model_name = sys.argv[5] if len(sys.argv) > 5 else "final0"
+# (default path: 1.5e-4 is what the GPU tests assert for final0; the small / narrow models amplify the frontend's share and are held to
+# 7.5e-4 there -- tests/test_gpu_model.py test_ablation_variants_against_oracle; north_star's gate is 1e-3)
 TOL = 3e-2 if what == "half" else 1.5e-4
 dev = torch.device("cuda:0")
-hp = W.resolve_hparams("final0")
+hp = W.resolve_hparams(model_name)
+if model_name != "final0" and what != "half":
+    TOL = 7.5e-4
 sd = W.random_state_dict(hp, seed=1, style=style)
 
 
