@@ -7,6 +7,7 @@
 #include <cstddef>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -51,6 +52,7 @@ struct FwdGraph { int B, T, prec; void* ws; hipGraphExec_t exec; unsigned long s
 struct bt_engine {
   bt_model_desc d;
   prof::State prof;
+  std::mutex mu;   // one engine may be shared by host threads (each on its own stream): the one-call path's bookkeeping -- graph cache, capture stream, options -- is serialised; the launches themselves go to the callers' streams
   std::vector<FwdGraph> graphs;   // (at most 8, least recently used goes first; dropped when an option changes)
   unsigned long graph_clock = 0;
   hipStream_t cap_stream = nullptr;   // private stream the forward is recorded on (the caller's may be the legacy default stream, which cannot capture)
@@ -377,6 +379,7 @@ void bt_engine_destroy(bt_engine* e) {
 int bt_engine_set_option(bt_engine* e, int option, int value) {
   if (!e) return bt_set_error(BT_ERR_ARG, "null argument");
   // (a captured forward replays the kernels it was recorded with: an option change drops them)
+  std::lock_guard<std::mutex> lock(e->mu);
   if (option == BT_OPT_X3_ATTN_P16 && value >= 0 && value <= 3) { if (e->x3_attn_p16 != value) drop_graphs(e); e->x3_attn_p16 = value; return BT_OK; }
   if (option == BT_OPT_X3_GEMM_FP8 && value >= 0 && value <= 2) { if (e->x3_gemm_fp8 != value) drop_graphs(e); e->x3_gemm_fp8 = value; return BT_OK; }
   return bt_set_error(BT_ERR_ARG, "unknown engine option / value");
@@ -852,6 +855,7 @@ int bt_audio2beats_enqueue(bt_engine* e, void* stream, int prec, const bt_logmel
   bt_a2b_plan pl;
   if (int rc = bt_audio2beats_plan(e, n_in, up, down, prec, &pl)) return rc;
   if (pl.ws_bytes > ws_bytes) return bt_set_error(BT_ERR_WORKSPACE, "workspace too small (bt_audio2beats_plan)");
+  std::lock_guard<std::mutex> lock(e->mu);   // (host-side enqueueing only: ~50 us per call)
   const int max_T = e->d.rope_len > 0 ? e->d.rope_len : 1536;
   if (pl.T > max_T) return bt_set_error(BT_ERR_ARG, "chunk longer than the rotary table");
   hipStream_t s = (hipStream_t)stream;

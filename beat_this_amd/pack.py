@@ -641,7 +641,8 @@ class _GraphEntry:
             capture = torch.cuda.Stream(device=dev)
             capture.wait_stream(torch.cuda.current_stream(dev))
             self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph, stream=capture):   # ... then recorded on a stream of the engine's device
+            # (thread_local: other host threads keep launching on their own streams while this one records)
+            with torch.cuda.graph(self.graph, stream=capture, capture_error_mode="thread_local"):   # ... then recorded on a stream of the engine's device
                 self._launch()
             # a capture is only trusted once a replay has reproduced the plain launches bit for bit (same kernels, same input)
             self.beat.fill_(float("nan"))

@@ -10,11 +10,14 @@ scope, SURVEY.md 2 #5)."""
 from __future__ import annotations
 
 import ctypes as C
+import threading
 
 import numpy as np
 import torch
 
 from . import _lib
+
+_PIN_LOCK = threading.Lock()
 
 
 def _host_post(bidx: np.ndarray, didx: np.ndarray, fps: float):
@@ -173,9 +176,10 @@ class Postprocessor:
     def _pinned(self, size: int) -> torch.Tensor:
         """A pinned host buffer of at least ``size`` int32 (pool of returned buffers: page-locking costs ~a millisecond)."""
         pool = self.__dict__.setdefault("_pin_pool", [])
-        for i, t in enumerate(pool):
-            if t.numel() >= size:
-                return pool.pop(i)
+        with _PIN_LOCK:   # (one Postprocessor may serve several host threads)
+            for i, t in enumerate(pool):
+                if t.numel() >= size:
+                    return pool.pop(i)
         return torch.empty((max(size, 1 << 16),), dtype=torch.int32, pin_memory=True)
 
     def postp_dbn(self, beat, downbeat, padding_mask=None):

@@ -884,3 +884,48 @@ def test_interleaved_graph_replays_on_the_default_stream_never_raise_the_range_f
         assert eng.last_fallbacks == 0, f"file {i} ({secs:.2f} s at {sr} Hz) raised the range flag"
         assert abs(len(b1) - len(b2)) <= 2 and abs(len(d1) - len(d2)) <= 2
     report("interleaved_default_stream", calls=n_calls, fallbacks=eng.last_fallbacks)
+
+
+@pytest.mark.timeout(300)
+def test_one_audio2beats_shared_by_host_threads():
+    """One Audio2Beats (one engine) called from several host threads, each on its own stream, while files of different chunk counts make
+    the one-call path capture and replay forwards: every result equals the single-threaded one.  (Round 6: the graph cache, the capture
+    stream and the pinned-buffer pool were unguarded -- `hipErrorIllegalState` from a launch into another thread's capture.)"""
+    import threading
+
+    from beat_this_amd import weights as W
+    from beat_this_amd.inference import Audio2Beats
+
+    a2b = Audio2Beats(checkpoint_path=None, device=dev(), float16=False, dbn=False)
+    a2b.model = _model("small0", 4, "lively")
+    rng = np.random.default_rng(3)
+    files = []
+    for i in range(10):
+        secs = float(rng.uniform(0.5, 45.0) if i % 2 else rng.uniform(45.0, 150.0))
+        sr = int(rng.choice([22050, 44100]))
+        files.append((W.synthetic_audio(secs, seed=3000 + i, sr=sr), sr))
+    want = [a2b(sig, sr) for sig, sr in files]
+    n_threads, errors, results = 3, [], [None] * 3
+
+    def work(t):
+        try:
+            out = []
+            with torch.cuda.stream(torch.cuda.Stream(device=dev())):
+                order = list(range(len(files)))
+                np.random.default_rng(t).shuffle(order)
+                for j in order:
+                    out.append((j, a2b(*files[j])))
+            results[t] = out
+        except Exception as e:  # noqa: BLE001
+            errors.append((t, repr(e)))
+
+    ths = [threading.Thread(target=work, args=(t,)) for t in range(n_threads)]
+    for th in ths:
+        th.start()
+    for th in ths:
+        th.join()
+    assert not errors, errors
+    for out in results:
+        for j, (b, d) in out:
+            assert np.array_equal(b, want[j][0]) and np.array_equal(d, want[j][1]), j
+    report("shared_engine_threads", threads=n_threads, files=len(files))
