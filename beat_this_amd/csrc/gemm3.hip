@@ -48,6 +48,9 @@ struct G3CfgT { static constexpr int BM = 192, BN = 256, BK = 64, WGM = 2, WGN =
 // BX / TX: the 256- / 192-row tiles of the long-K residual GEMM, 64 KB per stage.
 struct G3CfgSX { static constexpr int BM = 128, BN = 128, BK = 64, WGM = 2, WGN = 2, NST = 2, OCC = 2; };
 struct G3CfgBX { static constexpr int BM = 256, BN = 256, BK = 64, WGM = 2, WGN = 4, NST = 2, OCC = 1; };
+// (Round 6: the 256 x 256 tiles on k16 steps with four stages -- twice the prefetch distance in 128 KB -- ran FF2 6.8 % SLOWER inside the
+// bench step, 3.93 -> 4.20 ms, three alternations on one box: the long-K launches at batch size are not the chain of L2 round trips the
+// single-file ones were.)
 struct G3CfgTX { static constexpr int BM = 192, BN = 256, BK = 64, WGM = 2, WGN = 4, NST = 2, OCC = 1; };
 // MX (round 4): 256 x 128 tiles on k-steps of 16 (half an hl32 group per LDS row: 64 B = [16 hi | 16 lo]), 4 waves of 128 x 64,
 // 24 KB per stage, 3 stages -> still TWO workgroups per CU (147 KB), i.e. the second workgroup keeps hiding the epilogue,
